@@ -1,0 +1,206 @@
+/*
+ * basevar_amd.h -- C ABI of the MI355X-native per-site basetype likelihood engine.
+ *
+ * This is the drop-in boundary for ONE path of ShujiaHuang/basevar: the per-site
+ * caller (reference: src/basetype.cpp:22-295, src/algorithm.h:44-255,
+ * htslib/kfunc.c:39-143,245-313) as it is driven from _basevar_caller
+ * (src/basetype_caller.cpp:667-765) and the arithmetic of _out_vcf_line /
+ * _out_cvg_line (src/basetype_caller.cpp:1103-1260).
+ *
+ * The reference has no plugin API; its seam is the C++ class `BaseType`
+ * (src/basetype.h:64-153) plus the free functions `strand_bias` and
+ * `ref_vs_alt_ranksumtest` (src/basetype.h:168-181), all called once per site.
+ * This ABI is the batched equivalent: S sites x N samples per submit.
+ * Every entry point below names the reference interface it replaces.
+ *
+ * Plain C: pointers and sizes only; no C++/torch types cross this boundary.
+ * All functions return 0 (BV_OK) on success and a negative bv_status on error;
+ * bv_last_error() gives the message (C++ wrapper rethrows std::runtime_error,
+ * the reference's error type, src/basetype.cpp:54-56,113-115,272).
+ */
+#ifndef BASEVAR_AMD_H
+#define BASEVAR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BV_ABI_VERSION 1
+
+/* ---- cell encoding of the `base_strand` plane ---------------------------------
+ * bits 0-2: first character of the reference's per-sample token
+ *           (src/basetype.cpp:50; domain per src/basetype_caller.cpp:1060-1077)
+ *             0 'A'  1 'C'  2 'G'  3 'T'   (index in BASES, src/basetype.h:19)
+ *             4 'N'  (uncovered)   5 '+' (insertion token)  6 '-' (deletion token)
+ * bit 3   : 1 = reverse strand '-', 0 = forward '+' (src/basetype.cpp:257-264);
+ *           ignored for codes >= 4 (reference strand '.' there).
+ * bits 4-7: must be zero.
+ */
+#define BV_BASE_A 0u
+#define BV_BASE_C 1u
+#define BV_BASE_G 2u
+#define BV_BASE_T 3u
+#define BV_BASE_N 4u
+#define BV_BASE_INS 5u
+#define BV_BASE_DEL 6u
+#define BV_STRAND_REV 8u
+
+/* qual plane: phred value = (reference quality char) - 33, src/basetype.cpp:47.
+ * Valid domain 0..93 (chars '!'..'~').  Larger values set BV_SITE_BAD_QUAL. */
+#define BV_MAX_PHRED 93u
+#define BV_MAX_ALT 3
+#define BV_NO_GROUP 0xFFu
+#define BV_MAX_GROUPS 32u
+
+typedef enum bv_status {
+    BV_OK = 0,
+    BV_ERR_INVALID_ARG = -1,
+    BV_ERR_NO_DEVICE = -2,   /* no HIP device / kernel image not loadable: fail loudly */
+    BV_ERR_HIP = -3,         /* a HIP runtime call failed; see bv_last_error()       */
+    BV_ERR_TOO_LARGE = -4,   /* slab exceeds cfg.max_sites / max_samples             */
+    BV_ERR_SITE = -5         /* at least one site raised a reference-style exception */
+} bv_status;
+
+typedef enum bv_mem_kind {
+    BV_MEM_DEVICE = 0, /* planes and outputs are device (HBM) pointers of cfg.device */
+    BV_MEM_HOST = 1    /* planes and outputs are host pointers; engine stages them   */
+} bv_mem_kind;
+
+/* per-site status bits (bv_site_result.status) */
+#define BV_SITE_COVERED 0x1u   /* total_depth > 0  (CVG row emitted, caller.cpp:1246)  */
+#define BV_SITE_VARIANT 0x2u   /* alt set non-empty (VCF row emitted, caller.cpp:745)  */
+#define BV_SITE_BAD_QUAL 0x4u  /* a covered cell had phred > 93                        */
+#define BV_SITE_ZERO_FREQ 0x8u /* reference would throw at basetype.cpp:113-115        */
+#define BV_SITE_RANKSUM 0x10u  /* mapq/rpr rank sums were computed (planes present)    */
+#define BV_SITE_SOR_OVERFLOW 0x20u /* int product in SOR exceeded 2^31 (basetype.cpp:286 is UB there) */
+
+/* Input: SoA planes [n_sites][pitch], one row per genomic site, one cell per sample.
+ * Replaces `struct BatchInfo` (src/basetype.h:25-43) for a whole batch of sites. */
+typedef struct bv_slab {
+    uint32_t n_sites;
+    uint32_t n_samples;
+    uint64_t pitch;              /* cells per row, >= n_samples, multiple of 16       */
+    const uint8_t *base_strand;  /* [n_sites][pitch]  align_bases[i][0] + map_strands */
+    const uint8_t *qual;         /* [n_sites][pitch]  align_base_quals - 33           */
+    const uint8_t *mapq;         /* [n_sites][pitch]  mapqs; may be NULL              */
+    const uint16_t *rpr;         /* [n_sites][pitch]  base_pos_ranks; may be NULL     */
+    const uint8_t *ref_base;     /* [n_sites] toupper(ref_base[0]) as BV_BASE_*; 4 = not ACGT */
+    const uint8_t *group_id;     /* [n_samples] pop-group index or BV_NO_GROUP; may be NULL   */
+    uint32_t n_groups;           /* 0 if no groups (caller.cpp:746)                   */
+    uint32_t mem_kind;           /* bv_mem_kind                                       */
+} bv_slab;
+
+/* Output: one fixed-size record per site (192 bytes).
+ * Replaces the BaseType getters (src/basetype.h:121-151), StrandBiasInfo
+ * (src/basetype.h:57-62) and the INFO arithmetic of _out_vcf_line
+ * (src/basetype_caller.cpp:1113-1164). */
+typedef struct bv_site_result {
+    uint32_t depth[4];    /* get_base_depth('A','C','G','T'), basetype.cpp:58 (bit-exact) */
+    uint32_t total_depth; /* get_total_depth(), basetype.cpp:59                          */
+    uint32_t status;      /* BV_SITE_* bits                                              */
+    uint32_t cvg_sb[4];   /* ref_fwd, ref_rev, alt_fwd, alt_rev; alt = all non-ref ACGT  */
+                          /* (_out_cvg_line, caller.cpp:1236-1245)                       */
+    double cvg_fs;        /* StrandBiasInfo.fs  of that call, basetype.cpp:277-282       */
+    double cvg_sor;       /* StrandBiasInfo.sor of that call, basetype.cpp:286           */
+    uint8_t n_alt;        /* get_alt_bases().size(), basetype.cpp:172-177                */
+    uint8_t alt[BV_MAX_ALT]; /* alt base codes in reference order                        */
+    uint16_t em_iters;    /* diagnostic: EM loop iterations summed over all EM runs      */
+    uint16_t n_em;        /* diagnostic: number of EM runs (<= 10)                       */
+    double af[BV_MAX_ALT];  /* get_lrt_af(alt[i]), basetype.cpp:175 (CM_AF)              */
+    double caf[BV_MAX_ALT]; /* depth[alt]/total_depth, caller.cpp:1122 (CM_CAF)          */
+    double qual;          /* get_var_qual(), basetype.cpp:180-196                        */
+    double chi2;          /* last chi_sqrt_value of lrt(), basetype.cpp:160              */
+    double qd;            /* qual / sum depth[alt], caller.cpp:1160-1161                 */
+    uint32_t var_sb[4];   /* strand_bias w.r.t. chosen ALTs, caller.cpp:1164             */
+    double var_fs;
+    double var_sor;
+    double mq_ranksum;    /* ref_vs_alt_ranksumtest(mapqs), caller.cpp:1151 (caller truncates to int) */
+    double rpr_ranksum;   /* ... (base_pos_ranks), caller.cpp:1154                       */
+    double bq_ranksum;    /* ... (align_base_quals), caller.cpp:1157                     */
+} bv_site_result;
+
+/* Per (site, group) record (32 bytes), valid for BV_SITE_VARIANT sites only.
+ * Replaces __gb()/lrt([REF]+alts) (src/basetype_caller.cpp:756-777) and the
+ * "<group>_AF=" INFO values (caller.cpp:1182-1196). */
+typedef struct bv_group_result {
+    uint8_t n_alt;
+    uint8_t alt[BV_MAX_ALT];
+    uint32_t total_depth;
+    double af[BV_MAX_ALT];
+} bv_group_result;
+
+typedef struct bv_engine_config {
+    int32_t device;        /* HIP device ordinal                                        */
+    uint32_t max_sites;    /* largest n_sites per submit (sizes scratch)                */
+    uint32_t max_samples;  /* largest n_samples (host-staging only; 0 = no staging)     */
+    uint32_t flags;        /* reserved, 0                                               */
+    double min_af;         /* BaseType ctor arg 2 (basetype.cpp:30): already the        */
+                           /* float-rounded value of caller.cpp:122; see bv_min_af()    */
+} bv_engine_config;
+
+typedef struct bv_engine bv_engine;
+
+/* Library / ABI version string, e.g. "basevar_amd 0.1 abi1 gfx950". */
+const char *bv_version(void);
+
+/* min_af exactly as the reference derives it: (double)std::min(float(100)/n_files,
+ * user_min_af) -- src/basetype_caller.cpp:122, src/basetype_utils.h:80,94. */
+double bv_min_af(uint32_t n_samples, float user_min_af);
+
+/* Lifetime.  One engine == one HIP stream + scratch on cfg.device.  Thread-compatible:
+ * use one engine per host thread/GPU (mirrors one BaseType per ThreadPool worker,
+ * src/basetype_caller.cpp:485-510). */
+int bv_engine_create(const bv_engine_config *cfg, bv_engine **out);
+int bv_engine_destroy(bv_engine *e);
+
+/* Asynchronously run the whole per-site path over a slab:
+ *   BaseType(bi, min_af) + lrt()                  caller.cpp:742-743
+ *   strand_bias (CVG and VCF flavours)            caller.cpp:1245, 1164
+ *   3 x ref_vs_alt_ranksumtest                    caller.cpp:1151-1157
+ *   per-group __gb() when slab->n_groups > 0      caller.cpp:756-759
+ * `out`   : [n_sites] records, same mem_kind as the slab.
+ * `gout`  : [n_sites][n_groups] records or NULL when n_groups == 0.
+ * `stream`: hipStream_t to launch on, or NULL for the engine's own stream.
+ * No allocation crosses the ABI; caller owns slab and outputs. */
+int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
+                     bv_group_result *gout, void *stream);
+
+/* Block until the last submit has finished.  Returns BV_ERR_SITE if any site set
+ * BV_SITE_ZERO_FREQ (the reference would have thrown). */
+int bv_engine_wait(bv_engine *e);
+
+/* HIP-event timings (ms) of the last submit's kernels on the stream they ran on:
+ * pass 1 (tally + solve, all sites) and pass 2 (rank sums + groups, variant sites).
+ * Valid after bv_engine_wait(). */
+int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms);
+
+/* Number of BV_SITE_VARIANT sites found by the last submit (valid after wait). */
+int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant);
+
+/* Thread-safe: message of the last error on this engine (or global if e == NULL). */
+const char *bv_last_error(const bv_engine *e);
+
+/* ---- measurement helper (bench only; not part of the reference surface) --------
+ * Fill device planes with the synthetic pileup of SURVEY.md section 8(d) using a
+ * counter-based RNG (stateless in (seed, site, sample)), so any rank can generate
+ * any site range.  All plane pointers are device pointers; mapq/rpr may be NULL. */
+typedef struct bv_synth_params {
+    uint64_t seed;
+    uint64_t site_offset; /* global index of row 0 (for sharding across ranks)       */
+    float coverage;       /* P(cell covered), e.g. 0.08                              */
+    float indel_frac;     /* fraction of covered cells that are indel tokens         */
+    float qual_mean, qual_sd;
+    uint32_t qual_min, qual_max;
+} bv_synth_params;
+
+int bv_synth_fill(int device, const bv_synth_params *p, uint32_t n_sites, uint32_t n_samples,
+                  uint64_t pitch, uint8_t *base_strand, uint8_t *qual, uint8_t *mapq,
+                  uint16_t *rpr, uint8_t *ref_base, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASEVAR_AMD_H */
