@@ -1,0 +1,305 @@
+// bv_engine.hip -- host side of the C ABI declared in include/basevar_amd.h.
+//
+// One engine = one HIP stream + the small device scratch the two passes share (phred
+// tables, variant-site list, counters) + HIP events that time each pass on the stream it
+// runs on.  No oracle, no CPU arithmetic path: if no HIP device or no gfx950 code object is
+// usable, creation fails loudly with BV_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "bv_kernels.h"
+
+void bv_launch_synth(const bv_synth_params &p, uint32_t n_sites, uint32_t n_samples, uint64_t pitch, uint8_t *bs,
+                     uint8_t *q, uint8_t *mapq, uint16_t *rpr, uint8_t *ref_base, hipStream_t stream);
+
+namespace {
+std::mutex g_err_mu;
+std::string g_err;  // errors raised without an engine (create failures)
+
+void set_global_error(const std::string &m) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_err = m;
+}
+}  // namespace
+
+struct bv_engine {
+    bv_engine_config cfg;
+    hipStream_t stream = nullptr;      // engine-owned stream
+    hipStream_t last_stream = nullptr; // stream of the last submit
+    BvTables *d_tables = nullptr;
+    uint32_t *d_var_list = nullptr;
+    uint32_t *d_counters = nullptr;    // [0] variants, [1] zero-freq sites
+    uint32_t *h_counters = nullptr;    // pinned host mirror
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool submitted = false;
+    // host-slab staging (BV_MEM_HOST)
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    bv_site_result *stage_out = nullptr;
+    bv_group_result *stage_gout = nullptr;
+    bv_site_result *host_out = nullptr;
+    bv_group_result *host_gout = nullptr;
+    size_t host_out_bytes = 0, host_gout_bytes = 0;
+    mutable std::mutex mu;
+    std::string err;
+};
+
+namespace {
+int fail(bv_engine *e, int code, const std::string &msg) {
+    if (e) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        e->err = msg;
+    } else {
+        set_global_error(msg);
+    }
+    return code;
+}
+#define BV_HIP(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t _s = (call);                                                                 \
+        if (_s != hipSuccess)                                                                   \
+            return fail((e), BV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s));    \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+const char *bv_version(void) { return "basevar_amd 0.1 abi1 gfx950"; }
+
+double bv_min_af(uint32_t n_samples, float user_min_af) {
+    // src/basetype_caller.cpp:122: min_af = std::min(float(100)/input_bf.size(), min_af)
+    float a = float(100) / n_samples;
+    float m = (a < user_min_af) ? a : user_min_af;
+    return (double)m;
+}
+
+int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
+    if (!cfg || !out) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_create: null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, BV_ERR_NO_DEVICE, "bv_engine_create: no HIP device visible (the engine has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_create: device ordinal out of range");
+    if (cfg->max_sites == 0) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_create: max_sites == 0");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+        return fail(nullptr, BV_ERR_NO_DEVICE, "bv_engine_create: cannot query device");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, BV_ERR_NO_DEVICE,
+                    std::string("bv_engine_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+
+    bv_engine *e = new bv_engine();
+    e->cfg = *cfg;
+    auto bail = [&](int code) {
+        std::string m = e->err;
+        bv_engine_destroy(e);
+        set_global_error(m);
+        return code;
+    };
+#define BV_TRY(call)                                                                                  \
+    do {                                                                                              \
+        hipError_t _s = (call);                                                                       \
+        if (_s != hipSuccess) {                                                                       \
+            e->err = std::string(#call) + ": " + hipGetErrorString(_s);                               \
+            return bail(BV_ERR_HIP);                                                                  \
+        }                                                                                             \
+    } while (0)
+    BV_TRY(hipSetDevice(cfg->device));
+    BV_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto &ev : e->ev) BV_TRY(hipEventCreate(&ev));
+    BV_TRY(hipMalloc(&e->d_tables, sizeof(BvTables)));
+    BV_TRY(hipMalloc(&e->d_var_list, sizeof(uint32_t) * (size_t)cfg->max_sites));
+    BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * 4));
+    BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * 4));
+    std::memset(e->h_counters, 0, sizeof(uint32_t) * 4);
+
+    // eps table with the host libm, exactly the reference's expression (basetype.cpp:47-48, :63)
+    BvTables t;
+    const double MLN10TO10 = -0.23025850929940458;  // basetype.h:20
+    for (int qv = 0; qv < BV_QBINS; ++qv) {
+        double epsilon = exp((double)qv * MLN10TO10);
+        t.hit[qv] = 1.0 - epsilon;
+        t.miss[qv] = epsilon / 3;
+    }
+    BV_TRY(hipMemcpy(e->d_tables, &t, sizeof(t), hipMemcpyHostToDevice));
+#undef BV_TRY
+    *out = e;
+    return BV_OK;
+}
+
+int bv_engine_destroy(bv_engine *e) {
+    if (!e) return BV_OK;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto &ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->d_tables) (void)hipFree(e->d_tables);
+    if (e->d_var_list) (void)hipFree(e->d_var_list);
+    if (e->d_counters) (void)hipFree(e->d_counters);
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
+    if (e->stage) (void)hipFree(e->stage);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return BV_OK;
+}
+
+int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_group_result *gout, void *stream_) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_submit: null engine");
+    if (!slab || !out) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: null slab/out");
+    if (slab->n_sites == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: n_sites == 0");
+    if (slab->n_sites > e->cfg.max_sites)
+        return fail(e, BV_ERR_TOO_LARGE, "bv_engine_submit: n_sites exceeds cfg.max_sites");
+    if (slab->n_samples == 0 || slab->pitch < slab->n_samples || (slab->pitch & 15ull))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: pitch must be >= n_samples and a multiple of 16");
+    if (!slab->base_strand || !slab->qual || !slab->ref_base)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: base_strand, qual and ref_base planes are required");
+    if ((slab->mapq == nullptr) != (slab->rpr == nullptr))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: mapq and rpr planes must be given together");
+    if (slab->n_groups > BV_MAX_GROUPS)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: n_groups exceeds BV_MAX_GROUPS");
+    if (slab->n_groups > 0 && (!slab->group_id || !gout))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: n_groups > 0 needs group_id and gout");
+    auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
+    if (misaligned(slab->base_strand) || misaligned(slab->qual) || misaligned(slab->mapq) || misaligned(slab->rpr) ||
+        (slab->n_groups && misaligned(slab->group_id)))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: planes must be 16-byte aligned");
+
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    e->last_stream = st;
+
+    const uint8_t *bs = slab->base_strand, *q = slab->qual, *mq = slab->mapq, *refb = slab->ref_base,
+                  *gid = slab->group_id;
+    const uint16_t *rp = slab->rpr;
+    bv_site_result *dout = out;
+    bv_group_result *dgout = gout;
+    const size_t S = slab->n_sites, P = slab->pitch, G = slab->n_groups;
+    if (slab->mem_kind == BV_MEM_HOST) {
+        // stage host planes into one device allocation (grown on demand)
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        size_t o_bs = 0, o_q = o_bs + up(S * P), o_mq = o_q + up(S * P), o_rp = o_mq + (mq ? up(S * P) : 0),
+               o_ref = o_rp + (rp ? up(S * P * 2) : 0), o_gid = o_ref + up(S), o_out = o_gid + (G ? up(P) : 0),
+               o_gout = o_out + up(S * sizeof(bv_site_result)), total = o_gout + up(S * G * sizeof(bv_group_result));
+        if (total > e->stage_bytes) {
+            if (e->stage) BV_HIP(e, hipFree(e->stage));
+            e->stage = nullptr;
+            e->stage_bytes = 0;
+            BV_HIP(e, hipMalloc(&e->stage, total));
+            e->stage_bytes = total;
+        }
+        uint8_t *base = static_cast<uint8_t *>(e->stage);
+        BV_HIP(e, hipMemcpyAsync(base + o_bs, bs, S * P, hipMemcpyHostToDevice, st));
+        BV_HIP(e, hipMemcpyAsync(base + o_q, q, S * P, hipMemcpyHostToDevice, st));
+        if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, st));
+        if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, st));
+        BV_HIP(e, hipMemcpyAsync(base + o_ref, refb, S, hipMemcpyHostToDevice, st));
+        if (G) {
+            BV_HIP(e, hipMemsetAsync(base + o_gid, 0xFF, up(P), st));
+            BV_HIP(e, hipMemcpyAsync(base + o_gid, gid, slab->n_samples, hipMemcpyHostToDevice, st));
+        }
+        bs = base + o_bs; q = base + o_q;
+        mq = mq ? base + o_mq : nullptr;
+        rp = rp ? reinterpret_cast<const uint16_t *>(base + o_rp) : nullptr;
+        refb = base + o_ref;
+        gid = G ? base + o_gid : nullptr;
+        dout = reinterpret_cast<bv_site_result *>(base + o_out);
+        dgout = G ? reinterpret_cast<bv_group_result *>(base + o_gout) : nullptr;
+        e->stage_out = dout; e->stage_gout = dgout;
+        e->host_out = out; e->host_gout = gout;
+        e->host_out_bytes = S * sizeof(bv_site_result);
+        e->host_gout_bytes = S * G * sizeof(bv_group_result);
+    } else {
+        e->host_out = nullptr; e->host_gout = nullptr;
+    }
+
+    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * 4, st));
+    if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
+
+    BvPass1Args a1;
+    a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = slab->n_sites;
+    a1.n_samples = slab->n_samples; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
+    a1.var_list = e->d_var_list; a1.counters = e->d_counters;
+    BV_HIP(e, hipEventRecord(e->ev[0], st));
+    bv_launch_pass1(a1, st);
+    BV_HIP(e, hipGetLastError());
+    BV_HIP(e, hipEventRecord(e->ev[1], st));
+
+    BvPass2Args a2;
+    a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
+    a2.n_sites = slab->n_sites; a2.n_samples = slab->n_samples; a2.n_groups = slab->n_groups;
+    a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
+    a2.var_list = e->d_var_list; a2.counters = e->d_counters;
+    bv_launch_pass2(a2, st);
+    BV_HIP(e, hipGetLastError());
+    BV_HIP(e, hipEventRecord(e->ev[2], st));
+
+    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, st));
+    if (e->host_out) {
+        BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
+        if (e->host_gout && e->host_gout_bytes)
+            BV_HIP(e, hipMemcpyAsync(e->host_gout, e->stage_gout, e->host_gout_bytes, hipMemcpyDeviceToHost, st));
+    }
+    e->submitted = true;
+    return BV_OK;
+}
+
+int bv_engine_wait(bv_engine *e) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_wait: null engine");
+    if (!e->submitted) return BV_OK;
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    BV_HIP(e, hipStreamSynchronize(e->last_stream));
+    if (e->h_counters[1] > 0) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf,
+                      "The sum of frequence of active bases must always > 0 (%u site(s); see BV_SITE_ZERO_FREQ)",
+                      e->h_counters[1]);
+        return fail(e, BV_ERR_SITE, buf);  // message of src/basetype.cpp:114
+    }
+    return BV_OK;
+}
+
+int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms) {
+    if (!e || !e->submitted) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_kernel_ms: nothing submitted");
+    float a = 0.f, b = 0.f;
+    BV_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
+    BV_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    if (pass1_ms) *pass1_ms = a;
+    if (pass2_ms) *pass2_ms = b;
+    return BV_OK;
+}
+
+int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant) {
+    if (!e || !n_variant) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_last_variant_count: null argument");
+    *n_variant = e->h_counters[0];
+    return BV_OK;
+}
+
+const char *bv_last_error(const bv_engine *e) {
+    static thread_local std::string copy;
+    if (e) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        copy = e->err;
+    } else {
+        std::lock_guard<std::mutex> lk(g_err_mu);
+        copy = g_err;
+    }
+    return copy.c_str();
+}
+
+int bv_synth_fill(int device, const bv_synth_params *p, uint32_t n_sites, uint32_t n_samples, uint64_t pitch,
+                  uint8_t *base_strand, uint8_t *qual, uint8_t *mapq, uint16_t *rpr, uint8_t *ref_base, void *stream) {
+    if (!p || !base_strand || !qual || !ref_base || n_sites == 0 || n_samples == 0 || pitch < n_samples || (pitch & 15ull))
+        return fail(nullptr, BV_ERR_INVALID_ARG, "bv_synth_fill: bad argument");
+    BV_HIP(nullptr, hipSetDevice(device));
+    bv_launch_synth(*p, n_sites, n_samples, pitch, base_strand, qual, mapq, rpr, ref_base, (hipStream_t)stream);
+    BV_HIP(nullptr, hipGetLastError());
+    return BV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,43 @@
+// bv_kernels.h -- launch-argument blocks shared by the kernels (bv_pass1.hip, bv_pass2.hip)
+// and the engine (bv_engine.hip).
+#pragma once
+
+#include "bv_device.h"
+
+struct BvPass1Args {
+    const uint8_t *bs;        // [n_sites][pitch]
+    const uint8_t *q;         // [n_sites][pitch]
+    const uint8_t *ref_base;  // [n_sites]
+    uint64_t pitch;
+    uint32_t n_sites;
+    uint32_t n_samples;
+    double min_af;
+    const BvTables *tables;
+    bv_site_result *out;      // [n_sites]
+    uint32_t *var_list;       // [n_sites]  indices of BV_SITE_VARIANT sites (unordered)
+    uint32_t *counters;       // [0] = number of variant sites, [1] = sites with BV_SITE_ZERO_FREQ
+};
+
+struct BvPass2Args {
+    const uint8_t *bs;
+    const uint8_t *q;         // needed only when n_groups > 0
+    const uint8_t *mapq;      // may be NULL together with rpr: rank sums skipped
+    const uint16_t *rpr;
+    const uint8_t *ref_base;
+    const uint8_t *group_id;  // [n_samples] or NULL
+    uint64_t pitch;
+    uint32_t n_sites;
+    uint32_t n_samples;
+    uint32_t n_groups;
+    double min_af;
+    const BvTables *tables;
+    bv_site_result *out;
+    bv_group_result *gout;    // [n_sites][n_groups] or NULL
+    const uint32_t *var_list;
+    const uint32_t *counters;
+};
+
+// host-callable launchers (defined next to the kernels)
+void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);
+void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream);
+size_t bv_pass2_lds_bytes(uint32_t n_groups);

@@ -1,0 +1,169 @@
+"""Host-side mirror of the reference's per-site interface, batched.
+
+The reference calls, once per genomic site (src/basetype_caller.cpp:742-743, 1113-1164):
+
+    BaseType bt(&batchinfo, min_af);  bt.lrt();
+    bt.get_alt_bases(); bt.get_lrt_af(b); bt.get_var_qual(); bt.get_total_depth(); bt.get_base_depth(b)
+    strand_bias(ref, alts, bases, strands);  ref_vs_alt_ranksumtest(ref, alts, bases, values)
+
+``BaseTypeEngine.lrt(slab)`` does all of that for every site (row) of a slab in one submit
+through the C ABI (include/basevar_amd.h) and returns ``BaseTypeBatch``, whose getters carry
+the reference's names and take the site index as first argument.  Errors the reference
+raises as std::runtime_error surface as RuntimeError with the same message.
+
+torch is used only for device memory and streams; it never appears in the ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+BASES = "ACGT"  # src/basetype.h:19
+
+
+def min_af(n_samples, user_min_af=0.01):
+    """(double)std::min(float(100)/n, min_af): src/basetype_caller.cpp:122."""
+    return _capi.load().bv_min_af(int(n_samples), float(user_min_af))
+
+
+class BaseTypeBatch:
+    """Per-site records of one submit (numpy structured arrays on the host)."""
+
+    def __init__(self, sites, groups, n_variant, pass1_ms, pass2_ms):
+        self.sites = sites
+        self.groups = groups
+        self.n_variant = n_variant
+        self.pass1_ms = pass1_ms
+        self.pass2_ms = pass2_ms
+
+    # --- BaseType getters, src/basetype.h:121-151
+    def get_alt_bases(self, i):
+        r = self.sites[i]
+        return [BASES[b] for b in r["alt"][:r["n_alt"]]]
+
+    def get_lrt_af(self, i, b):
+        r = self.sites[i]
+        alts = [BASES[x] for x in r["alt"][:r["n_alt"]]]
+        if b not in alts:  # std::map::at -> out_of_range -> runtime_error, basetype.h:141-149
+            raise RuntimeError("[ERROR] out_of_range:: map::at '%s' not found." % b)
+        return float(r["af"][alts.index(b)])
+
+    def get_var_qual(self, i):
+        return float(self.sites[i]["qual"])
+
+    def get_total_depth(self, i):
+        return int(self.sites[i]["total_depth"])
+
+    def get_base_depth(self, i, b):
+        if b not in BASES:
+            raise RuntimeError("[ERROR] out_of_range:: map::at '%s' not found." % b)
+        return float(self.sites[i]["depth"][BASES.index(b)])
+
+    # --- StrandBiasInfo of the two strand_bias() calls, src/basetype.h:57-62
+    def strand_bias(self, i, flavour="vcf"):
+        r = self.sites[i]
+        k = "var" if flavour == "vcf" else "cvg"
+        sb = r[k + "_sb"]
+        return {"ref_fwd": int(sb[0]), "ref_rev": int(sb[1]), "alt_fwd": int(sb[2]), "alt_rev": int(sb[3]),
+                "fs": float(r[k + "_fs"]), "sor": float(r[k + "_sor"])}
+
+    # --- the three ref_vs_alt_ranksumtest() values; the reference truncates them to int
+    def rank_sums(self, i):
+        r = self.sites[i]
+        return float(r["mq_ranksum"]), float(r["rpr_ranksum"]), float(r["bq_ranksum"])
+
+
+class BaseTypeEngine:
+    """One engine per GPU / host thread (mirrors one BaseType per ThreadPool worker)."""
+
+    def __init__(self, max_sites, min_af_value, device=0):
+        self._lib = _capi.load()
+        cfg = _capi.EngineConfig(int(device), int(max_sites), 0, 0, float(min_af_value))
+        h = C.c_void_p()
+        rc = self._lib.bv_engine_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError("bv_engine_create failed (%d): %s" % (rc, self._lib.bv_last_error(None).decode()))
+        self._h = h
+        self.device = int(device)
+        self.max_sites = int(max_sites)
+        self.min_af = float(min_af_value)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bv_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return self._lib.bv_last_error(self._h).decode()
+
+    # ---- raw pointer interface (device or host pointers as ints)
+    def submit_ptrs(self, n_sites, n_samples, pitch, base_strand, qual, ref_base, out, mapq=0, rpr=0, group_id=0,
+                    n_groups=0, gout=0, mem_kind=_capi.BV_MEM_DEVICE, stream=0):
+        slab = _capi.Slab(int(n_sites), int(n_samples), int(pitch), base_strand or None, qual or None, mapq or None,
+                          rpr or None, ref_base or None, group_id or None, int(n_groups), int(mem_kind))
+        rc = self._lib.bv_engine_submit(self._h, C.byref(slab), out or None, gout or None, stream or None)
+        if rc != 0:
+            raise RuntimeError("bv_engine_submit failed (%d): %s" % (rc, self._err()))
+
+    def wait(self):
+        rc = self._lib.bv_engine_wait(self._h)
+        if rc == _capi.BV_ERR_SITE:
+            raise RuntimeError(self._err())  # the reference's runtime_error text, basetype.cpp:114
+        if rc != 0:
+            raise RuntimeError("bv_engine_wait failed (%d): %s" % (rc, self._err()))
+
+    def kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        rc = self._lib.bv_engine_kernel_ms(self._h, C.byref(a), C.byref(b))
+        if rc != 0:
+            raise RuntimeError("bv_engine_kernel_ms failed (%d): %s" % (rc, self._err()))
+        return a.value, b.value
+
+    def last_variant_count(self):
+        n = C.c_uint32()
+        self._lib.bv_engine_last_variant_count(self._h, C.byref(n))
+        return n.value
+
+    # ---- numpy slab (host memory; the engine stages it to HBM)
+    def lrt(self, slab):
+        """slab: dict of numpy planes as produced by basevar_amd.synth.make_slab()."""
+        bs = np.ascontiguousarray(slab["base_strand"], dtype=np.uint8)
+        S, pitch = bs.shape
+        N = int(slab.get("n_samples", pitch))
+        q = np.ascontiguousarray(slab["qual"], dtype=np.uint8)
+        mq = slab.get("mapq")
+        rp = slab.get("rpr")
+        mq = None if mq is None else np.ascontiguousarray(mq, dtype=np.uint8)
+        rp = None if rp is None else np.ascontiguousarray(rp, dtype=np.uint16)
+        ref = np.ascontiguousarray(slab["ref_base"], dtype=np.uint8)
+        gid = slab.get("group_id")
+        ng = int(slab.get("n_groups", 0)) if gid is not None else 0
+        gid = None if gid is None else np.ascontiguousarray(gid, dtype=np.uint8)
+        out = np.zeros(S, dtype=_capi.SITE_DTYPE)
+        gout = np.zeros((S, ng), dtype=_capi.GROUP_DTYPE) if ng else None
+        p = lambda a: 0 if a is None else a.ctypes.data
+        self.submit_ptrs(S, N, pitch, p(bs), p(q), p(ref), p(out), p(mq), p(rp), p(gid), ng, p(gout),
+                         mem_kind=_capi.BV_MEM_HOST)
+        self.wait()
+        ms1, ms2 = self.kernel_ms()
+        return BaseTypeBatch(out, gout, self.last_variant_count(), ms1, ms2)
+
+
+def synth_fill(device, n_sites, n_samples, pitch, base_strand, qual, ref_base, mapq=0, rpr=0, seed=0xBA5E7A7,
+               site_offset=0, coverage=0.08, indel_frac=0.005, qual_mean=32.0, qual_sd=6.0, qual_min=2, qual_max=41,
+               stream=0):
+    """Device-side synthetic pileup (bench helper): all pointers are device pointers (ints)."""
+    lib = _capi.load()
+    sp = _capi.SynthParams(int(seed), int(site_offset), float(coverage), float(indel_frac), float(qual_mean),
+                           float(qual_sd), int(qual_min), int(qual_max))
+    rc = lib.bv_synth_fill(int(device), C.byref(sp), int(n_sites), int(n_samples), int(pitch), base_strand, qual,
+                           mapq or None, rpr or None, ref_base, stream or None)
+    if rc != 0:
+        raise RuntimeError("bv_synth_fill failed (%d): %s" % (rc, lib.bv_last_error(None).decode()))

@@ -4,7 +4,7 @@ Used by the parity tests to build seeded inputs; the throughput bench uses the
 device-side generator ``bv_synth_fill`` (csrc/bv_synth.hip), which draws from the same
 distributions with a counter-based RNG.
 
-Cell encoding: see include/basevar_amd.h (bits 0-2 base code, bit 3 reverse strand).
+Cell encoding: see include/basevar_amd.h (bits 0-1 base, bit 2 reverse strand, bit 3 no-call).
 """
 import numpy as np
 
@@ -42,13 +42,12 @@ def make_slab(n_sites, n_samples, seed=0, coverage=0.08, indel_frac=0.005, qual_
     covered = rng.random((S, N)) < coverage
     indel = covered & (rng.random((S, N)) < indel_frac)
     strand = rng.integers(0, 2, size=(S, N), dtype=np.uint8)
-    code = np.where(covered, base, 4).astype(np.uint8)
-    code = np.where(indel, 5 + rng.integers(0, 2, size=(S, N), dtype=np.uint8), code).astype(np.uint8)
-    bs = np.where(code != 4, code | (strand << 3), code).astype(np.uint8)
+    code = np.where(covered, base | (strand << 2), 8).astype(np.uint8)
+    bs = np.where(indel, 9 + rng.integers(0, 2, size=(S, N), dtype=np.uint8), code).astype(np.uint8)
     mapq = np.where(rng.random((S, N)) < 0.8, 60, rng.integers(10, 60, size=(S, N))).astype(np.uint8)
     rpr = rng.integers(1, 101, size=(S, N)).astype(np.uint16)
     # uncovered cells carry the batchfile's placeholders: qual '!' (0), mapq 0, rank 0, strand '.'
-    unc = code == 4
+    unc = bs == 8
     q = np.where(unc, 0, q).astype(np.uint8)
     mapq = np.where(unc, 0, mapq).astype(np.uint8)
     rpr = np.where(unc, 0, rpr).astype(np.uint16)

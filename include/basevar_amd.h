@@ -31,27 +31,34 @@ extern "C" {
 #define BV_ABI_VERSION 1
 
 /* ---- cell encoding of the `base_strand` plane ---------------------------------
- * bits 0-2: first character of the reference's per-sample token
- *           (src/basetype.cpp:50; domain per src/basetype_caller.cpp:1060-1077)
- *             0 'A'  1 'C'  2 'G'  3 'T'   (index in BASES, src/basetype.h:19)
- *             4 'N'  (uncovered)   5 '+' (insertion token)  6 '-' (deletion token)
- * bit 3   : 1 = reverse strand '-', 0 = forward '+' (src/basetype.cpp:257-264);
- *           ignored for codes >= 4 (reference strand '.' there).
- * bits 4-7: must be zero.
+ * One byte per (site, sample): the first character of the reference's per-sample token
+ * (src/basetype.cpp:50; domain per src/basetype_caller.cpp:1060-1077) plus the strand
+ * (src/basetype.cpp:257-264).
+ *   bits 0-1: base call  0 'A'  1 'C'  2 'G'  3 'T'   (index in BASES, src/basetype.h:19)
+ *   bit 2   : 1 = reverse strand '-', 0 = forward '+'
+ *   bit 3   : 1 = not a base call; then bits 0-1 select  0 'N' (uncovered, strand '.')
+ *             1 '+' (insertion token)  2 '-' (deletion token); bit 2 is ignored
+ *   bits 4-7: must be zero.
+ * A covered base call is therefore a value 0..7 that directly indexes the kernel's
+ * (strand, base) histogram row; every other value is skipped with one bit test.
  */
+#define BV_CELL_BASE_MASK 0x03u
+#define BV_CELL_REV 0x04u
+#define BV_CELL_NOCALL 0x08u
+#define BV_CELL_N 0x08u
+#define BV_CELL_INS 0x09u
+#define BV_CELL_DEL 0x0Au
+/* codes used by bv_slab.ref_base[] and bv_site_result.alt[] */
 #define BV_BASE_A 0u
 #define BV_BASE_C 1u
 #define BV_BASE_G 2u
 #define BV_BASE_T 3u
-#define BV_BASE_N 4u
-#define BV_BASE_INS 5u
-#define BV_BASE_DEL 6u
-#define BV_STRAND_REV 8u
+#define BV_BASE_OTHER 4u
 
 /* qual plane: phred value = (reference quality char) - 33, src/basetype.cpp:47.
  * Valid domain 0..93 (chars '!'..'~').  Larger values set BV_SITE_BAD_QUAL. */
 #define BV_MAX_PHRED 93u
-#define BV_MAX_ALT 3
+#define BV_MAX_ALT 4 /* ref not in ACGT + four active bases (basetype.cpp:172-177) */
 #define BV_NO_GROUP 0xFFu
 #define BV_MAX_GROUPS 32u
 
@@ -87,13 +94,13 @@ typedef struct bv_slab {
     const uint8_t *qual;         /* [n_sites][pitch]  align_base_quals - 33           */
     const uint8_t *mapq;         /* [n_sites][pitch]  mapqs; may be NULL              */
     const uint16_t *rpr;         /* [n_sites][pitch]  base_pos_ranks; may be NULL     */
-    const uint8_t *ref_base;     /* [n_sites] toupper(ref_base[0]) as BV_BASE_*; 4 = not ACGT */
+    const uint8_t *ref_base;     /* [n_sites] toupper(ref_base[0]) as BV_BASE_*; 4 = not ACGT  */
     const uint8_t *group_id;     /* [n_samples] pop-group index or BV_NO_GROUP; may be NULL   */
     uint32_t n_groups;           /* 0 if no groups (caller.cpp:746)                   */
     uint32_t mem_kind;           /* bv_mem_kind                                       */
 } bv_slab;
 
-/* Output: one fixed-size record per site (192 bytes).
+/* Output: one fixed-size record per site (208 bytes).
  * Replaces the BaseType getters (src/basetype.h:121-151), StrandBiasInfo
  * (src/basetype.h:57-62) and the INFO arithmetic of _out_vcf_line
  * (src/basetype_caller.cpp:1113-1164). */
@@ -107,8 +114,8 @@ typedef struct bv_site_result {
     double cvg_sor;       /* StrandBiasInfo.sor of that call, basetype.cpp:286           */
     uint8_t n_alt;        /* get_alt_bases().size(), basetype.cpp:172-177                */
     uint8_t alt[BV_MAX_ALT]; /* alt base codes in reference order                        */
+    uint8_t n_em;         /* diagnostic: number of EM runs (<= 10)                       */
     uint16_t em_iters;    /* diagnostic: EM loop iterations summed over all EM runs      */
-    uint16_t n_em;        /* diagnostic: number of EM runs (<= 10)                       */
     double af[BV_MAX_ALT];  /* get_lrt_af(alt[i]), basetype.cpp:175 (CM_AF)              */
     double caf[BV_MAX_ALT]; /* depth[alt]/total_depth, caller.cpp:1122 (CM_CAF)          */
     double qual;          /* get_var_qual(), basetype.cpp:180-196                        */
@@ -122,13 +129,15 @@ typedef struct bv_site_result {
     double bq_ranksum;    /* ... (align_base_quals), caller.cpp:1157                     */
 } bv_site_result;
 
-/* Per (site, group) record (32 bytes), valid for BV_SITE_VARIANT sites only.
+/* Per (site, group) record (48 bytes), valid for BV_SITE_VARIANT sites only.
  * Replaces __gb()/lrt([REF]+alts) (src/basetype_caller.cpp:756-777) and the
  * "<group>_AF=" INFO values (caller.cpp:1182-1196). */
 typedef struct bv_group_result {
     uint8_t n_alt;
     uint8_t alt[BV_MAX_ALT];
-    uint32_t total_depth;
+    uint8_t reserved[3];
+    uint32_t total_depth; /* ACGT depth of the group's samples                           */
+    uint32_t reserved2;
     double af[BV_MAX_ALT];
 } bv_group_result;
 

@@ -22,8 +22,8 @@ class SiteResult(C.Structure):
     _fields_ = [
         ("depth", C.c_uint32 * 4), ("total_depth", C.c_uint32), ("status", C.c_uint32),
         ("cvg_sb", C.c_uint32 * 4), ("cvg_fs", C.c_double), ("cvg_sor", C.c_double),
-        ("n_alt", C.c_uint8), ("alt", C.c_uint8 * 3), ("em_iters", C.c_uint16), ("n_em", C.c_uint16),
-        ("af", C.c_double * 3), ("caf", C.c_double * 3), ("qual", C.c_double), ("chi2", C.c_double),
+        ("n_alt", C.c_uint8), ("alt", C.c_uint8 * 4), ("n_em", C.c_uint8), ("em_iters", C.c_uint16),
+        ("af", C.c_double * 4), ("caf", C.c_double * 4), ("qual", C.c_double), ("chi2", C.c_double),
         ("qd", C.c_double), ("var_sb", C.c_uint32 * 4), ("var_fs", C.c_double), ("var_sor", C.c_double),
         ("mq_ranksum", C.c_double), ("rpr_ranksum", C.c_double), ("bq_ranksum", C.c_double),
     ]
@@ -32,14 +32,15 @@ class SiteResult(C.Structure):
 SITE_DTYPE = np.dtype([
     ("depth", "<u4", 4), ("total_depth", "<u4"), ("status", "<u4"),
     ("cvg_sb", "<u4", 4), ("cvg_fs", "<f8"), ("cvg_sor", "<f8"),
-    ("n_alt", "u1"), ("alt", "u1", 3), ("em_iters", "<u2"), ("n_em", "<u2"),
-    ("af", "<f8", 3), ("caf", "<f8", 3), ("qual", "<f8"), ("chi2", "<f8"), ("qd", "<f8"),
+    ("n_alt", "u1"), ("alt", "u1", 4), ("n_em", "u1"), ("em_iters", "<u2"),
+    ("af", "<f8", 4), ("caf", "<f8", 4), ("qual", "<f8"), ("chi2", "<f8"), ("qd", "<f8"),
     ("var_sb", "<u4", 4), ("var_fs", "<f8"), ("var_sor", "<f8"),
     ("mq_ranksum", "<f8"), ("rpr_ranksum", "<f8"), ("bq_ranksum", "<f8"),
 ])
-GROUP_DTYPE = np.dtype([("n_alt", "u1"), ("alt", "u1", 3), ("total_depth", "<u4"), ("af", "<f8", 3)])
-assert SITE_DTYPE.itemsize == 192 and C.sizeof(SiteResult) == 192
-assert GROUP_DTYPE.itemsize == 32
+GROUP_DTYPE = np.dtype([("n_alt", "u1"), ("alt", "u1", 4), ("reserved", "u1", 3), ("total_depth", "<u4"),
+                        ("reserved2", "<u4"), ("af", "<f8", 4)])
+assert SITE_DTYPE.itemsize == 208 and C.sizeof(SiteResult) == 208
+assert GROUP_DTYPE.itemsize == 48
 
 
 def build(with_ref=True):

@@ -39,7 +39,8 @@ double wilcoxon_ranksum_test(const std::vector<double> &, const std::vector<doub
 
 namespace {
 
-const char CODE2CHAR[8] = {'A', 'C', 'G', 'T', 'N', '+', '-', 'N'};
+const char BASE2CHAR[8] = {'A', 'C', 'G', 'T', 'N', 'N', 'N', 'N'};   // bv_slab.ref_base codes
+const char NOCALL2CHAR[4] = {'N', '+', '-', 'N'};                     // cell bits 0-1 when bit 3 set
 
 inline int base_index(char b) {
     switch (b) {
@@ -56,7 +57,7 @@ void fill_batchinfo(BatchInfo &bi, const uint8_t *bs, const uint8_t *q, const ui
     bi.n = n;
     bi.ref_id = "chrS";
     bi.ref_pos = 1;
-    bi.ref_base = std::string(1, CODE2CHAR[ref_code & 7]);
+    bi.ref_base = std::string(1, BASE2CHAR[ref_code & 7]);
     bi.depth = 0;
     bi.align_bases.resize(n);
     bi.align_base_quals.resize(n);
@@ -64,9 +65,9 @@ void fill_batchinfo(BatchInfo &bi, const uint8_t *bs, const uint8_t *q, const ui
     bi.map_strands.resize(n);
     bi.base_pos_ranks.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
-        unsigned code = bs[i] & 7u;
-        char c = CODE2CHAR[code];
-        if (code == BV_BASE_INS || code == BV_BASE_DEL) {
+        bool nocall = (bs[i] & BV_CELL_NOCALL) != 0;
+        char c = nocall ? NOCALL2CHAR[bs[i] & 3u] : BASE2CHAR[bs[i] & 3u];
+        if (c == '+' || c == '-') {
             bi.align_bases[i] = std::string(1, c) + "A";  // indel token, e.g. "+A"
         } else {
             bi.align_bases[i] = std::string(1, c);
@@ -74,10 +75,10 @@ void fill_batchinfo(BatchInfo &bi, const uint8_t *bs, const uint8_t *q, const ui
         bi.align_base_quals[i] = (char)(q[i] + 33);
         bi.mapqs[i] = mq ? mq[i] : 0;
         bi.base_pos_ranks[i] = rp ? rp[i] : 0;
-        if (code == BV_BASE_N) {
+        if (c == 'N') {
             bi.map_strands[i] = '.';
         } else {
-            bi.map_strands[i] = (bs[i] & BV_STRAND_REV) ? '-' : '+';
+            bi.map_strands[i] = (bs[i] & BV_CELL_REV) ? '-' : '+';
             bi.depth++;
         }
     }
@@ -100,15 +101,18 @@ void run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint
     for (uint32_t i = 0; i < n; ++i) align_bases[i] = bi.align_bases[i][0];
     char upper_ref = toupper(bi.ref_base[0]);
 
-    // ---- _out_cvg_line: caller.cpp:1236-1245
+    // ---- _out_cvg_line: caller.cpp:1236-1245.  The CVG row (and with it fs/sor) is only
+    // written when the ACGT depth is > 0 (caller.cpp:1246); otherwise the record stays zero.
     {
         std::string alts;
         for (char b : std::string("ACGT"))
             if (b != upper_ref) alts.push_back(b);
         StrandBiasInfo s = strand_bias(upper_ref, alts, align_bases, bi.map_strands);
-        r->cvg_sb[0] = s.ref_fwd; r->cvg_sb[1] = s.ref_rev;
-        r->cvg_sb[2] = s.alt_fwd; r->cvg_sb[3] = s.alt_rev;
-        r->cvg_fs = s.fs; r->cvg_sor = s.sor;
+        if (s.ref_fwd + s.ref_rev + s.alt_fwd + s.alt_rev > 0) {
+            r->cvg_sb[0] = s.ref_fwd; r->cvg_sb[1] = s.ref_rev;
+            r->cvg_sb[2] = s.alt_fwd; r->cvg_sb[3] = s.alt_rev;
+            r->cvg_fs = s.fs; r->cvg_sor = s.sor;
+        }
     }
 
     // ---- caller.cpp:742-743

@@ -326,8 +326,8 @@ static void o_bt_init(o_bt *bt, const uint8_t *bs, const uint8_t *q, uint32_t n,
     for (uint32_t k = 0; k < cnt; ++k) {
         uint32_t i = idx ? idx[k] : k;
         double epsilon = exp((double)q[i] * MLN10TO10); /* (qual_char - 33) * MLN10TO10, :47 */
-        unsigned fb = bs[i] & 7u;
-        if (fb < 4) { /* not 'N', '+', '-' : basetype.cpp:51 */
+        unsigned fb = bs[i] & 3u;
+        if (!(bs[i] & BV_CELL_NOCALL)) { /* not 'N', '+', '-' : basetype.cpp:51 */
             bt->depth[fb]++;
             bt->total_depth++;
             for (unsigned j = 0; j < 4; ++j) bt->w.lh[rows][j] = (fb == j) ? 1.0 - epsilon : epsilon / 3;
@@ -451,10 +451,10 @@ static void o_strand_bias(int ref_code, unsigned alt_mask, const uint8_t *bs, ui
                           double *fs_out, double *sor_out) {
     int ref_fwd = 0, ref_rev = 0, alt_fwd = 0, alt_rev = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        unsigned b = bs[i] & 7u;
-        if (b >= 4) continue;
+        unsigned b = bs[i] & 3u;
+        if (bs[i] & BV_CELL_NOCALL) continue;
         int is_ref = ((int)b == ref_code), is_alt = (alt_mask >> b) & 1u;
-        if (!(bs[i] & BV_STRAND_REV)) {
+        if (!(bs[i] & BV_CELL_REV)) {
             if (is_ref) ++ref_fwd; else if (is_alt) ++alt_fwd;
         } else {
             if (is_ref) ++ref_rev; else if (is_alt) ++alt_rev;
@@ -477,8 +477,8 @@ static double o_ranksum(int ref_code, unsigned alt_mask, const uint8_t *bs, uint
     double *alt = (double *)malloc(sizeof(double) * (n ? n : 1));
     size_t nr = 0, na = 0;
     for (uint32_t i = 0; i < n; ++i) {
-        unsigned b = bs[i] & 7u;
-        if (b >= 4) continue;
+        unsigned b = bs[i] & 3u;
+        if (bs[i] & BV_CELL_NOCALL) continue;
         double v = v8 ? (double)v8[i] : (double)v16[i];
         if ((int)b == ref_code) ref[nr++] = v;
         else if ((alt_mask >> b) & 1u) alt[na++] = v;
@@ -505,12 +505,16 @@ static void o_run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, c
     r->mq_ranksum = r->rpr_ranksum = r->bq_ranksum = NAN;
     if (g) memset(g, 0, sizeof(*g) * n_groups);
     uint32_t depth_all = 0;
-    for (uint32_t i = 0; i < n; ++i) depth_all += ((bs[i] & 7u) != BV_BASE_N);
+    for (uint32_t i = 0; i < n; ++i) depth_all += (bs[i] != BV_CELL_N);
     if (depth_all == 0) return; /* caller.cpp:718 */
 
     int ref = (ref_code < 4) ? (int)ref_code : 4;
     unsigned nonref_mask = 0xFu & ~((ref < 4) ? (1u << ref) : 0u);
     o_strand_bias(ref, nonref_mask, bs, n, r->cvg_sb, &r->cvg_fs, &r->cvg_sor);
+    if (r->cvg_sb[0] + r->cvg_sb[1] + r->cvg_sb[2] + r->cvg_sb[3] == 0) { /* no CVG row: caller.cpp:1246 */
+        r->cvg_fs = 0;
+        r->cvg_sor = 0;
+    }
 
     o_bt bt;
     o_bt_init(&bt, bs, q, n, NULL, 0, min_af);
@@ -521,10 +525,10 @@ static void o_run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, c
     if (bt.total_depth > 0) r->status |= BV_SITE_COVERED;
     if (bt.zero_freq) r->status |= BV_SITE_ZERO_FREQ;
     r->em_iters = (uint16_t)bt.em_iters;
-    r->n_em = (uint16_t)bt.n_em;
+    r->n_em = (uint8_t)bt.n_em;
     r->chi2 = bt.chi2;
     for (uint32_t i = 0; i < n; ++i)
-        if ((bs[i] & 7u) < 4 && q[i] > BV_MAX_PHRED) r->status |= BV_SITE_BAD_QUAL;
+        if (!(bs[i] & BV_CELL_NOCALL) && q[i] > BV_MAX_PHRED) r->status |= BV_SITE_BAD_QUAL;
 
     if (bt.n_alt > 0) {
         r->status |= BV_SITE_VARIANT;

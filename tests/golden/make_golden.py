@@ -1,0 +1,126 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ from the REAL reference.
+
+Run in the build container (where /root/reference exists):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+Each fixture is data only: the seeded input planes and the per-site records that the
+reference's own code (compiled unmodified into oracle/_ref/libbvref.so, see oracle/Makefile
+and oracle/ref_driver.cpp) produced for them.  The reference has no golden outputs of its
+own for this path (tests/io/test_algorithm.cpp:41: "how to test EM?"); its test *inputs*
+(test_algorithm.cpp:13-31) are evaluated here too and stored in known_answers.json.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from basevar_amd.synth import make_slab  # noqa: E402
+
+A, Cc, G, T, N, INS, DEL, REV = 0, 1, 2, 3, 8, 9, 10, 4
+
+
+def edge_slab():
+    """Hand-built sites: the reference's observable corner cases."""
+    n = 16
+    sites = []
+
+    def site(ref, cells):
+        bs = np.full(n, N, np.uint8); q = np.zeros(n, np.uint8); mq = np.zeros(n, np.uint8); rp = np.zeros(n, np.uint16)
+        for i, c in enumerate(cells):
+            b, ph = c[0], c[1]
+            rev = c[2] if len(c) > 2 else 0
+            bs[i] = b | (REV if (rev and b < 8) else 0)
+            q[i] = ph
+            mq[i] = c[3] if len(c) > 3 else (60 if b != N else 0)
+            rp[i] = c[4] if len(c) > 4 else (i + 1 if b != N else 0)
+        sites.append((ref, bs, q, mq, rp))
+
+    site(G, [(Cc, 30), (T, 30)])                       # exact tie: only C reported, AF 1
+    site(G, [(T, 30), (Cc, 30)])                       # same with the order swapped
+    site(G, [(A, 30), (Cc, 30), (T, 30)])              # three-way tie
+    site(A, [(A, 30), (A, 30), (G, 30), (G, 35)])      # ref given as 'a' upstream -> toupper
+    site(A, [(G, 30)] * 11)                            # mono-allelic, depth 11 -> QUAL 5000
+    site(A, [(G, 30)] * 10)                            # depth 10 -> QUAL 0
+    site(4, [(A, 30), (A, 30)])                        # ref 'N'
+    site(Cc, [(INS, 20), (N, 0), (DEL, 25)])           # only indel / N tokens: depth 0, no call
+    site(T, [])                                        # nothing covered at all
+    # strand-bias / rank-sum example of SURVEY 8a: ref A; bases A A G N G A + C A G
+    bases = [A, A, G, N, G, A, INS, Cc, A, G]
+    strands = [0, 1, 0, 0, 1, 1, 0, 0, 0, 0]
+    mapq = [60, 50, 60, 0, 30, 60, 60, 20, 60, 40]
+    rank = [5, 10, 5, 0, 30, 12, 7, 7, 20, 1]
+    bq = [ord(c) - 33 for c in "I5I!?II+I5"]
+    site(A, [(b, bq[i], strands[i], mapq[i], rank[i]) for i, b in enumerate(bases)])
+    site(A, [(A, 40)] * 8 + [(G, 40, 1)] * 8)          # every cell covered, perfectly strand-biased ALT
+    site(Cc, [(A, 2), (Cc, 2), (G, 2), (T, 2)] * 4)    # phred 2 everywhere: all four bases active
+    site(G, [(G, 93)] * 3 + [(T, 93)] * 2)             # maximum phred
+    site(T, [(T, 35, 0, 60, 300), (T, 35, 1, 60, 2000), (A, 35, 0, 20, 1500), (A, 30, 1, 10, 65535)])  # long reads
+    site(A, [(A, 0)])                                  # phred 0, reference base only
+    site(Cc, [(A, 0)])                                 # phred 0 ALT: the reference reports AF = NaN
+    site(A, [(A, 30)] * 15 + [(Cc, 10)])               # weak alt below the LRT threshold
+    S = len(sites)
+    slab = {
+        "n_sites": S, "n_samples": n, "pitch": n, "n_groups": 2,
+        "base_strand": np.stack([s[1] for s in sites]), "qual": np.stack([s[2] for s in sites]),
+        "mapq": np.stack([s[3] for s in sites]), "rpr": np.stack([s[4] for s in sites]),
+        "ref_base": np.array([s[0] for s in sites], np.uint8),
+        "group_id": np.array([0, 0, 0, 0, 1, 1, 1, 1, 0, 1, 0, 1, 0xFF, 0xFF, 0, 1], np.uint8),
+    }
+    return slab
+
+
+FIXTURES = {
+    # name: (slab factory, user min_af)
+    "edge16": (edge_slab, 0.01),
+    "dense_64x500": (lambda: make_slab(64, 500, seed=11, coverage=0.6, n_groups=2, ref_n_frac=0.05), 0.01),
+    "nipt_96x4000": (lambda: make_slab(96, 4000, seed=12, coverage=0.08, n_groups=2), 0.01),
+    "ragged_40x1003": (lambda: make_slab(40, 1003, seed=13, coverage=0.25, n_groups=3, pitch=1008), 0.01),
+    "lowq_48x800": (lambda: make_slab(48, 800, seed=14, coverage=0.4, qual_mean=12.0, qual_sd=8.0, qual_min=1,
+                                      qual_max=60), 0.01),
+}
+
+
+def main():
+    ref = oracle.Reference()
+    res = oracle.Restatement()
+    for name, (factory, user_af) in FIXTURES.items():
+        slab = factory()
+        maf = res.min_af(slab["n_samples"], user_af)
+        sites, groups = ref.run(slab, maf)
+        out = {k: v for k, v in slab.items() if isinstance(v, np.ndarray)}
+        out["n_samples"] = np.int64(slab["n_samples"])
+        out["n_groups"] = np.int64(slab.get("n_groups", 0))
+        out["min_af"] = np.float64(maf)
+        out["expected_sites"] = sites.view(np.uint8)
+        if groups is not None:
+            out["expected_groups"] = groups.view(np.uint8).reshape(groups.shape[0], -1)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print("%-16s sites=%d variants=%d -> %s (%d bytes)" % (
+            name, len(sites), int(((sites["status"] & 2) != 0).sum()), os.path.basename(path), os.path.getsize(path)))
+
+    ka = {
+        "source": "reference functions of src/algorithm.h called through oracle/_ref (inputs: tests/io/test_algorithm.cpp:13-31 and SURVEY.md section 4)",
+        "chi2_test": [[x, 1.0, ref.chi2_test(x, 1.0)] for x in (24.0, 0.0, 3.84, 1500.0, -0.1, 1.0, 30.5, 100.0)],
+        "norm_dist": [[x, ref.norm_dist(x)] for x in (1.96, 0.0, 0.5, 5.0, 40.0)],
+        "fisher_exact_test": [[list(t), ref.fisher(*t)] for t in
+                              [(345, 455, 260, 345), (8, 4, 4, 9), (10, 5, 4, 9), (3, 4, 4, 5), (1, 1, 1, 1),
+                               (4000, 4100, 3, 2), (0, 10, 10, 0), (1200, 1300, 900, 700), (50000, 50000, 40000, 41000)]],
+        "wilcoxon_ranksum_test": [[[1, 5, 3, 10, 3, 3, 4, 5], [6, 7, 2, 2, 8, 9, 10],
+                                   ref.wilcoxon([1, 5, 3, 10, 3, 3, 4, 5], [6, 7, 2, 2, 8, 9, 10])]],
+    }
+    with open(os.path.join(HERE, "known_answers.json"), "w") as f:
+        json.dump(ka, f, indent=1, default=lambda v: None if v != v else v)
+    print("known_answers.json written")
+
+
+if __name__ == "__main__":
+    main()

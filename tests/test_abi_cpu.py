@@ -1,0 +1,93 @@
+"""CPU tests (no GPU): the C-ABI library builds, loads, exports every declared symbol,
+its records have the documented layout, and it refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from basevar_amd import _capi
+    return _capi.load()
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "basevar_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(bv_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    from basevar_amd import _capi
+    names = declared_functions()
+    assert sorted(_capi.EXPORTS) == names
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+def test_record_layout_matches_header(tmp_path):
+    from basevar_amd import _capi
+    src = tmp_path / "layout.c"
+    fields = [f for f in _capi.SITE_DTYPE.names]
+    gfields = [f for f in _capi.GROUP_DTYPE.names]
+    body = "".join('printf("s %s %%zu\\n", offsetof(bv_site_result, %s));\n' % (f, f) for f in fields)
+    body += "".join('printf("g %s %%zu\\n", offsetof(bv_group_result, %s));\n' % (f, f) for f in gfields)
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "basevar_amd.h"\nint main(void){\n'
+                   'printf("S %zu\\nG %zu\\nslab %zu\\ncfg %zu\\nsynth %zu\\n", sizeof(bv_site_result), sizeof(bv_group_result),'
+                   ' sizeof(bv_slab), sizeof(bv_engine_config), sizeof(bv_synth_params));\n' + body + "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    vals = {}
+    for line in out:
+        p = line.split()
+        if len(p) == 2:
+            vals[p[0]] = int(p[1])
+        elif len(p) == 3:
+            vals[(p[0], p[1])] = int(p[2])
+    assert vals["S"] == _capi.SITE_DTYPE.itemsize == 208
+    assert vals["G"] == _capi.GROUP_DTYPE.itemsize == 48
+    assert vals["slab"] == C.sizeof(_capi.Slab)
+    assert vals["cfg"] == C.sizeof(_capi.EngineConfig)
+    assert vals["synth"] == C.sizeof(_capi.SynthParams)
+    for f in fields:
+        assert vals[("s", f)] == _capi.SITE_DTYPE.fields[f][1], f
+    for f in gfields:
+        assert vals[("g", f)] == _capi.GROUP_DTYPE.fields[f][1], f
+
+
+def test_min_af_matches_reference_rounding(lib):
+    import basevar_amd
+    assert basevar_amd.min_af(100000) == 0.0010000000474974513
+    assert basevar_amd.min_af(10) == float(np.float32(0.01))
+    assert b"gfx950" in lib.bv_version()
+
+
+def test_engine_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import basevar_amd
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        basevar_amd.BaseTypeEngine(16, 0.001)
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not import, link or load anything under oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "basevar_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp", "Makefile")):
+                txt = open(os.path.join(base, f), errors="ignore").read()
+                if re.search(r"\boracle\b|liboracle|libbvref|refcpu", txt) and "no oracle" not in txt.lower():
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

@@ -1,0 +1,229 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI, against
+  * the committed golden vectors (outputs of the real reference), and
+  * the oracle restatement (and the real reference where oracle/_ref is present)
+on the same seeded inputs, plus size-independent properties at larger sizes."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from basevar_amd.synth import make_slab
+from parity import ambiguous_sites, compare_groups, compare_sites, describe
+from test_oracle_cpu import load_fixture
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def bv():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import __graft_entry__ as g
+    g.build()
+    import basevar_amd
+    return basevar_amd
+
+
+def run_engine(bv, slab, maf):
+    eng = bv.BaseTypeEngine(max_sites=slab["base_strand"].shape[0], min_af_value=maf, device=0)
+    try:
+        return eng.lrt(slab)
+    finally:
+        eng.close()
+
+
+def check(got, exp, gexp, **kw):
+    amb = ambiguous_sites(exp)
+    bad = compare_sites(got.sites, exp, **kw)
+    bad.update(compare_groups(got.groups, gexp, (exp["status"] & 2) != 0))
+    # sites whose call hinges on an exact floating-point tie are reported separately
+    bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
+    bad = {f: idx for f, idx in bad.items() if idx.size}
+    assert not bad, describe(bad, got.sites, exp)
+    assert amb.sum() <= max(1, len(exp) // 1000)
+    assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum())
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
+def test_golden_vectors(bv, path):
+    slab, maf, exp, gexp = load_fixture(path)
+    if os.path.basename(path) == "edge16.npz":
+        # the phred-0 ALT site yields NaN AF in the reference (0/0); the NaN must survive
+        q0 = np.nonzero(np.isnan(exp["af"][:, 0]) & (exp["n_alt"] > 0))[0]
+        assert q0.size == 1
+    got = run_engine(bv, slab, maf)
+    check(got, exp, gexp, check_chi2=False)  # chi2 is not observable through the reference API
+
+
+@pytest.mark.parametrize("n,cov,sites,groups,seed", [
+    (1500, 0.30, 256, 2, 21),     # one wave per site
+    (10000, 0.08, 384, 0, 22),    # config #2 row length
+    (16400, 0.08, 128, 2, 23),    # just past the 64 -> 256 thread switch, ragged tail
+    (100000, 0.08, 96, 2, 24),    # NIPT row length (config #3)
+    (100003, 0.02, 40, 0, 25),    # ragged, sparse
+    (450000, 0.05, 12, 1, 26),    # 1024-thread teams
+])
+def test_fresh_slabs_vs_restatement(bv, restatement, n, cov, sites, groups, seed):
+    slab = make_slab(sites, n, seed=seed, coverage=cov, n_groups=groups, ref_n_frac=0.03)
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp = restatement.run(slab, maf, n_threads=8)
+    check(got, exp, gexp)
+    assert ((exp["status"] & 2) != 0).sum() >= 2
+
+
+def test_vs_real_reference_when_present(bv):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref/libbvref.so not present")
+    n = 30000
+    slab = make_slab(64, n, seed=31, coverage=0.1, n_groups=2)
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp = oracle.Reference().run(slab, maf, n_threads=8)
+    check(got, exp, gexp, check_chi2=False)
+
+
+def test_no_rank_planes_and_no_groups(bv, restatement):
+    slab = make_slab(64, 5000, seed=41, coverage=0.2)
+    slab.pop("mapq"); slab.pop("rpr")
+    maf = bv.min_af(5000)
+    got = run_engine(bv, slab, maf)
+    exp, _ = restatement.run(slab, maf)
+    check(got, exp, None, check_ranks=False)
+    assert np.isnan(got.sites["mq_ranksum"]).all() and np.isnan(got.sites["rpr_ranksum"]).all()
+    assert (got.sites["status"] & 0x10).sum() == 0
+
+
+def test_high_depth_all_covered(bv, restatement):
+    """Every cell covered: dense LDS-atomic contention and long Fisher ranges."""
+    slab = make_slab(24, 40000, seed=42, coverage=1.0, indel_frac=0.0, n_groups=2)
+    maf = bv.min_af(40000)
+    got = run_engine(bv, slab, maf)
+    exp, gexp = restatement.run(slab, maf, n_threads=8)
+    check(got, exp, gexp)
+
+
+def test_long_read_position_ranks(bv, restatement):
+    """Ranks beyond the 1024-wide LDS window take extra sweeps."""
+    slab = make_slab(32, 3000, seed=43, coverage=0.5, class_af=[(0.3, 0.0), (0.2, 0.1)])
+    rng = np.random.default_rng(5)
+    slab["rpr"] = np.where(slab["base_strand"] < 8, rng.integers(1, 5000, size=slab["rpr"].shape), 0).astype(np.uint16)
+    slab["rpr"][3, :] = np.where(slab["base_strand"][3] < 8, 65535 - (np.arange(slab["rpr"].shape[1]) % 7), 0)
+    maf = bv.min_af(3000)
+    got = run_engine(bv, slab, maf)
+    exp, gexp = restatement.run(slab, maf, n_threads=4)
+    check(got, exp, gexp)
+
+
+def test_bad_qual_is_flagged(bv):
+    slab = make_slab(8, 2000, seed=44, coverage=0.3)
+    slab["qual"][2, np.nonzero(slab["base_strand"][2] < 8)[0][:3]] = 120
+    got = run_engine(bv, slab, bv.min_af(2000))
+    flagged = (got.sites["status"] & 0x4) != 0
+    assert flagged[2] and flagged.sum() == 1
+
+
+def test_zero_freq_raises_like_reference(bv):
+    """min_af == 0 lets a zero-depth base become active; the reference throws
+    "The sum of frequence of active bases must always > 0" (basetype.cpp:113-115)."""
+    slab = make_slab(4, 64, seed=45, coverage=0.9, class_af=[(0.0, 0.0)], qual_mean=40, qual_sd=0.1, qual_min=40,
+                     qual_max=40)
+    # make site 0 hold a single base only
+    cov = slab["base_strand"][0] < 8
+    slab["base_strand"][0, cov] = slab["ref_base"][0]
+    eng = bv.BaseTypeEngine(max_sites=4, min_af_value=0.0, device=0)
+    with pytest.raises(RuntimeError, match="sum of frequence of active bases"):
+        eng.lrt(slab)
+    eng.close()
+
+
+def test_device_pointers_and_idempotence(bv, restatement):
+    """Device-resident planes (torch tensors as plain device memory), caller-provided stream,
+    two submits give byte-identical records."""
+    import torch
+    n, S = 20000, 128
+    slab = make_slab(S, n, seed=46, coverage=0.08, n_groups=2)
+    maf = bv.min_af(n)
+    dev = torch.device("cuda:0")
+    t = {k: torch.from_numpy(np.ascontiguousarray(slab[k].view(np.uint8) if slab[k].dtype != np.uint8 else slab[k])).to(dev)
+         for k in ("base_strand", "qual", "mapq", "rpr", "ref_base", "group_id")}
+    out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    gout = torch.zeros(S * 2 * bv.GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    stream = torch.cuda.Stream()
+    recs = []
+    for _ in range(2):
+        with torch.cuda.stream(stream):
+            eng.submit_ptrs(S, n, slab["pitch"], t["base_strand"].data_ptr(), t["qual"].data_ptr(),
+                            t["ref_base"].data_ptr(), out.data_ptr(), t["mapq"].data_ptr(), t["rpr"].data_ptr(),
+                            t["group_id"].data_ptr(), 2, gout.data_ptr(), stream=stream.cuda_stream)
+        eng.wait()
+        recs.append((out.cpu().numpy().copy(), gout.cpu().numpy().copy()))
+    assert np.array_equal(recs[0][0], recs[1][0]) and np.array_equal(recs[0][1], recs[1][1])
+    sites = recs[0][0].view(bv.SITE_DTYPE)
+    groups = recs[0][1].view(bv.GROUP_DTYPE).reshape(S, 2)
+    exp, gexp = restatement.run(slab, maf, n_threads=8)
+
+    class R:
+        pass
+    r = R(); r.sites = sites; r.groups = groups; r.n_variant = eng.last_variant_count()
+    check(r, exp, gexp)
+    ms1, ms2 = eng.kernel_ms()
+    assert ms1 > 0
+    eng.close()
+
+
+def test_synthetic_generator_and_full_size_properties(bv, restatement):
+    """Device generator -> engine at a multi-GB slab; properties that need no oracle:
+    depth == count of base calls per row (torch, independent of the kernels), site-range
+    sharding invariance; plus oracle parity on a sample of rows copied back."""
+    import torch
+    n, S = 100000, 4096
+    pitch = (n + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    bs = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    q = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    mq = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    rp = torch.empty((S, pitch), dtype=torch.int16, device=dev)
+    ref = torch.empty(S, dtype=torch.uint8, device=dev)
+    bv.synth_fill(0, S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), mq.data_ptr(), rp.data_ptr(), seed=99)
+    torch.cuda.synchronize()
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    eng.submit_ptrs(S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(), mq.data_ptr(), rp.data_ptr())
+    eng.wait()
+    sites = out.cpu().numpy().view(bv.SITE_DTYPE)
+    # (1) integer depths vs an independent torch count
+    for b in range(4):
+        cnt = ((bs[:, :n] & 0x0B) == b).sum(dim=1).cpu().numpy()
+        assert np.array_equal(cnt, sites["depth"][:, b])
+    assert np.array_equal(sites["depth"].sum(axis=1), sites["total_depth"])
+    assert np.array_equal(sites["cvg_sb"].sum(axis=1), sites["total_depth"])
+    # (2) sharding invariance: two half-range submits == one whole-range submit
+    out2 = torch.zeros_like(out)
+    h = S // 2
+    rec = bv.SITE_DTYPE.itemsize
+    eng.submit_ptrs(h, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out2.data_ptr(), mq.data_ptr(), rp.data_ptr())
+    eng.wait()
+    eng.submit_ptrs(S - h, n, pitch, bs[h:].data_ptr(), q[h:].data_ptr(), ref[h:].data_ptr(),
+                    out2.data_ptr() + h * rec, mq[h:].data_ptr(), rp[h:].data_ptr())
+    eng.wait()
+    assert torch.equal(out, out2)
+    # (3) oracle parity on 48 sampled rows (site classes cycle with period 20)
+    pick = np.arange(0, S, S // 48)[:48]
+    sub = {"base_strand": bs[pick].cpu().numpy(), "qual": q[pick].cpu().numpy(), "mapq": mq[pick].cpu().numpy(),
+           "rpr": rp[pick].cpu().numpy().view(np.uint16), "ref_base": ref[pick].cpu().numpy(), "n_samples": n}
+    exp, _ = restatement.run(sub, maf, n_threads=8)
+
+    class R:
+        pass
+    r = R(); r.sites = sites[pick]; r.groups = None; r.n_variant = int(((sites[pick]["status"] & 2) != 0).sum())
+    check(r, exp, None)
+    nvar = int(((sites["status"] & 2) != 0).sum())
+    assert 0.2 * S < nvar < 0.45 * S  # 30 % of the synthetic sites carry an ALT allele
+    eng.close()
