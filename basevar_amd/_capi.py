@@ -58,7 +58,8 @@ class SynthParams(C.Structure):
 
 # every symbol include/basevar_amd.h declares
 EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_wait",
-           "bv_engine_kernel_ms", "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
+           "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get",
+           "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
 
 _lib = None
 
@@ -87,6 +88,10 @@ def load():
     L.bv_engine_wait.argtypes = [C.c_void_p]
     L.bv_engine_kernel_ms.restype = C.c_int
     L.bv_engine_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.bv_engine_timing_reset.restype = C.c_int
+    L.bv_engine_timing_reset.argtypes = [C.c_void_p]
+    L.bv_engine_timing_get.restype = C.c_int
+    L.bv_engine_timing_get.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.bv_engine_last_variant_count.restype = C.c_int
     L.bv_engine_last_variant_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.bv_last_error.restype = C.c_char_p

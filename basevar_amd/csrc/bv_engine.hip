@@ -35,7 +35,12 @@ struct bv_engine {
     uint32_t *d_var_list = nullptr;
     uint32_t *d_counters = nullptr;    // [0] variants, [1] zero-freq sites
     uint32_t *h_counters = nullptr;    // pinned host mirror
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kRing = 256;
+    hipEvent_t ring[kRing][3] = {};    // per-submit event triplets
+    int ring_head = 0, ring_count = 0; // pending (not yet accumulated) triplets
+    int last_slot = -1;
+    double acc1_ms = 0., acc2_ms = 0.;
+    uint32_t acc_n = 0;
     bool submitted = false;
     // host-slab staging (BV_MEM_HOST)
     void *stage = nullptr;
@@ -65,6 +70,29 @@ int fail(bv_engine *e, int code, const std::string &msg) {
         if (_s != hipSuccess)                                                                   \
             return fail((e), BV_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_s));    \
     } while (0)
+}  // namespace
+
+namespace {
+// fold every completed pending triplet into the accumulators; `block` waits for them
+int drain_timings(bv_engine *e, bool block) {
+    while (e->ring_count > 0) {
+        int slot = (e->ring_head - e->ring_count + bv_engine::kRing * 2) % bv_engine::kRing;
+        hipEvent_t *t = e->ring[slot];
+        if (block) {
+            BV_HIP(e, hipEventSynchronize(t[2]));
+        } else if (hipEventQuery(t[2]) != hipSuccess) {
+            break;
+        }
+        float a = 0.f, b = 0.f;
+        BV_HIP(e, hipEventElapsedTime(&a, t[0], t[1]));
+        BV_HIP(e, hipEventElapsedTime(&b, t[1], t[2]));
+        e->acc1_ms += a;
+        e->acc2_ms += b;
+        e->acc_n += 1;
+        e->ring_count -= 1;
+    }
+    return BV_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -112,7 +140,8 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
     } while (0)
     BV_TRY(hipSetDevice(cfg->device));
     BV_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (auto &ev : e->ev) BV_TRY(hipEventCreate(&ev));
+    for (auto &tri : e->ring)
+        for (auto &ev : tri) BV_TRY(hipEventCreate(&ev));
     BV_TRY(hipMalloc(&e->d_tables, sizeof(BvTables)));
     BV_TRY(hipMalloc(&e->d_var_list, sizeof(uint32_t) * (size_t)cfg->max_sites));
     BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * 4));
@@ -137,8 +166,9 @@ int bv_engine_destroy(bv_engine *e) {
     if (!e) return BV_OK;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (auto &ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
+    for (auto &tri : e->ring)
+        for (auto &ev : tri)
+            if (ev) (void)hipEventDestroy(ev);
     if (e->d_tables) (void)hipFree(e->d_tables);
     if (e->d_var_list) (void)hipFree(e->d_var_list);
     if (e->d_counters) (void)hipFree(e->d_counters);
@@ -225,10 +255,19 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = slab->n_sites;
     a1.n_samples = slab->n_samples; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
     a1.var_list = e->d_var_list; a1.counters = e->d_counters;
-    BV_HIP(e, hipEventRecord(e->ev[0], st));
+    if (e->ring_count == bv_engine::kRing) {
+        int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
+        if (rc != BV_OK) return rc;
+    }
+    const int slot = e->ring_head;
+    e->ring_head = (e->ring_head + 1) % bv_engine::kRing;
+    e->ring_count += 1;
+    e->last_slot = slot;
+    hipEvent_t *ev = e->ring[slot];
+    BV_HIP(e, hipEventRecord(ev[0], st));
     bv_launch_pass1(a1, st);
     BV_HIP(e, hipGetLastError());
-    BV_HIP(e, hipEventRecord(e->ev[1], st));
+    BV_HIP(e, hipEventRecord(ev[1], st));
 
     BvPass2Args a2;
     a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
@@ -237,7 +276,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     a2.var_list = e->d_var_list; a2.counters = e->d_counters;
     bv_launch_pass2(a2, st);
     BV_HIP(e, hipGetLastError());
-    BV_HIP(e, hipEventRecord(e->ev[2], st));
+    BV_HIP(e, hipEventRecord(ev[2], st));
 
     BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, st));
     if (e->host_out) {
@@ -267,10 +306,33 @@ int bv_engine_wait(bv_engine *e) {
 int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms) {
     if (!e || !e->submitted) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_kernel_ms: nothing submitted");
     float a = 0.f, b = 0.f;
-    BV_HIP(e, hipEventElapsedTime(&a, e->ev[0], e->ev[1]));
-    BV_HIP(e, hipEventElapsedTime(&b, e->ev[1], e->ev[2]));
+    hipEvent_t *t = e->ring[e->last_slot];
+    BV_HIP(e, hipEventSynchronize(t[2]));
+    BV_HIP(e, hipEventElapsedTime(&a, t[0], t[1]));
+    BV_HIP(e, hipEventElapsedTime(&b, t[1], t[2]));
     if (pass1_ms) *pass1_ms = a;
     if (pass2_ms) *pass2_ms = b;
+    return BV_OK;
+}
+
+int bv_engine_timing_reset(bv_engine *e) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_timing_reset: null engine");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    int rc = drain_timings(e, true);
+    if (rc != BV_OK) return rc;
+    e->acc1_ms = e->acc2_ms = 0.;
+    e->acc_n = 0;
+    return BV_OK;
+}
+
+int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_total_ms, uint32_t *n_submits) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_timing_get: null engine");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    int rc = drain_timings(e, true);
+    if (rc != BV_OK) return rc;
+    if (pass1_total_ms) *pass1_total_ms = e->acc1_ms;
+    if (pass2_total_ms) *pass2_total_ms = e->acc2_ms;
+    if (n_submits) *n_submits = e->acc_n;
     return BV_OK;
 }
 

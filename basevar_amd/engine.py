@@ -126,6 +126,17 @@ class BaseTypeEngine:
             raise RuntimeError("bv_engine_kernel_ms failed (%d): %s" % (rc, self._err()))
         return a.value, b.value
 
+    def timing_reset(self):
+        if self._lib.bv_engine_timing_reset(self._h) != 0:
+            raise RuntimeError("bv_engine_timing_reset: " + self._err())
+
+    def timing_get(self):
+        """(total pass-1 ms, total pass-2 ms, number of submits) since timing_reset()."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        if self._lib.bv_engine_timing_get(self._h, C.byref(a), C.byref(b), C.byref(n)) != 0:
+            raise RuntimeError("bv_engine_timing_get: " + self._err())
+        return a.value, b.value, n.value
+
     def last_variant_count(self):
         n = C.c_uint32()
         self._lib.bv_engine_last_variant_count(self._h, C.byref(n))

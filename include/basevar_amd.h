@@ -186,6 +186,12 @@ int bv_engine_wait(bv_engine *e);
  * Valid after bv_engine_wait(). */
 int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms);
 
+/* Accumulated HIP-event timings since the last reset: every submit records its own event
+ * triplet (ring of 256 submits); totals are over all completed submits.  Used by bench.py
+ * to quote the average launch duration of each pass over the timed region. */
+int bv_engine_timing_reset(bv_engine *e);
+int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_total_ms, uint32_t *n_submits);
+
 /* Number of BV_SITE_VARIANT sites found by the last submit (valid after wait). */
 int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant);
 

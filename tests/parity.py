@@ -75,6 +75,8 @@ def compare_groups(got, exp, variant_mask):
     if exp is None:
         return bad
     v = np.nonzero(variant_mask)[0]
+    if v.size == 0:
+        return bad
     g, e = got[v], exp[v]
     for f in ["n_alt", "alt", "total_depth"]:
         m = (g[f] != e[f]).reshape(len(v), -1).any(axis=1)

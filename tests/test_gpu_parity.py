@@ -68,7 +68,7 @@ def test_golden_vectors(bv, path):
     (450000, 0.05, 12, 1, 26),    # 1024-thread teams
 ])
 def test_fresh_slabs_vs_restatement(bv, restatement, n, cov, sites, groups, seed):
-    slab = make_slab(sites, n, seed=seed, coverage=cov, n_groups=groups, ref_n_frac=0.03)
+    slab = make_slab(sites, n, seed=seed, coverage=cov, n_groups=groups, ref_n_frac=0.03, site_offset=10)
     maf = bv.min_af(n)
     got = run_engine(bv, slab, maf)
     exp, gexp = restatement.run(slab, maf, n_threads=8)
