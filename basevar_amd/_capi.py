@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libbasevar_amd.so")
+LIB_PATH = os.environ.get("BASEVAR_AMD_LIB") or os.path.join(HERE, "lib", "libbasevar_amd.so")  # override: A/B builds
 
 BV_MAX_ALT = 4
 BV_MAX_GROUPS = 32

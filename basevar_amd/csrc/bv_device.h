@@ -6,8 +6,8 @@
 // so its n_cov x 4 EM collapses exactly onto <= 4 x 94 weighted bins.
 //
 // Execution model: wave64.  Every solver routine is a *wave-level* function: the 64 lanes
-// of one wavefront cooperate through __shfl_xor butterflies (all lanes end up with the
-// bit-identical sum because IEEE addition is commutative), and independent routines
+// of one wavefront cooperate through DPP scans (lane 63's total is broadcast with
+// v_readlane, so every lane holds the bit-identical sum), and independent routines
 // (the up-to-4 EM runs of one LRT level, Fisher tests, rank sums) are spread over the
 // waves of the workgroup.  No MFMA: this is categorical-table arithmetic in FP64.
 #pragma once
@@ -45,39 +45,98 @@ struct BvTables {
 };
 
 // ------------------------------------------------------------------ wave reductions
-__device__ __forceinline__ double bv_wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, BV_WAVE);
+// All cross-lane sums use DPP (data-parallel primitives: a VALU operand read from another
+// lane), not ds_bpermute: a bpermute round trip costs an LDS latency per butterfly step,
+// six dependent steps per reduction, and the solver does several reductions per EM pass.
+// Pattern (gfx9 family): inclusive scan inside each row of 16 lanes by row_shr 1,2,4,8,
+// then row_bcast15 / row_bcast31 carry the row totals across rows; lane 63 ends up holding
+// the wave total, which v_readlane broadcasts.  Fixed order => deterministic FP sums, and
+// every lane receives the bit-identical value.
+#define BV_DPP_ROW_SHR(n) (0x110 + (n))
+#define BV_DPP_BCAST15 0x142
+#define BV_DPP_BCAST31 0x143
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int bv_dpp_i32(int ident, int v) {
+    return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double bv_dpp_f64(double v) {  // identity 0.0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = bv_dpp_i32<CTRL, ROW_MASK>(0, lo);
+    hi = bv_dpp_i32<CTRL, ROW_MASK>(0, hi);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long bv_dpp_u64(unsigned long long v) {
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = bv_dpp_i32<CTRL, ROW_MASK>(0, lo);
+    hi = bv_dpp_i32<CTRL, ROW_MASK>(0, hi);
+    return ((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ int bv_readlane63_i32(int v) { return __builtin_amdgcn_readlane(v, 63); }
+
+// inclusive prefix sums over the 64 lanes
+__device__ __forceinline__ double bv_wave_incl_scan_f64(double v) {
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(1), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(2), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(4), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(8), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_BCAST15, 0xa>(v);
+    v += bv_dpp_f64<BV_DPP_BCAST31, 0xc>(v);
     return v;
+}
+__device__ __forceinline__ uint32_t bv_wave_incl_scan_u32(uint32_t v, int /*lane*/) {
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(1), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(2), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(4), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(8), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_BCAST15, 0xa>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_BCAST31, 0xc>(0, (int)v);
+    return v;
+}
+__device__ __forceinline__ unsigned long long bv_wave_incl_scan_u64(unsigned long long v) {
+    v += bv_dpp_u64<BV_DPP_ROW_SHR(1), 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_ROW_SHR(2), 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_ROW_SHR(4), 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_ROW_SHR(8), 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_BCAST15, 0xa>(v);
+    v += bv_dpp_u64<BV_DPP_BCAST31, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ double bv_wave_sum(double v) {
+    v = bv_wave_incl_scan_f64(v);
+    int lo = bv_readlane63_i32(__double2loint(v)), hi = bv_readlane63_i32(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ uint32_t bv_wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, BV_WAVE);
-    return v;
+    return (uint32_t)bv_readlane63_i32((int)bv_wave_incl_scan_u32(v, 0));
 }
 __device__ __forceinline__ unsigned long long bv_wave_sum_u64(unsigned long long v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += (unsigned long long)__shfl_xor((long long)v, m, BV_WAVE);
-    return v;
+    v = bv_wave_incl_scan_u64(v);
+    uint32_t lo = (uint32_t)bv_readlane63_i32((int)(uint32_t)v), hi = (uint32_t)bv_readlane63_i32((int)(uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
 }
+// min / max: same scan shape with the matching identity
 __device__ __forceinline__ int bv_wave_min_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = min(v, __shfl_xor(v, m, BV_WAVE));
-    return v;
+    const int I = 0x7fffffff;
+    v = min(v, bv_dpp_i32<BV_DPP_ROW_SHR(1), 0xf>(I, v));
+    v = min(v, bv_dpp_i32<BV_DPP_ROW_SHR(2), 0xf>(I, v));
+    v = min(v, bv_dpp_i32<BV_DPP_ROW_SHR(4), 0xf>(I, v));
+    v = min(v, bv_dpp_i32<BV_DPP_ROW_SHR(8), 0xf>(I, v));
+    v = min(v, bv_dpp_i32<BV_DPP_BCAST15, 0xa>(I, v));
+    v = min(v, bv_dpp_i32<BV_DPP_BCAST31, 0xc>(I, v));
+    return bv_readlane63_i32(v);
 }
 __device__ __forceinline__ int bv_wave_max_i32(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, BV_WAVE));
-    return v;
-}
-// inclusive prefix sum over lanes (Hillis-Steele with shfl_up)
-__device__ __forceinline__ uint32_t bv_wave_incl_scan_u32(uint32_t v, int lane) {
-#pragma unroll
-    for (int d = 1; d < BV_WAVE; d <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)v, d, BV_WAVE);
-        if (lane >= d) v += t;
-    }
-    return v;
+    const int I = (int)0x80000000;
+    v = max(v, bv_dpp_i32<BV_DPP_ROW_SHR(1), 0xf>(I, v));
+    v = max(v, bv_dpp_i32<BV_DPP_ROW_SHR(2), 0xf>(I, v));
+    v = max(v, bv_dpp_i32<BV_DPP_ROW_SHR(4), 0xf>(I, v));
+    v = max(v, bv_dpp_i32<BV_DPP_ROW_SHR(8), 0xf>(I, v));
+    v = max(v, bv_dpp_i32<BV_DPP_BCAST15, 0xa>(I, v));
+    v = max(v, bv_dpp_i32<BV_DPP_BCAST31, 0xc>(I, v));
+    return bv_readlane63_i32(v);
 }
 
 // ------------------------------------------------------------------ special functions
@@ -174,14 +233,88 @@ __device__ inline double bv_qual_from_chi2(double chi) {
 // tables (seed + <= 10 multiplicative steps -- the same arithmetic), 64 blocks per sweep;
 // the reference's stopping rule ("first p >= 0.99999999 q") becomes a wave-min over the
 // lanes' first violating index, valid because the pmf is unimodal.
-__device__ inline double bv_lbinom(int n, int k) {
-    if (k == 0 || n == k) return 0;
-    return lgamma((double)(n + 1)) - lgamma((double)(k + 1)) - lgamma((double)(n - k + 1));
+// log(n!) == lgamma(n + 1), the only way kfunc.c:197-201 uses lgamma.  ocml's general
+// lgamma() is several hundred FP64 instructions and the Fisher tails call it 6x per seeded
+// table; for integer arguments a 16-entry table (glibc lgamma values) plus the Stirling
+// series (7 terms, |error| < 1e-16 relative for n + 1 >= 17, i.e. at the level of glibc's
+// own rounding) is ~10x cheaper.  Differences vs glibc are ~1 ulp of a value ~n log n and
+// reach the p-values at the 1e-10 relative level, far inside the 1e-6 parity bar.
+__device__ __forceinline__ double bv_lnfact(int n) {
+    if (n < 16) {
+        const double T0 = 0.0, T2 = 0.693147180559945, T3 = 1.7917594692280554, T4 = 3.178053830347945,
+                     T5 = 4.787491742782047, T6 = 6.579251212010102, T7 = 8.525161361065415, T8 = 10.604602902745249,
+                     T9 = 12.801827480081467, T10 = 15.104412573075514, T11 = 17.502307845873887,
+                     T12 = 19.987214495661885, T13 = 22.55216385312342, T14 = 25.191221182738683,
+                     T15 = 27.89927138384089;
+        // select chain instead of a memory table: no scratch / constant-memory traffic
+        double lo = n < 2 ? T0 : (n == 2 ? T2 : (n == 3 ? T3 : (n == 4 ? T4 : (n == 5 ? T5 : (n == 6 ? T6 : T7)))));
+        double hi = n == 8 ? T8 : (n == 9 ? T9 : (n == 10 ? T10 : (n == 11 ? T11 : (n == 12 ? T12 : (n == 13 ? T13 : (n == 14 ? T14 : T15))))));
+        return n < 8 ? lo : hi;
+    }
+    const double x = (double)n + 1.0;
+    const double xi = 1.0 / x, x2 = xi * xi;
+    double s = 1.0 / 156.0;
+    s = s * x2 + (-691.0 / 360360.0);
+    s = s * x2 + (1.0 / 1188.0);
+    s = s * x2 + (-1.0 / 1680.0);
+    s = s * x2 + (1.0 / 1260.0);
+    s = s * x2 + (-1.0 / 360.0);
+    s = s * x2 + (1.0 / 12.0);
+    s *= xi;
+    return (x - 0.5) * log(x) - x + 0.91893853320467274178 + s;
 }
-__device__ inline double bv_hypergeo(int n11, int n1_, int n_1, int n) {
-    return exp(bv_lbinom(n1_, n11) + bv_lbinom(n - n1_, n_1 - n11) - bv_lbinom(n, n_1));
+__device__ __forceinline__ double bv_readlane_f64(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
 }
 
+// One 2x2 table family: margins fixed, n11 = i varies over [imin, imax].
+//   p(i) = exp( lbinom(n1_, i) + lbinom(n - n1_, n_1 - i) - lbinom(n, n_1) )   (kfunc.c:197-212)
+// lbinom(n, k) = lnfact(n) - lnfact(k) - lnfact(n - k); its k == 0 / k == n special case
+// (kfunc.c:199) needs no branch here because lnfact(0) == 0 makes the difference exactly 0.
+struct BvHyper {
+    int n1_, n_1, n, n22off;
+    double lf_n1;   // lnfact(n1_)
+    double lf_n2;   // lnfact(n - n1_)
+    double lb3;     // lbinom(n, n_1)
+};
+__device__ __forceinline__ double bv_hyper_logp(const BvHyper &h, int i) {
+    double a = h.lf_n1 - bv_lnfact(i) - bv_lnfact(h.n1_ - i);
+    double b = h.lf_n2 - bv_lnfact(h.n_1 - i) - bv_lnfact(i + h.n22off);
+    return a + b - h.lb3;
+}
+__device__ __forceinline__ double bv_hyper_p(const BvHyper &h, int i) { return exp(bv_hyper_logp(h, i)); }
+
+// The five table-independent log-factorials are evaluated by five lanes in ONE pass of
+// bv_lnfact and broadcast with v_readlane (instead of five passes).
+__device__ __forceinline__ void bv_hyper_init(BvHyper &h, int n1_, int n_1, int n, int lane) {
+    h.n1_ = n1_; h.n_1 = n_1; h.n = n; h.n22off = n - n1_ - n_1;
+    int arg = lane == 0 ? n1_ : (lane == 1 ? n - n1_ : (lane == 2 ? n : (lane == 3 ? n_1 : n - n_1)));
+    double v = bv_lnfact(arg);
+    h.lf_n1 = bv_readlane_f64(v, 0);
+    h.lf_n2 = bv_readlane_f64(v, 1);
+    h.lb3 = bv_readlane_f64(v, 2) - bv_readlane_f64(v, 3) - bv_readlane_f64(v, 4);
+}
+
+// kt_fisher_exact (two-sided), wave-parallel.  Semantics of the reference's two loops
+// (kfunc.c:291-307): with lo = 0.99999999 q and hi = 1.00000001 q,
+//   L* = first table from the left  with p >= lo,  left  = sum_{i < L*} p(i) + (p(L*) < hi ? p(L*) : 0)
+//   R* = first table from the right with p >= lo,  right = sum_{i > R*} p(i) + (p(R*) < hi ? p(R*) : 0)
+//   two = min(1, left + right)
+// The pmf is unimodal, so the tables that pass "p < lo" form a prefix / suffix and the stopping
+// rule is a wave-min / wave-max over the lanes' violating indices.
+//
+// Three regimes by the number of tables R = imax - imin + 1:
+//   R <= 64   one table per lane, each p(i) seeded from log-factorials (the common case: a
+//             hom-ref site has only a handful of non-reference reads);
+//   <= 64 blocks of 11 (R <~ 704): one sweep: each lane owns a block of 11 consecutive tables -- seed + <= 10
+//             multiplicative steps, the reference's own re-seeding period (kfunc.c:225);
+//   larger    left tail ascending, right tail descending, 704 tables per sweep, after a
+//             64-point probe of log p has skipped the far tails whose terms are below
+//             q * 2^-86 (they cannot change a double-precision sum that is >= ~q).
+// Where the reference updates p multiplicatively across what are separate lanes / directions
+// here, the values differ from it at the 1e-13 relative level (parity bar: 1e-6).
 __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int n21, int n22, int lane) {
 #ifdef BV_PROBE_NOFISHER
     return 0.5;
@@ -191,22 +324,98 @@ __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int 
     int imin = n1_ + n_1 - n;
     if (imin < 0) imin = 0;
     if (imin == imax) return 1.;
-    const double q = bv_hypergeo(n11, n1_, n_1, n);
+    BvHyper h;
+    bv_hyper_init(h, n1_, n_1, n, lane);
+    const int R = imax - imin + 1;
+    const int INF = 0x7fffffff;
+
+    if (R <= BV_WAVE) {
+        // ---- one table per lane; q is the value of the lane that holds the observed table
+        const int i = imin + lane;
+        const bool have = i <= imax;
+        const double p = have ? bv_hyper_p(h, have ? i : imin) : 0.;
+        const double q = bv_readlane_f64(p, n11 - imin);
+        if (q == 0.0) return 0.0;  // kfunc.c:260-289
+        const double lo = 0.99999999 * q, hi = 1.00000001 * q;
+        const bool viol = have && !(p < lo);
+        const int Ls = bv_wave_min_i32(viol ? i : INF), Rs = bv_wave_max_i32(viol ? i : -1);
+        double left = bv_wave_sum((have && i < Ls) ? p : 0.);
+        double right = bv_wave_sum((have && i > Rs) ? p : 0.);
+        const double pL = bv_readlane_f64(p, Ls - imin), pR = bv_readlane_f64(p, Rs - imin);
+        if (pL < hi) left += pL;
+        if (pR < hi) right += pR;
+        double two = left + right;
+        return two > 1. ? 1. : two;
+    }
+
+    const double logq = bv_hyper_logp(h, n11);
+    const double q = exp(logq);
     if (q == 0.0) return 0.0;  // kfunc.c:260-289
     const double lo = 0.99999999 * q, hi = 1.00000001 * q;
-    const int n22off = n - n1_ - n_1;  // n22 of table i is i + n22off
 
-    // ---- left tail: ascending from imin
+    if (imax / 11 - imin / 11 < BV_WAVE) {
+        // ---- one ascending sweep covers every table: block b = imin/11 + lane
+        const int b = imin / 11 + lane;
+        const int start = max(b * 11, imin), end = min(b * 11 + 10, imax);
+        const bool have = start <= end;
+        double before = 0., after = 0., pf = 0., pl = 0.;  // sums around / values at the block's violations
+        int vf = INF, vl = -1;
+        if (have) {
+            double p = bv_hyper_p(h, start);
+            for (int i = start;; ++i) {
+                if (p < lo) {
+                    if (vl < 0) before += p; else after += p;
+                } else {
+                    if (vf == INF) { vf = i; pf = p; }
+                    vl = i; pl = p;
+                    after = 0.;
+                }
+                if (i == end) break;
+                p *= (double)(n1_ - i) / (i + 1) * (n_1 - i) / (i + 1 + h.n22off);  // kfunc.c:226-231
+            }
+        }
+        const int Ls = bv_wave_min_i32(vf), Rs = bv_wave_max_i32(vl);
+        // left: whole blocks before L*, plus the part of L*'s block before it
+        double left = bv_wave_sum(have ? ((end < Ls) ? before : ((vf == Ls) ? before : 0.)) : 0.);
+        // right: whole blocks after R*, plus the part of R*'s block after it
+        double right = bv_wave_sum(have ? ((start > Rs) ? before : ((vl == Rs) ? after : 0.)) : 0.);
+        const double pL = bv_wave_sum(vf == Ls ? pf : 0.), pR = bv_wave_sum(vl == Rs ? pl : 0.);
+        if (pL < hi) left += pL;
+        if (pR < hi) right += pR;
+        double two = left + right;
+        return two > 1. ? 1. : two;
+    }
+
+    // ---- many tables: skip the far tails, then sweep towards the observed table
+    const double cut = logq - 60.0;  // exp(-60) ~ 2^-86.6
+    int wl = imin, wr = imax;
+    {
+        // probes on [imin, n11]: tables before the last probe that is still below the cut are negligible
+        // (rising side, or between mode and n11 where p >= q): a prefix by unimodality
+        const int span = n11 - imin, step = span / 63 + 1;
+        const int i = imin + lane * step;
+        const bool below = (i <= n11) && (bv_hyper_logp(h, min(i, n11)) < cut);
+        const int last = bv_wave_max_i32(below ? i : -1);
+        if (last >= 0) wl = last;
+    }
+    {
+        const int span = imax - n11, step = span / 63 + 1;
+        const int i = imax - lane * step;
+        const bool below = (i >= n11) && (bv_hyper_logp(h, max(i, n11)) < cut);
+        const int first = bv_wave_min_i32(below ? i : INF);
+        if (first != INF) wr = first;
+    }
+    // left tail: ascending from wl; block b covers [11b, 11b+10]
     double left = 0.;
     {
-        int blk0 = imin / 11;  // block b covers [11b, 11b+10]
+        int blk0 = wl / 11;
         for (;;) {
-            int b = blk0 + lane;
-            int start = max(b * 11, imin), end = min(b * 11 + 10, imax);
+            const int b = blk0 + lane;
+            const int start = max(b * 11, wl), end = min(b * 11 + 10, imax);
             double acc = 0., pv = 0.;
-            int viol = 0x7fffffff;
+            int viol = INF;
             if (start <= end) {
-                double p = bv_hypergeo(start, n1_, n_1, n);
+                double p = bv_hyper_p(h, start);
                 for (int i = start;; ++i) {
                     if (p < lo) {
                         acc += p;
@@ -216,17 +425,13 @@ __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int 
                         break;
                     }
                     if (i == end) break;
-                    // incremental step i -> i+1 (kfunc.c:226-231)
-                    p *= (double)(n1_ - i) / (i + 1) * (n_1 - i) / (i + 1 + n22off);
+                    p *= (double)(n1_ - i) / (i + 1) * (n_1 - i) / (i + 1 + h.n22off);  // kfunc.c:226-231
                 }
             }
-            int first = bv_wave_min_i32(viol);
-            // unimodal pmf: blocks that start at or before the first violating table hold only
-            // tail terms (the block containing it stopped accumulating there); later blocks none
-            double contrib = (start <= end && start <= first) ? acc : 0.;
-            left += bv_wave_sum(contrib);
-            if (first != 0x7fffffff) {
-                double pb = bv_wave_sum(viol == first ? pv : 0.);  // exactly one lane holds it
+            const int first = bv_wave_min_i32(viol);
+            left += bv_wave_sum((start <= end && start <= first) ? acc : 0.);
+            if (first != INF) {
+                const double pb = bv_wave_sum(viol == first ? pv : 0.);
                 if (pb < hi) left += pb;
                 break;
             }
@@ -234,16 +439,16 @@ __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int 
             if (blk0 * 11 > imax) break;
         }
     }
-    // ---- right tail: descending from imax; block b covers [11b+1, 11b+11], seeded at its top
+    // right tail: descending from wr; block b covers [11b+1, 11b+11], seeded at its top
     double right = 0.;
     {
-        int blk0 = (imax - 1) / 11;  // block containing imax (imax >= 1 here since imin < imax)
+        int blk0 = (wr - 1) / 11;  // wr >= n11 >= imin, and wr >= 1 here
+        if (wr < 1) blk0 = -1;
         for (;;) {
-            int b = blk0 - lane;
-            int start = min(b * 11 + 11, imax), end = max(b * 11 + 1, imin);
+            const int b = blk0 - lane;
+            int start = min(b * 11 + 11, wr), end = max(b * 11 + 1, imin);
             bool have = (b >= 0) && (start >= end);
-            // table 0 belongs to block -1 (index 0 is a multiple of 11: its own seed)
-            if (b == -1 && imin == 0) {
+            if (b == -1 && imin == 0) {  // table 0 is its own seed (0 % 11 == 0)
                 start = 0;
                 end = 0;
                 have = true;
@@ -251,7 +456,7 @@ __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int 
             double acc = 0., pv = 0.;
             int viol = -1;
             if (have) {
-                double p = bv_hypergeo(start, n1_, n_1, n);
+                double p = bv_hyper_p(h, start);
                 for (int j = start;; --j) {
                     if (p < lo) {
                         acc += p;
@@ -261,15 +466,13 @@ __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int 
                         break;
                     }
                     if (j == end) break;
-                    // decremental step j -> j-1 (kfunc.c:232-237)
-                    p *= (double)j / (n1_ - (j - 1)) * (j + n22off) / (n_1 - (j - 1));
+                    p *= (double)j / (n1_ - (j - 1)) * (j + h.n22off) / (n_1 - (j - 1));  // kfunc.c:232-237
                 }
             }
-            int first = bv_wave_max_i32(viol);
-            double contrib = (have && start >= first) ? acc : 0.;
-            right += bv_wave_sum(contrib);
+            const int first = bv_wave_max_i32(viol);
+            right += bv_wave_sum((have && start >= first) ? acc : 0.);
             if (first >= 0) {
-                double pb = bv_wave_sum(viol == first ? pv : 0.);
+                const double pb = bv_wave_sum(viol == first ? pv : 0.);
                 if (pb < hi) right += pb;
                 break;
             }
@@ -278,8 +481,7 @@ __device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int 
         }
     }
     double two = left + right;
-    if (two > 1.) two = 1.;
-    return two;
+    return two > 1. ? 1. : two;
 }
 
 // strand_bias tail, src/basetype.cpp:277-286
@@ -314,7 +516,7 @@ __device__ inline unsigned long long bv_ranksum_window(uint32_t ref_v, uint32_t 
     unsigned long long below_v = below + (incl - t);
     unsigned long long term = (unsigned long long)ref_v * (2ull * n - 2ull * below_v - t + 1ull);
     unsigned long long s = bv_wave_sum_u64(term);
-    below += (unsigned long long)__shfl((int)incl, BV_WAVE - 1, BV_WAVE);
+    below += (unsigned long long)(uint32_t)bv_readlane63_i32((int)incl);
     return s;
 }
 // z statistic -> phred, algorithm.h:130-132 + basetype.cpp:222-231
@@ -356,6 +558,10 @@ __device__ __forceinline__ double bv_int_abs_trunc(double d) {
 // k = 1..100 are the `while (iter_num--)` body (algorithm.h:235-251).  Each pass is one
 // fused sweep over the bins: e_step (algorithm.h:161-171), the m_step numerators
 // (algorithm.h:190-193), log-marginals and the convergence sum (algorithm.h:243-247).
+// Bin i lives in lane i % 64, slot i / 64; only the per-bin log-marginal of the previous pass
+// is carried (in registers).  (A branch-free variant that kept three bins per lane in flight
+// for ILP, with the log-marginals in LDS, was measured 13 % SLOWER end to end: the solver wave
+// shares its SIMD with tally waves, so its instruction count matters more than its latency.)
 __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n_cov, double *lr_out, int lane) {
     const double epsilon = (double)0.001f;  // `const float epsilon=0.001`, algorithm.h:213
     const int nslots = (B.nb + BV_WAVE - 1) / BV_WAVE;
@@ -380,11 +586,10 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n
                     double L1 = (b == 1 ? hit : miss) * f[1];
                     double L2 = (b == 2 ? hit : miss) * f[2];
                     double L3 = (b == 3 ? hit : miss) * f[3];
-                    double marg = L0;  // 0 + L0, then += in j order (algorithm.h:162-165)
+                    double marg = L0;
                     marg += L1;
                     marg += L2;
                     marg += L3;
-                    // one IEEE division then four multiplies (reference: four divisions; <= 1 ulp apart)
                     double r = 1.0 / marg;
                     pf0 += c * (L0 * r);
                     pf1 += c * (L1 * r);
@@ -397,17 +602,16 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n
                 }
             }
         }
-        f[0] = bv_wave_sum(pf0) / n_cov;  // m_step, algorithm.h:194
+        f[0] = bv_wave_sum(pf0) / n_cov;
         f[1] = bv_wave_sum(pf1) / n_cov;
         f[2] = bv_wave_sum(pf2) / n_cov;
         f[3] = bv_wave_sum(pf3) / n_cov;
-        if (k == 0) continue;  // llh^0 is only the baseline of the first delta
+        if (k == 0) continue;
         delta = bv_wave_sum(delta);
         ++iters;
         if (delta < epsilon) break;
     }
-    // final m_step (algorithm.h:253) recomputes f from the unchanged posteriors: idempotent.
-    *lr_out = bv_wave_sum(lr);  // sum(log_marginal_likelihood), basetype.cpp:120
+    *lr_out = bv_wave_sum(lr);
     return iters;
 }
 
@@ -462,7 +666,7 @@ __device__ __forceinline__ void bv_lrt_sync() {
 template <int NW>
 __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t total, int specific_packed,
                               int nspec, int ref_code, double min_af, BvLrtShared *sh, int wave, int lane,
-                              BvLrtOut &o) {
+                              BvLrtOut &o, uint32_t q0_mask = 0xFu) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
     o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false;
     // active_bases as a packed ordered list: position k in bits [2k, 2k+1]
@@ -475,6 +679,17 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
         }
     }
     if (m == 0) return;
+    if (m == 1 && !((q0_mask >> (act & 3)) & 1u)) {
+        // One active base b and none of its calls has phred 0.  The reference's EM is then exact
+        // and needs no arithmetic: every row's posterior for b is L_b / L_b == 1.0, the m_step
+        // gives f_b == n/n == 1.0, the first delta is |int(-log(f_init))| == 0 because
+        // f_init > 1 - 3*min_af, so the loop stops after one iteration; there is no smaller subset
+        // to test (chi stays 0, basetype.cpp:146-151) and the log-likelihood sum is never read.
+        const int b = act & 3;
+        o.m = 1; o.first = b; o.chi2 = 0.; o.em_iters = 1; o.n_em = 1;
+        if (b != ref_code) { o.n_alt = 1; o.alt_packed = b; o.af[0] = 1.0; }
+        return;
+    }
     const double n_cov = (double)total;
     const int m0 = m;
     const int first_c = (NW > 0) ? wave : 0, step_c = (NW > 0) ? NW : 1;

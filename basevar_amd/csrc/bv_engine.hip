@@ -253,7 +253,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
 
     BvPass1Args a1;
     a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = slab->n_sites;
-    a1.n_samples = slab->n_samples; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
+    a1.n_samples = slab->n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
     a1.var_list = e->d_var_list; a1.counters = e->d_counters;
     if (e->ring_count == bv_engine::kRing) {
         int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
@@ -293,6 +293,8 @@ int bv_engine_wait(bv_engine *e) {
     if (!e->submitted) return BV_OK;
     BV_HIP(e, hipSetDevice(e->cfg.device));
     BV_HIP(e, hipStreamSynchronize(e->last_stream));
+    if (e->h_counters[3] != 0)
+        return fail(e, BV_ERR_HIP, "pass 1: an intra-workgroup hand-off timed out (internal error; results invalid)");
     if (e->h_counters[1] > 0) {
         char buf[160];
         std::snprintf(buf, sizeof buf,

@@ -11,11 +11,14 @@ struct BvPass1Args {
     uint64_t pitch;
     uint32_t n_sites;
     uint32_t n_samples;
+    uint32_t flags;           // BV_FLAG_*
     double min_af;
     const BvTables *tables;
     bv_site_result *out;      // [n_sites]
     uint32_t *var_list;       // [n_sites]  indices of BV_SITE_VARIANT sites (unordered)
-    uint32_t *counters;       // [0] = number of variant sites, [1] = sites with BV_SITE_ZERO_FREQ
+    uint32_t *counters;       // [0] = number of variant sites, [1] = sites with BV_SITE_ZERO_FREQ,
+                              // [2] = pass-1 site ticket counter, [3] = pipeline time-out flag
+                              // (all zeroed before the launch)
 };
 
 struct BvPass2Args {

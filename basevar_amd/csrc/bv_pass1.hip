@@ -1,41 +1,72 @@
 // bv_pass1.hip -- pass 1 of the per-site basetype path: tally + solve, every site.
 //
-// One workgroup owns one site (row of the slab).  Its waves stream the row's two byte
-// planes with 16-byte coalesced loads along the sample axis (2 B / cell, read exactly
-// once), tally covered cells into a 4 KiB LDS histogram over (strand, base, phred) with
-// LDS atomics, and then run the whole reference solver on that histogram:
+// Wave-specialised, persistent workgroups.  A workgroup is NTALLY tally waves + NSOLVE solver
+// waves:
+//
+//   tally waves  stream one site (one slab row) after another, the row's 4 KiB blocks dealt
+//                round-robin to the NTALLY waves: 16-byte coalesced, non-temporal loads of the
+//                two byte planes along the sample axis (2 B/cell, each byte read exactly once),
+//                software-pipelined (16 KiB in flight per wave), covered cells tallied with LDS
+//                atomics into a (strand, base, phred) histogram -- 8 KiB, one of a small ring.
+//   solver wave  takes a finished histogram and runs the whole reference solver on it
+//                (cites below), writes the site's 208-byte record, re-zeroes the histogram
+//                and hands it back.
+//
+// The roles meet only through LDS sequence flags (published[] / filled[] / drained[]), never
+// through s_barrier, so the HBM stream of site k+1 runs under the FP64 dependency chains of site k.
+// (A first version that tallied and then solved with the same waves ran both phases in
+// lock-step across the workgroups of a CU and reached 39 % of HBM peak; its tally alone
+// ran at 75 %.  See DESIGN.md.)
+//
+// Reference functions realised here, all on the histogram:
 //   BaseType ctor counts        src/basetype.cpp:45-71      -> depth[], total_depth
 //   strand_bias (CVG flavour)   src/basetype.cpp:244-295    via caller.cpp:1236-1245
 //   lrt(): EM / LRT / AF / QUAL src/basetype.cpp:130-199, src/algorithm.h:148-255
 //   strand_bias (VCF flavour)   caller.cpp:1164
 //   base-quality rank sum       src/basetype.cpp:201-242 via caller.cpp:1157
 //   QD, CM_CAF                  caller.cpp:1122, 1160-1161
-// The kernel is HBM-bound by design (no inter-site reuse, so no XCD-aware remap is needed:
-// nothing is shared between workgroups).  No MFMA: categorical tallies + small FP64 tables.
+// HBM-bound by design; no inter-site reuse, so nothing to gain from an XCD-aware block
+// remap (no two workgroups share a byte).  No MFMA: categorical tallies + small FP64 tables.
 #include "bv_kernels.h"
 
-struct __attribute__((aligned(16))) BvSiteShared {
-    uint32_t hist[BV_HIST_WORDS];        // [(rev<<2)|base][phred]
+#define BV_H2_ROWQ 256                         /* phred axis: the raw phred byte indexes the row */
+#define BV_H2_WORDS (BV_ROWS * BV_H2_ROWQ)     /* 2048 x u32 = 8 KiB per histogram               */
+
+struct BvSolverShared {
     uint32_t bin_code[BV_SLOTS * BV_WAVE];  // compacted non-empty (base<<7 | phred) bins
     uint32_t bin_cnt[BV_SLOTS * BV_WAVE];
-    uint32_t fwd[4], rev[4];
-    uint32_t nb, badq;
-    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];  // LDS copy of BvTables
     BvLrtShared lrt;
-    bv_site_result res;                  // staged record, stored with one coalesced write
+    bv_site_result res;                     // staged record, stored with one coalesced write
 };
 
-// ---- tally of one 16-cell chunk (one lane's 16 B of each plane)
-__device__ __forceinline__ void bv_tally_dword(uint32_t w, uint32_t qq, uint32_t *hist) {
-    qq &= 0x7F7F7F7Fu;  // keep the histogram index inside its 128-wide row whatever the input
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t c = (w >> (8 * j)) & 0xFFu;
-        if (!(c & BV_CELL_NOCALL)) {
-            uint32_t idx = ((c & 7u) << 7) | ((qq >> (8 * j)) & 0xFFu);
-            atomicAdd(&hist[idx], 1u);  // ds_add_u32, no return
-        }
-    }
+template <int NBUF, int NSOLVE>
+struct __attribute__((aligned(16))) BvPass1Shared {
+    uint32_t hist[NBUF][BV_H2_WORDS];  // ring of histograms [(rev<<2)|base][phred byte]
+    uint32_t published[NBUF];          // times a site has been assigned to the slot (lead tally wave)
+    uint32_t filled[NBUF];             // tally-wave arrivals on the slot (NTALLY per fill)
+    uint32_t drained[NBUF];            // times the slot has been solved and re-zeroed
+    uint32_t site_of[NBUF];            // site held by the slot (0xFFFFFFFF = no more work)
+    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];  // LDS copy of BvTables
+    BvSolverShared sv[NSOLVE];
+};
+
+// ------------------------------------------------------------------------------ tally
+// One cell = one byte of each plane.  v_perm_b32 glues the call byte and the phred byte into
+// X = call << 8 | phred; covered calls are 0..7, so X < 0x800 is the coverage test and X
+// is directly the histogram word index: 3 VALU + 1 ds_add_u32 per cell, and no phred byte can
+// index outside its 256-wide row.
+template <int J>
+__device__ __forceinline__ void bv_tally_cell(uint32_t w, uint32_t qq, uint32_t *hist, uint32_t one) {
+    // selector bytes: result byte0 = qq.byte[J] (S1 is bytes 0-3), byte1 = w.byte[J] (S0 is 4-7)
+    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
+    uint32_t x = __builtin_amdgcn_perm(w, qq, SEL);
+    if (x < 0x800u) atomicAdd(&hist[x], one);  // ds_add_u32, no return
+}
+__device__ __forceinline__ void bv_tally_dword(uint32_t w, uint32_t qq, uint32_t *hist, uint32_t one) {
+    bv_tally_cell<0>(w, qq, hist, one);
+    bv_tally_cell<1>(w, qq, hist, one);
+    bv_tally_cell<2>(w, qq, hist, one);
+    bv_tally_cell<3>(w, qq, hist, one);
 }
 
 // cells at or beyond n_samples in the row's last chunk are forced to 'N'
@@ -46,160 +77,187 @@ __device__ __forceinline__ uint32_t bv_mask_tail_dword(uint32_t w, int keep) {
     return (w & low) | (0x08080808u & ~low);
 }
 
-template <int NT>
-__device__ __forceinline__ void bv_tally_row(const uint8_t *bs_row, const uint8_t *q_row, uint32_t n_samples,
-                                             uint32_t *hist, int tid) {
+// One wave streams one row, software-pipelined: two register sets of U chunks per plane, the
+// loads of the next set are in flight (16 KiB per wave) while the current set is tallied.
+#define BV_TALLY_U 4
+struct BvChunkSet {
+    bv_u32x4 vb[BV_TALLY_U], vq[BV_TALLY_U];
+};
+__device__ __forceinline__ void bv_chunks_load(BvChunkSet &c, const bv_u32x4 *b4, const bv_u32x4 *q4, uint32_t base,
+                                               uint32_t n_chunks, int lane) {
+#pragma unroll
+    for (int u = 0; u < BV_TALLY_U; ++u) {
+        uint32_t idx = base + u * BV_WAVE + lane;
+        if (idx < n_chunks) {
+            c.vb[u] = __builtin_nontemporal_load(b4 + idx);
+            c.vq[u] = __builtin_nontemporal_load(q4 + idx);
+        } else {
+            c.vb[u] = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+            c.vq[u] = bv_u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+}
+__device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, uint32_t n_chunks, int tail, int lane,
+                                                uint32_t *hist, uint32_t one) {
+#pragma unroll
+    for (int u = 0; u < BV_TALLY_U; ++u) {
+        uint32_t idx = base + u * BV_WAVE + lane;
+        if (tail && idx == n_chunks - 1) {
+            c.vb[u].x = bv_mask_tail_dword(c.vb[u].x, tail);
+            c.vb[u].y = bv_mask_tail_dword(c.vb[u].y, tail - 4);
+            c.vb[u].z = bv_mask_tail_dword(c.vb[u].z, tail - 8);
+            c.vb[u].w = bv_mask_tail_dword(c.vb[u].w, tail - 12);
+        }
+        bv_tally_dword(c.vb[u].x, c.vq[u].x, hist, one);
+        bv_tally_dword(c.vb[u].y, c.vq[u].y, hist, one);
+        bv_tally_dword(c.vb[u].z, c.vq[u].z, hist, one);
+        bv_tally_dword(c.vb[u].w, c.vq[u].w, hist, one);
+    }
+}
+template <int NTALLY>
+__device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const uint8_t *q_row, uint32_t n_samples,
+                                                  uint32_t *hist, int t, int lane) {
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(bs_row);
     const bv_u32x4 *q4 = reinterpret_cast<const bv_u32x4 *>(q_row);
     const uint32_t n_chunks = (n_samples + 15u) >> 4;
     const int tail = (int)(n_samples & 15u);
-#ifndef BV_TALLY_U
-#define BV_TALLY_U 4
+    constexpr uint32_t BLK = BV_WAVE * BV_TALLY_U;  // chunks per wave-iteration (4 KiB of each plane)
+    constexpr uint32_t STRIDE = BLK * NTALLY;       // the row's blocks go round-robin over the tally waves
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));  // opaque: not re-materialised per cell
+    BvChunkSet A, B;
+    uint32_t base = (uint32_t)t * BLK;
+    bv_chunks_load(A, b4, q4, base, n_chunks, lane);
+    for (; base < n_chunks; base += 2 * STRIDE) {
+        bv_chunks_load(B, b4, q4, base + STRIDE, n_chunks, lane);
+        bv_chunks_tally(A, base, n_chunks, tail, lane, hist, one);
+        bv_chunks_load(A, b4, q4, base + 2 * STRIDE, n_chunks, lane);
+        bv_chunks_tally(B, base + STRIDE, n_chunks, tail, lane, hist, one);
+    }
+}
+
+// ------------------------------------------------------------------------------ solver
+// strand/base row sums and deterministic compaction of the non-empty (base, phred) bins
+__device__ __forceinline__ void bv_prologue_wave(const uint32_t *hist, BvSolverShared *sv, int lane, uint32_t fwd[4],
+                                                 uint32_t rev[4], uint32_t *nb_out, uint32_t *badq_out) {
+    uint32_t nb = 0;
+    bool bad = false;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        uint32_t facc = 0, racc = 0;
+#pragma unroll
+        for (int qr = 0; qr < 4; ++qr) {  // four 64-wide quarters of the 256-wide phred axis
+            const int q = (qr << 6) | lane;
+            uint32_t f = hist[(b << 8) | q], v = hist[((b | 4) << 8) | q];
+            facc += f;
+            racc += v;
+            uint32_t c = f + v;
+            bad |= (c != 0) && (q >= BV_NQ_VALID);
+            if (qr < 2) {  // phred 0..127 hold every valid bin
+                bool valid = (c != 0) && (q < BV_NQ_VALID);
+                unsigned long long m = __ballot(valid);
+                uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (valid) {
+                    sv->bin_code[pos] = ((uint32_t)b << 7) | (uint32_t)q;
+                    sv->bin_cnt[pos] = c;
+                }
+                nb += (uint32_t)__popcll(m);
+            }
+        }
+        fwd[b] = bv_wave_sum_u32(facc);
+        rev[b] = bv_wave_sum_u32(racc);
+    }
+    *nb_out = nb;
+    *badq_out = (__ballot(bad) != 0ull) ? 1u : 0u;
+}
+
+// what the solver needs from the launch arguments (passed by value, in registers)
+struct BvSolveArgs {
+    const uint8_t *ref_base;
+    bv_site_result *out;
+    uint32_t *var_list;
+    uint32_t *counters;
+    double min_af;
+    uint32_t flags;
+};
+
+#define BV_LDS __attribute__((address_space(3)))
+
+// Everything the reference computes for one site, from its histogram, on one wave.
+// Register-pressure note: this body sits inside the persistent loop of the kernel.  With
+// MachineLICM enabled, every libm polynomial constant of log/exp is hoisted out of that loop
+// and kept live around it -> 240 VGPRs, 2 waves/SIMD.  This file is therefore compiled with
+// `-mllvm -disable-machine-licm` (see Makefile): 121 VGPRs, 4 waves/SIMD.  (A noinline call
+// is no way out: device functions are register-allocated without an occupancy target.)
+#ifndef BV_SOLVER_ATTR
+#define BV_SOLVER_ATTR __forceinline__
 #endif
-    constexpr int U = BV_TALLY_U;  // 2*U x 16-byte loads in flight per lane
-    for (uint32_t base = 0; base < n_chunks; base += NT * U) {
-        bv_u32x4 vb[U], vq[U];
+__device__ BV_SOLVER_ATTR void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
+                                                             BV_LDS const uint32_t *hist_l, BV_LDS BvSolverShared *sv_l,
+                                                             BV_LDS const double *tab_hit_l,
+                                                             BV_LDS const double *tab_miss_l, int lane) {
+    const uint32_t *hist = (const uint32_t *)hist_l;
+    BvSolverShared *sv = (BvSolverShared *)sv_l;
+    const double *tab_hit = (const double *)tab_hit_l, *tab_miss = (const double *)tab_miss_l;
+    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+    uint32_t *res_words = reinterpret_cast<uint32_t *>(&sv->res);
+    if (lane < REC_WORDS) res_words[lane] = 0u;
+
+    uint32_t fwd[4], rev[4], depth[4], nb, badq, total = 0;
+    bv_prologue_wave(hist, sv, lane, fwd, rev, &nb, &badq);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t idx = base + u * NT + tid;
-            if (idx < n_chunks) {
-                vb[u] = __builtin_nontemporal_load(b4 + idx);
-                vq[u] = __builtin_nontemporal_load(q4 + idx);
-            } else {
-                vb[u] = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
-                vq[u] = bv_u32x4{0u, 0u, 0u, 0u};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            uint32_t idx = base + u * NT + tid;
-            if (tail && idx == n_chunks - 1) {
-                vb[u].x = bv_mask_tail_dword(vb[u].x, tail);
-                vb[u].y = bv_mask_tail_dword(vb[u].y, tail - 4);
-                vb[u].z = bv_mask_tail_dword(vb[u].z, tail - 8);
-                vb[u].w = bv_mask_tail_dword(vb[u].w, tail - 12);
-            }
-            bv_tally_dword(vb[u].x, vq[u].x, hist);
-            bv_tally_dword(vb[u].y, vq[u].y, hist);
-            bv_tally_dword(vb[u].z, vq[u].z, hist);
-            bv_tally_dword(vb[u].w, vq[u].w, hist);
-        }
+    for (int b = 0; b < 4; ++b) {
+        depth[b] = fwd[b] + rev[b];
+        total += depth[b];
     }
-}
+    bv_lrt_sync<0>();  // bin_code / bin_cnt / res zeroing visible to every lane
+    int ref = a.ref_base[site];
+    if (ref > 4) ref = 4;
+    const double qnan = __builtin_nan("");
 
-// ---- wave 0: strand/base row sums and deterministic compaction of non-empty bins
-__device__ __forceinline__ void bv_prologue_wave(BvSiteShared *sh, int lane) {
-    uint32_t nb = 0, badq = 0;
-    uint32_t fwd[4], rev[4];
+    if (a.flags & BV_FLAG_TALLY_ONLY) {  // diagnostic: streaming part only
+        if (lane == 0) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int b = r >> 1;
-        const int q = ((r & 1) << 6) | lane;
-        uint32_t f = sh->hist[(b << 7) | q], v = sh->hist[((b | 4) << 7) | q];
-        uint32_t fs = bv_wave_sum_u32(f), rs = bv_wave_sum_u32(v);
-        if (r & 1) { fwd[b] += fs; rev[b] += rs; } else { fwd[b] = fs; rev[b] = rs; }
-        uint32_t c = f + v;
-        bool valid = (c != 0) && (q < BV_NQ_VALID);
-        bool bad = (c != 0) && (q >= BV_NQ_VALID);
-        unsigned long long m = __ballot(valid);
-        uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (valid) {
-            sh->bin_code[pos] = ((uint32_t)b << 7) | (uint32_t)q;
-            sh->bin_cnt[pos] = c;
+            for (int b = 0; b < 4; ++b) sv->res.depth[b] = depth[b];
+            sv->res.total_depth = total;
         }
-        nb += (uint32_t)__popcll(m);
-        badq |= (__ballot(bad) != 0ull) ? 1u : 0u;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { sh->fwd[b] = fwd[b]; sh->rev[b] = rev[b]; }
-        sh->nb = nb;
-        sh->badq = badq;
-    }
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void bv_pass1_kernel(BvPass1Args a) {
-    __shared__ BvSiteShared sh;
-    constexpr int NW = NT / BV_WAVE;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    for (int i = tid; i < BV_QBINS; i += NT) {
-        sh.tab_hit[i] = a.tables->hit[i];
-        sh.tab_miss[i] = a.tables->miss[i];
-    }
-    // one site per workgroup (no grid-stride loop: a loop around the whole body lets LICM hoist
-    // every libm polynomial constant of the solver into registers that then stay live across
-    // the streaming phase and cost it its occupancy)
-    const uint32_t site = blockIdx.x;
-    {
-        // ---- clear the histogram and the staged record
-        {
-            uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist);
-            for (int i = tid; i < BV_HIST_WORDS / 4; i += NT) h4[i] = make_uint4(0, 0, 0, 0);
-            if (tid < (int)(sizeof(bv_site_result) / 4)) reinterpret_cast<uint32_t *>(&sh.res)[tid] = 0u;
-        }
-        __syncthreads();
-
-        // ---- tally: the only HBM traffic of this pass, 2 B per cell
-        bv_tally_row<NT>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, sh.hist, tid);
-        __syncthreads();
-
-        if (wave == 0) bv_prologue_wave(&sh, lane);
-        __syncthreads();
-
-        uint32_t depth[4], fwd[4], rev[4], total = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            fwd[b] = sh.fwd[b];
-            rev[b] = sh.rev[b];
-            depth[b] = fwd[b] + rev[b];
-            total += depth[b];
-        }
-        const int nb = (int)sh.nb;
-        const uint32_t badq = sh.badq;
-        int ref = a.ref_base[site];
-        if (ref > 4) ref = 4;
-
-        if (total == 0) {  // nothing to call: caller.cpp:718 / basetype.cpp:132; record stays zero
-            if (tid == 0) {
-                sh.res.mq_ranksum = sh.res.rpr_ranksum = sh.res.bq_ranksum = __builtin_nan("");
-            }
-            __syncthreads();
-            if (tid < (int)(sizeof(bv_site_result) / 4))
-                reinterpret_cast<uint32_t *>(&a.out[site])[tid] = reinterpret_cast<uint32_t *>(&sh.res)[tid];
-            return;
-        }
-
-        BvBins B;
-        B.code = sh.bin_code; B.cnt = sh.bin_cnt; B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.nb = nb;
-
+    } else if (total == 0) {
+        // nothing to call (caller.cpp:718 / basetype.cpp:132): the record stays zero
+        if (lane == 0) sv->res.mq_ranksum = sv->res.rpr_ranksum = sv->res.bq_ranksum = qnan;
+    } else {
         uint32_t flags = BV_SITE_COVERED | (badq ? BV_SITE_BAD_QUAL : 0u);
 
-        // ---- CVG strand bias: alt = every non-ref ACGT base (caller.cpp:1236-1245).
-        // Runs on wave 1 while wave 0 does the top-level EM.
-        if (wave == (NW > 1 ? 1 : 0)) {
+        // ---- CVG strand bias: alt = every non-ref ACGT base (caller.cpp:1236-1245)
+        if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
             uint32_t rf = 0, rr = 0, af = 0, ar = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
                 if (b == ref) { rf += fwd[b]; rr += rev[b]; } else { af += fwd[b]; ar += rev[b]; }
             }
             double fs, sor;
-            uint32_t fl = 0;
-            bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &fl);
+            bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &flags);
             if (lane == 0) {
-                sh.res.cvg_sb[0] = rf; sh.res.cvg_sb[1] = rr; sh.res.cvg_sb[2] = af; sh.res.cvg_sb[3] = ar;
-                sh.res.cvg_fs = fs;
-                sh.res.cvg_sor = sor;
-                if (fl) atomicOr(&sh.res.status, fl);
+                sv->res.cvg_sb[0] = rf; sv->res.cvg_sb[1] = rr; sv->res.cvg_sb[2] = af; sv->res.cvg_sb[3] = ar;
+                sv->res.cvg_fs = fs;
+                sv->res.cvg_sor = sor;
             }
         }
 
         // ---- lrt() over ACGT (basetype.h:115)
+        BvBins B;
+        B.code = sv->bin_code; B.cnt = sv->bin_cnt; B.hit = tab_hit; B.miss = tab_miss; B.nb = (int)nb;
         BvLrtOut L;
-        bv_lrt<NW>(B, depth, total, /*A,C,G,T*/ 0 | (1 << 3) | (2 << 6) | (3 << 9), 4, ref, a.min_af, &sh.lrt, wave, lane, L);
+        // bases that hold a phred-0 call (1 - eps == 0): they keep the generic EM path, because the
+        // reference's 0/0 there yields NaN frequencies that must be reproduced
+        uint32_t q0_mask = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if (hist[b << 8] + hist[(b | 4) << 8]) q0_mask |= 1u << b;
+        bv_lrt<0>(B, depth, total, /*A,C,G,T*/ 0 | (1 << 3) | (2 << 6) | (3 << 9), (a.flags & BV_FLAG_SKIP_LRT) ? 0 : 4, ref,
+                  a.min_af, &sv->lrt, 0, lane, L, q0_mask);
         if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
 
+        double bq_ranksum = qnan;
         if (L.n_alt > 0) {
             flags |= BV_SITE_VARIANT;
             uint32_t alt_mask = 0, ad_sum_u = 0;
@@ -211,7 +269,7 @@ __global__ __launch_bounds__(NT) void bv_pass1_kernel(BvPass1Args a) {
                 }
             }
             // QUAL / QD / AF / CAF (basetype.cpp:180-196, caller.cpp:1113-1122, 1160-1161)
-            if (wave == 0 && lane == 0) {
+            {
                 double r = (double)bv_sel4u(depth, L.first) / (double)total;
                 double qual;
                 if (L.m == 1 && total > 10 && r > 0.5) qual = 5000.0;
@@ -222,19 +280,23 @@ __global__ __launch_bounds__(NT) void bv_pass1_kernel(BvPass1Args a) {
                     if (k < L.n_alt) {
                         const uint32_t d = bv_sel4u(depth, bv_alt_at(L, k));
                         ad_sum = ad_sum + (double)d;
-                        sh.res.alt[k] = (uint8_t)bv_alt_at(L, k);
-                        sh.res.af[k] = L.af[k];
-                        sh.res.caf[k] = (double)d / (int)total;
+                        if (lane == 0) {
+                            sv->res.alt[k] = (uint8_t)bv_alt_at(L, k);
+                            sv->res.af[k] = L.af[k];
+                            sv->res.caf[k] = (double)d / (int)total;
+                        }
                     }
                 }
                 double qd = qual / ad_sum;
                 if (qd == 0) qd = 0.0;
-                sh.res.n_alt = (uint8_t)L.n_alt;
-                sh.res.qual = qual;
-                sh.res.qd = qd;
+                if (lane == 0) {
+                    sv->res.n_alt = (uint8_t)L.n_alt;
+                    sv->res.qual = qual;
+                    sv->res.qd = qd;
+                }
             }
             // VCF strand bias w.r.t. the chosen ALTs (caller.cpp:1164)
-            if (wave == (1 % NW)) {
+            {
                 uint32_t rf = 0, rr = 0, af = 0, ar = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -242,17 +304,15 @@ __global__ __launch_bounds__(NT) void bv_pass1_kernel(BvPass1Args a) {
                     else if ((alt_mask >> b) & 1u) { af += fwd[b]; ar += rev[b]; }
                 }
                 double fs, sor;
-                uint32_t fl = 0;
-                bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &fl);
+                bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &flags);
                 if (lane == 0) {
-                    sh.res.var_sb[0] = rf; sh.res.var_sb[1] = rr; sh.res.var_sb[2] = af; sh.res.var_sb[3] = ar;
-                    sh.res.var_fs = fs;
-                    sh.res.var_sor = sor;
-                    if (fl) atomicOr(&sh.res.status, fl);
+                    sv->res.var_sb[0] = rf; sv->res.var_sb[1] = rr; sv->res.var_sb[2] = af; sv->res.var_sb[3] = ar;
+                    sv->res.var_fs = fs;
+                    sv->res.var_sor = sor;
                 }
             }
             // base-quality rank sum from the histogram this pass already holds (caller.cpp:1157)
-            if (wave == (2 % NW)) {
+            {
                 unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
                 unsigned long long below = 0, twoR = 0;
 #pragma unroll
@@ -261,48 +321,174 @@ __global__ __launch_bounds__(NT) void bv_pass1_kernel(BvPass1Args a) {
                     uint32_t rv = 0, av = 0;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        uint32_t c = sh.hist[(b << 7) | q] + sh.hist[((b | 4) << 7) | q];
+                        uint32_t c = hist[(b << 8) | q] + hist[((b | 4) << 8) | q];
                         if (b == ref) rv += c;
                         else if ((alt_mask >> b) & 1u) av += c;
                     }
                     twoR += bv_ranksum_window(rv, av, n1 + n2, below, lane);
                 }
-                double ph = bv_ranksum_phred(twoR, n1, n2);
-                if (lane == 0) sh.res.bq_ranksum = ph;
+                bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
             }
         }
-        if (tid == 0) {
+        if (lane == 0) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) sh.res.depth[b] = depth[b];
-            sh.res.total_depth = total;
-            atomicOr(&sh.res.status, flags);
-            sh.res.chi2 = L.chi2;
-            sh.res.em_iters = (uint16_t)L.em_iters;
-            sh.res.n_em = (uint8_t)L.n_em;
-            sh.res.mq_ranksum = __builtin_nan("");
-            sh.res.rpr_ranksum = __builtin_nan("");
-            if (L.n_alt == 0) sh.res.bq_ranksum = __builtin_nan("");
+            for (int b = 0; b < 4; ++b) sv->res.depth[b] = depth[b];
+            sv->res.total_depth = total;
+            sv->res.status = flags;
+            sv->res.chi2 = L.chi2;
+            sv->res.em_iters = (uint16_t)L.em_iters;
+            sv->res.n_em = (uint8_t)L.n_em;
+            sv->res.mq_ranksum = qnan;
+            sv->res.rpr_ranksum = qnan;
+            sv->res.bq_ranksum = bq_ranksum;
             if (L.n_alt > 0) {
                 uint32_t slot = atomicAdd(&a.counters[0], 1u);
                 a.var_list[slot] = site;
             }
             if (L.zero_freq) atomicAdd(&a.counters[1], 1u);
         }
-        __syncthreads();
-        if (tid < (int)(sizeof(bv_site_result) / 4))
-            reinterpret_cast<uint32_t *>(&a.out[site])[tid] = reinterpret_cast<uint32_t *>(&sh.res)[tid];
+    }
+    bv_lrt_sync<0>();
+    if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&a.out[site])[lane] = res_words[lane];
+}
+
+// ------------------------------------------------------------------------------ kernel
+// Every spin is bounded (~1 s): a protocol bug must end the kernel with counters[3] set
+// (reported by bv_engine_wait) instead of hanging the GPU.
+__device__ __forceinline__ void bv_wait_flag(const uint32_t *flag, uint32_t want, uint32_t *err) {
+    uint32_t spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1u << 23)) {
+            atomicOr(err, 1u);
+            break;
+        }
+    }
+}
+__device__ __forceinline__ void bv_set_flag(uint32_t *flag, uint32_t v) {
+    __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// one arrival per WAVE (lane 0 only; the wave's earlier LDS atomics are ahead of it in the
+// in-order LDS queue)
+__device__ __forceinline__ void bv_add_flag(uint32_t *flag, int lane) {
+    if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int NTALLY, int NSOLVE>
+__global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 ? 4 : ((NTALLY + NSOLVE) <= 8 ? 2 : 1) * ((NTALLY + NSOLVE + 3) / 4)) void bv_pass1_kernel(BvPass1Args a) {
+    constexpr int NT = BV_WAVE * (NTALLY + NSOLVE);
+    constexpr int NBUF = NSOLVE + 2;  // the tally may run two sites ahead of a slow (variant-site) solve
+    __shared__ BvPass1Shared<NBUF, NSOLVE> sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // one-time set-up by the whole workgroup: zero the ring, copy the phred tables
+    {
+        uint4 *h4 = reinterpret_cast<uint4 *>(&sh.hist[0][0]);
+        for (int i = tid; i < NBUF * BV_H2_WORDS / 4; i += NT) h4[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < BV_QBINS; i += NT) {
+            sh.tab_hit[i] = a.tables->hit[i];
+            sh.tab_miss[i] = a.tables->miss[i];
+        }
+        if (tid < NBUF) {
+            sh.published[tid] = 0u;
+            sh.filled[tid] = 0u;
+            sh.drained[tid] = 0u;
+        }
+    }
+    __syncthreads();
+
+    // Sites are handed out by a global ticket counter (a.counters[2], zeroed by the engine before
+    // the launch): a workgroup that drew cheap hom-ref sites simply draws more, so the persistent
+    // grid drains evenly whatever the batch size.  Which workgroup solves a site has no influence
+    // on the site's record, so results stay bit-reproducible.
+    if (wave < NTALLY) {
+        // ------------------------------------------------ tally waves (wave 0 leads)
+        // (s_setprio(3) for this role was measured: 2 % slower, so priorities stay equal.)
+        uint32_t next = 0;
+        if (wave == 0 && lane == 0) next = atomicAdd(&a.counters[2], 1u);
+        for (uint32_t k = 0;; ++k) {
+            const uint32_t buf = k % NBUF, gen = k / NBUF;
+            uint32_t site;
+            if (wave == 0) {
+                site = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+                if (site >= a.n_sites) site = 0xFFFFFFFFu;
+                bv_wait_flag(&sh.drained[buf], gen, &a.counters[3]);  // the solver has re-zeroed this slot
+                if (lane == 0) sh.site_of[buf] = site;
+                bv_set_flag(&sh.published[buf], gen + 1u);
+                if (site != 0xFFFFFFFFu && lane == 0)
+                    next = atomicAdd(&a.counters[2], 1u);  // in flight under this row's stream
+            } else {
+                bv_wait_flag(&sh.published[buf], gen + 1u, &a.counters[3]);
+                site = sh.site_of[buf];
+            }
+            if (site == 0xFFFFFFFFu) {
+                // end of work: this slot is the first solver's marker; the leader adds the others
+                bv_add_flag(&sh.filled[buf], lane);
+                if (wave == 0) {
+                    for (int j = 1; j < NSOLVE; ++j) {
+                        const uint32_t kk = k + j, b2 = kk % NBUF, g2 = kk / NBUF;
+                        bv_wait_flag(&sh.drained[b2], g2, &a.counters[3]);
+                        if (lane == 0) sh.site_of[b2] = 0xFFFFFFFFu;
+                        bv_set_flag(&sh.filled[b2], (g2 + 1u) * NTALLY);
+                    }
+                }
+                break;
+            }
+            bv_tally_row_wave<NTALLY>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples,
+                                      sh.hist[buf], wave, lane);
+            bv_add_flag(&sh.filled[buf], lane);  // release: this wave's ds_add of the row are done
+        }
+    } else {
+        // ------------------------------------------------ solver waves
+        const int s = wave - NTALLY;
+        BvSolveArgs sa;
+        sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
+        sa.min_af = a.min_af; sa.flags = a.flags;
+        for (uint32_t k = (uint32_t)s;; k += NSOLVE) {
+            const uint32_t buf = k % NBUF, gen = k / NBUF;
+            bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[3]);
+            const uint32_t site = sh.site_of[buf];
+            if (site == 0xFFFFFFFFu) break;
+            bv_solve_site_wave(sa, site, (BV_LDS const uint32_t *)sh.hist[buf], (BV_LDS BvSolverShared *)&sh.sv[s],
+                               (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
+            // hand the slot back, zeroed
+            uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[buf]);
+#pragma unroll
+            for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+            bv_set_flag(&sh.drained[buf], gen + 1u);
+        }
     }
 }
 
+template <int NTALLY, int NSOLVE>
+static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
+    // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
+    // never more than there are sites.
+    uint32_t grid = 256u * (16u / (NTALLY + NSOLVE));
+    if (grid > a.n_sites) grid = a.n_sites;
+    hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
+}
+
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
-    // team size by row length: one wave per site for short rows, 4 or 16 waves for long ones
-    const uint32_t n = a.n_samples;
-    uint32_t grid = a.n_sites;
-    if (n <= 16384u) {
-        hipLaunchKernelGGL(bv_pass1_kernel<64>, dim3(grid), dim3(64), 0, stream, a);
-    } else if (n <= 400000u) {
-        hipLaunchKernelGGL(bv_pass1_kernel<256>, dim3(grid), dim3(256), 0, stream, a);
+    // bits 8-11 of the flags select a workgroup shape for tuning runs (0 = default by row length)
+    const uint32_t shape = (a.flags >> 8) & 0xFu;
+    switch (shape) {
+        case 1: return bv_launch_pass1_cfg<3, 1>(a, stream);
+        case 2: return bv_launch_pass1_cfg<3, 2>(a, stream);
+        case 3: return bv_launch_pass1_cfg<2, 2>(a, stream);
+        case 4: return bv_launch_pass1_cfg<4, 2>(a, stream);
+        case 5: return bv_launch_pass1_cfg<2, 1>(a, stream);
+        case 6: return bv_launch_pass1_cfg<1, 3>(a, stream);
+        case 7: return bv_launch_pass1_cfg<1, 1>(a, stream);
+        case 8: return bv_launch_pass1_cfg<6, 2>(a, stream);
+        default: break;
+    }
+    if (a.n_samples > 24576u) {
+        // long rows: several tally waves share a row (short per-site latency => short tail)
+        bv_launch_pass1_cfg<3, 1>(a, stream);
     } else {
-        hipLaunchKernelGGL(bv_pass1_kernel<1024>, dim3(grid), dim3(1024), 0, stream, a);
+        // short rows: solve-bound -> 3 solver waves per tally wave
+        bv_launch_pass1_cfg<1, 3>(a, stream);
     }
 }

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- genomic sites/s through the basetype engine on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[2], the configuration the metric and the north-star target
+are quoted on): synthetic NIPT-scale pileup, 100,000 samples per site, generated on the
+device.  The 1 M-site job does not fit HBM at once (5 B/cell = 500 GB),
+so it is processed in HBM-resident batches: ONE STEP = one pass of the whole hot path
+(pass 1: tally + EM/LRT/AF/QUAL/strand bias/BaseQRankSum for every site; pass 2: MQ and
+ReadPos rank sums for the variant sites) over one batch of --batch-sites sites, followed
+(N > 1) by the gather of the batch's result records to rank 0 (RCCL over xGMI).
+Inputs are resident in HBM before the timed region starts; several distinct batches are
+cycled so no step re-reads cache-resident data (each batch is >> the 256 MiB Infinity Cache).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (pass 1): algorithmic
+bytes = 2 B/cell (u8 call plane + u8 phred plane) x sites x samples per launch, divided by the
+average launch duration measured with HIP events on the launch stream.  `cpu_baseline` times
+the reference's own code (oracle/_ref, kind "reference"; or the C restatement, kind "port",
+if that library is absent) on the host cores over a bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--samples", type=int, default=100000, help="samples per site (row length)")
+    ap.add_argument("--batch-sites", type=int, default=8192, help="sites per step and per GPU")
+    ap.add_argument("--coverage", type=float, default=0.08)
+    ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--no-rank-planes", action="store_true", help="omit mapq/rpr planes (pass 2 skipped)")
+    ap.add_argument("--cpu-sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0xBA5E7A7)
+    ap.add_argument("--tally-only", action="store_true", help="diagnostic: time pass 1 without its solver")
+    ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
+    return ap.parse_args()
+
+
+def cpu_baseline(torch, planes, n_samples, maf, want_sites):
+    """Times the reference's per-site path on the host cores over rows copied back from HBM."""
+    import numpy as np
+    import oracle
+    try:
+        oracle.build(with_ref=True)
+    except Exception as ex:  # the prebuilt libraries travel with the repo; a rebuild is optional
+        print("[bench] oracle build skipped: %s" % ex, file=sys.stderr)
+    if oracle.ref_available():
+        chk, kind = oracle.Reference(), "reference"
+    else:
+        chk, kind = oracle.Restatement(), "port"
+    cores = len(os.sched_getaffinity(0))
+    threads = max(1, min(cores, 64))
+    bs, q, mq, rp, ref = planes
+    S = bs.shape[0]
+
+    def sub(k):
+        idx = np.linspace(0, S - 1, num=k).astype(np.int64)  # spread over the 20-site class cycle
+        ti = torch.from_numpy(idx).to(bs.device)
+        d = {"base_strand": bs[ti].cpu().numpy(), "qual": q[ti].cpu().numpy(), "ref_base": ref[ti].cpu().numpy(),
+             "n_samples": n_samples}
+        if mq is not None:
+            d["mapq"] = mq[ti].cpu().numpy()
+            d["rpr"] = rp[ti].cpu().numpy().view(np.uint16)
+        return d
+
+    # pilot to size the sample to ~15 s of CPU work
+    pilot = sub(threads)
+    t0 = time.perf_counter()
+    chk.run(pilot, maf, n_threads=threads)
+    dt = time.perf_counter() - t0
+    per_site_cpu_s = dt  # one site per thread in parallel: wall == cpu-seconds per site
+    n = want_sites or int(max(threads * 2, min(S, 15.0 / max(per_site_cpu_s, 1e-6))))
+    n = max(threads, (n // threads) * threads)
+    d = sub(n)
+    t0 = time.perf_counter()
+    chk.run(d, maf, n_threads=threads)
+    wall = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    one = sub(max(8, min(64, n // threads)))
+    chk.run(one, maf, n_threads=1)
+    wall1 = time.perf_counter() - t0
+    return {
+        "value": n / wall, "unit": "sites/s", "cores": threads, "kind": kind,
+        "sample": "%d of the batch's %d sites (same synthetic rows, copied back from HBM), %d samples/site, "
+                  "%d host threads, static site-range partition; single-thread: %.1f sites/s" % (
+                      n, S, n_samples, threads, one["base_strand"].shape[0] / wall1),
+        "single_thread_value": one["base_strand"].shape[0] / wall1,
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (
+                args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import basevar_amd
+    from basevar_amd.shard import gather_records_sized
+
+    N = args.samples
+    B = args.batch_sites
+    pitch = (N + 255) // 256 * 256
+    maf = basevar_amd.min_af(N)
+    nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    ranks = not args.no_rank_planes
+
+    # ---- synthetic batches, resident in HBM.  Global site index = ((batch * world) + rank) * B + row,
+    # so every rank owns a contiguous site range of every batch (sites shard embarrassingly).
+    batches = []
+    for b in range(nb):
+        bs = torch.empty((B, pitch), dtype=torch.uint8, device=dev)
+        q = torch.empty((B, pitch), dtype=torch.uint8, device=dev)
+        mq = torch.empty((B, pitch), dtype=torch.uint8, device=dev) if ranks else None
+        rp = torch.empty((B, pitch), dtype=torch.int16, device=dev) if ranks else None
+        ref = torch.empty(B, dtype=torch.uint8, device=dev)
+        basevar_amd.synth_fill(local_rank, B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(),
+                               mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0, seed=args.seed,
+                               site_offset=(b * world + rank) * B, coverage=args.coverage)
+        batches.append((bs, q, mq, rp, ref))
+    torch.cuda.synchronize()
+
+    eng = basevar_amd.BaseTypeEngine(max_sites=B, min_af_value=maf, device=local_rank,
+                                     flags=(1 if args.tally_only else 0) | args.flags)
+    rec = basevar_amd.SITE_DTYPE.itemsize
+    out = torch.zeros(B * rec, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+    sizes = [B * rec] * world
+
+    def step(i):
+        bs, q, mq, rp, ref = batches[i % nb]
+        eng.submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                        mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0, stream=stream.cuda_stream)
+        if world > 1:
+            return gather_records_sized(out, sizes, dst=0)  # ordered records on rank 0
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.wait()
+    p1_ms, p2_ms, nsub = eng.timing_get()
+    nvar = eng.last_variant_count()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        sites_per_s = world * B * args.steps / elapsed
+        p1_avg_s = p1_ms / max(nsub, 1) / 1e3
+        p2_avg_s = p2_ms / max(nsub, 1) / 1e3
+        algo_bytes = 2.0 * B * N  # pass 1: u8 call + u8 phred per cell
+        achieved = algo_bytes / p1_avg_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile))
+                key = "pass1_%dx%d" % (B, N)
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "genomic sites/sec through basetype caller at N samples",
+            "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
+                            "HBM-resident batches of %d sites per GPU per step (1M-site job = %d such steps)" % (
+                                N, args.coverage, B, (1000000 + B - 1) // B),
+                "samples": N, "batch_sites": B, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
+                "parallelism": "site-sharded x%d, gather of %d-byte records to rank 0" % (world, rec),
+                "variant_sites_last_batch": nvar,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "bv_pass1_kernel", "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_ms": p1_avg_s * 1e3, "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)
+                line["cpu_baseline"] = cb
+                line["gpu_over_cpu_allcore"] = sites_per_s / cb["value"]
+                line["gpu_over_cpu_1thread"] = sites_per_s / cb["single_thread_value"]
+            except Exception as ex:
+                line["cpu_baseline"] = None
+                print("[bench] cpu_baseline failed: %r" % (ex,), file=sys.stderr)
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

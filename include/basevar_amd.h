@@ -141,11 +141,17 @@ typedef struct bv_group_result {
     double af[BV_MAX_ALT];
 } bv_group_result;
 
+/* diagnostic: pass 1 stops after the tally (depth[] / total_depth only are valid); used by
+ * bench.py --ablate to time the HBM streaming part of pass 1 without the solver */
+#define BV_FLAG_TALLY_ONLY 0x1u
+#define BV_FLAG_SKIP_FISHER 0x2u /* diagnostic: strand-bias Fisher tests return p = 1 */
+#define BV_FLAG_SKIP_LRT 0x4u    /* diagnostic: no EM / LRT (no site is called variant) */
+
 typedef struct bv_engine_config {
     int32_t device;        /* HIP device ordinal                                        */
     uint32_t max_sites;    /* largest n_sites per submit (sizes scratch)                */
     uint32_t max_samples;  /* largest n_samples (host-staging only; 0 = no staging)     */
-    uint32_t flags;        /* reserved, 0                                               */
+    uint32_t flags;        /* BV_FLAG_* bits, normally 0                                */
     double min_af;         /* BaseType ctor arg 2 (basetype.cpp:30): already the        */
                            /* float-rounded value of caller.cpp:122; see bv_min_af()    */
 } bv_engine_config;
