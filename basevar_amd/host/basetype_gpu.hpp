@@ -1,0 +1,188 @@
+// basetype_gpu.hpp -- header-only C++17 host wrapper over the C ABI (include/basevar_amd.h).
+//
+// This is what a maintainer of the reference would include in src/basetype_caller.cpp: it
+// mirrors the per-site interface of the reference, batched.
+//
+//   reference (per site, src/basetype_caller.cpp:742-743, 1113-1164)      here (per batch of sites)
+//   ---------------------------------------------------------------      ---------------------------------
+//   BatchInfo bi; ... fill from batchfile lines                            SlabBuilder::add_site(bi)
+//   BaseType bt(&bi, min_af); bt.lrt();                                    BaseTypeEngine::lrt(builder) -> batch
+//   bt.get_alt_bases() / get_lrt_af(b) / get_var_qual()                    batch.get_alt_bases(i) / get_lrt_af(i,b) / ...
+//   strand_bias(...), ref_vs_alt_ranksumtest(...)                          batch.strand_bias(i, flavour), batch.rank_sums(i)
+//
+// Errors keep the reference's type (std::runtime_error) and, where the reference has one,
+// its message (src/basetype.cpp:54-56, 113-115, 272; src/basetype.h:133-149).
+#pragma once
+
+#include <cctype>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/basevar_amd.h"
+
+namespace bvamd {
+
+static const std::vector<char> BASES = {'A', 'C', 'G', 'T'};  // src/basetype.h:19
+
+inline int base_code(char b) {
+    switch (b) {
+        case 'A': return BV_BASE_A;
+        case 'C': return BV_BASE_C;
+        case 'G': return BV_BASE_G;
+        case 'T': return BV_BASE_T;
+        default: return BV_BASE_OTHER;
+    }
+}
+
+// Packs reference-style per-site inputs (any type with the members of `struct BatchInfo`,
+// src/basetype.h:25-43) into the SoA planes of bv_slab.  Host memory; the engine stages it.
+class SlabBuilder {
+public:
+    explicit SlabBuilder(uint32_t n_samples) : n_(n_samples), pitch_((n_samples + 255u) / 256u * 256u) {}
+
+    template <class BatchInfoLike>
+    void add_site(const BatchInfoLike &bi) {
+        if (bi.align_bases.size() != n_ || bi.align_base_quals.size() != n_ || bi.mapqs.size() != n_ ||
+            bi.map_strands.size() != n_ || bi.base_pos_ranks.size() != n_)
+            throw std::runtime_error("[ERROR] Something is wrong in batchfiles.");  // caller.cpp:736
+        const size_t off = bs_.size();
+        bs_.resize(off + pitch_, BV_CELL_N);
+        q_.resize(off + pitch_, 0);
+        mq_.resize(off + pitch_, 0);
+        rp_.resize(off + pitch_, 0);
+        for (uint32_t i = 0; i < n_; ++i) {
+            const std::string &tok = bi.align_bases[i];
+            const char fb = tok.empty() ? 'N' : tok[0];
+            uint8_t cell;
+            if (fb == 'N') {
+                cell = BV_CELL_N;
+            } else if (fb == '+') {
+                cell = BV_CELL_INS;
+            } else if (fb == '-') {
+                cell = BV_CELL_DEL;
+            } else {
+                if (tok.size() != 1)  // src/basetype.cpp:54-56
+                    throw std::runtime_error("[ERROR] Why dose the size of aligned base is not 1? Check: " + tok);
+                const int c = base_code(fb);
+                if (c == BV_BASE_OTHER) {
+                    cell = BV_CELL_N;  // non-ACGT single characters never reach the path (bam_record.h:28-31)
+                } else {
+                    const char s = bi.map_strands[i];
+                    if (s != '+' && s != '-')  // src/basetype.cpp:272
+                        throw std::runtime_error(std::string("[ERROR] Get strange strand symbol: ") + s);
+                    cell = (uint8_t)(c | (s == '-' ? BV_CELL_REV : 0));
+                }
+            }
+            bs_[off + i] = cell;
+            q_[off + i] = (uint8_t)(bi.align_base_quals[i] - 33);  // src/basetype.cpp:47
+            mq_[off + i] = (uint8_t)bi.mapqs[i];
+            rp_[off + i] = (uint16_t)bi.base_pos_ranks[i];
+        }
+        ref_.push_back((uint8_t)base_code((char)std::toupper((unsigned char)(bi.ref_base.empty() ? 'N' : bi.ref_base[0]))));
+    }
+
+    void set_groups(const std::vector<uint8_t> &group_id, uint32_t n_groups) {
+        gid_ = group_id;
+        gid_.resize(pitch_, BV_NO_GROUP);
+        n_groups_ = n_groups;
+    }
+    void clear() { bs_.clear(); q_.clear(); mq_.clear(); rp_.clear(); ref_.clear(); }
+    uint32_t n_sites() const { return (uint32_t)ref_.size(); }
+    uint32_t n_samples() const { return n_; }
+    uint32_t n_groups() const { return n_groups_; }
+
+    bv_slab slab() const {
+        bv_slab s{};
+        s.n_sites = n_sites(); s.n_samples = n_; s.pitch = pitch_;
+        s.base_strand = bs_.data(); s.qual = q_.data(); s.mapq = mq_.data(); s.rpr = rp_.data();
+        s.ref_base = ref_.data();
+        s.group_id = n_groups_ ? gid_.data() : nullptr;
+        s.n_groups = n_groups_;
+        s.mem_kind = BV_MEM_HOST;
+        return s;
+    }
+
+private:
+    uint32_t n_, n_groups_ = 0;
+    uint64_t pitch_;
+    std::vector<uint8_t> bs_, q_, mq_, ref_, gid_;
+    std::vector<uint16_t> rp_;
+};
+
+struct StrandBiasInfo {  // src/basetype.h:57-62
+    int ref_fwd, ref_rev, alt_fwd, alt_rev;
+    double fs, sor;
+};
+
+// Results of one batch; getters carry the reference's names (src/basetype.h:121-151).
+class BaseTypeBatch {
+public:
+    std::vector<bv_site_result> sites;
+    std::vector<bv_group_result> groups;
+    uint32_t n_groups = 0;
+
+    std::vector<char> get_alt_bases(size_t i) const {
+        std::vector<char> v;
+        for (int k = 0; k < sites[i].n_alt; ++k) v.push_back(BASES[sites[i].alt[k] & 3]);
+        return v;
+    }
+    double get_lrt_af(size_t i, char b) const {
+        for (int k = 0; k < sites[i].n_alt; ++k)
+            if (BASES[sites[i].alt[k] & 3] == b) return sites[i].af[k];
+        throw std::runtime_error(std::string("[ERROR] out_of_range:: map::at '") + b + "' not found.");
+    }
+    double get_var_qual(size_t i) const { return sites[i].qual; }
+    int get_total_depth(size_t i) const { return (int)sites[i].total_depth; }
+    double get_base_depth(size_t i, char b) const {
+        const int c = base_code(b);
+        if (c == BV_BASE_OTHER) throw std::runtime_error(std::string("[ERROR] out_of_range:: map::at '") + b + "' not found.");
+        return (double)sites[i].depth[c];
+    }
+    bool has_variant(size_t i) const { return (sites[i].status & BV_SITE_VARIANT) != 0; }
+    StrandBiasInfo strand_bias(size_t i, bool vcf_flavour) const {
+        const bv_site_result &r = sites[i];
+        const uint32_t *sb = vcf_flavour ? r.var_sb : r.cvg_sb;
+        return {(int)sb[0], (int)sb[1], (int)sb[2], (int)sb[3], vcf_flavour ? r.var_fs : r.cvg_fs,
+                vcf_flavour ? r.var_sor : r.cvg_sor};
+    }
+    // the three INFO rank sums, truncated to int exactly as the caller does (caller.cpp:1151-1157)
+    int mq_rank_sum(size_t i) const { return (int)sites[i].mq_ranksum; }
+    int read_pos_rank_sum(size_t i) const { return (int)sites[i].rpr_ranksum; }
+    int base_q_rank_sum(size_t i) const { return (int)sites[i].bq_ranksum; }
+    const bv_group_result &group(size_t i, uint32_t g) const { return groups[i * n_groups + g]; }
+};
+
+class BaseTypeEngine {
+public:
+    // user_min_af is the CLI value (float, src/basetype_utils.h:94); the engine applies
+    // min(100/n_samples, user_min_af) in float exactly as caller.cpp:122 does.
+    BaseTypeEngine(uint32_t max_sites, uint32_t n_samples, float user_min_af = 0.01f, int device = 0) {
+        bv_engine_config cfg{};
+        cfg.device = device; cfg.max_sites = max_sites; cfg.max_samples = n_samples; cfg.flags = 0;
+        cfg.min_af = bv_min_af(n_samples, user_min_af);
+        if (bv_engine_create(&cfg, &e_) != BV_OK) throw std::runtime_error(bv_last_error(nullptr));
+    }
+    ~BaseTypeEngine() { if (e_) bv_engine_destroy(e_); }
+    BaseTypeEngine(const BaseTypeEngine &) = delete;
+    BaseTypeEngine &operator=(const BaseTypeEngine &) = delete;
+
+    BaseTypeBatch lrt(const SlabBuilder &b) {
+        BaseTypeBatch out;
+        out.sites.resize(b.n_sites());
+        out.n_groups = b.n_groups();
+        out.groups.resize((size_t)b.n_sites() * b.n_groups());
+        bv_slab s = b.slab();
+        if (bv_engine_submit(e_, &s, out.sites.data(), out.n_groups ? out.groups.data() : nullptr, nullptr) != BV_OK)
+            throw std::runtime_error(bv_last_error(e_));
+        if (bv_engine_wait(e_) != BV_OK) throw std::runtime_error(bv_last_error(e_));
+        return out;
+    }
+
+private:
+    bv_engine *e_ = nullptr;
+};
+
+}  // namespace bvamd

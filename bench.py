@@ -6,7 +6,8 @@
 Workload (BASELINE.json configs[2], the configuration the metric and the north-star target
 are quoted on): synthetic NIPT-scale pileup, 100,000 samples per site, generated on the
 device.  The 1 M-site job does not fit HBM at once (5 B/cell = 500 GB),
-so it is processed in HBM-resident batches: ONE STEP = one pass of the whole hot path
+so it is processed in HBM-resident batches (default 32,768 sites = 16.4 GB of planes; the 1 M
+sites are 31 such steps): ONE STEP = one pass of the whole hot path
 (pass 1: tally + EM/LRT/AF/QUAL/strand bias/BaseQRankSum for every site; pass 2: MQ and
 ReadPos rank sums for the variant sites) over one batch of --batch-sites sites, followed
 (N > 1) by the gather of the batch's result records to rank 0 (RCCL over xGMI).
@@ -38,9 +39,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=100000, help="samples per site (row length)")
-    ap.add_argument("--batch-sites", type=int, default=8192, help="sites per step and per GPU")
+    ap.add_argument("--batch-sites", type=int, default=32768, help="sites per step and per GPU")
     ap.add_argument("--coverage", type=float, default=0.08)
-    ap.add_argument("--distinct-batches", type=int, default=4)
+    ap.add_argument("--distinct-batches", type=int, default=2)
     ap.add_argument("--no-rank-planes", action="store_true", help="omit mapq/rpr planes (pass 2 skipped)")
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,28 +78,34 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
             d["rpr"] = rp[ti].cpu().numpy().view(np.uint16)
         return d
 
+    def timed(d, nthreads):
+        """(wall seconds of the path, per-thread path seconds or None)"""
+        t0 = time.perf_counter()
+        if kind == "reference":
+            _, _, secs = chk.run_timed(d, maf, n_threads=nthreads)
+            # the threads run concurrently: the path's wall time is the slowest thread's path time
+            # (the driver's slab -> BatchInfo conversion is not part of the reference path)
+            return float(secs.max()), secs
+        chk.run(d, maf, n_threads=nthreads)
+        return time.perf_counter() - t0, None
+
     # pilot to size the sample to ~15 s of CPU work
-    pilot = sub(threads)
-    t0 = time.perf_counter()
-    chk.run(pilot, maf, n_threads=threads)
-    dt = time.perf_counter() - t0
-    per_site_cpu_s = dt  # one site per thread in parallel: wall == cpu-seconds per site
-    n = want_sites or int(max(threads * 2, min(S, 15.0 / max(per_site_cpu_s, 1e-6))))
+    pilot = sub(threads * 2)
+    dt, secs = timed(pilot, threads)
+    per_site_cpu_s = max((float(secs.sum()) if secs is not None else dt * threads) / (threads * 2), 1e-6)
+    n = want_sites or int(max(threads * 2, min(S, 4096, 20.0 / per_site_cpu_s)))
     n = max(threads, (n // threads) * threads)
-    d = sub(n)
-    t0 = time.perf_counter()
-    chk.run(d, maf, n_threads=threads)
-    wall = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    wall, _ = timed(sub(n), threads)
     one = sub(max(8, min(64, n // threads)))
-    chk.run(one, maf, n_threads=1)
-    wall1 = time.perf_counter() - t0
+    wall1, _ = timed(one, 1)
+    n1 = one["base_strand"].shape[0]
     return {
         "value": n / wall, "unit": "sites/s", "cores": threads, "kind": kind,
         "sample": "%d of the batch's %d sites (same synthetic rows, copied back from HBM), %d samples/site, "
-                  "%d host threads, static site-range partition; single-thread: %.1f sites/s" % (
-                      n, S, n_samples, threads, one["base_strand"].shape[0] / wall1),
-        "single_thread_value": one["base_strand"].shape[0] / wall1,
+                  "%d host threads, static site-range partition, in-memory BatchInfo (no text parsing), timing "
+                  "BaseType ctor + lrt + strand_bias x2 + 3 rank sums; single-thread: %.1f sites/s" % (
+                      n, S, n_samples, threads, n1 / wall1),
+        "single_thread_value": n1 / wall1,
     }
 
 

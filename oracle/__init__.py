@@ -143,6 +143,19 @@ class Reference(_Checker):
     """oracle/_ref/libbvref.so: the real reference code behind oracle/ref_driver.cpp."""
     _has_err = True
 
+    def run_timed(self, slab, min_af, n_threads=1):
+        """As run(); also returns per-thread seconds spent inside the reference's path proper
+        (the driver's slab -> BatchInfo conversion is excluded)."""
+        secs = np.zeros(max(1, int(n_threads)), dtype=np.float64)
+        fn = self._fn
+        lib_fn = self.lib.bvref_run_timed
+        self._fn = lambda *a: lib_fn(*a, _ptr(secs))
+        try:
+            out, gout = self.run(slab, min_af, n_threads)
+        finally:
+            self._fn = fn
+        return out, gout, secs
+
     def __init__(self):
         path = os.path.join(HERE, "_ref", "libbvref.so")
         if not os.path.exists(path):
@@ -151,6 +164,8 @@ class Reference(_Checker):
         L.bvref_run.restype = C.c_int
         L.bvref_run.argtypes = _RUN_ARGS + [C.c_char_p, C.c_size_t]
         self._fn = L.bvref_run
+        L.bvref_run_timed.restype = C.c_int
+        L.bvref_run_timed.argtypes = _RUN_ARGS + [C.c_char_p, C.c_size_t, C.c_void_p]
         L.bvref_chi2_test.restype = C.c_double
         L.bvref_chi2_test.argtypes = [C.c_double, C.c_double]
         L.bvref_norm_dist.restype = C.c_double

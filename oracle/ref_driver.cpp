@@ -17,6 +17,7 @@
 // using only the reference's public API (src/basetype.h:102-181).
 
 #include <cctype>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -84,9 +85,12 @@ void fill_batchinfo(BatchInfo &bi, const uint8_t *bs, const uint8_t *q, const ui
     }
 }
 
+// `path_seconds` (optional) accumulates the time spent inside the reference's own code only:
+// the conversion of the slab row into a BatchInfo above is this driver's overhead, not part of
+// the path (the reference fills BatchInfo while parsing text, caller.cpp:688-715, also off-path).
 void run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
               uint8_t ref_code, const uint8_t *group_id, uint32_t n_groups, uint32_t n,
-              double min_af, bv_site_result *r, bv_group_result *g) {
+              double min_af, bv_site_result *r, bv_group_result *g, double *path_seconds) {
     std::memset(r, 0, sizeof(*r));
     r->chi2 = NAN;  // not observable through the reference's public API
     r->mq_ranksum = r->rpr_ranksum = r->bq_ranksum = NAN;
@@ -95,6 +99,14 @@ void run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint
     BatchInfo bi;
     fill_batchinfo(bi, bs, q, mq, rp, n, ref_code);
     if (bi.depth == 0) return;  // caller.cpp:718
+    struct Timer {
+        double *acc;
+        std::chrono::steady_clock::time_point t0;
+        explicit Timer(double *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+        ~Timer() {
+            if (acc) *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    } timer(path_seconds);
 
     // first characters, as both emitters build them (caller.cpp:1131-1134, 1229-1233)
     std::vector<char> align_bases(n);
@@ -187,11 +199,11 @@ void run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint
 extern "C" {
 
 // Runs the reference path over a host slab.  Returns 0, or -1 if the reference threw.
-int bvref_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq,
+static int run_impl(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq,
               const uint16_t *rpr, const uint8_t *ref_base, const uint8_t *group_id,
               uint32_t n_groups, uint32_t n_sites, uint32_t n_samples, uint64_t pitch,
               double min_af, bv_site_result *out, bv_group_result *gout, int n_threads,
-              char *errbuf, size_t errlen) {
+              char *errbuf, size_t errlen, double *path_seconds_per_thread) {
     if (n_threads < 1) n_threads = 1;
     std::vector<std::string> errs(n_threads);
     auto work = [&](int t) {
@@ -202,7 +214,8 @@ int bvref_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *ma
             for (uint64_t s = lo; s < hi; ++s) {
                 run_site(base_strand + s * pitch, qual + s * pitch, mapq ? mapq + s * pitch : nullptr,
                          rpr ? rpr + s * pitch : nullptr, ref_base[s], group_id, n_groups, n_samples,
-                         min_af, out + s, gout ? gout + s * n_groups : nullptr);
+                         min_af, out + s, gout ? gout + s * n_groups : nullptr,
+                         path_seconds_per_thread ? path_seconds_per_thread + t : nullptr);
             }
         } catch (const std::exception &ex) {
             errs[t] = ex.what();
@@ -224,6 +237,27 @@ int bvref_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *ma
             return -1;
         }
     return 0;
+}
+
+int bvref_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq,
+              const uint16_t *rpr, const uint8_t *ref_base, const uint8_t *group_id,
+              uint32_t n_groups, uint32_t n_sites, uint32_t n_samples, uint64_t pitch,
+              double min_af, bv_site_result *out, bv_group_result *gout, int n_threads,
+              char *errbuf, size_t errlen) {
+    return run_impl(base_strand, qual, mapq, rpr, ref_base, group_id, n_groups, n_sites, n_samples, pitch, min_af,
+                    out, gout, n_threads, errbuf, errlen, nullptr);
+}
+
+// Same, and reports per thread the seconds spent inside the reference's path proper (BaseType
+// ctor + lrt + strand_bias + rank sums + group calls), excluding this driver's slab -> BatchInfo
+// conversion.  `path_seconds` must hold n_threads zero-initialised doubles.
+int bvref_run_timed(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq,
+                    const uint16_t *rpr, const uint8_t *ref_base, const uint8_t *group_id,
+                    uint32_t n_groups, uint32_t n_sites, uint32_t n_samples, uint64_t pitch,
+                    double min_af, bv_site_result *out, bv_group_result *gout, int n_threads,
+                    char *errbuf, size_t errlen, double *path_seconds) {
+    return run_impl(base_strand, qual, mapq, rpr, ref_base, group_id, n_groups, n_sites, n_samples, pitch, min_af,
+                    out, gout, n_threads, errbuf, errlen, path_seconds);
 }
 
 // Scalar entry points for the known-answer inputs of tests/io/test_algorithm.cpp:13-31.
