@@ -461,6 +461,55 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
     }
 }
 
+// ------------------------------------------------------------------------------ short rows
+// For short rows (N <~ 24 k samples: <= 48 KB of stream per site) the solve, not the stream,
+// dominates a site, so every wave should be a solver: one independent wave per workgroup tallies
+// its own site and solves it, persistent with the same ticket counter.  No hand-off, no flags.
+struct __attribute__((aligned(16))) BvPass1FusedShared {
+    uint32_t hist[BV_H2_WORDS];
+    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    BvSolverShared sv;
+};
+
+__global__ __launch_bounds__(BV_WAVE, 4) void bv_pass1_fused_kernel(BvPass1Args a) {
+    __shared__ BvPass1FusedShared sh;
+    const int lane = threadIdx.x;
+    {
+        uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist);
+#pragma unroll
+        for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+        for (int i = lane; i < BV_QBINS; i += BV_WAVE) {
+            sh.tab_hit[i] = a.tables->hit[i];
+            sh.tab_miss[i] = a.tables->miss[i];
+        }
+    }
+    bv_lrt_sync<0>();
+    BvSolveArgs sa;
+    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
+    sa.min_af = a.min_af; sa.flags = a.flags;
+    uint32_t next = 0;
+    if (lane == 0) next = atomicAdd(&a.counters[2], 1u);
+    for (;;) {
+        const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (site >= a.n_sites) break;
+        if (lane == 0) next = atomicAdd(&a.counters[2], 1u);  // in flight under this site's work
+        bv_tally_row_wave<1>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, sh.hist, 0, lane);
+        bv_lrt_sync<0>();
+        bv_solve_site_wave(sa, site, (BV_LDS const uint32_t *)sh.hist, (BV_LDS BvSolverShared *)&sh.sv,
+                           (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
+        uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist);
+#pragma unroll
+        for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+        bv_lrt_sync<0>();
+    }
+}
+
+static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
+    uint32_t grid = 256u * 11u;  // LDS: ~14 KiB per single-wave workgroup -> 11 per CU
+    if (grid > a.n_sites) grid = a.n_sites;
+    hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE), 0, stream, a);
+}
+
 template <int NTALLY, int NSOLVE>
 static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
@@ -482,13 +531,14 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
         case 6: return bv_launch_pass1_cfg<1, 3>(a, stream);
         case 7: return bv_launch_pass1_cfg<1, 1>(a, stream);
         case 8: return bv_launch_pass1_cfg<6, 2>(a, stream);
+        case 9: return bv_launch_pass1_fused(a, stream);
         default: break;
     }
     if (a.n_samples > 24576u) {
         // long rows: several tally waves share a row (short per-site latency => short tail)
         bv_launch_pass1_cfg<3, 1>(a, stream);
     } else {
-        // short rows: solve-bound -> 3 solver waves per tally wave
-        bv_launch_pass1_cfg<1, 3>(a, stream);
+        // short rows: solve-bound -> every wave tallies and solves its own site
+        bv_launch_pass1_fused(a, stream);
     }
 }
