@@ -22,7 +22,7 @@ from . import _capi
 BASES = "ACGT"  # src/basetype.h:19
 
 
-def min_af(n_samples, user_min_af=0.01):
+def min_af(n_samples, user_min_af=0.01):  # noqa: D401
     """(double)std::min(float(100)/n, min_af): src/basetype_caller.cpp:122."""
     return _capi.load().bv_min_af(int(n_samples), float(user_min_af))
 

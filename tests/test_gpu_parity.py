@@ -227,3 +227,64 @@ def test_synthetic_generator_and_full_size_properties(bv, restatement):
     nvar = int(((sites["status"] & 2) != 0).sum())
     assert 0.2 * S < nvar < 0.45 * S  # 30 % of the synthetic sites carry an ALT allele
     eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 63, 64, 65, 255, 1024, 4097])
+def test_tiny_and_ragged_row_lengths(bv, restatement, n):
+    """Row lengths around the 16-cell chunk, the 64-lane wave and the 4 KiB block boundaries."""
+    slab = make_slab(40, n, seed=100 + n, coverage=0.7, n_groups=2, ref_n_frac=0.1, site_offset=3)
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp = restatement.run(slab, maf)
+    check(got, exp, gexp)
+
+
+def test_random_shapes_and_distributions(bv, restatement):
+    """Seeded sweep over coverage, phred distribution, allele mix and group count."""
+    rng = np.random.default_rng(2024)
+    for it in range(12):
+        n = int(rng.integers(50, 30000))
+        cov = float(rng.choice([0.01, 0.05, 0.3, 1.0]))
+        qm = float(rng.choice([8.0, 20.0, 35.0]))
+        classes = [(float(rng.choice([0, 0.001, 0.01, 0.2, 0.5, 0.9, 1.0])), float(rng.choice([0, 0, 0.05, 0.3])))
+                   for _ in range(6)]
+        classes = [(a, min(b, 1.0 - a)) for a, b in classes]
+        slab = make_slab(48, n, seed=500 + it, coverage=cov, qual_mean=qm, qual_sd=10.0, qual_min=1, qual_max=70,
+                         n_groups=int(rng.integers(0, 5)), class_af=classes, ref_n_frac=0.05)
+        maf = bv.min_af(n, float(rng.choice([0.01, 0.001])))
+        got = run_engine(bv, slab, maf)
+        exp, gexp = restatement.run(slab, maf, n_threads=8)
+        check(got, exp, gexp)
+
+
+def test_config2_full_size_100k_sites_x_10k_samples(bv, restatement):
+    """BASELINE configs[1]: 100k sites x 10k samples on one MI355X, EVERY site checked against the
+    oracle restatement (run on the host cores), AF/QUAL/LRT within 1e-6, integer fields bit-exact."""
+    import torch
+    n, S = 10000, 100000
+    pitch = (n + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    bs = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    q = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    mq = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    rp = torch.empty((S, pitch), dtype=torch.int16, device=dev)
+    ref = torch.empty(S, dtype=torch.uint8, device=dev)
+    bv.synth_fill(0, S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), mq.data_ptr(), rp.data_ptr(), seed=7)
+    torch.cuda.synchronize()
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    eng.submit_ptrs(S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(), mq.data_ptr(), rp.data_ptr())
+    eng.wait()
+    sites = out.cpu().numpy().view(bv.SITE_DTYPE)
+    slab = {"base_strand": bs.cpu().numpy(), "qual": q.cpu().numpy(), "mapq": mq.cpu().numpy(),
+            "rpr": rp.cpu().numpy().view(np.uint16), "ref_base": ref.cpu().numpy(), "n_samples": n}
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    exp, _ = restatement.run(slab, maf, n_threads=threads)
+
+    class R:
+        pass
+    r = R(); r.sites = sites; r.groups = None; r.n_variant = eng.last_variant_count()
+    check(r, exp, None)
+    assert 0.15 * S < r.n_variant < 0.40 * S  # the AF 0.002 class is below min_af = 0.01 at N = 10k
+    eng.close()
