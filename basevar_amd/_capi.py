@@ -73,6 +73,14 @@ def load():
         raise RuntimeError(
             "basevar_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C basevar_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64.  If this
+    # library were loaded first it would bind the system runtime, torch would then bring a second
+    # one, and the two cannot both own the device.  Importing torch first (when it is installed)
+    # lets the dynamic loader resolve libamdhip64.so.* to the copy already in the process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.bv_version.restype = C.c_char_p
     L.bv_version.argtypes = []
