@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0xBA5E7A7)
     ap.add_argument("--tally-only", action="store_true", help="diagnostic: time pass 1 without its solver")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
+    ap.add_argument("--with-host-path", action="store_true",
+                    help="also time the PCIe-inclusive path: pinned host planes staged by the engine (never `value`)")
     return ap.parse_args()
 
 
@@ -124,11 +126,19 @@ def main():
                 args.gpus, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
+    # BASEVAR_BENCH_BACKEND=gloo + BASEVAR_BENCH_ONE_DEVICE=1 let the multi-rank plumbing be exercised
+    # on a single-GPU box (tests/test_bench_multirank.py); the driver's runs use nccl (= RCCL), one GPU per rank.
+    backend = os.environ.get("BASEVAR_BENCH_BACKEND", "nccl")
+    if os.environ.get("BASEVAR_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import basevar_amd
     from basevar_amd.shard import gather_records_sized
@@ -167,6 +177,8 @@ def main():
         eng.submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                         mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0, stream=stream.cuda_stream)
         if world > 1:
+            if backend != "nccl":  # gloo has no GPU gather: stage through the host (test plumbing only)
+                return gather_records_sized(out.cpu(), sizes, dst=0)
             return gather_records_sized(out, sizes, dst=0)  # ordered records on rank 0
         return out
 
@@ -175,15 +187,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    last = None
     for i in range(args.warmup):
-        step(i)
+        last = step(i)
     fence()
     eng.timing_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        last = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    gathered_ok = None
+    if rank == 0 and world > 1:
+        # the gathered buffer holds world x B records in rank order: every record must be a covered site
+        import numpy as _np
+        recs = last.cpu().numpy().view(basevar_amd.SITE_DTYPE)
+        gathered_ok = bool(len(recs) == world * B and (recs["total_depth"] > 0).all())
     eng.wait()
     p1_ms, p2_ms, nsub = eng.timing_get()
     nvar = eng.last_variant_count()
@@ -220,7 +239,7 @@ def main():
                                 N, args.coverage, B, (1000000 + B - 1) // B),
                 "samples": N, "batch_sites": B, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
                 "parallelism": "site-sharded x%d, gather of %d-byte records to rank 0" % (world, rec),
-                "variant_sites_last_batch": nvar,
+                "variant_sites_last_batch": nvar, "gathered_records_ok": gathered_ok,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -229,6 +248,26 @@ def main():
                 "avg_launch_ms": p1_avg_s * 1e3, "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
             },
         }
+        if world == 1 and args.with_host_path:
+            # PCIe-inclusive rate when the boundary hands over HOST buffers (DESIGN.md note; not `value`)
+            hb = min(B, 4096)
+            bs, q, mq, rp, ref = batches[0]
+            host = [t[:hb].cpu().pin_memory() if t is not None else None for t in (bs, q, mq, rp)]
+            href = ref[:hb].cpu().pin_memory()
+            hout = torch.zeros(hb * rec, dtype=torch.uint8).pin_memory()
+            from basevar_amd import _capi
+            def hstep():
+                eng.submit_ptrs(hb, N, pitch, host[0].data_ptr(), host[1].data_ptr(), href.data_ptr(), hout.data_ptr(),
+                                host[2].data_ptr() if ranks else 0, host[3].data_ptr() if ranks else 0,
+                                mem_kind=_capi.BV_MEM_HOST)
+                eng.wait()
+            hstep()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                hstep()
+            dt = (time.perf_counter() - t0) / 3
+            line["pcie_inclusive"] = {"value": hb / dt, "unit": "sites/s", "batch_sites": hb,
+                                      "host_GBps": hb * pitch * (5 if ranks else 2) / dt / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)

@@ -1,0 +1,30 @@
+"""bench.py launched exactly as the driver does for N > 1 (torch.distributed.run, one process per
+rank), here with 2 ranks.  On the single-GPU box both ranks share cuda:0 and use the gloo backend
+(RCCL refuses two ranks on one device), which still exercises rank/env handling, per-rank site
+ranges, the ordered gather of records to rank 0, max-over-ranks timing and the JSON contract."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gloo_one_device():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BASEVAR_BENCH_BACKEND="gloo", BASEVAR_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--samples", "20000", "--batch-sites", "2048", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout  # rank 0 prints ONE JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "sites/s"
+    assert d["config"]["gathered_records_ok"] is True
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
