@@ -537,12 +537,16 @@ __device__ inline double bv_ranksum_phred(unsigned long long twoR, unsigned long
 // previous iteration is carried in registers, so the solver stays light on VGPRs and the
 // streaming phase of the same kernel keeps its occupancy.
 struct BvBins {
-    const uint32_t *code;  // LDS
+    const uint32_t *code;  // LDS; bin i is at code[bv_bin_at(B, i)]
     const uint32_t *cnt;   // LDS
+    uint32_t skip_mask;    // 0: dense arrays; ~127u: 128 entries, then 128 words skipped, ... (bins
+                           // stored in the unused upper halves of the histogram rows, bv_pass1.hip)
     const double *hit;     // LDS copy of BvTables::hit  (1 - eps)
     const double *miss;    // LDS copy of BvTables::miss (eps / 3)
     int nb;                // number of bins (wave-uniform)
 };
+
+__device__ __forceinline__ int bv_bin_at(const BvBins &B, int i) { return i + (int)((uint32_t)i & B.skip_mask); }
 
 // The reference's convergence term: algorithm.h:245 binds to int abs(int), so the double
 // difference is truncated to int first (x86 cvttsd2si: NaN / out-of-range -> INT_MIN,
@@ -578,8 +582,9 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n
             if (s < nslots) {
                 const int i = s * BV_WAVE + lane;
                 if (i < B.nb) {
-                    const uint32_t code = B.code[i];
-                    const double c = (double)B.cnt[i];
+                    const int at = bv_bin_at(B, i);
+                    const uint32_t code = B.code[at];
+                    const double c = (double)B.cnt[at];
                     const uint32_t b = code >> 7;
                     const double hit = B.hit[code & 127u], miss = B.miss[code & 127u];
                     double L0 = (b == 0 ? hit : miss) * f[0];

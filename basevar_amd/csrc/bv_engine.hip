@@ -33,7 +33,7 @@ struct bv_engine {
     hipStream_t last_stream = nullptr; // stream of the last submit
     BvTables *d_tables = nullptr;
     uint32_t *d_var_list = nullptr;
-    uint32_t *d_counters = nullptr;    // [0] variants, [1] zero-freq sites
+    uint32_t *d_counters = nullptr;    // BV_CTR_* words (bv_kernels.h)
     uint32_t *h_counters = nullptr;    // pinned host mirror
     static constexpr int kRing = 256;
     hipEvent_t ring[kRing][3] = {};    // per-submit event triplets
@@ -144,9 +144,9 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         for (auto &ev : tri) BV_TRY(hipEventCreate(&ev));
     BV_TRY(hipMalloc(&e->d_tables, sizeof(BvTables)));
     BV_TRY(hipMalloc(&e->d_var_list, sizeof(uint32_t) * (size_t)cfg->max_sites));
-    BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * 4));
-    BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * 4));
-    std::memset(e->h_counters, 0, sizeof(uint32_t) * 4);
+    BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS));
+    BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * BV_CTR_WORDS));
+    std::memset(e->h_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS);
 
     // eps table with the host libm, exactly the reference's expression (basetype.cpp:47-48, :63)
     BvTables t;
@@ -248,7 +248,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         e->host_out = nullptr; e->host_gout = nullptr;
     }
 
-    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * 4, st));
+    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
 
     BvPass1Args a1;
@@ -278,7 +278,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     BV_HIP(e, hipGetLastError());
     BV_HIP(e, hipEventRecord(ev[2], st));
 
-    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, st));
+    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS, hipMemcpyDeviceToHost, st));
     if (e->host_out) {
         BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
         if (e->host_gout && e->host_gout_bytes)
@@ -293,13 +293,13 @@ int bv_engine_wait(bv_engine *e) {
     if (!e->submitted) return BV_OK;
     BV_HIP(e, hipSetDevice(e->cfg.device));
     BV_HIP(e, hipStreamSynchronize(e->last_stream));
-    if (e->h_counters[3] != 0)
+    if (e->h_counters[BV_CTR_TIMEOUT] != 0)
         return fail(e, BV_ERR_HIP, "pass 1: an intra-workgroup hand-off timed out (internal error; results invalid)");
-    if (e->h_counters[1] > 0) {
+    if (e->h_counters[BV_CTR_ZEROFREQ] > 0) {
         char buf[160];
         std::snprintf(buf, sizeof buf,
                       "The sum of frequence of active bases must always > 0 (%u site(s); see BV_SITE_ZERO_FREQ)",
-                      e->h_counters[1]);
+                      e->h_counters[BV_CTR_ZEROFREQ]);
         return fail(e, BV_ERR_SITE, buf);  // message of src/basetype.cpp:114
     }
     return BV_OK;
@@ -340,7 +340,7 @@ int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_tot
 
 int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant) {
     if (!e || !n_variant) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_last_variant_count: null argument");
-    *n_variant = e->h_counters[0];
+    *n_variant = e->h_counters[BV_CTR_VARIANTS];
     return BV_OK;
 }
 

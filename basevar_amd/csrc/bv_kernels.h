@@ -4,6 +4,15 @@
 
 #include "bv_device.h"
 
+// Device counters, each on a 128-byte line of its own (they are hit by atomics from every
+// workgroup; sharing one line would serialise them at the memory-side atomic unit).
+#define BV_CTR_STRIDE 32u                  /* words */
+#define BV_CTR_VARIANTS (0u * BV_CTR_STRIDE)  /* number of BV_SITE_VARIANT sites = length of var_list */
+#define BV_CTR_ZEROFREQ (1u * BV_CTR_STRIDE)  /* sites with BV_SITE_ZERO_FREQ                         */
+#define BV_CTR_TICKET (2u * BV_CTR_STRIDE)    /* pass-1 site ticket counter                           */
+#define BV_CTR_TIMEOUT (3u * BV_CTR_STRIDE)   /* pass-1 pipeline time-out flag                        */
+#define BV_CTR_WORDS (4u * BV_CTR_STRIDE)
+
 struct BvPass1Args {
     const uint8_t *bs;        // [n_sites][pitch]
     const uint8_t *q;         // [n_sites][pitch]
@@ -16,9 +25,7 @@ struct BvPass1Args {
     const BvTables *tables;
     bv_site_result *out;      // [n_sites]
     uint32_t *var_list;       // [n_sites]  indices of BV_SITE_VARIANT sites (unordered)
-    uint32_t *counters;       // [0] = number of variant sites, [1] = sites with BV_SITE_ZERO_FREQ,
-                              // [2] = pass-1 site ticket counter, [3] = pipeline time-out flag
-                              // (all zeroed before the launch)
+    uint32_t *counters;       // BV_CTR_* words, all zeroed before the launch
 };
 
 struct BvPass2Args {

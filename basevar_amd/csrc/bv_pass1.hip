@@ -32,12 +32,20 @@
 #define BV_H2_ROWQ 256                         /* phred axis: the raw phred byte indexes the row */
 #define BV_H2_WORDS (BV_ROWS * BV_H2_ROWQ)     /* 2048 x u32 = 8 KiB per histogram               */
 
+struct BvSolverScratch {
+    BvLrtShared lrt;
+    bv_site_result res;  // staged record, stored with one coalesced write
+};
 struct BvSolverShared {
     uint32_t bin_code[BV_SLOTS * BV_WAVE];  // compacted non-empty (base<<7 | phred) bins
     uint32_t bin_cnt[BV_SLOTS * BV_WAVE];
-    BvLrtShared lrt;
-    bv_site_result res;                     // staged record, stored with one coalesced write
+    BvSolverScratch sc;
 };
+// ALIAS mode (short-row kernel, LDS-limited): the compacted bins live in the histogram itself, in
+// the upper halves (phred 128..255) of rows 0-2 (codes) and 3-5 (counts).  Valid input never
+// touches those words; they are read (bad-phred check, depth) before the bins overwrite them.
+#define BV_ALIAS_CODE_OFF (0 * BV_H2_ROWQ + 128)
+#define BV_ALIAS_CNT_OFF (3 * BV_H2_ROWQ + 128)
 
 template <int NBUF, int NSOLVE>
 struct __attribute__((aligned(16))) BvPass1Shared {
@@ -138,34 +146,48 @@ __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const u
 
 // ------------------------------------------------------------------------------ solver
 // strand/base row sums and deterministic compaction of the non-empty (base, phred) bins
-__device__ __forceinline__ void bv_prologue_wave(const uint32_t *hist, BvSolverShared *sv, int lane, uint32_t fwd[4],
-                                                 uint32_t rev[4], uint32_t *nb_out, uint32_t *badq_out) {
+template <bool ALIAS>
+__device__ __forceinline__ void bv_prologue_wave(const uint32_t *hist, uint32_t *bin_code, uint32_t *bin_cnt, int lane,
+                                                 uint32_t fwd[4], uint32_t rev[4], uint32_t *nb_out, uint32_t *badq_out) {
     uint32_t nb = 0;
     bool bad = false;
+    uint32_t facc[4], racc[4];
+    // phred 128..255 first: only invalid input puts counts there (they still belong to the depth)
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        uint32_t facc = 0, racc = 0;
+        facc[b] = 0; racc[b] = 0;
 #pragma unroll
-        for (int qr = 0; qr < 4; ++qr) {  // four 64-wide quarters of the 256-wide phred axis
+        for (int qr = 2; qr < 4; ++qr) {
             const int q = (qr << 6) | lane;
             uint32_t f = hist[(b << 8) | q], v = hist[((b | 4) << 8) | q];
-            facc += f;
-            racc += v;
+            facc[b] += f;
+            racc[b] += v;
+            bad |= (f | v) != 0;
+        }
+    }
+    if (ALIAS) bv_lrt_sync<0>();  // every lane has read the upper halves before bins land in them
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int qr = 0; qr < 2; ++qr) {  // phred 0..127 hold every valid bin
+            const int q = (qr << 6) | lane;
+            uint32_t f = hist[(b << 8) | q], v = hist[((b | 4) << 8) | q];
+            facc[b] += f;
+            racc[b] += v;
             uint32_t c = f + v;
             bad |= (c != 0) && (q >= BV_NQ_VALID);
-            if (qr < 2) {  // phred 0..127 hold every valid bin
-                bool valid = (c != 0) && (q < BV_NQ_VALID);
-                unsigned long long m = __ballot(valid);
-                uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (valid) {
-                    sv->bin_code[pos] = ((uint32_t)b << 7) | (uint32_t)q;
-                    sv->bin_cnt[pos] = c;
-                }
-                nb += (uint32_t)__popcll(m);
+            bool valid = (c != 0) && (q < BV_NQ_VALID);
+            unsigned long long m = __ballot(valid);
+            uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (valid) {
+                const uint32_t at = ALIAS ? pos + (pos & ~127u) : pos;
+                bin_code[at] = ((uint32_t)b << 7) | (uint32_t)q;
+                bin_cnt[at] = c;
             }
+            nb += (uint32_t)__popcll(m);
         }
-        fwd[b] = bv_wave_sum_u32(facc);
-        rev[b] = bv_wave_sum_u32(racc);
+        fwd[b] = bv_wave_sum_u32(facc[b]);
+        rev[b] = bv_wave_sum_u32(racc[b]);
     }
     *nb_out = nb;
     *badq_out = (__ballot(bad) != 0ull) ? 1u : 0u;
@@ -192,19 +214,28 @@ struct BvSolveArgs {
 #ifndef BV_SOLVER_ATTR
 #define BV_SOLVER_ATTR __forceinline__
 #endif
-__device__ BV_SOLVER_ATTR void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
-                                                             BV_LDS const uint32_t *hist_l, BV_LDS BvSolverShared *sv_l,
-                                                             BV_LDS const double *tab_hit_l,
-                                                             BV_LDS const double *tab_miss_l, int lane) {
-    const uint32_t *hist = (const uint32_t *)hist_l;
-    BvSolverShared *sv = (BvSolverShared *)sv_l;
+template <bool ALIAS>
+__device__ BV_SOLVER_ATTR void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
+                                                  BV_LDS uint32_t *bin_code_l, BV_LDS uint32_t *bin_cnt_l,
+                                                  BV_LDS BvSolverScratch *sv_l, BV_LDS const double *tab_hit_l,
+                                                  BV_LDS const double *tab_miss_l, int lane) {
+    uint32_t *hist = (uint32_t *)hist_l;
+    uint32_t *bin_code = ALIAS ? hist + BV_ALIAS_CODE_OFF : (uint32_t *)bin_code_l;
+    uint32_t *bin_cnt = ALIAS ? hist + BV_ALIAS_CNT_OFF : (uint32_t *)bin_cnt_l;
+    BvSolverScratch *sv = (BvSolverScratch *)sv_l;
     const double *tab_hit = (const double *)tab_hit_l, *tab_miss = (const double *)tab_miss_l;
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
     uint32_t *res_words = reinterpret_cast<uint32_t *>(&sv->res);
     if (lane < REC_WORDS) res_words[lane] = 0u;
 
     uint32_t fwd[4], rev[4], depth[4], nb, badq, total = 0;
-    bv_prologue_wave(hist, sv, lane, fwd, rev, &nb, &badq);
+    // phred-0 calls per base, read before ALIAS-mode bins can overwrite anything (they never touch
+    // phred < 128, but keep every histogram read of the prologue in one place)
+    uint32_t q0_mask = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (hist[b << 8] + hist[(b | 4) << 8]) q0_mask |= 1u << b;
+    bv_prologue_wave<ALIAS>(hist, bin_code, bin_cnt, lane, fwd, rev, &nb, &badq);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         depth[b] = fwd[b] + rev[b];
@@ -245,14 +276,11 @@ __device__ BV_SOLVER_ATTR void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
 
         // ---- lrt() over ACGT (basetype.h:115)
         BvBins B;
-        B.code = sv->bin_code; B.cnt = sv->bin_cnt; B.hit = tab_hit; B.miss = tab_miss; B.nb = (int)nb;
+        B.code = bin_code; B.cnt = bin_cnt; B.skip_mask = ALIAS ? ~127u : 0u; B.hit = tab_hit; B.miss = tab_miss;
+        B.nb = (int)nb;
         BvLrtOut L;
-        // bases that hold a phred-0 call (1 - eps == 0): they keep the generic EM path, because the
-        // reference's 0/0 there yields NaN frequencies that must be reproduced
-        uint32_t q0_mask = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-            if (hist[b << 8] + hist[(b | 4) << 8]) q0_mask |= 1u << b;
+        // q0_mask: bases that hold a phred-0 call (1 - eps == 0) keep the generic EM path, because
+        // the reference's 0/0 there yields NaN frequencies that must be reproduced
         bv_lrt<0>(B, depth, total, /*A,C,G,T*/ 0 | (1 << 3) | (2 << 6) | (3 << 9), (a.flags & BV_FLAG_SKIP_LRT) ? 0 : 4, ref,
                   a.min_af, &sv->lrt, 0, lane, L, q0_mask);
         if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
@@ -342,10 +370,10 @@ __device__ BV_SOLVER_ATTR void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
             sv->res.rpr_ranksum = qnan;
             sv->res.bq_ranksum = bq_ranksum;
             if (L.n_alt > 0) {
-                uint32_t slot = atomicAdd(&a.counters[0], 1u);
+                uint32_t slot = atomicAdd(&a.counters[BV_CTR_VARIANTS], 1u);
                 a.var_list[slot] = site;
             }
-            if (L.zero_freq) atomicAdd(&a.counters[1], 1u);
+            if (L.zero_freq) atomicAdd(&a.counters[BV_CTR_ZEROFREQ], 1u);
         }
     }
     bv_lrt_sync<0>();
@@ -398,7 +426,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
     }
     __syncthreads();
 
-    // Sites are handed out by a global ticket counter (a.counters[2], zeroed by the engine before
+    // Sites are handed out by a global ticket counter (a.counters[BV_CTR_TICKET], zeroed by the engine before
     // the launch): a workgroup that drew cheap hom-ref sites simply draws more, so the persistent
     // grid drains evenly whatever the batch size.  Which workgroup solves a site has no influence
     // on the site's record, so results stay bit-reproducible.
@@ -406,20 +434,20 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
         // ------------------------------------------------ tally waves (wave 0 leads)
         // (s_setprio(3) for this role was measured: 2 % slower, so priorities stay equal.)
         uint32_t next = 0;
-        if (wave == 0 && lane == 0) next = atomicAdd(&a.counters[2], 1u);
+        if (wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], 1u);
         for (uint32_t k = 0;; ++k) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             uint32_t site;
             if (wave == 0) {
                 site = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
                 if (site >= a.n_sites) site = 0xFFFFFFFFu;
-                bv_wait_flag(&sh.drained[buf], gen, &a.counters[3]);  // the solver has re-zeroed this slot
+                bv_wait_flag(&sh.drained[buf], gen, &a.counters[BV_CTR_TIMEOUT]);  // the solver has re-zeroed this slot
                 if (lane == 0) sh.site_of[buf] = site;
                 bv_set_flag(&sh.published[buf], gen + 1u);
                 if (site != 0xFFFFFFFFu && lane == 0)
-                    next = atomicAdd(&a.counters[2], 1u);  // in flight under this row's stream
+                    next = atomicAdd(&a.counters[BV_CTR_TICKET], 1u);  // in flight under this row's stream
             } else {
-                bv_wait_flag(&sh.published[buf], gen + 1u, &a.counters[3]);
+                bv_wait_flag(&sh.published[buf], gen + 1u, &a.counters[BV_CTR_TIMEOUT]);
                 site = sh.site_of[buf];
             }
             if (site == 0xFFFFFFFFu) {
@@ -428,7 +456,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
                 if (wave == 0) {
                     for (int j = 1; j < NSOLVE; ++j) {
                         const uint32_t kk = k + j, b2 = kk % NBUF, g2 = kk / NBUF;
-                        bv_wait_flag(&sh.drained[b2], g2, &a.counters[3]);
+                        bv_wait_flag(&sh.drained[b2], g2, &a.counters[BV_CTR_TIMEOUT]);
                         if (lane == 0) sh.site_of[b2] = 0xFFFFFFFFu;
                         bv_set_flag(&sh.filled[b2], (g2 + 1u) * NTALLY);
                     }
@@ -447,11 +475,12 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
         sa.min_af = a.min_af; sa.flags = a.flags;
         for (uint32_t k = (uint32_t)s;; k += NSOLVE) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
-            bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[3]);
+            bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[BV_CTR_TIMEOUT]);
             const uint32_t site = sh.site_of[buf];
             if (site == 0xFFFFFFFFu) break;
-            bv_solve_site_wave(sa, site, (BV_LDS const uint32_t *)sh.hist[buf], (BV_LDS BvSolverShared *)&sh.sv[s],
-                               (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
+            bv_solve_site_wave<false>(sa, site, (BV_LDS uint32_t *)sh.hist[buf], (BV_LDS uint32_t *)sh.sv[s].bin_code,
+                                      (BV_LDS uint32_t *)sh.sv[s].bin_cnt, (BV_LDS BvSolverScratch *)&sh.sv[s].sc,
+                                      (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
             // hand the slot back, zeroed
             uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[buf]);
 #pragma unroll
@@ -465,49 +494,64 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
 // For short rows (N <~ 24 k samples: <= 48 KB of stream per site) the solve, not the stream,
 // dominates a site, so every wave should be a solver: one independent wave per workgroup tallies
 // its own site and solves it, persistent with the same ticket counter.  No hand-off, no flags.
+#define BV_FUSED_TICKET 4
+#define BV_FUSED_WAVES 4
 struct __attribute__((aligned(16))) BvPass1FusedShared {
-    uint32_t hist[BV_H2_WORDS];
+    uint32_t hist[BV_FUSED_WAVES][BV_H2_WORDS];  // one per wave; also holds that wave's bins (ALIAS mode)
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    BvSolverShared sv;
+    BvSolverScratch sc[BV_FUSED_WAVES];
 };
 
-__global__ __launch_bounds__(BV_WAVE, 4) void bv_pass1_fused_kernel(BvPass1Args a) {
+// Four INDEPENDENT waves per workgroup (they share only the phred tables): ~9 KiB of LDS per wave
+// -> 16 waves per CU, the VGPR limit.
+__global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, 4) void bv_pass1_fused_kernel(BvPass1Args a) {
     __shared__ BvPass1FusedShared sh;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *hist = sh.hist[wave];
     {
-        uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist);
+        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
         for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
-        for (int i = lane; i < BV_QBINS; i += BV_WAVE) {
+        for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_FUSED_WAVES) {
             sh.tab_hit[i] = a.tables->hit[i];
             sh.tab_miss[i] = a.tables->miss[i];
         }
     }
-    bv_lrt_sync<0>();
+    __syncthreads();  // the only workgroup-wide barrier: tables ready; from here the waves never meet
     BvSolveArgs sa;
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = a.flags;
+    // Tickets are drawn BV_FUSED_TICKET sites at a time: at ~70 M short-row sites/s one ticket per
+    // site would run into the ~88 M/s ceiling of atomics on a single address (measured: throughput
+    // flat from 6 to 11 waves per CU until the draws were chunked).
     uint32_t next = 0;
-    if (lane == 0) next = atomicAdd(&a.counters[2], 1u);
+    if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);
     for (;;) {
-        const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-        if (site >= a.n_sites) break;
-        if (lane == 0) next = atomicAdd(&a.counters[2], 1u);  // in flight under this site's work
-        bv_tally_row_wave<1>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, sh.hist, 0, lane);
-        bv_lrt_sync<0>();
-        bv_solve_site_wave(sa, site, (BV_LDS const uint32_t *)sh.hist, (BV_LDS BvSolverShared *)&sh.sv,
-                           (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
-        uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist);
+        const uint32_t site0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (site0 >= a.n_sites) break;
+        if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);  // in flight under this work
+        const uint32_t site1 = min(site0 + (uint32_t)BV_FUSED_TICKET, a.n_sites);
+        for (uint32_t site = site0; site < site1; ++site) {
+            bv_tally_row_wave<1>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, hist, 0, lane);
+            bv_lrt_sync<0>();
+            bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)hist, (BV_LDS uint32_t *)nullptr,
+                                     (BV_LDS uint32_t *)nullptr, (BV_LDS BvSolverScratch *)&sh.sc[wave],
+                                     (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
-        for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
-        bv_lrt_sync<0>();
+            for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+            bv_lrt_sync<0>();
+        }
     }
 }
 
 static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
-    uint32_t grid = 256u * 11u;  // LDS: ~14 KiB per single-wave workgroup -> 11 per CU
-    if (grid > a.n_sites) grid = a.n_sites;
-    hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE), 0, stream, a);
+    uint32_t per_cu = (a.flags >> 12) & 0xFu;  // tuning knob: resident workgroups per CU (0 = default)
+    if (per_cu == 0) per_cu = 4u;             // ~38 KiB of LDS per 4-wave workgroup, 128 VGPRs -> 4 per CU
+    uint32_t grid = 256u * per_cu;
+    const uint32_t need = (a.n_sites + BV_FUSED_TICKET * BV_FUSED_WAVES - 1) / (BV_FUSED_TICKET * BV_FUSED_WAVES);
+    if (grid > need) grid = need > 0 ? need : 1;
+    hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_FUSED_WAVES), 0, stream, a);
 }
 
 template <int NTALLY, int NSOLVE>

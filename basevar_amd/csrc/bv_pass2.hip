@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     __shared__ BvPass2Shared<NW> sh;
     uint32_t *hg = bv_dyn_lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t n_var = a.counters[0];
+    const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
     if (GROUPS) {
         for (int i = tid; i < BV_QBINS; i += NT) {
             sh.tab_hit[i] = a.tables->hit[i];
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                 L.n_alt = 0; L.alt_packed = 0; L.af[0] = L.af[1] = L.af[2] = L.af[3] = 0.;
                 if (gtotal > 0) {
                     BvBins B;
-                    B.code = sh.bin_code[wave]; B.cnt = sh.bin_cnt[wave];
+                    B.code = sh.bin_code[wave]; B.cnt = sh.bin_cnt[wave]; B.skip_mask = 0u;
                     B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.nb = (int)nb;
                     bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.lrt[wave], wave, lane, L);
                 }

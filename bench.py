@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=0xBA5E7A7)
     ap.add_argument("--tally-only", action="store_true", help="diagnostic: time pass 1 without its solver")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="engines/HIP streams used round-robin for consecutive batches (tails of one batch overlap the next)")
     ap.add_argument("--with-host-path", action="store_true",
                     help="also time the PCIe-inclusive path: pinned host planes staged by the engine (never `value`)")
     return ap.parse_args()
@@ -165,21 +167,27 @@ def main():
         batches.append((bs, q, mq, rp, ref))
     torch.cuda.synchronize()
 
-    eng = basevar_amd.BaseTypeEngine(max_sites=B, min_af_value=maf, device=local_rank,
-                                     flags=(1 if args.tally_only else 0) | args.flags)
+    ns = max(1, args.streams)
+    engs = [basevar_amd.BaseTypeEngine(max_sites=B, min_af_value=maf, device=local_rank,
+                                       flags=(1 if args.tally_only else 0) | args.flags) for _ in range(ns)]
+    eng = engs[0]
     rec = basevar_amd.SITE_DTYPE.itemsize
-    out = torch.zeros(B * rec, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
+    outs = [torch.zeros(B * rec, dtype=torch.uint8, device=dev) for _ in range(ns)]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(ns - 1)]
     sizes = [B * rec] * world
 
     def step(i):
         bs, q, mq, rp, ref = batches[i % nb]
-        eng.submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
-                        mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0, stream=stream.cuda_stream)
-        if world > 1:
-            if backend != "nccl":  # gloo has no GPU gather: stage through the host (test plumbing only)
-                return gather_records_sized(out.cpu(), sizes, dst=0)
-            return gather_records_sized(out, sizes, dst=0)  # ordered records on rank 0
+        k = i % ns
+        out = outs[k]
+        with torch.cuda.stream(streams[k]):
+            engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                                mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
+                                stream=streams[k].cuda_stream)
+            if world > 1:
+                if backend != "nccl":  # gloo has no GPU gather: stage through the host (test plumbing only)
+                    return gather_records_sized(out.cpu(), sizes, dst=0)
+                return gather_records_sized(out, sizes, dst=0)  # ordered records on rank 0
         return out
 
     def fence():
@@ -191,7 +199,8 @@ def main():
     for i in range(args.warmup):
         last = step(i)
     fence()
-    eng.timing_reset()
+    for e in engs:
+        e.timing_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(args.warmup + i)
@@ -203,8 +212,12 @@ def main():
         import numpy as _np
         recs = last.cpu().numpy().view(basevar_amd.SITE_DTYPE)
         gathered_ok = bool(len(recs) == world * B and (recs["total_depth"] > 0).all())
-    eng.wait()
-    p1_ms, p2_ms, nsub = eng.timing_get()
+    p1_ms = p2_ms = 0.0
+    nsub = 0
+    for e in engs:
+        e.wait()
+        a1, a2, n_ = e.timing_get()
+        p1_ms += a1; p2_ms += a2; nsub += n_
     nvar = eng.last_variant_count()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -278,7 +291,8 @@ def main():
                 line["cpu_baseline"] = None
                 print("[bench] cpu_baseline failed: %r" % (ex,), file=sys.stderr)
         print(json.dumps(line), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
