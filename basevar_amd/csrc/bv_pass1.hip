@@ -491,7 +491,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 
 }
 
 // ------------------------------------------------------------------------------ short rows
-// For short rows (N <~ 24 k samples: <= 48 KB of stream per site) the solve, not the stream,
+// For short rows (N <~ 50 k samples: <= 100 KB of stream per site) the solve, not the stream,
 // dominates a site, so every wave should be a solver: one independent wave per workgroup tallies
 // its own site and solves it, persistent with the same ticket counter.  No hand-off, no flags.
 #define BV_FUSED_TICKET 4
@@ -578,7 +578,7 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
         case 9: return bv_launch_pass1_fused(a, stream);
         default: break;
     }
-    if (a.n_samples > 24576u) {
+    if (a.n_samples > 49152u) {  // measured crossover of the two kernels: ~50 k samples per row
         // long rows: several tally waves share a row (short per-site latency => short tail)
         bv_launch_pass1_cfg<3, 1>(a, stream);
     } else {

@@ -62,7 +62,8 @@ def test_golden_vectors(bv, path):
 @pytest.mark.parametrize("n,cov,sites,groups,seed", [
     (1500, 0.30, 256, 2, 21),     # one wave per site
     (10000, 0.08, 384, 0, 22),    # config #2 row length
-    (16400, 0.08, 128, 2, 23),    # just past the 64 -> 256 thread switch, ragged tail
+    (16400, 0.08, 128, 2, 23),    # ragged tail, short-row kernel
+    (49200, 0.08, 64, 2, 27),     # just past the short-row / pipelined kernel switch
     (100000, 0.08, 96, 2, 24),    # NIPT row length (config #3)
     (100003, 0.02, 40, 0, 25),    # ragged, sparse
     (450000, 0.05, 12, 1, 26),    # 1024-thread teams
