@@ -490,11 +490,14 @@ __device__ inline void bv_strand_bias_wave(uint32_t ref_fwd, uint32_t ref_rev, u
     double fs = -10 * log10(bv_fisher_two_sided_wave((int)ref_fwd, (int)ref_rev, (int)alt_fwd, (int)alt_rev, lane));
     if (isinf(fs)) fs = 10000;
     else if (fs == 0) fs = 0.0;
-    // `int` products as in the reference (wrap like x86 imul; flagged because it is UB there)
+    // basetype.cpp:286 multiplies `int`s; past 2^31 that is UB in the reference.  Its compiled
+    // form (gcc -O3 x86-64, pinned by tests/golden/deep_sor.npz) folds the guard
+    // `ref_rev * alt_fwd > 0` into "both factors non-zero" and divides the 32-bit wrapped products.
+    // Reproduced exactly, and flagged so that a caller can tell such a value is not meaningful.
     int den = (int)(ref_rev * alt_fwd), num = (int)(ref_fwd * alt_rev);
     if ((unsigned long long)ref_rev * alt_fwd > 0x7fffffffull || (unsigned long long)ref_fwd * alt_rev > 0x7fffffffull)
         *flags |= BV_SITE_SOR_OVERFLOW;
-    double sor = (den > 0) ? (double)num / (double)den : 10000;
+    double sor = (ref_rev != 0u && alt_fwd != 0u) ? (double)num / (double)den : 10000;
     *fs_out = fs;
     *sor_out = sor;
 }

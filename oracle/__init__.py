@@ -106,6 +106,8 @@ class Restatement(_Checker):
         L.oracle_run.restype = C.c_int
         L.oracle_run.argtypes = _RUN_ARGS
         self._fn = L.oracle_run
+        L.oracle_run_ex.restype = C.c_int
+        L.oracle_run_ex.argtypes = _RUN_ARGS + [C.c_void_p]
         L.oracle_chi2_test.restype = C.c_double
         L.oracle_chi2_test.argtypes = [C.c_double, C.c_double]
         L.oracle_norm_dist.restype = C.c_double
@@ -116,6 +118,22 @@ class Restatement(_Checker):
         L.oracle_wilcoxon.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         L.oracle_min_af.restype = C.c_double
         L.oracle_min_af.argtypes = [C.c_uint32, C.c_float]
+
+    def run_with_margins(self, slab, min_af, n_threads=1):
+        """As run(); also returns, per site, the smallest gap that decided a discrete choice in the
+        LRT (argmin runner-up or distance to the threshold 24), including the site's group calls.
+        Diagnostic for the parity tests: sites with a rounding-noise margin are order-dependent ties
+        in the reference and are reported as ambiguous instead of being compared."""
+        S = np.asarray(slab["base_strand"]).shape[0]
+        margins = np.full(S, np.inf, dtype=np.float64)
+        fn = self._fn
+        ex = self.lib.oracle_run_ex
+        self._fn = lambda *a: ex(*a, _ptr(margins))
+        try:
+            out, gout = self.run(slab, min_af, n_threads)
+        finally:
+            self._fn = fn
+        return out, gout, margins
 
     def chi2_test(self, x, df=1.0):
         return self.lib.oracle_chi2_test(x, df)

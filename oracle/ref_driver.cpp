@@ -17,6 +17,7 @@
 // using only the reference's public API (src/basetype.h:102-181).
 
 #include <cctype>
+#include <climits>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -124,6 +125,9 @@ void run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint
             r->cvg_sb[0] = s.ref_fwd; r->cvg_sb[1] = s.ref_rev;
             r->cvg_sb[2] = s.alt_fwd; r->cvg_sb[3] = s.alt_rev;
             r->cvg_fs = s.fs; r->cvg_sor = s.sor;
+            // ABI bookkeeping (not reference behaviour): mark SOR values whose `int` products overflowed
+            if ((int64_t)s.ref_fwd * s.alt_rev > INT32_MAX || (int64_t)s.ref_rev * s.alt_fwd > INT32_MAX)
+                r->status |= BV_SITE_SOR_OVERFLOW;
         }
     }
 
@@ -162,6 +166,8 @@ void run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint
     r->var_sb[0] = s.ref_fwd; r->var_sb[1] = s.ref_rev;
     r->var_sb[2] = s.alt_fwd; r->var_sb[3] = s.alt_rev;
     r->var_fs = s.fs; r->var_sor = s.sor;
+    if ((int64_t)s.ref_fwd * s.alt_rev > INT32_MAX || (int64_t)s.ref_rev * s.alt_fwd > INT32_MAX)
+        r->status |= BV_SITE_SOR_OVERFLOW;
 
     // ---- per-group calls: caller.cpp:746-759, __gb :767-797
     if (g && n_groups > 0 && group_id) {

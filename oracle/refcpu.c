@@ -312,6 +312,7 @@ typedef struct {
     double var_qual;
     double chi2;
     int em_iters, n_em, zero_freq;
+    double margin; /* diagnostic: smallest gap that decided a discrete choice in lrt() (see o_lrt) */
 } o_bt;
 
 /* BaseType::BaseType, basetype.cpp:22-72.  `idx` optionally selects a subset of samples
@@ -391,6 +392,7 @@ static void o_lrt(o_bt *bt, const int *specific, int n_specific, int ref_code) {
     bt->n_alt = 0;
     bt->chi2 = 0;
     bt->var_qual = 0;
+    bt->margin = INFINITY;
     if (bt->total_depth == 0) return;
     int active[4], m = 0;
     for (int k = 0; k < n_specific; ++k) {
@@ -415,6 +417,14 @@ static void o_lrt(o_bt *bt, const int *specific, int n_specific, int ref_code) {
             chiv[j] = 2 * (lr_alt - var.lr[j]);
             if (chiv[j] < chiv[i_min]) i_min = j; /* std::min_element: first minimum */
         }
+        /* DIAGNOSTIC ONLY (not reference behaviour): how close this level's two discrete decisions
+         * were -- the runner-up subset in the argmin, and the LRT threshold.  The reference's
+         * tie-breaking depends on the order in which it adds the per-sample log-likelihoods; an
+         * engine that works on (base, phred) histograms cannot see that order, so the parity tests
+         * report (not fail) the sites whose margin is at rounding-noise level. */
+        for (int j = 0; j < var.n; ++j)
+            if (j != i_min && chiv[j] - chiv[i_min] < bt->margin) bt->margin = chiv[j] - chiv[i_min];
+        if (fabs(chiv[i_min] - LRT_THRESHOLD) < bt->margin) bt->margin = fabs(chiv[i_min] - LRT_THRESHOLD);
         lr_alt = var.lr[i_min];
         chi = chiv[i_min];
         if (chi < LRT_THRESHOLD) {
@@ -463,8 +473,15 @@ static void o_strand_bias(int ref_code, unsigned alt_mask, const uint8_t *bs, ui
     double fs = -10 * log10(oracle_fisher_exact_test(ref_fwd, ref_rev, alt_fwd, alt_rev));
     if (isinf(fs)) fs = 10000;
     else if (fs == 0) fs = 0.0;
-    /* int products, basetype.cpp:286 */
-    double sor = (ref_rev * alt_fwd > 0) ? (double)(ref_fwd * alt_rev) / (double)(ref_rev * alt_fwd) : 10000;
+    /* basetype.cpp:286 multiplies `int`s.  Once a product reaches 2^31 that is signed overflow
+     * (undefined behaviour); what the reference AS COMPILED (gcc -O3, x86-64: oracle/_ref) does is
+     * pinned by tests/golden/deep_sor.npz: the guard `ref_rev * alt_fwd > 0` is folded under the
+     * no-overflow assumption into "both factors non-zero", while the quotient uses the 32-bit
+     * wrapped products (imul r32).  Written out explicitly here so that this file does not depend
+     * on how a compiler treats the UB. */
+    int num = (int)((uint32_t)ref_fwd * (uint32_t)alt_rev);
+    int den = (int)((uint32_t)ref_rev * (uint32_t)alt_fwd);
+    double sor = (ref_rev > 0 && alt_fwd > 0) ? (double)num / (double)den : 10000;
     cnt[0] = ref_fwd; cnt[1] = ref_rev; cnt[2] = alt_fwd; cnt[3] = alt_rev;
     *fs_out = fs;
     *sor_out = sor;
@@ -500,7 +517,8 @@ static double o_ranksum(int ref_code, unsigned alt_mask, const uint8_t *bs, uint
  * (:1236-1245) and _out_vcf_line (:1113-1164). */
 static void o_run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp, uint8_t ref_code,
                        const uint8_t *group_id, uint32_t n_groups, uint32_t n, double min_af, bv_site_result *r,
-                       bv_group_result *g) {
+                       bv_group_result *g, double *margin_out) {
+    if (margin_out) *margin_out = INFINITY;
     memset(r, 0, sizeof(*r));
     r->mq_ranksum = r->rpr_ranksum = r->bq_ranksum = NAN;
     if (g) memset(g, 0, sizeof(*g) * n_groups);
@@ -520,6 +538,7 @@ static void o_run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, c
     o_bt_init(&bt, bs, q, n, NULL, 0, min_af);
     static const int ACGT[4] = {0, 1, 2, 3};
     o_lrt(&bt, ACGT, 4, ref);
+    if (margin_out) *margin_out = bt.margin;
     for (int j = 0; j < 4; ++j) r->depth[j] = (uint32_t)bt.depth[j];
     r->total_depth = (uint32_t)bt.total_depth;
     if (bt.total_depth > 0) r->status |= BV_SITE_COVERED;
@@ -569,6 +588,7 @@ static void o_run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, c
                 o_bt gb;
                 o_bt_init(&gb, bs, q, n, idx, ni, min_af);
                 o_lrt(&gb, comb, nc, ref);
+                if (margin_out && gb.margin < *margin_out) *margin_out = gb.margin;
                 g[gi].n_alt = (uint8_t)gb.n_alt;
                 g[gi].total_depth = (uint32_t)gb.total_depth;
                 for (int k = 0; k < gb.n_alt; ++k) {
@@ -593,6 +613,7 @@ typedef struct {
     double min_af;
     bv_site_result *out;
     bv_group_result *gout;
+    double *margins;
 } o_job;
 
 static void *o_worker(void *arg) {
@@ -600,15 +621,16 @@ static void *o_worker(void *arg) {
     for (uint64_t s = j->lo; s < j->hi; ++s)
         o_run_site(j->bs + s * j->pitch, j->q + s * j->pitch, j->mq ? j->mq + s * j->pitch : NULL,
                    j->rp ? j->rp + s * j->pitch : NULL, j->ref[s], j->gid, j->n_groups, j->n, j->min_af, j->out + s,
-                   j->gout ? j->gout + s * j->n_groups : NULL);
+                   j->gout ? j->gout + s * j->n_groups : NULL, j->margins ? j->margins + s : NULL);
     return NULL;
 }
 
-/* Same signature as bvref_run (oracle/ref_driver.cpp) minus the error buffer. */
-int oracle_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq, const uint16_t *rpr,
-               const uint8_t *ref_base, const uint8_t *group_id, uint32_t n_groups, uint32_t n_sites,
-               uint32_t n_samples, uint64_t pitch, double min_af, bv_site_result *out, bv_group_result *gout,
-               int n_threads) {
+/* Same signature as bvref_run (oracle/ref_driver.cpp) minus the error buffer; `margins` (optional,
+ * [n_sites]) receives the decision margin of every site (see o_lrt). */
+int oracle_run_ex(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq, const uint16_t *rpr,
+                  const uint8_t *ref_base, const uint8_t *group_id, uint32_t n_groups, uint32_t n_sites,
+                  uint32_t n_samples, uint64_t pitch, double min_af, bv_site_result *out, bv_group_result *gout,
+                  int n_threads, double *margins) {
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     pthread_t th[256];
@@ -617,7 +639,7 @@ int oracle_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *m
         o_job *j = &jobs[t];
         j->bs = base_strand; j->q = qual; j->mq = mapq; j->rp = rpr; j->ref = ref_base; j->gid = group_id;
         j->n_groups = n_groups; j->n = n_samples; j->pitch = pitch; j->min_af = min_af;
-        j->out = out; j->gout = gout;
+        j->out = out; j->gout = gout; j->margins = margins;
         j->lo = (uint64_t)n_sites * t / n_threads;
         j->hi = (uint64_t)n_sites * (t + 1) / n_threads;
         if (n_threads == 1) o_worker(j);
@@ -626,6 +648,14 @@ int oracle_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *m
     if (n_threads > 1)
         for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
     return 0;
+}
+
+int oracle_run(const uint8_t *base_strand, const uint8_t *qual, const uint8_t *mapq, const uint16_t *rpr,
+               const uint8_t *ref_base, const uint8_t *group_id, uint32_t n_groups, uint32_t n_sites,
+               uint32_t n_samples, uint64_t pitch, double min_af, bv_site_result *out, bv_group_result *gout,
+               int n_threads) {
+    return oracle_run_ex(base_strand, qual, mapq, rpr, ref_base, group_id, n_groups, n_sites, n_samples, pitch, min_af,
+                         out, gout, n_threads, NULL);
 }
 
 /* float-rounded min_af, src/basetype_caller.cpp:122 with src/basetype_utils.h:80 */

@@ -77,9 +77,35 @@ def edge_slab():
     return slab
 
 
+def deep_sor_slab():
+    """Very deep sites whose strand-count products pass 2^31: pins what the compiled reference does
+    with the `int` overflow of basetype.cpp:286.  Run-structured so that the fixture stays small."""
+    n = 260000
+    sites = []
+    #            A+      A-      G+      G-     (ref A, alt G; rest uncovered)
+    layouts = [(60000, 61000, 50000, 52000), (90000, 47000, 46400, 70000), (120000, 20000, 18000, 100000),
+               (46341, 46341, 46341, 46341), (130000, 129000, 400, 300)]
+    for l in layouts:
+        bs = np.full(n, N, np.uint8); q = np.zeros(n, np.uint8); mq = np.zeros(n, np.uint8); rp = np.zeros(n, np.uint16)
+        o = 0
+        for k, cnt in enumerate(l):
+            code = (A if k < 2 else G) | (REV if k & 1 else 0)
+            bs[o:o + cnt] = code
+            q[o:o + cnt] = 30 + (k % 3)
+            mq[o:o + cnt] = 60 - k
+            rp[o:o + cnt] = 10 + 5 * k
+            o += cnt
+        sites.append((A, bs, q, mq, rp))
+    return {"n_sites": len(sites), "n_samples": n, "pitch": n, "n_groups": 0,
+            "base_strand": np.stack([s[1] for s in sites]), "qual": np.stack([s[2] for s in sites]),
+            "mapq": np.stack([s[3] for s in sites]), "rpr": np.stack([s[4] for s in sites]),
+            "ref_base": np.array([s[0] for s in sites], np.uint8)}
+
+
 FIXTURES = {
     # name: (slab factory, user min_af)
     "edge16": (edge_slab, 0.01),
+    "deep_sor": (deep_sor_slab, 0.01),
     "dense_64x500": (lambda: make_slab(64, 500, seed=11, coverage=0.6, n_groups=2, ref_n_frac=0.05), 0.01),
     "nipt_96x4000": (lambda: make_slab(96, 4000, seed=12, coverage=0.08, n_groups=2), 0.01),
     "ragged_40x1003": (lambda: make_slab(40, 1003, seed=13, coverage=0.25, n_groups=3, pitch=1008), 0.01),

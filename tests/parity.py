@@ -25,13 +25,24 @@ def _close(x, y, rtol, atol):
     return ok | both_nan | same_inf
 
 
-def ambiguous_sites(exp):
-    """Sites whose discrete outcome hinges on a floating-point tie: the LRT statistic sits on
-    the threshold 24 (basetype.h:21) to within the float tolerance.  Reported, never silently
-    dropped: the caller asserts that they are rare."""
+TIE_EPS = 1e-9
+
+
+def ambiguous_sites(exp, margins=None):
+    """Sites whose discrete outcome hinges on a floating-point tie.  `margins` comes from
+    oracle.Restatement.run_with_margins(): the smallest gap that decided an argmin or the
+    `chi2 < 24` test (basetype.cpp:157-161) anywhere in the site's LRT (and its group calls).  When
+    two allele subsets have mathematically equal likelihood (e.g. two bases seen once each with the
+    same phred), the reference's choice depends on the ORDER in which it adds the per-sample
+    log-likelihoods; the engine works on order-free histograms.  Such sites are reported, never
+    silently dropped: callers assert that they are rare."""
     chi = exp["chi2"]
     with np.errstate(invalid="ignore"):
-        return np.abs(chi - 24.0) <= 24.0 * 1e-9
+        amb = np.abs(chi - 24.0) <= 24.0 * TIE_EPS
+    if margins is not None:
+        scale = np.maximum(1.0, np.abs(np.nan_to_num(chi, nan=0.0)))
+        amb = amb | (np.asarray(margins) <= TIE_EPS * scale)
+    return amb
 
 
 def compare_sites(got, exp, check_ranks=True, check_chi2=True):

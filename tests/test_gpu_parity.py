@@ -36,16 +36,26 @@ def run_engine(bv, slab, maf):
         eng.close()
 
 
-def check(got, exp, gexp, **kw):
-    amb = ambiguous_sites(exp)
+def check(got, exp, gexp, margins=None, **kw):
+    """Every site is compared.  A mismatching site is excused only if the oracle says its call was
+    decided by a rounding-noise tie (parity.ambiguous_sites); excused sites must stay rare."""
+    amb = ambiguous_sites(exp, margins)
     bad = compare_sites(got.sites, exp, **kw)
     bad.update(compare_groups(got.groups, gexp, (exp["status"] & 2) != 0))
-    # sites whose call hinges on an exact floating-point tie are reported separately
+    excused = set()
+    for f, idx in bad.items():
+        excused.update(idx[amb[idx]].tolist())
     bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
     bad = {f: idx for f, idx in bad.items() if idx.size}
     assert not bad, describe(bad, got.sites, exp)
-    assert amb.sum() <= max(1, len(exp) // 1000)
+    assert len(excused) <= max(1, len(exp) // 200), "too many tie-excused sites: %d of %d" % (len(excused), len(exp))
     assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum())
+    return len(excused)
+
+
+def oracle_run(restatement, slab, maf, n_threads=8):
+    exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=n_threads)
+    return exp, gexp, margins
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))), ids=os.path.basename)
@@ -72,8 +82,8 @@ def test_fresh_slabs_vs_restatement(bv, restatement, n, cov, sites, groups, seed
     slab = make_slab(sites, n, seed=seed, coverage=cov, n_groups=groups, ref_n_frac=0.03, site_offset=10)
     maf = bv.min_af(n)
     got = run_engine(bv, slab, maf)
-    exp, gexp = restatement.run(slab, maf, n_threads=8)
-    check(got, exp, gexp)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
     assert ((exp["status"] & 2) != 0).sum() >= 2
 
 
@@ -236,8 +246,8 @@ def test_tiny_and_ragged_row_lengths(bv, restatement, n):
     slab = make_slab(40, n, seed=100 + n, coverage=0.7, n_groups=2, ref_n_frac=0.1, site_offset=3)
     maf = bv.min_af(n)
     got = run_engine(bv, slab, maf)
-    exp, gexp = restatement.run(slab, maf)
-    check(got, exp, gexp)
+    exp, gexp, margins = oracle_run(restatement, slab, maf, 1)
+    check(got, exp, gexp, margins)
 
 
 def test_random_shapes_and_distributions(bv, restatement):
@@ -254,8 +264,8 @@ def test_random_shapes_and_distributions(bv, restatement):
                          n_groups=int(rng.integers(0, 5)), class_af=classes, ref_n_frac=0.05)
         maf = bv.min_af(n, float(rng.choice([0.01, 0.001])))
         got = run_engine(bv, slab, maf)
-        exp, gexp = restatement.run(slab, maf, n_threads=8)
-        check(got, exp, gexp)
+        exp, gexp, margins = oracle_run(restatement, slab, maf)
+        check(got, exp, gexp, margins)
 
 
 def test_config2_full_size_100k_sites_x_10k_samples(bv, restatement):

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Randomised differential campaign on a GPU box: engine (C ABI) vs the oracle on many seeded
+slabs of varied shape/distribution.  Prints one summary line per slab and a total; exits 1 on
+any non-ambiguous mismatch.  Not a pytest (minutes, not seconds)."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import basevar_amd  # noqa: E402
+import oracle  # noqa: E402
+from basevar_amd.synth import make_slab  # noqa: E402
+from parity import ambiguous_sites, compare_groups, compare_sites, describe  # noqa: E402
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    use_ref = oracle.ref_available() and os.environ.get("CAMPAIGN_ORACLE", "ref") == "ref"
+    chk = oracle.Reference() if use_ref else oracle.Restatement()
+    res = oracle.Restatement()
+    rng = np.random.default_rng(int(os.environ.get("CAMPAIGN_SEED", "1")))
+    threads = max(1, min(64, len(os.sched_getaffinity(0))))
+    tot_sites = tot_var = tot_amb = tot_bad = 0
+    t0 = time.time()
+    for it in range(rounds):
+        n = int(rng.choice([37, 300, 2500, 10000, 40000, 60000, 120000, 300000]))
+        sites = int(max(16, min(4096, 6_000_000 // n)))
+        cov = float(rng.choice([0.02, 0.08, 0.3, 0.9]))
+        qm = float(rng.choice([10.0, 25.0, 33.0]))
+        classes = []
+        for _ in range(8):
+            a = float(rng.choice([0, 0, 0.0005, 0.002, 0.01, 0.05, 0.2, 0.5, 0.95, 1.0]))
+            b = float(rng.choice([0, 0, 0, 0.01, 0.1, 0.3]))
+            classes.append((a, min(b, 1.0 - a)))
+        ng = int(rng.choice([0, 0, 2, 5]))
+        slab = make_slab(sites, n, seed=int(rng.integers(1 << 30)), coverage=cov, qual_mean=qm, qual_sd=9.0,
+                         qual_min=1, qual_max=60, n_groups=ng, class_af=classes, ref_n_frac=0.03)
+        maf = res.min_af(n, float(rng.choice([0.01, 0.001])))
+        eng = basevar_amd.BaseTypeEngine(sites, maf)
+        got = eng.lrt(slab)
+        eng.close()
+        exp, gexp = chk.run(slab, maf, n_threads=threads)
+        # decision margins always come from the restatement (bit-identical to the reference)
+        exp_r, _, margins = res.run_with_margins(slab, maf, n_threads=threads)
+        amb = ambiguous_sites(exp_r, margins)
+        bad = compare_sites(got.sites, exp, check_chi2=not use_ref)
+        bad.update(compare_groups(got.groups, gexp, (exp["status"] & 2) != 0))
+        excused = set()
+        for f, idx in bad.items():
+            excused.update(idx[amb[idx]].tolist())
+        bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
+        bad = {f: idx for f, idx in bad.items() if idx.size}
+        nvar = int(((exp["status"] & 2) != 0).sum())
+        tot_sites += sites; tot_var += nvar; tot_amb += len(excused); tot_bad += sum(len(v) for v in bad.values())
+        print("slab %2d: %5d sites x %6d samples cov %.2f groups %d -> %4d variant, mismatching fields %d, tie-excused sites %d" % (
+            it, sites, n, cov, ng, nvar, len(bad), len(excused)), flush=True)
+        if bad and gexp is not None:
+            for f, idx in bad.items():
+                if f.startswith("group."):
+                    for i in idx[:3]:
+                        print("   group detail site %d margin %g got=%s exp=%s" % (i, margins[i], got.groups[i].tolist(), gexp[i].tolist()))
+        if bad:
+            print(describe(bad, got.sites, exp))
+    print("TOTAL: %d sites (%d variant) against %s in %.0f s: %d mismatches, %d tie-excused sites" % (
+        tot_sites, tot_var, "the real reference" if use_ref else "the restatement", time.time() - t0, tot_bad, tot_amb))
+    sys.exit(1 if tot_bad else 0)
+
+
+if __name__ == "__main__":
+    main()
