@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "basetype.h"  // reference header (-I/root/reference/src)
+#include "utils.h"     // reference header: ngslib::split / join / tostring
 
 #include "../include/basevar_amd.h"
 
@@ -284,6 +285,59 @@ int bvref_strand_bias(char ref, const char *alts, const char *bases, const char 
     counts[0] = s.ref_fwd; counts[1] = s.ref_rev; counts[2] = s.alt_fwd; counts[3] = s.alt_rev;
     *fs = s.fs; *sor = s.sor;
     return 0;
+}
+
+// ---- the reference's own text primitives (src/utils.h:38-43, 75-122; src/utils.cpp:81-99), used
+// to pin the tokenisers / formatters of basevar_amd/host/batchfile.hpp.  Results are written
+// '\x1f'-separated into `out` (truncated at outlen - 1); the return value is the item count.
+static int pack_items(const std::vector<std::string> &v, char *out, size_t outlen) {
+    std::string s;
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (i) s.push_back('\x1f');
+        s += v[i];
+    }
+    if (out && outlen) {
+        std::strncpy(out, s.c_str(), outlen - 1);
+        out[outlen - 1] = 0;
+    }
+    return (int)v.size();
+}
+int bvref_split_str(const char *in, const char *delim, char *out, size_t outlen) {
+    std::vector<std::string> v;
+    ngslib::split(std::string(in), v, delim);
+    return pack_items(v, out, outlen);
+}
+int bvref_split_int(const char *in, const char *delim, char *out, size_t outlen) {
+    std::vector<int> v;
+    ngslib::split(std::string(in), v, delim);
+    std::vector<std::string> sv;
+    for (int x : v) sv.push_back(std::to_string(x));
+    return pack_items(sv, out, outlen);
+}
+int bvref_split_char(const char *in, const char *delim, char *out, size_t outlen) {
+    std::vector<char> v;
+    ngslib::split(std::string(in), v, delim);
+    std::vector<std::string> sv;
+    for (char x : v) sv.push_back(std::to_string((int)x));
+    return pack_items(sv, out, outlen);
+}
+int bvref_join_double(const double *v, int n, const char *delim, char *out, size_t outlen) {
+    std::string s = ngslib::join(std::vector<double>(v, v + n), delim);
+    std::strncpy(out, s.c_str(), outlen - 1);
+    out[outlen - 1] = 0;
+    return (int)s.size();
+}
+int bvref_join_int(const int *v, int n, const char *delim, char *out, size_t outlen) {
+    std::string s = ngslib::join(std::vector<int>(v, v + n), delim);
+    std::strncpy(out, s.c_str(), outlen - 1);
+    out[outlen - 1] = 0;
+    return (int)s.size();
+}
+int bvref_join_char(const char *v, int n, const char *delim, char *out, size_t outlen) {
+    std::string s = ngslib::join(std::vector<char>(v, v + n), delim);
+    std::strncpy(out, s.c_str(), outlen - 1);
+    out[outlen - 1] = 0;
+    return (int)s.size();
 }
 
 }  // extern "C"
