@@ -15,7 +15,7 @@
 // `bv_call` tool uses zlib, which reads bgzip members transparently).
 //
 // PARITY STATUS: the tokenisers below restate ngslib::split (src/utils.cpp:81-99, src/utils.h:75-122)
-// and are pinned against the reference's own functions through oracle/_ref (tests/test_host_formats.py).
+// and are pinned against the reference's own compiled functions in tests/test_host_formats.py.
 // The row layout is transcribed from the lines cited above; the full reference binary cannot be
 // built under this round's rules (htslib needs generated config.h/version.h), so whole-file parity
 // is not pinned by a reference run.

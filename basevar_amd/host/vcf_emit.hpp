@@ -11,7 +11,7 @@
 // the group AFs; the three rank sums truncated to int (caller.cpp:1151-1157).
 //
 // PARITY STATUS: the numeric inputs are the pinned bv_site_result fields; join()/tostring() are
-// pinned against the reference's own ngslib functions (tests/test_host_formats.py); the field order
+// pinned against the reference's own compiled ngslib functions (tests/test_host_formats.py); the field order
 // and literals are transcribed from the cited lines -- whole-line parity is not pinned by a run of
 // the reference binary (not buildable under this round's rules).
 #pragma once
