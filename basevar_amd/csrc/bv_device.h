@@ -17,9 +17,6 @@
 
 #include "../../include/basevar_amd.h"
 
-#ifndef BV_FISHER_ATTR
-#define BV_FISHER_ATTR inline
-#endif
 #define BV_WAVE 64
 #define BV_QBINS 128                       /* phred axis of the LDS histogram          */
 #define BV_ROWS 8                          /* (reverse << 2) | base                    */
@@ -315,10 +312,7 @@ __device__ __forceinline__ void bv_hyper_init(BvHyper &h, int n1_, int n_1, int 
 //             q * 2^-86 (they cannot change a double-precision sum that is >= ~q).
 // Where the reference updates p multiplicatively across what are separate lanes / directions
 // here, the values differ from it at the 1e-13 relative level (parity bar: 1e-6).
-__device__ BV_FISHER_ATTR double bv_fisher_two_sided_wave(int n11, int n12, int n21, int n22, int lane) {
-#ifdef BV_PROBE_NOFISHER
-    return 0.5;
-#endif
+__device__ inline double bv_fisher_two_sided_wave(int n11, int n12, int n21, int n22, int lane) {
     const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
     const int imax = (n_1 < n1_) ? n_1 : n1_;
     int imin = n1_ + n_1 - n;
@@ -628,7 +622,8 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n
 // the current active set, Combinations order: external/combinations.h:55-69) are independent.
 //   NW >= 1: "block mode" -- the runs of a level are dealt to the NW waves of the workgroup,
 //            results meet in LDS behind __syncthreads(); every thread then replays the cheap,
-//            uniform argmin / threshold decision.
+//            uniform argmin / threshold decision.  (Kept for workgroup-wide callers; the
+//            shipped kernels use wave mode.)
 //   NW == 0: "wave mode"  -- the calling wave does every run itself (used for the pop-group
 //            calls of pass 2, where each wave owns a different group); `sh` is wave-private.
 struct BvLrtShared {

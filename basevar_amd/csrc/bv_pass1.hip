@@ -87,7 +87,9 @@ __device__ __forceinline__ uint32_t bv_mask_tail_dword(uint32_t w, int keep) {
 
 // One wave streams one row, software-pipelined: two register sets of U chunks per plane, the
 // loads of the next set are in flight (16 KiB per wave) while the current set is tallied.
+#ifndef BV_TALLY_U
 #define BV_TALLY_U 4
+#endif
 struct BvChunkSet {
     bv_u32x4 vb[BV_TALLY_U], vq[BV_TALLY_U];
 };
@@ -211,11 +213,8 @@ struct BvSolveArgs {
 // and kept live around it -> 240 VGPRs, 2 waves/SIMD.  This file is therefore compiled with
 // `-mllvm -disable-machine-licm` (see Makefile): 121 VGPRs, 4 waves/SIMD.  (A noinline call
 // is no way out: device functions are register-allocated without an occupancy target.)
-#ifndef BV_SOLVER_ATTR
-#define BV_SOLVER_ATTR __forceinline__
-#endif
 template <bool ALIAS>
-__device__ BV_SOLVER_ATTR void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
+__device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
                                                   BV_LDS uint32_t *bin_code_l, BV_LDS uint32_t *bin_cnt_l,
                                                   BV_LDS BvSolverScratch *sv_l, BV_LDS const double *tab_hit_l,
                                                   BV_LDS const double *tab_miss_l, int lane) {

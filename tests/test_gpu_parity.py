@@ -299,3 +299,37 @@ def test_config2_full_size_100k_sites_x_10k_samples(bv, restatement):
     check(r, exp, None)
     assert 0.15 * S < r.n_variant < 0.40 * S  # the AF 0.002 class is below min_af = 0.01 at N = 10k
     eng.close()
+
+
+def test_many_groups_and_engine_reuse(bv, restatement):
+    """BV_MAX_GROUPS pop-groups (64 KiB of dynamic LDS in pass 2) and one engine reused across
+    slabs of different shape, with and without groups / rank planes."""
+    eng = bv.BaseTypeEngine(max_sites=4096, min_af_value=bv.min_af(5000), device=0)
+    rng = np.random.default_rng(9)
+    for n, ng, sites, ranks in [(5000, 32, 96, True), (5000, 17, 64, True), (5000, 0, 200, False), (5000, 3, 128, True)]:
+        slab = make_slab(sites, n, seed=int(rng.integers(1 << 20)), coverage=0.3, n_groups=0, site_offset=12)
+        if ng:
+            slab["group_id"] = rng.integers(0, ng + 1, size=n).astype(np.uint8)
+            slab["group_id"][slab["group_id"] == ng] = 0xFF
+            slab["n_groups"] = ng
+        if not ranks:
+            slab.pop("mapq"); slab.pop("rpr")
+        got = eng.lrt(slab)
+        exp, gexp, margins = restatement.run_with_margins(slab, eng.min_af, n_threads=8)
+        check(got, exp, gexp, margins, check_ranks=ranks)
+    eng.close()
+
+
+def test_very_many_short_sites(bv, restatement):
+    """300k sites in one submit (ticket counter, variant list and record writes at scale)."""
+    n, S = 64, 300000
+    slab = make_slab(S, n, seed=77, coverage=0.5, class_af=[(0.0, 0.0), (0.5, 0.0), (0.2, 0.2), (0.0, 0.0)])
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=8)
+    amb = ambiguous_sites(exp, margins)
+    bad = compare_sites(got.sites, exp)
+    bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
+    bad = {f: idx for f, idx in bad.items() if idx.size}
+    assert not bad, describe(bad, got.sites, exp)
+    assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum()) > 50000
