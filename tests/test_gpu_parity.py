@@ -333,3 +333,33 @@ def test_very_many_short_sites(bv, restatement):
     bad = {f: idx for f, idx in bad.items() if idx.size}
     assert not bad, describe(bad, got.sites, exp)
     assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum()) > 50000
+
+
+def test_two_engines_on_two_host_threads(bv, restatement):
+    """One engine per host thread (the reference runs one BaseType per ThreadPool worker,
+    src/basetype_caller.cpp:485-510): concurrent submits must not interfere."""
+    import threading
+    slabs = [make_slab(256, 30000 + 7000 * k, seed=300 + k, coverage=0.1, n_groups=2, site_offset=5) for k in range(2)]
+    results = [None, None]
+    errors = []
+
+    def work(k):
+        try:
+            maf = bv.min_af(slabs[k]["n_samples"])
+            eng = bv.BaseTypeEngine(max_sites=256, min_af_value=maf, device=0)
+            for _ in range(5):
+                results[k] = (eng.lrt(slabs[k]), maf)
+            eng.close()
+        except Exception as ex:  # pragma: no cover
+            errors.append(ex)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        got, maf = results[k]
+        exp, gexp, margins = restatement.run_with_margins(slabs[k], maf, n_threads=8)
+        check(got, exp, gexp, margins)
