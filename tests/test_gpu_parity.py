@@ -76,7 +76,8 @@ def test_golden_vectors(bv, path):
     (49200, 0.08, 64, 2, 27),     # just past the short-row / pipelined kernel switch
     (100000, 0.08, 96, 2, 24),    # NIPT row length (config #3)
     (100003, 0.02, 40, 0, 25),    # ragged, sparse
-    (450000, 0.05, 12, 1, 26),    # 1024-thread teams
+    (450000, 0.05, 12, 1, 26),    # long rows
+    (1000003, 0.03, 6, 0, 28),    # BASELINE's largest row length (1 M samples), ragged
 ])
 def test_fresh_slabs_vs_restatement(bv, restatement, n, cov, sites, groups, seed):
     slab = make_slab(sites, n, seed=seed, coverage=cov, n_groups=groups, ref_n_frac=0.03, site_offset=10)
