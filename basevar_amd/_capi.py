@@ -20,7 +20,7 @@ BV_MEM_DEVICE, BV_MEM_HOST = 0, 1
 BV_OK, BV_ERR_INVALID_ARG, BV_ERR_NO_DEVICE, BV_ERR_HIP, BV_ERR_TOO_LARGE, BV_ERR_SITE = 0, -1, -2, -3, -4, -5
 
 BV_SITE_COVERED, BV_SITE_VARIANT, BV_SITE_BAD_QUAL = 0x1, 0x2, 0x4
-BV_SITE_ZERO_FREQ, BV_SITE_RANKSUM, BV_SITE_SOR_OVERFLOW = 0x8, 0x10, 0x20
+BV_SITE_ZERO_FREQ, BV_SITE_RANKSUM, BV_SITE_SOR_OVERFLOW, BV_SITE_RPR_RANGE = 0x8, 0x10, 0x20, 0x40
 
 # cell encoding of the base_strand plane
 BV_CELL_REV, BV_CELL_NOCALL, BV_CELL_N, BV_CELL_INS, BV_CELL_DEL = 0x04, 0x08, 0x08, 0x09, 0x0A
@@ -58,6 +58,7 @@ class SynthParams(C.Structure):
 
 # every symbol include/basevar_amd.h declares
 EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_wait",
+           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_finish",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get",
            "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
 
@@ -92,6 +93,12 @@ def load():
     L.bv_engine_destroy.argtypes = [C.c_void_p]
     L.bv_engine_submit.restype = C.c_int
     L.bv_engine_submit.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bv_engine_tiles_begin.restype = C.c_int
+    L.bv_engine_tiles_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.bv_engine_tiles_add.restype = C.c_int
+    L.bv_engine_tiles_add.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p]
+    L.bv_engine_tiles_finish.restype = C.c_int
+    L.bv_engine_tiles_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.bv_engine_wait.restype = C.c_int
     L.bv_engine_wait.argtypes = [C.c_void_p]
     L.bv_engine_kernel_ms.restype = C.c_int

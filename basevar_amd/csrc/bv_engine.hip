@@ -50,6 +50,12 @@ struct bv_engine {
     bv_site_result *host_out = nullptr;
     bv_group_result *host_gout = nullptr;
     size_t host_out_bytes = 0, host_gout_bytes = 0;
+    // sample-axis tile mode
+    uint32_t *tile_state = nullptr;
+    uint32_t *tile_maxr = nullptr;
+    size_t tile_state_bytes = 0, tile_maxr_bytes = 0;
+    uint32_t tile_sites = 0, tile_groups = 0, tile_stride = 0, tile_samples_total = 0, tile_samples_seen = 0;
+    bool tile_ranks = false, tile_open = false;
     mutable std::mutex mu;
     std::string err;
 };
@@ -174,6 +180,8 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->stage) (void)hipFree(e->stage);
+    if (e->tile_state) (void)hipFree(e->tile_state);
+    if (e->tile_maxr) (void)hipFree(e->tile_maxr);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return BV_OK;
@@ -284,6 +292,141 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         if (e->host_gout && e->host_gout_bytes)
             BV_HIP(e, hipMemcpyAsync(e->host_gout, e->stage_gout, e->host_gout_bytes, hipMemcpyDeviceToHost, st));
     }
+    e->submitted = true;
+    return BV_OK;
+}
+
+// ---------------------------------------------------------------- sample-axis tile mode
+namespace {
+int ensure_stage(bv_engine *e, size_t bytes) {
+    if (bytes <= e->stage_bytes) return BV_OK;
+    if (e->stage) BV_HIP(e, hipFree(e->stage));  // synchronises with work that still uses it
+    e->stage = nullptr;
+    e->stage_bytes = 0;
+    BV_HIP(e, hipMalloc(&e->stage, bytes));
+    e->stage_bytes = bytes;
+    return BV_OK;
+}
+}  // namespace
+
+int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_total, uint32_t n_groups, int with_ranks) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: null engine");
+    if (n_sites == 0 || n_samples_total == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: empty job");
+    if (n_sites > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_tiles_begin: n_sites exceeds cfg.max_sites");
+    if (n_groups > BV_MAX_GROUPS) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: n_groups exceeds BV_MAX_GROUPS");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    const uint32_t stride = 7168u + n_groups * 512u;  // H1 2048 + Hm 1024 + Hr 4096 + Hg 512/group (bv_tiles.hip)
+    const size_t bytes = (size_t)n_sites * stride * sizeof(uint32_t), mbytes = (size_t)n_sites * sizeof(uint32_t);
+    if (bytes > e->tile_state_bytes) {
+        if (e->tile_state) BV_HIP(e, hipFree(e->tile_state));
+        e->tile_state = nullptr;
+        e->tile_state_bytes = 0;
+        BV_HIP(e, hipMalloc(&e->tile_state, bytes));
+        e->tile_state_bytes = bytes;
+    }
+    if (mbytes > e->tile_maxr_bytes) {
+        if (e->tile_maxr) BV_HIP(e, hipFree(e->tile_maxr));
+        e->tile_maxr = nullptr;
+        e->tile_maxr_bytes = 0;
+        BV_HIP(e, hipMalloc(&e->tile_maxr, mbytes));
+        e->tile_maxr_bytes = mbytes;
+    }
+    BV_HIP(e, hipMemset(e->tile_state, 0, bytes));
+    BV_HIP(e, hipMemset(e->tile_maxr, 0, mbytes));
+    e->tile_sites = n_sites; e->tile_groups = n_groups; e->tile_stride = stride;
+    e->tile_samples_total = n_samples_total; e->tile_samples_seen = 0;
+    e->tile_ranks = with_ranks != 0;
+    e->tile_open = true;
+    return BV_OK;
+}
+
+int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
+    if (!e || !t) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: null argument");
+    if (!e->tile_open) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: call bv_engine_tiles_begin first");
+    if (t->n_sites != e->tile_sites) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: tile n_sites differs from the job's");
+    if (t->n_samples == 0 || t->pitch < t->n_samples || (t->pitch & 15ull) || !t->base_strand || !t->qual)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: bad tile geometry or missing planes");
+    if (e->tile_ranks && (!t->mapq || !t->rpr)) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: job was opened with rank planes");
+    if (e->tile_groups && !t->group_id) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: job has groups, tile has no group_id");
+    if ((uint64_t)e->tile_samples_seen + t->n_samples > e->tile_samples_total)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: more samples than announced");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    e->last_stream = st;
+    const uint8_t *bs = t->base_strand, *q = t->qual, *mq = e->tile_ranks ? t->mapq : nullptr, *gid = e->tile_groups ? t->group_id : nullptr;
+    const uint16_t *rp = e->tile_ranks ? t->rpr : nullptr;
+    const size_t S = t->n_sites, P = t->pitch;
+    if (t->mem_kind == BV_MEM_HOST) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        size_t o_bs = 0, o_q = o_bs + up(S * P), o_mq = o_q + up(S * P), o_rp = o_mq + (mq ? up(S * P) : 0),
+               o_gid = o_rp + (rp ? up(S * P * 2) : 0), total = o_gid + (gid ? up(P) : 0);
+        int rc = ensure_stage(e, total);
+        if (rc != BV_OK) return rc;
+        uint8_t *base = static_cast<uint8_t *>(e->stage);
+        BV_HIP(e, hipMemcpyAsync(base + o_bs, bs, S * P, hipMemcpyHostToDevice, st));
+        BV_HIP(e, hipMemcpyAsync(base + o_q, q, S * P, hipMemcpyHostToDevice, st));
+        if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, st));
+        if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, st));
+        if (gid) BV_HIP(e, hipMemcpyAsync(base + o_gid, gid, t->n_samples, hipMemcpyHostToDevice, st));
+        bs = base + o_bs; q = base + o_q;
+        mq = mq ? base + o_mq : nullptr;
+        rp = rp ? reinterpret_cast<const uint16_t *>(base + o_rp) : nullptr;
+        gid = gid ? base + o_gid : nullptr;
+    }
+    BvTileArgs a;
+    a.bs = bs; a.q = q; a.mapq = mq; a.rpr = rp; a.group_id = gid; a.pitch = P; a.n_sites = t->n_sites;
+    a.width = t->n_samples; a.n_groups = e->tile_groups; a.stride = e->tile_stride; a.state = e->tile_state;
+    a.maxr = e->tile_maxr;
+    bv_launch_tile_tally(a, st);
+    BV_HIP(e, hipGetLastError());
+    e->tile_samples_seen += t->n_samples;
+    return BV_OK;
+}
+
+int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result *out, bv_group_result *gout,
+                           uint32_t mem_kind, void *stream_) {
+    if (!e || !ref_base || !out) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_finish: null argument");
+    if (!e->tile_open) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_finish: no open tile job");
+    if (e->tile_groups && !gout) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_finish: job has groups, gout is NULL");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    e->last_stream = st;
+    const size_t S = e->tile_sites, G = e->tile_groups;
+    const uint8_t *dref = ref_base;
+    bv_site_result *dout = out;
+    bv_group_result *dgout = gout;
+    e->host_out = nullptr; e->host_gout = nullptr;
+    if (mem_kind == BV_MEM_HOST) {
+        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+        size_t o_ref = 0, o_out = up(S), o_gout = o_out + up(S * sizeof(bv_site_result)),
+               total = o_gout + up(S * G * sizeof(bv_group_result));
+        int rc = ensure_stage(e, total);
+        if (rc != BV_OK) return rc;
+        uint8_t *base = static_cast<uint8_t *>(e->stage);
+        BV_HIP(e, hipMemcpyAsync(base + o_ref, ref_base, S, hipMemcpyHostToDevice, st));
+        dref = base + o_ref;
+        dout = reinterpret_cast<bv_site_result *>(base + o_out);
+        dgout = G ? reinterpret_cast<bv_group_result *>(base + o_gout) : nullptr;
+        e->stage_out = dout; e->stage_gout = dgout;
+        e->host_out = out; e->host_gout = gout;
+        e->host_out_bytes = S * sizeof(bv_site_result);
+        e->host_gout_bytes = S * G * sizeof(bv_group_result);
+    }
+    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
+    if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
+    BvTileFinishArgs f;
+    f.state = e->tile_state; f.maxr = e->tile_maxr; f.ref_base = dref; f.n_sites = e->tile_sites; f.n_groups = e->tile_groups;
+    f.stride = e->tile_stride; f.have_ranks = e->tile_ranks ? 1u : 0u; f.min_af = e->cfg.min_af; f.tables = e->d_tables;
+    f.out = dout; f.gout = dgout; f.var_list = e->d_var_list; f.counters = e->d_counters;
+    bv_launch_tile_finish(f, st);
+    BV_HIP(e, hipGetLastError());
+    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS, hipMemcpyDeviceToHost, st));
+    if (e->host_out) {
+        BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
+        if (e->host_gout && e->host_gout_bytes)
+            BV_HIP(e, hipMemcpyAsync(e->host_gout, e->stage_gout, e->host_gout_bytes, hipMemcpyDeviceToHost, st));
+    }
+    e->tile_open = false;
     e->submitted = true;
     return BV_OK;
 }

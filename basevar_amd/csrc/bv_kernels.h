@@ -47,6 +47,39 @@ struct BvPass2Args {
     const uint32_t *counters;
 };
 
+// sample-axis tile mode (bv_tiles.hip)
+struct BvTileArgs {
+    const uint8_t *bs;        // [n_sites][pitch] tile planes (device)
+    const uint8_t *q;
+    const uint8_t *mapq;      // may be NULL together with rpr
+    const uint16_t *rpr;
+    const uint8_t *group_id;  // [width] group of each sample of THIS tile, or NULL
+    uint64_t pitch;
+    uint32_t n_sites;
+    uint32_t width;           // samples in this tile
+    uint32_t n_groups;
+    uint32_t stride;          // state words per site
+    uint32_t *state;          // [n_sites][stride]
+    uint32_t *maxr;           // [n_sites] largest read-position rank seen
+};
+struct BvTileFinishArgs {
+    const uint32_t *state;
+    const uint32_t *maxr;
+    const uint8_t *ref_base;
+    uint32_t n_sites;
+    uint32_t n_groups;
+    uint32_t stride;
+    uint32_t have_ranks;
+    double min_af;
+    const BvTables *tables;
+    bv_site_result *out;
+    bv_group_result *gout;
+    uint32_t *var_list;
+    uint32_t *counters;
+};
+void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream);
+void bv_launch_tile_finish(const BvTileFinishArgs &a, hipStream_t stream);
+
 // host-callable launchers (defined next to the kernels)
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);
 void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream);

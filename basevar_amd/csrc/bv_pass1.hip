@@ -29,23 +29,7 @@
 // remap (no two workgroups share a byte).  No MFMA: categorical tallies + small FP64 tables.
 #include "bv_kernels.h"
 
-#define BV_H2_ROWQ 256                         /* phred axis: the raw phred byte indexes the row */
-#define BV_H2_WORDS (BV_ROWS * BV_H2_ROWQ)     /* 2048 x u32 = 8 KiB per histogram               */
-
-struct BvSolverScratch {
-    BvLrtShared lrt;
-    bv_site_result res;  // staged record, stored with one coalesced write
-};
-struct BvSolverShared {
-    uint32_t bin_code[BV_SLOTS * BV_WAVE];  // compacted non-empty (base<<7 | phred) bins
-    uint32_t bin_cnt[BV_SLOTS * BV_WAVE];
-    BvSolverScratch sc;
-};
-// ALIAS mode (short-row kernel, LDS-limited): the compacted bins live in the histogram itself, in
-// the upper halves (phred 128..255) of rows 0-2 (codes) and 3-5 (counts).  Valid input never
-// touches those words; they are read (bad-phred check, depth) before the bins overwrite them.
-#define BV_ALIAS_CODE_OFF (0 * BV_H2_ROWQ + 128)
-#define BV_ALIAS_CNT_OFF (3 * BV_H2_ROWQ + 128)
+#include "bv_solver.h"
 
 template <int NBUF, int NSOLVE>
 struct __attribute__((aligned(16))) BvPass1Shared {
@@ -146,239 +130,6 @@ __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const u
     }
 }
 
-// ------------------------------------------------------------------------------ solver
-// strand/base row sums and deterministic compaction of the non-empty (base, phred) bins
-template <bool ALIAS>
-__device__ __forceinline__ void bv_prologue_wave(const uint32_t *hist, uint32_t *bin_code, uint32_t *bin_cnt, int lane,
-                                                 uint32_t fwd[4], uint32_t rev[4], uint32_t *nb_out, uint32_t *badq_out) {
-    uint32_t nb = 0;
-    bool bad = false;
-    uint32_t facc[4], racc[4];
-    // phred 128..255 first: only invalid input puts counts there (they still belong to the depth)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        facc[b] = 0; racc[b] = 0;
-#pragma unroll
-        for (int qr = 2; qr < 4; ++qr) {
-            const int q = (qr << 6) | lane;
-            uint32_t f = hist[(b << 8) | q], v = hist[((b | 4) << 8) | q];
-            facc[b] += f;
-            racc[b] += v;
-            bad |= (f | v) != 0;
-        }
-    }
-    if (ALIAS) bv_lrt_sync<0>();  // every lane has read the upper halves before bins land in them
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-#pragma unroll
-        for (int qr = 0; qr < 2; ++qr) {  // phred 0..127 hold every valid bin
-            const int q = (qr << 6) | lane;
-            uint32_t f = hist[(b << 8) | q], v = hist[((b | 4) << 8) | q];
-            facc[b] += f;
-            racc[b] += v;
-            uint32_t c = f + v;
-            bad |= (c != 0) && (q >= BV_NQ_VALID);
-            bool valid = (c != 0) && (q < BV_NQ_VALID);
-            unsigned long long m = __ballot(valid);
-            uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (valid) {
-                const uint32_t at = ALIAS ? pos + (pos & ~127u) : pos;
-                bin_code[at] = ((uint32_t)b << 7) | (uint32_t)q;
-                bin_cnt[at] = c;
-            }
-            nb += (uint32_t)__popcll(m);
-        }
-        fwd[b] = bv_wave_sum_u32(facc[b]);
-        rev[b] = bv_wave_sum_u32(racc[b]);
-    }
-    *nb_out = nb;
-    *badq_out = (__ballot(bad) != 0ull) ? 1u : 0u;
-}
-
-// what the solver needs from the launch arguments (passed by value, in registers)
-struct BvSolveArgs {
-    const uint8_t *ref_base;
-    bv_site_result *out;
-    uint32_t *var_list;
-    uint32_t *counters;
-    double min_af;
-    uint32_t flags;
-};
-
-#define BV_LDS __attribute__((address_space(3)))
-
-// Everything the reference computes for one site, from its histogram, on one wave.
-// Register-pressure note: this body sits inside the persistent loop of the kernel.  With
-// MachineLICM enabled, every libm polynomial constant of log/exp is hoisted out of that loop
-// and kept live around it -> 240 VGPRs, 2 waves/SIMD.  This file is therefore compiled with
-// `-mllvm -disable-machine-licm` (see Makefile): 121 VGPRs, 4 waves/SIMD.  (A noinline call
-// is no way out: device functions are register-allocated without an occupancy target.)
-template <bool ALIAS>
-__device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
-                                                  BV_LDS uint32_t *bin_code_l, BV_LDS uint32_t *bin_cnt_l,
-                                                  BV_LDS BvSolverScratch *sv_l, BV_LDS const double *tab_hit_l,
-                                                  BV_LDS const double *tab_miss_l, int lane) {
-    uint32_t *hist = (uint32_t *)hist_l;
-    uint32_t *bin_code = ALIAS ? hist + BV_ALIAS_CODE_OFF : (uint32_t *)bin_code_l;
-    uint32_t *bin_cnt = ALIAS ? hist + BV_ALIAS_CNT_OFF : (uint32_t *)bin_cnt_l;
-    BvSolverScratch *sv = (BvSolverScratch *)sv_l;
-    const double *tab_hit = (const double *)tab_hit_l, *tab_miss = (const double *)tab_miss_l;
-    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
-    uint32_t *res_words = reinterpret_cast<uint32_t *>(&sv->res);
-    if (lane < REC_WORDS) res_words[lane] = 0u;
-
-    uint32_t fwd[4], rev[4], depth[4], nb, badq, total = 0;
-    // phred-0 calls per base, read before ALIAS-mode bins can overwrite anything (they never touch
-    // phred < 128, but keep every histogram read of the prologue in one place)
-    uint32_t q0_mask = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-        if (hist[b << 8] + hist[(b | 4) << 8]) q0_mask |= 1u << b;
-    bv_prologue_wave<ALIAS>(hist, bin_code, bin_cnt, lane, fwd, rev, &nb, &badq);
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        depth[b] = fwd[b] + rev[b];
-        total += depth[b];
-    }
-    bv_lrt_sync<0>();  // bin_code / bin_cnt / res zeroing visible to every lane
-    int ref = a.ref_base[site];
-    if (ref > 4) ref = 4;
-    const double qnan = __builtin_nan("");
-
-    if (a.flags & BV_FLAG_TALLY_ONLY) {  // diagnostic: streaming part only
-        if (lane == 0) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) sv->res.depth[b] = depth[b];
-            sv->res.total_depth = total;
-        }
-    } else if (total == 0) {
-        // nothing to call (caller.cpp:718 / basetype.cpp:132): the record stays zero
-        if (lane == 0) sv->res.mq_ranksum = sv->res.rpr_ranksum = sv->res.bq_ranksum = qnan;
-    } else {
-        uint32_t flags = BV_SITE_COVERED | (badq ? BV_SITE_BAD_QUAL : 0u);
-
-        // ---- CVG strand bias: alt = every non-ref ACGT base (caller.cpp:1236-1245)
-        if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
-            uint32_t rf = 0, rr = 0, af = 0, ar = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b == ref) { rf += fwd[b]; rr += rev[b]; } else { af += fwd[b]; ar += rev[b]; }
-            }
-            double fs, sor;
-            bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &flags);
-            if (lane == 0) {
-                sv->res.cvg_sb[0] = rf; sv->res.cvg_sb[1] = rr; sv->res.cvg_sb[2] = af; sv->res.cvg_sb[3] = ar;
-                sv->res.cvg_fs = fs;
-                sv->res.cvg_sor = sor;
-            }
-        }
-
-        // ---- lrt() over ACGT (basetype.h:115)
-        BvBins B;
-        B.code = bin_code; B.cnt = bin_cnt; B.skip_mask = ALIAS ? ~127u : 0u; B.hit = tab_hit; B.miss = tab_miss;
-        B.nb = (int)nb;
-        BvLrtOut L;
-        // q0_mask: bases that hold a phred-0 call (1 - eps == 0) keep the generic EM path, because
-        // the reference's 0/0 there yields NaN frequencies that must be reproduced
-        bv_lrt<0>(B, depth, total, /*A,C,G,T*/ 0 | (1 << 3) | (2 << 6) | (3 << 9), (a.flags & BV_FLAG_SKIP_LRT) ? 0 : 4, ref,
-                  a.min_af, &sv->lrt, 0, lane, L, q0_mask);
-        if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
-
-        double bq_ranksum = qnan;
-        if (L.n_alt > 0) {
-            flags |= BV_SITE_VARIANT;
-            uint32_t alt_mask = 0, ad_sum_u = 0;
-#pragma unroll
-            for (int k = 0; k < BV_MAX_ALT; ++k) {
-                if (k < L.n_alt) {
-                    alt_mask |= 1u << bv_alt_at(L, k);
-                    ad_sum_u += bv_sel4u(depth, bv_alt_at(L, k));
-                }
-            }
-            // QUAL / QD / AF / CAF (basetype.cpp:180-196, caller.cpp:1113-1122, 1160-1161)
-            {
-                double r = (double)bv_sel4u(depth, L.first) / (double)total;
-                double qual;
-                if (L.m == 1 && total > 10 && r > 0.5) qual = 5000.0;
-                else qual = bv_qual_from_chi2(L.chi2);
-                double ad_sum = 0;
-#pragma unroll
-                for (int k = 0; k < BV_MAX_ALT; ++k) {
-                    if (k < L.n_alt) {
-                        const uint32_t d = bv_sel4u(depth, bv_alt_at(L, k));
-                        ad_sum = ad_sum + (double)d;
-                        if (lane == 0) {
-                            sv->res.alt[k] = (uint8_t)bv_alt_at(L, k);
-                            sv->res.af[k] = L.af[k];
-                            sv->res.caf[k] = (double)d / (int)total;
-                        }
-                    }
-                }
-                double qd = qual / ad_sum;
-                if (qd == 0) qd = 0.0;
-                if (lane == 0) {
-                    sv->res.n_alt = (uint8_t)L.n_alt;
-                    sv->res.qual = qual;
-                    sv->res.qd = qd;
-                }
-            }
-            // VCF strand bias w.r.t. the chosen ALTs (caller.cpp:1164)
-            {
-                uint32_t rf = 0, rr = 0, af = 0, ar = 0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b == ref) { rf += fwd[b]; rr += rev[b]; }
-                    else if ((alt_mask >> b) & 1u) { af += fwd[b]; ar += rev[b]; }
-                }
-                double fs, sor;
-                bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &flags);
-                if (lane == 0) {
-                    sv->res.var_sb[0] = rf; sv->res.var_sb[1] = rr; sv->res.var_sb[2] = af; sv->res.var_sb[3] = ar;
-                    sv->res.var_fs = fs;
-                    sv->res.var_sor = sor;
-                }
-            }
-            // base-quality rank sum from the histogram this pass already holds (caller.cpp:1157)
-            {
-                unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
-                unsigned long long below = 0, twoR = 0;
-#pragma unroll
-                for (int w = 0; w < 2; ++w) {
-                    int q = w * 64 + lane;
-                    uint32_t rv = 0, av = 0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        uint32_t c = hist[(b << 8) | q] + hist[((b | 4) << 8) | q];
-                        if (b == ref) rv += c;
-                        else if ((alt_mask >> b) & 1u) av += c;
-                    }
-                    twoR += bv_ranksum_window(rv, av, n1 + n2, below, lane);
-                }
-                bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
-            }
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int b = 0; b < 4; ++b) sv->res.depth[b] = depth[b];
-            sv->res.total_depth = total;
-            sv->res.status = flags;
-            sv->res.chi2 = L.chi2;
-            sv->res.em_iters = (uint16_t)L.em_iters;
-            sv->res.n_em = (uint8_t)L.n_em;
-            sv->res.mq_ranksum = qnan;
-            sv->res.rpr_ranksum = qnan;
-            sv->res.bq_ranksum = bq_ranksum;
-            if (L.n_alt > 0) {
-                uint32_t slot = atomicAdd(&a.counters[BV_CTR_VARIANTS], 1u);
-                a.var_list[slot] = site;
-            }
-            if (L.zero_freq) atomicAdd(&a.counters[BV_CTR_ZEROFREQ], 1u);
-        }
-    }
-    bv_lrt_sync<0>();
-    if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&a.out[site])[lane] = res_words[lane];
-}
-
 // ------------------------------------------------------------------------------ kernel
 // Every spin is bounded (~1 s): a protocol bug must end the kernel with counters[3] set
 // (reported by bv_engine_wait) instead of hanging the GPU.
@@ -403,7 +154,7 @@ __device__ __forceinline__ void bv_add_flag(uint32_t *flag, int lane) {
 }
 
 template <int NTALLY, int NSOLVE>
-__global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), (NTALLY + NSOLVE) <= 4 ? 4 : ((NTALLY + NSOLVE) <= 8 ? 2 : 1) * ((NTALLY + NSOLVE + 3) / 4)) void bv_pass1_kernel(BvPass1Args a) {
+__global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel(BvPass1Args a) {
     constexpr int NT = BV_WAVE * (NTALLY + NSOLVE);
     constexpr int NBUF = NSOLVE + 2;  // the tally may run two sites ahead of a slow (variant-site) solve
     __shared__ BvPass1Shared<NBUF, NSOLVE> sh;
@@ -567,13 +318,8 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
     const uint32_t shape = (a.flags >> 8) & 0xFu;
     switch (shape) {
         case 1: return bv_launch_pass1_cfg<3, 1>(a, stream);
-        case 2: return bv_launch_pass1_cfg<3, 2>(a, stream);
-        case 3: return bv_launch_pass1_cfg<2, 2>(a, stream);
-        case 4: return bv_launch_pass1_cfg<4, 2>(a, stream);
-        case 5: return bv_launch_pass1_cfg<2, 1>(a, stream);
-        case 6: return bv_launch_pass1_cfg<1, 3>(a, stream);
-        case 7: return bv_launch_pass1_cfg<1, 1>(a, stream);
-        case 8: return bv_launch_pass1_cfg<6, 2>(a, stream);
+        case 2: return bv_launch_pass1_cfg<3, 2>(a, stream);  // measured: 15-30 % slower than <3,1>
+        case 5: return bv_launch_pass1_cfg<2, 1>(a, stream);  // measured:  4 % slower than <3,1>
         case 9: return bv_launch_pass1_fused(a, stream);
         default: break;
     }

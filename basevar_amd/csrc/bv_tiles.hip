@@ -1,0 +1,209 @@
+// bv_tiles.hip -- sample-axis tile mode (BASELINE config #5; SURVEY.md sections 5 and 8e).
+//
+// The reference stores the sample axis in batchfiles of B samples each (`-B/--batch-count`,
+// src/basetype_caller.cpp:419-453) and re-joins them per site.  Because every per-site quantity
+// of the path is a function of tallies that are ADDITIVE over samples, a site does not have to be
+// presented as one full row: column tiles [n_sites][tile_width] can be streamed (e.g. from host
+// DRAM, one batchfile at a time) and accumulated into per-site state in HBM; the solve runs once
+// at the end.  State per site (u32 words):
+//     H1 [ (rev<<2|base) << 8 | phred ]        2048   same layout as the LDS histogram of pass 1
+//     Hm [ base << 8  | mapq ]                 1024   mapq tally per called base
+//     Hr [ base << 10 | rank ]                 4096   read-position ranks 0..1023 per called base
+//     Hg [ (group*4 + base) << 7 | phred ]     512 per pop-group
+// Keeping Hm/Hr per BASE (not per REF/ALT class) is what makes a single sweep enough: the alt set
+// is only known after the last tile, and any (ref, alts) partition can be read off per-base tallies.
+// Ranks >= 1024 cannot be tallied exactly in this layout: such sites get BV_SITE_RPR_RANGE and a
+// NaN ReadPosRankSum (use the row mode, whose pass 2 sweeps rank windows, for long reads).
+//
+// Tally: one LANE per site (a narrow tile row is only a few 16-byte chunks), covered cells go to the
+// site's state with global atomics -- lanes of a wave hit different sites, so no two lanes of an
+// instruction collide.  The tile path is PCIe- or ingest-bound by two orders of magnitude
+// (DESIGN.md), so this kernel is written for correctness and simplicity, not for the HBM roofline.
+#include "bv_solver.h"
+
+#define BV_TS_H1 0u
+#define BV_TS_HM 2048u
+#define BV_TS_HR 3072u
+#define BV_TS_HG 7168u
+#define BV_TS_RPR_WIN 1024u
+
+__global__ __launch_bounds__(256) void bv_tile_tally_kernel(BvTileArgs a) {
+    const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
+    if (site >= a.n_sites) return;
+    uint32_t *S = a.state + (size_t)site * a.stride;
+    const size_t row = (size_t)site * a.pitch;
+    const uint32_t n_chunks = (a.width + 15u) >> 4;
+    uint32_t maxr = 0;
+    for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+        const bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(a.bs + row + (size_t)ch * 16u);
+        const bv_u32x4 vq = *reinterpret_cast<const bv_u32x4 *>(a.q + row + (size_t)ch * 16u);
+        const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w}, wq[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t smp = ch * 16u + j;
+            const uint32_t c = (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            if (smp >= a.width || (c & BV_CELL_NOCALL) || c > 7u) continue;
+            const uint32_t q = (wq[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t b = c & 3u;
+            atomicAdd(&S[BV_TS_H1 + ((c << 8) | q)], 1u);
+            if (a.mapq) {
+                const uint32_t mq = a.mapq[row + smp];
+                const uint32_t r = a.rpr[row + smp];
+                atomicAdd(&S[BV_TS_HM + ((b << 8) | mq)], 1u);
+                maxr = max(maxr, r);
+                if (r < BV_TS_RPR_WIN) atomicAdd(&S[BV_TS_HR + ((b << 10) | r)], 1u);
+            }
+            if (a.n_groups) {
+                const uint32_t g = a.group_id[smp];
+                if (g < a.n_groups) atomicAdd(&S[BV_TS_HG + (((g * 4u + b) << 7) | (q & 127u))], 1u);
+            }
+        }
+    }
+    if (a.mapq && maxr) atomicMax(&a.maxr[site], maxr);
+}
+
+struct __attribute__((aligned(16))) BvTileFinishShared {
+    uint32_t hist[BV_H2_WORDS];
+    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    BvSolverScratch sc;
+    uint32_t bin_code[BV_SLOTS * BV_WAVE];  // group calls
+    uint32_t bin_cnt[BV_SLOTS * BV_WAVE];
+};
+
+// One wave per site: the record from the accumulated state.
+__global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArgs a) {
+    __shared__ BvTileFinishShared sh;
+    const int lane = threadIdx.x;
+    const uint32_t site = blockIdx.x;
+    const uint32_t *S = a.state + (size_t)site * a.stride;
+    {
+        const uint4 *g4 = reinterpret_cast<const uint4 *>(S + BV_TS_H1);
+        uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist);
+#pragma unroll
+        for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = g4[i * BV_WAVE + lane];
+        for (int i = lane; i < BV_QBINS; i += BV_WAVE) {
+            sh.tab_hit[i] = a.tables->hit[i];
+            sh.tab_miss[i] = a.tables->miss[i];
+        }
+    }
+    bv_lrt_sync<0>();
+    BvSolveArgs sa;
+    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
+    sa.min_af = a.min_af; sa.flags = 0;
+    bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)sh.hist, (BV_LDS uint32_t *)nullptr, (BV_LDS uint32_t *)nullptr,
+                             (BV_LDS BvSolverScratch *)&sh.sc, (BV_LDS const double *)sh.tab_hit,
+                             (BV_LDS const double *)sh.tab_miss, lane);
+    // what the solver decided (its staged record is still in LDS)
+    const int n_alt = sh.sc.res.n_alt;
+    if (n_alt == 0) return;
+    int ref = a.ref_base[site];
+    if (ref > 4) ref = 4;
+    uint32_t depth[4] = {sh.sc.res.depth[0], sh.sc.res.depth[1], sh.sc.res.depth[2], sh.sc.res.depth[3]};
+    uint32_t alt_mask = 0;
+    unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = 0;
+    int comb = ref, nc = 1;
+#pragma unroll
+    for (int k = 0; k < BV_MAX_ALT; ++k) {
+        if (k < n_alt) {
+            const int b = sh.sc.res.alt[k] & 3;
+            alt_mask |= 1u << b;
+            n2 += bv_sel4u(depth, b);
+            comb |= b << (3 * nc);
+            ++nc;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);  // the record store of the solver has been issued before the field updates below
+
+    if (a.have_ranks) {
+        // MQRankSum / ReadPosRankSum from per-base tallies (caller.cpp:1151-1154)
+        unsigned long long below = 0, twoR = 0;
+        for (int w = 0; w < 4; ++w) {
+            const int v = w * 64 + lane;
+            uint32_t rv = 0, av = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t c = S[BV_TS_HM + ((b << 8) | v)];
+                if (b == ref) rv += c;
+                else if ((alt_mask >> b) & 1u) av += c;
+            }
+            twoR += bv_ranksum_window(rv, av, n1 + n2, below, lane);
+        }
+        const double mq_ph = bv_ranksum_phred(twoR, n1, n2);
+        double rp_ph = __builtin_nan("");
+        const bool in_range = a.maxr[site] < BV_TS_RPR_WIN;
+        if (in_range) {
+            below = 0; twoR = 0;
+            for (int w = 0; w < (int)BV_TS_RPR_WIN / 64; ++w) {
+                const int v = w * 64 + lane;
+                uint32_t rv = 0, av = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t c = S[BV_TS_HR + ((b << 10) | v)];
+                    if (b == ref) rv += c;
+                    else if ((alt_mask >> b) & 1u) av += c;
+                }
+                twoR += bv_ranksum_window(rv, av, n1 + n2, below, lane);
+            }
+            rp_ph = bv_ranksum_phred(twoR, n1, n2);
+        }
+        if (lane == 0) {
+            a.out[site].mq_ranksum = mq_ph;
+            a.out[site].rpr_ranksum = rp_ph;
+            atomicOr(&a.out[site].status, in_range ? BV_SITE_RANKSUM : (BV_SITE_RANKSUM | BV_SITE_RPR_RANGE));
+        }
+    }
+
+    // per-group calls (caller.cpp:756-759): lrt([REF] + alts) on each group's tallies
+    for (uint32_t g = 0; g < a.n_groups; ++g) {
+        const uint32_t *h = S + BV_TS_HG + g * 512u;
+        uint32_t nb = 0, gdepth[4], gtotal = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int b = r >> 1;
+            const int q = ((r & 1) << 6) | lane;
+            const uint32_t c = h[(b << 7) | q];
+            const uint32_t cs = bv_wave_sum_u32(c);
+            if (r & 1) gdepth[b] += cs; else gdepth[b] = cs;
+            const bool valid = (c != 0) && (q < BV_NQ_VALID);
+            const unsigned long long m = __ballot(valid);
+            const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (valid) {
+                sh.bin_code[pos] = ((uint32_t)b << 7) | (uint32_t)q;
+                sh.bin_cnt[pos] = c;
+            }
+            nb += (uint32_t)__popcll(m);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) gtotal += gdepth[b];
+        bv_lrt_sync<0>();
+        BvLrtOut L;
+        L.n_alt = 0; L.alt_packed = 0; L.af[0] = L.af[1] = L.af[2] = L.af[3] = 0.;
+        if (gtotal > 0) {
+            BvBins B;
+            B.code = sh.bin_code; B.cnt = sh.bin_cnt; B.skip_mask = 0u; B.hit = sh.tab_hit; B.miss = sh.tab_miss;
+            B.nb = (int)nb;
+            bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.sc.lrt, 0, lane, L);
+        }
+        if (lane == 0) {
+            bv_group_result gr;
+            gr.n_alt = (uint8_t)L.n_alt;
+            gr.reserved[0] = gr.reserved[1] = gr.reserved[2] = 0;
+            gr.total_depth = gtotal;
+            gr.reserved2 = 0;
+#pragma unroll
+            for (int k = 0; k < BV_MAX_ALT; ++k) {
+                gr.alt[k] = (k < L.n_alt) ? (uint8_t)bv_alt_at(L, k) : 0;
+                gr.af[k] = (k < L.n_alt) ? L.af[k] : 0.0;
+            }
+            a.gout[(size_t)site * a.n_groups + g] = gr;
+        }
+        bv_lrt_sync<0>();
+    }
+}
+
+void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(bv_tile_tally_kernel, dim3((a.n_sites + 255u) / 256u), dim3(256), 0, stream, a);
+}
+void bv_launch_tile_finish(const BvTileFinishArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(bv_tile_finish_kernel, dim3(a.n_sites), dim3(BV_WAVE), 0, stream, a);
+}

@@ -142,6 +142,54 @@ class BaseTypeEngine:
         self._lib.bv_engine_last_variant_count(self._h, C.byref(n))
         return n.value
 
+    # ---- sample-axis tile mode (numpy tiles in host memory)
+    def lrt_tiles(self, slab, tile_width):
+        """Same result as lrt(slab), but the slab is fed as column tiles of `tile_width` samples
+        (the reference's `-B/--batch-count` batchfiles) that the engine accumulates in HBM."""
+        bs = np.ascontiguousarray(slab["base_strand"], dtype=np.uint8)
+        S = bs.shape[0]
+        N = int(slab.get("n_samples", bs.shape[1]))
+        q = np.asarray(slab["qual"], dtype=np.uint8)
+        mq, rp = slab.get("mapq"), slab.get("rpr")
+        ranks = mq is not None and rp is not None
+        gid = slab.get("group_id")
+        ng = int(slab.get("n_groups", 0)) if gid is not None else 0
+        ref = np.ascontiguousarray(slab["ref_base"], dtype=np.uint8)
+        rc = self._lib.bv_engine_tiles_begin(self._h, S, N, ng, 1 if ranks else 0)
+        if rc != 0:
+            raise RuntimeError("bv_engine_tiles_begin failed (%d): %s" % (rc, self._err()))
+        keep = []
+        for lo in range(0, N, tile_width):
+            w = min(tile_width, N - lo)
+            pitch = (w + 15) // 16 * 16
+
+            def tile(a, dt, fill):
+                t = np.full((S, pitch), fill, dtype=dt)
+                t[:, :w] = a[:, lo:lo + w]
+                return t
+            tb, tq = tile(bs, np.uint8, 8), tile(q, np.uint8, 0)
+            tm = tile(np.asarray(mq), np.uint8, 0) if ranks else None
+            tr = tile(np.asarray(rp), np.uint16, 0) if ranks else None
+            tg = None
+            if ng:
+                tg = np.full(pitch, 0xFF, dtype=np.uint8)
+                tg[:w] = np.asarray(gid, dtype=np.uint8)[lo:lo + w]
+            keep.append((tb, tq, tm, tr, tg))
+            p = lambda a: None if a is None else a.ctypes.data
+            t = _capi.Slab(S, w, pitch, p(tb), p(tq), p(tm), p(tr), None, p(tg), ng, _capi.BV_MEM_HOST)
+            rc = self._lib.bv_engine_tiles_add(self._h, C.byref(t), None)
+            if rc != 0:
+                raise RuntimeError("bv_engine_tiles_add failed (%d): %s" % (rc, self._err()))
+            self.wait()  # host tiles are staged through one buffer: keep it simple and safe here
+        out = np.zeros(S, dtype=_capi.SITE_DTYPE)
+        gout = np.zeros((S, ng), dtype=_capi.GROUP_DTYPE) if ng else None
+        rc = self._lib.bv_engine_tiles_finish(self._h, ref.ctypes.data, out.ctypes.data,
+                                              gout.ctypes.data if ng else None, _capi.BV_MEM_HOST, None)
+        if rc != 0:
+            raise RuntimeError("bv_engine_tiles_finish failed (%d): %s" % (rc, self._err()))
+        self.wait()
+        return BaseTypeBatch(out, gout, self.last_variant_count(), 0.0, 0.0)
+
     # ---- numpy slab (host memory; the engine stages it to HBM)
     def lrt(self, slab):
         """slab: dict of numpy planes as produced by basevar_amd.synth.make_slab()."""

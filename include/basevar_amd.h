@@ -83,6 +83,7 @@ typedef enum bv_mem_kind {
 #define BV_SITE_ZERO_FREQ 0x8u /* reference would throw at basetype.cpp:113-115        */
 #define BV_SITE_RANKSUM 0x10u  /* mapq/rpr rank sums were computed (planes present)    */
 #define BV_SITE_SOR_OVERFLOW 0x20u /* int product in SOR exceeded 2^31 (basetype.cpp:286 is UB there) */
+#define BV_SITE_RPR_RANGE 0x40u    /* tile mode only: a read-position rank >= 1024 was seen; rpr_ranksum = NaN */
 
 /* Input: SoA planes [n_sites][pitch], one row per genomic site, one cell per sample.
  * Replaces `struct BatchInfo` (src/basetype.h:25-43) for a whole batch of sites. */
@@ -186,6 +187,24 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
 /* Block until the last submit has finished.  Returns BV_ERR_SITE if any site set
  * BV_SITE_ZERO_FREQ (the reference would have thrown). */
 int bv_engine_wait(bv_engine *e);
+
+/* ---- sample-axis tile mode -----------------------------------------------------
+ * The reference keeps the sample axis in batchfiles of B samples (`-B`, src/basetype_caller.cpp:
+ * 419-453) and re-joins one row from each per site (:589-601).  Every quantity of the path is a
+ * function of tallies that are additive over samples, so the engine can instead take column
+ * tiles [n_sites][tile_width] one at a time (e.g. one batchfile after the other, streamed from
+ * host DRAM: BASELINE config #5) and accumulate per-site state in HBM:
+ *     bv_engine_tiles_begin(e, n_sites, n_samples_total, n_groups, with_ranks)
+ *     bv_engine_tiles_add(e, tile, stream)      for every tile; tile->n_sites must match;
+ *                                               tile->group_id covers the tile's samples
+ *     bv_engine_tiles_finish(e, ref_base, out, gout, mem_kind, stream)   then bv_engine_wait()
+ * Results equal those of one bv_engine_submit on the joined rows, except that read-position
+ * ranks >= 1024 are not supported in this mode (BV_SITE_RPR_RANGE, rpr_ranksum = NaN). */
+int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_total, uint32_t n_groups,
+                          int with_ranks);
+int bv_engine_tiles_add(bv_engine *e, const bv_slab *tile, void *stream);
+int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result *out, bv_group_result *gout,
+                           uint32_t mem_kind, void *stream);
 
 /* HIP-event timings (ms) of the last submit's kernels on the stream they ran on:
  * pass 1 (tally + solve, all sites) and pass 2 (rank sums + groups, variant sites).

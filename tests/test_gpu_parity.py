@@ -364,3 +364,35 @@ def test_two_engines_on_two_host_threads(bv, restatement):
         got, maf = results[k]
         exp, gexp, margins = restatement.run_with_margins(slabs[k], maf, n_threads=8)
         check(got, exp, gexp, margins)
+
+
+@pytest.mark.parametrize("n,width,groups,ranks", [(1000, 200, 2, True), (3001, 200, 0, True), (700, 64, 3, False),
+                                                  (5000, 5000, 2, True), (257, 16, 1, True)])
+def test_sample_axis_tiles_equal_rows(bv, restatement, n, width, groups, ranks):
+    """BASELINE config #5 mechanism: column tiles of `width` samples accumulated in HBM give the same
+    records as the joined rows (and the oracle)."""
+    slab = make_slab(96, n, seed=900 + n, coverage=0.4, n_groups=groups, site_offset=9, ref_n_frac=0.05)
+    if not ranks:
+        slab.pop("mapq"); slab.pop("rpr")
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=96, min_af_value=maf, device=0)
+    rows = eng.lrt(slab)
+    tiles = eng.lrt_tiles(slab, width)
+    eng.close()
+    exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=4)
+    check(tiles, exp, gexp, margins, check_ranks=ranks)
+    # and bit-identical to the row mode wherever the arithmetic is order-free (integers)
+    for f in ("depth", "total_depth", "cvg_sb", "var_sb", "n_alt", "alt"):
+        assert np.array_equal(rows.sites[f], tiles.sites[f]), f
+
+
+def test_sample_axis_tiles_long_read_ranks_are_flagged(bv):
+    slab = make_slab(16, 400, seed=950, coverage=0.6, class_af=[(0.4, 0.0)])
+    cov = slab["base_strand"] < 8
+    slab["rpr"][3, np.nonzero(cov[3])[0][:2]] = 2000
+    eng = bv.BaseTypeEngine(max_sites=16, min_af_value=bv.min_af(400), device=0)
+    t = eng.lrt_tiles(slab, 100)
+    eng.close()
+    flagged = (t.sites["status"] & 0x40) != 0
+    assert flagged[3] and flagged.sum() == 1 and np.isnan(t.sites["rpr_ranksum"][3])
+    assert not np.isnan(t.sites["mq_ranksum"][3])
