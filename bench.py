@@ -82,15 +82,17 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
             d["rpr"] = rp[ti].cpu().numpy().view(np.uint16)
         return d
 
+    last = {}
+
     def timed(d, nthreads):
         """(wall seconds of the path, per-thread path seconds or None)"""
         t0 = time.perf_counter()
         if kind == "reference":
-            _, _, secs = chk.run_timed(d, maf, n_threads=nthreads)
+            last["rec"], _, secs = chk.run_timed(d, maf, n_threads=nthreads)
             # the threads run concurrently: the path's wall time is the slowest thread's path time
             # (the driver's slab -> BatchInfo conversion is not part of the reference path)
             return float(secs.max()), secs
-        chk.run(d, maf, n_threads=nthreads)
+        last["rec"], _ = chk.run(d, maf, n_threads=nthreads)
         return time.perf_counter() - t0, None
 
     # pilot to size the sample to ~15 s of CPU work
@@ -100,6 +102,7 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
     n = want_sites or int(max(threads * 2, min(S, 4096, 20.0 / per_site_cpu_s)))
     n = max(threads, (n // threads) * threads)
     wall, _ = timed(sub(n), threads)
+    cpu_records, cpu_idx = last["rec"], np.linspace(0, S - 1, num=n).astype(np.int64)
     one = sub(max(8, min(64, n // threads)))
     wall1, _ = timed(one, 1)
     n1 = one["base_strand"].shape[0]
@@ -110,7 +113,35 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
                   "BaseType ctor + lrt + strand_bias x2 + 3 rank sums; single-thread: %.1f sites/s" % (
                       n, S, n_samples, threads, n1 / wall1),
         "single_thread_value": n1 / wall1,
-    }
+    }, cpu_records, cpu_idx
+
+
+def parity_on_sample(gpu, cpu):
+    """Max relative error of the float fields and exactness of the integer fields, GPU records vs the
+    CPU baseline's records of the same sites (reported next to the timing)."""
+    import numpy as np
+
+    def rel(a, b):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        m = ~(np.isnan(a) & np.isnan(b))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            e = np.abs(a - b) / np.maximum(np.abs(b), 1e-300)
+        e = np.where((a == b) | ~m, 0.0, e)
+        return float(np.nanmax(e)) if e.size else 0.0
+
+    def rel_or_abs(a, b, atol=1e-9):
+        a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            e = np.abs(a - b)
+            e = np.where(e <= atol, 0.0, e / np.maximum(np.abs(b), 1e-300))
+        e = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, e)
+        return float(np.nanmax(e)) if e.size else 0.0
+    ints_ok = all(bool(np.array_equal(gpu[f], cpu[f])) for f in ("depth", "total_depth", "cvg_sb", "var_sb", "n_alt", "alt"))
+    return {"sites": int(len(cpu)), "variant_sites": int(((cpu["status"] & 2) != 0).sum()), "integer_fields_bit_exact": ints_ok,
+            "max_rel_err_af": rel(gpu["af"], cpu["af"]), "max_rel_err_qual": rel(gpu["qual"], cpu["qual"]),
+            "max_rel_err_qd": rel(gpu["qd"], cpu["qd"]),
+            "max_rel_err_fs_sor_ranksums": max(rel_or_abs(gpu[f], cpu[f]) for f in (
+                "cvg_fs", "var_fs", "cvg_sor", "var_sor", "mq_ranksum", "rpr_ranksum", "bq_ranksum"))}
 
 
 def main():
@@ -261,6 +292,16 @@ def main():
                 "avg_launch_ms": p1_avg_s * 1e3, "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
             },
         }
+        if world == 1:
+            # measured device-copy ceiling on this box (read + write bytes), for context next to the spec peak
+            src = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+            dst.copy_(src); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            line["roofline"]["measured_copy_GBps"] = 5 * 2 * src.numel() / (time.perf_counter() - t0) / 1e9
+            del src, dst
         if world == 1 and args.with_host_path:
             # PCIe-inclusive rate when the boundary hands over HOST buffers (DESIGN.md note; not `value`)
             hb = min(B, 4096)
@@ -283,8 +324,16 @@ def main():
                                       "host_GBps": hb * pitch * (5 if ranks else 2) / dt / 1e9}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)
+                cb, cpu_rec, cpu_idx = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)
                 line["cpu_baseline"] = cb
+                # GPU records of the same sites (one more submit of batch 0)
+                bs0, q0, mq0, rp0, ref0 = batches[0]
+                eng.submit_ptrs(B, N, pitch, bs0.data_ptr(), q0.data_ptr(), ref0.data_ptr(), outs[0].data_ptr(),
+                                mq0.data_ptr() if ranks else 0, rp0.data_ptr() if ranks else 0,
+                                stream=streams[0].cuda_stream)
+                eng.wait()
+                gpu_rec = outs[0].cpu().numpy().view(basevar_amd.SITE_DTYPE)[cpu_idx]
+                line["parity_sample"] = parity_on_sample(gpu_rec, cpu_rec)
                 line["gpu_over_cpu_allcore"] = sites_per_s / cb["value"]
                 line["gpu_over_cpu_1thread"] = sites_per_s / cb["single_thread_value"]
             except Exception as ex:
