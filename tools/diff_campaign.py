@@ -28,7 +28,7 @@ def main():
     tot_sites = tot_var = tot_amb = tot_bad = 0
     t0 = time.time()
     for it in range(rounds):
-        n = int(rng.choice([37, 300, 2500, 10000, 40000, 60000, 120000, 300000]))
+        n = int(rng.choice([37, 300, 2500, 10000, 40000, 49152, 49153, 60000, 120000, 300000, 1000000]))
         sites = int(max(16, min(4096, 6_000_000 // n)))
         cov = float(rng.choice([0.02, 0.08, 0.3, 0.9]))
         qm = float(rng.choice([10.0, 25.0, 33.0]))
@@ -37,7 +37,7 @@ def main():
             a = float(rng.choice([0, 0, 0.0005, 0.002, 0.01, 0.05, 0.2, 0.5, 0.95, 1.0]))
             b = float(rng.choice([0, 0, 0, 0.01, 0.1, 0.3]))
             classes.append((a, min(b, 1.0 - a)))
-        ng = int(rng.choice([0, 0, 2, 5]))
+        ng = int(rng.choice([0, 0, 2, 5, 32]))
         slab = make_slab(sites, n, seed=int(rng.integers(1 << 30)), coverage=cov, qual_mean=qm, qual_sd=9.0,
                          qual_min=1, qual_max=60, n_groups=ng, class_af=classes, ref_n_frac=0.03)
         maf = res.min_af(n, float(rng.choice([0.01, 0.001])))
