@@ -50,3 +50,38 @@ def gather_records_sized(local, sizes, dst=0, group=None):
         return torch.cat([p[:s] for p, s in zip(parts, sizes)])
     dist.gather(buf, gather_list=None, dst=dst, group=group)
     return None
+
+
+class RecordGatherer:
+    """Per-batch gather of equal-sized record buffers to rank `dst`, kept off the critical path:
+    the collective of batch i is issued asynchronously and only waited for when its buffers are
+    about to be reused (ring of `depth` slots), so it overlaps the kernels of batches i+1, i+2.
+    On `dst`, `parts(slot)` holds the ranks' buffers in rank order == genomic order."""
+
+    def __init__(self, nbytes, device, depth=3, dst=0, group=None):
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.dst, self.group, self.depth = dst, group, depth
+        self.pending = [None] * depth
+        self._parts = None
+        if self.rank == dst:
+            self._parts = [[torch.empty(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)]
+                           for _ in range(depth)]
+
+    def before_reuse(self, slot):
+        """Call before overwriting the buffer that was passed to issue(slot, ...) last time."""
+        w = self.pending[slot]
+        if w is not None:
+            w.wait()
+            self.pending[slot] = None
+
+    def issue(self, slot, local):
+        parts = self._parts[slot] if self.rank == self.dst else None
+        self.pending[slot] = dist.gather(local, gather_list=parts, dst=self.dst, group=self.group, async_op=True)
+
+    def drain(self):
+        for k in range(self.depth):
+            self.before_reuse(k)
+
+    def parts(self, slot):
+        return self._parts[slot] if self._parts is not None else None

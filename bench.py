@@ -174,7 +174,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import basevar_amd
-    from basevar_amd.shard import gather_records_sized
+    from basevar_amd.shard import RecordGatherer
 
     N = args.samples
     B = args.batch_sites
@@ -203,25 +203,42 @@ def main():
                                        flags=(1 if args.tally_only else 0) | args.flags) for _ in range(ns)]
     eng = engs[0]
     rec = basevar_amd.SITE_DTYPE.itemsize
-    outs = [torch.zeros(B * rec, dtype=torch.uint8, device=dev) for _ in range(ns)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(ns - 1)]
-    sizes = [B * rec] * world
+    # record buffers: one per stream at N = 1; a ring of 3 per rank at N > 1 so that the gather of
+    # batch i (RCCL, asynchronous) overlaps the kernels of batches i+1 and i+2
+    depth = 3 if world > 1 else ns
+    gloo_host = world > 1 and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
+    outs = [torch.zeros(B * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    houts = [torch.zeros(B * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None
+    # explicit (non-default) streams: the legacy default stream's handle is 0, which the C ABI reads as
+    # "use the engine's own stream" -- the gather issued from torch would then not be ordered behind the kernels
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    gatherer = RecordGatherer(B * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if world > 1 else None
+    last_slot = [0]
 
     def step(i):
         bs, q, mq, rp, ref = batches[i % nb]
         k = i % ns
-        out = outs[k]
+        slot = i % depth
+        out = outs[slot]
+        if gatherer is not None:
+            gatherer.before_reuse(slot)  # the gather that last read this buffer has completed
         with torch.cuda.stream(streams[k]):
             engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                 mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
                                 stream=streams[k].cuda_stream)
-            if world > 1:
-                if backend != "nccl":  # gloo has no GPU gather: stage through the host (test plumbing only)
-                    return gather_records_sized(out.cpu(), sizes, dst=0)
-                return gather_records_sized(out, sizes, dst=0)  # ordered records on rank 0
+            if gatherer is not None:
+                if gloo_host:
+                    houts[slot].copy_(out)
+                    gatherer.issue(slot, houts[slot])
+                else:
+                    gatherer.issue(slot, out)  # ordered records on rank 0: parts in rank order
+        last_slot[0] = slot
         return out
 
     def fence():
+        if gatherer is not None:
+            gatherer.drain()
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -240,9 +257,10 @@ def main():
     gathered_ok = None
     if rank == 0 and world > 1:
         # the gathered buffer holds world x B records in rank order: every record must be a covered site
-        import numpy as _np
-        recs = last.cpu().numpy().view(basevar_amd.SITE_DTYPE)
-        gathered_ok = bool(len(recs) == world * B and (recs["total_depth"] > 0).all())
+        recs = torch.cat([p.cpu() for p in gatherer.parts(last_slot[0])]).numpy().view(basevar_amd.SITE_DTYPE)
+        mine = outs[last_slot[0]].cpu().numpy().view(basevar_amd.SITE_DTYPE)
+        gathered_ok = bool(len(recs) == world * B and (recs["total_depth"] > 0).all() and
+                           recs[:B].tobytes() == mine.tobytes())
     p1_ms = p2_ms = 0.0
     nsub = 0
     for e in engs:

@@ -179,7 +179,9 @@ int bv_engine_destroy(bv_engine *e);
  *   per-group __gb() when slab->n_groups > 0      caller.cpp:756-759
  * `out`   : [n_sites] records, same mem_kind as the slab.
  * `gout`  : [n_sites][n_groups] records or NULL when n_groups == 0.
- * `stream`: hipStream_t to launch on, or NULL for the engine's own stream.
+ * `stream`: hipStream_t to launch on, or NULL for the engine's own stream.  (NULL is also the handle of
+ *           the legacy default stream: a caller that wants ordering with other work must pass an
+ *           explicit stream.)
  * No allocation crosses the ABI; caller owns slab and outputs. */
 int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
                      bv_group_result *gout, void *stream);

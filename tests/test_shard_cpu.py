@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from basevar_amd import _capi  # noqa: E402
-from basevar_amd.shard import gather_records, gather_records_sized, site_range  # noqa: E402
+from basevar_amd.shard import RecordGatherer, gather_records, gather_records_sized, site_range  # noqa: E402
 
 
 def test_site_ranges_partition_exactly():
@@ -47,7 +47,23 @@ def _worker(rank, world, port, n_sites, q):
              for k in range(world)]
     a = gather_records(local, dst=0)
     b = gather_records_sized(local, sizes, dst=0)
+    # asynchronous ring gatherer (what bench.py uses): equal-sized buffers, several batches in flight
+    nb = 64 * _capi.SITE_DTYPE.itemsize
+    g = RecordGatherer(nb, torch.device("cpu"), depth=3)
+    bufs = [torch.zeros(nb, dtype=torch.uint8) for _ in range(3)]
+    ring_ok = True
+    for i in range(7):
+        slot = i % 3
+        g.before_reuse(slot)
+        bufs[slot].fill_((17 * i + rank) % 251)
+        g.issue(slot, bufs[slot])
+    g.drain()
     if rank == 0:
+        for i in (4, 5, 6):  # the last use of every slot
+            parts = g.parts(i % 3)
+            ring_ok &= all(bool((parts[r] == (17 * i + r) % 251).all()) for r in range(world))
+    if rank == 0:
+        assert ring_ok
         q.put((a.numpy().tobytes(), b.numpy().tobytes()))
     else:
         assert a is None and b is None
