@@ -220,9 +220,11 @@ def main():
         k = i % ns
         slot = i % depth
         out = outs[slot]
-        if gatherer is not None:
-            gatherer.before_reuse(slot)  # the gather that last read this buffer has completed
         with torch.cuda.stream(streams[k]):
+            if gatherer is not None:
+                # the gather that last read this buffer must have completed; Work.wait() orders the
+                # CURRENT stream behind the collective, so it has to be called on the stream that writes
+                gatherer.before_reuse(slot)
             engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                 mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
                                 stream=streams[k].cuda_stream)
@@ -237,7 +239,8 @@ def main():
 
     def fence():
         if gatherer is not None:
-            gatherer.drain()
+            with torch.cuda.stream(streams[0]):
+                gatherer.drain()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
