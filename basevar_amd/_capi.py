@@ -58,7 +58,7 @@ class SynthParams(C.Structure):
 
 # every symbol include/basevar_amd.h declares
 EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_wait",
-           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_finish",
+           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_finish", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get",
            "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
 
@@ -99,6 +99,8 @@ def load():
     L.bv_engine_tiles_add.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p]
     L.bv_engine_tiles_finish.restype = C.c_int
     L.bv_engine_tiles_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.bv_engine_stream.restype = C.c_void_p
+    L.bv_engine_stream.argtypes = [C.c_void_p]
     L.bv_engine_wait.restype = C.c_int
     L.bv_engine_wait.argtypes = [C.c_void_p]
     L.bv_engine_kernel_ms.restype = C.c_int

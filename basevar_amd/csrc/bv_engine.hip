@@ -431,6 +431,8 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     return BV_OK;
 }
 
+void *bv_engine_stream(bv_engine *e) { return e ? (void *)e->stream : nullptr; }
+
 int bv_engine_wait(bv_engine *e) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_wait: null engine");
     if (!e->submitted) return BV_OK;

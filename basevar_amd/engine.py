@@ -112,6 +112,10 @@ class BaseTypeEngine:
         if rc != 0:
             raise RuntimeError("bv_engine_submit failed (%d): %s" % (rc, self._err()))
 
+    def stream_handle(self):
+        """hipStream_t of the engine's own stream as an int (e.g. for torch.cuda.ExternalStream)."""
+        return int(self._lib.bv_engine_stream(self._h) or 0)
+
     def wait(self):
         rc = self._lib.bv_engine_wait(self._h)
         if rc == _capi.BV_ERR_SITE:

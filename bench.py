@@ -209,9 +209,12 @@ def main():
     gloo_host = world > 1 and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
     outs = [torch.zeros(B * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
     houts = [torch.zeros(B * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None
-    # explicit (non-default) streams: the legacy default stream's handle is 0, which the C ABI reads as
-    # "use the engine's own stream" -- the gather issued from torch would then not be ordered behind the kernels
-    streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+    # Everything of engine k -- its kernels and the gather of its records -- is issued on that engine's OWN
+    # HIP stream, wrapped for torch.  (Not torch's default stream: its handle is 0, which the C ABI reads as
+    # "engine's own stream", so a gather issued from torch would not be ordered behind the kernels.  Not
+    # torch's pooled streams either: two of them may share one hardware queue, and --streams 2 then
+    # overlaps nothing.)
+    streams = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in engs]
     gatherer = RecordGatherer(B * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if world > 1 else None
     last_slot = [0]
 

@@ -186,6 +186,10 @@ int bv_engine_destroy(bv_engine *e);
 int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
                      bv_group_result *gout, void *stream);
 
+/* The engine's own HIP stream (hipStream_t), so that a caller can order other work on it -- e.g.
+ * wrap it (torch.cuda.ExternalStream) and issue the RCCL gather of the records behind the kernels. */
+void *bv_engine_stream(bv_engine *e);
+
 /* Block until the last submit has finished.  Returns BV_ERR_SITE if any site set
  * BV_SITE_ZERO_FREQ (the reference would have thrown). */
 int bv_engine_wait(bv_engine *e);

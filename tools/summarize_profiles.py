@@ -24,7 +24,12 @@ def find(tag, kind, pattern):
 def main():
     tag, B, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     out = {"tag": tag, "batch_sites": B, "samples": N, "kernels": {}}
-    lines = ["# rocprofv3 summary, %s (batch %d sites x %d samples)" % (tag, B, N), ""]
+    lines = ["# rocprofv3 summary, %s (batch %d sites x %d samples)" % (tag, B, N), "",
+             "Commands (on the MI355X box, from /tmp with TMPDIR=/tmp):", "",
+             "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s_stats -- python3 bench.py --no-cpu-baseline" % tag,
+             "    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_%s_fetch -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1" % tag,
+             "    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_%s_write -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1" % tag,
+             ""]
     for fn in find(tag, "stats", "*kernel_stats.csv"):
         lines += ["## kernel-trace --stats (%s)" % os.path.relpath(fn, ROOT), "", "```"]
         rows = list(csv.DictReader(open(fn)))
