@@ -577,7 +577,7 @@ static void o_run_site(const uint8_t *bs, const uint8_t *q, const uint8_t *mq, c
             r->status |= BV_SITE_SOR_OVERFLOW;
 
         if (g && n_groups && group_id) { /* caller.cpp:746-759 */
-            int comb[4], nc = 0;
+            int comb[5], nc = 0; /* [REF] + up to four alts (ref not ACGT) */
             comb[nc++] = ref;
             for (int k = 0; k < bt.n_alt; ++k) comb[nc++] = bt.alt[k];
             uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * n);

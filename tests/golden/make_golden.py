@@ -66,6 +66,7 @@ def edge_slab():
     site(A, [(A, 0)])                                  # phred 0, reference base only
     site(Cc, [(A, 0)])                                 # phred 0 ALT: the reference reports AF = NaN
     site(A, [(A, 30)] * 15 + [(Cc, 10)])               # weak alt below the LRT threshold
+    site(4, [(A, 35), (Cc, 35, 1), (G, 35), (T, 35, 1)] * 4)  # ref 'N', four supported bases: FOUR alts
     S = len(sites)
     slab = {
         "n_sites": S, "n_samples": n, "pitch": n, "n_groups": 2,
