@@ -39,6 +39,9 @@ typedef uint32_t bv_u32x4 __attribute__((ext_vector_type(4)));
 struct BvTables {
     double hit[BV_QBINS];
     double miss[BV_QBINS];
+    const double *lnfact;  // lnfact[k] = lgamma(k + 1) (host glibc), k < lnfact_n; device memory
+    uint32_t lnfact_n;
+    uint32_t pad_;
 };
 
 // ------------------------------------------------------------------ wave reductions
@@ -113,6 +116,52 @@ __device__ __forceinline__ unsigned long long bv_wave_sum_u64(unsigned long long
     v = bv_wave_incl_scan_u64(v);
     uint32_t lo = (uint32_t)bv_readlane63_i32((int)(uint32_t)v), hi = (uint32_t)bv_readlane63_i32((int)(uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
+}
+// Packed sums: gfx950's v_permlane32_swap / v_permlane16_swap fold two (four) per-lane values into
+// one register whose halves (rows of 16 lanes) carry the partial sums of different values, so two
+// (four) wave totals cost one scan instead of two (four).  Fixed order => deterministic.
+__device__ __forceinline__ double bv_fold32_f64(double a, double b) {
+    // lanes 0-31: a[l] + a[l+32];  lanes 32-63: b[l-32] + b[l]
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    auto rl = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto rh = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+__device__ __forceinline__ double bv_fold16_f64(double p, double q) {
+    // rows of 16 lanes: [p0+p1, q0+q1, p2+p3, q2+q3]
+    unsigned plo = (unsigned)__double2loint(p), phi = (unsigned)__double2hiint(p);
+    unsigned qlo = (unsigned)__double2loint(q), qhi = (unsigned)__double2hiint(q);
+    auto rl = __builtin_amdgcn_permlane16_swap(plo, qlo, false, false);
+    auto rh = __builtin_amdgcn_permlane16_swap(phi, qhi, false, false);
+    return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
+}
+__device__ __forceinline__ double bv_readlane_f64_c(double v, int srclane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void bv_wave_sum2(double a, double b, double &sa, double &sb) {
+    double v = bv_fold32_f64(a, b);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(1), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(2), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(4), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(8), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_BCAST15, 0xa>(v);
+    sa = bv_readlane_f64_c(v, 31);
+    sb = bv_readlane_f64_c(v, 63);
+}
+__device__ __forceinline__ void bv_wave_sum4(double a, double b, double c, double d, double &sa, double &sb, double &sc,
+                                             double &sd) {
+    double v = bv_fold16_f64(bv_fold32_f64(a, b), bv_fold32_f64(c, d));  // rows: [a, c, b, d]
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(1), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(2), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(4), 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_SHR(8), 0xf>(v);
+    sa = bv_readlane_f64_c(v, 15);
+    sc = bv_readlane_f64_c(v, 31);
+    sb = bv_readlane_f64_c(v, 47);
+    sd = bv_readlane_f64_c(v, 63);
 }
 // min / max: same scan shape with the matching identity
 __device__ __forceinline__ int bv_wave_min_i32(int v) {
@@ -225,18 +274,20 @@ __device__ inline double bv_qual_from_chi2(double chi) {
 // kt_fisher_exact (two-sided), htslib/kfunc.c:197-313, wave-parallel.
 //
 // The reference walks the hypergeometric pmf from both ends towards the observed table,
-// updating p(i) multiplicatively and re-seeding it from lgamma() whenever i % 11 == 0
-// (hypergeo_acc, kfunc.c:220-243).  Here each lane owns one such block of 11 consecutive
-// tables (seed + <= 10 multiplicative steps -- the same arithmetic), 64 blocks per sweep;
-// the reference's stopping rule ("first p >= 0.99999999 q") becomes a wave-min over the
-// lanes' first violating index, valid because the pmf is unimodal.
-// log(n!) == lgamma(n + 1), the only way kfunc.c:197-201 uses lgamma.  ocml's general
-// lgamma() is several hundred FP64 instructions and the Fisher tails call it 6x per seeded
-// table; for integer arguments a 16-entry table (glibc lgamma values) plus the Stirling
-// series (7 terms, |error| < 1e-16 relative for n + 1 >= 17, i.e. at the level of glibc's
-// own rounding) is ~10x cheaper.  Differences vs glibc are ~1 ulp of a value ~n log n and
-// reach the p-values at the 1e-10 relative level, far inside the 1e-6 parity bar.
-__device__ __forceinline__ double bv_lnfact(int n) {
+// updating p(i) multiplicatively and re-seeding it from lgamma() every 11 tables
+// (hypergeo_acc, kfunc.c:220-243).  Here every table probability is evaluated on its own,
+// one table per lane, from log-factorials:
+//   p(i) = exp( lbinom(n1_, i) + lbinom(n - n1_, n_1 - i) - lbinom(n, n_1) )   (kfunc.c:197-212)
+// log(n!) == lgamma(n + 1) is the only way kfunc.c:197-201 uses lgamma; the engine keeps a table of
+// it in HBM (L2-resident), filled on the host with glibc's lgamma -- the reference's own values --
+// for every n up to the largest possible depth.  Arguments beyond the table fall back to the
+// Stirling series (7 terms, |error| < 1e-16 relative for n + 1 >= 17).  Values differ from the
+// reference's multiplicative walk at the 1e-13 relative level (parity bar: 1e-6).
+struct BvLnTab {
+    const double *t;  // t[k] = lgamma(k + 1), k < n
+    int n;
+};
+__device__ __forceinline__ double bv_lnfact_series(int n) {
     if (n < 16) {
         const double T0 = 0.0, T2 = 0.693147180559945, T3 = 1.7917594692280554, T4 = 3.178053830347945,
                      T5 = 4.787491742782047, T6 = 6.579251212010102, T7 = 8.525161361065415, T8 = 10.604602902745249,
@@ -260,6 +311,10 @@ __device__ __forceinline__ double bv_lnfact(int n) {
     s *= xi;
     return (x - 0.5) * log(x) - x + 0.91893853320467274178 + s;
 }
+__device__ __forceinline__ double bv_lnfact(const BvLnTab &T, int n) {
+    if (n < T.n) return T.t[n];
+    return bv_lnfact_series(n);
+}
 __device__ __forceinline__ double bv_readlane_f64(double v, int srclane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
@@ -267,31 +322,27 @@ __device__ __forceinline__ double bv_readlane_f64(double v, int srclane) {
 }
 
 // One 2x2 table family: margins fixed, n11 = i varies over [imin, imax].
-//   p(i) = exp( lbinom(n1_, i) + lbinom(n - n1_, n_1 - i) - lbinom(n, n_1) )   (kfunc.c:197-212)
 // lbinom(n, k) = lnfact(n) - lnfact(k) - lnfact(n - k); its k == 0 / k == n special case
 // (kfunc.c:199) needs no branch here because lnfact(0) == 0 makes the difference exactly 0.
 struct BvHyper {
+    BvLnTab T;
     int n1_, n_1, n, n22off;
     double lf_n1;   // lnfact(n1_)
     double lf_n2;   // lnfact(n - n1_)
     double lb3;     // lbinom(n, n_1)
 };
 __device__ __forceinline__ double bv_hyper_logp(const BvHyper &h, int i) {
-    double a = h.lf_n1 - bv_lnfact(i) - bv_lnfact(h.n1_ - i);
-    double b = h.lf_n2 - bv_lnfact(h.n_1 - i) - bv_lnfact(i + h.n22off);
+    double a = h.lf_n1 - bv_lnfact(h.T, i) - bv_lnfact(h.T, h.n1_ - i);
+    double b = h.lf_n2 - bv_lnfact(h.T, h.n_1 - i) - bv_lnfact(h.T, i + h.n22off);
     return a + b - h.lb3;
 }
 __device__ __forceinline__ double bv_hyper_p(const BvHyper &h, int i) { return exp(bv_hyper_logp(h, i)); }
-
-// The five table-independent log-factorials are evaluated by five lanes in ONE pass of
-// bv_lnfact and broadcast with v_readlane (instead of five passes).
-__device__ __forceinline__ void bv_hyper_init(BvHyper &h, int n1_, int n_1, int n, int lane) {
+__device__ __forceinline__ void bv_hyper_init(BvHyper &h, const BvLnTab &T, int n1_, int n_1, int n) {
+    h.T = T;
     h.n1_ = n1_; h.n_1 = n_1; h.n = n; h.n22off = n - n1_ - n_1;
-    int arg = lane == 0 ? n1_ : (lane == 1 ? n - n1_ : (lane == 2 ? n : (lane == 3 ? n_1 : n - n_1)));
-    double v = bv_lnfact(arg);
-    h.lf_n1 = bv_readlane_f64(v, 0);
-    h.lf_n2 = bv_readlane_f64(v, 1);
-    h.lb3 = bv_readlane_f64(v, 2) - bv_readlane_f64(v, 3) - bv_readlane_f64(v, 4);
+    h.lf_n1 = bv_lnfact(T, n1_);
+    h.lf_n2 = bv_lnfact(T, n - n1_);
+    h.lb3 = bv_lnfact(T, n) - bv_lnfact(T, n_1) - bv_lnfact(T, n - n_1);
 }
 
 // kt_fisher_exact (two-sided), wave-parallel.  Semantics of the reference's two loops
@@ -299,34 +350,28 @@ __device__ __forceinline__ void bv_hyper_init(BvHyper &h, int n1_, int n_1, int 
 //   L* = first table from the left  with p >= lo,  left  = sum_{i < L*} p(i) + (p(L*) < hi ? p(L*) : 0)
 //   R* = first table from the right with p >= lo,  right = sum_{i > R*} p(i) + (p(R*) < hi ? p(R*) : 0)
 //   two = min(1, left + right)
-// The pmf is unimodal, so the tables that pass "p < lo" form a prefix / suffix and the stopping
-// rule is a wave-min / wave-max over the lanes' violating indices.
-//
-// Regimes (after the small-row-margin product form at the top of the function), by the number of
-// tables R = imax - imin + 1:
-//   R <= 64   one table per lane, each p(i) seeded from log-factorials (the common case: a
-//             hom-ref site has only a handful of non-reference reads);
-//   <= 64 blocks of 11 (R <~ 704): one sweep: each lane owns a block of 11 consecutive tables -- seed + <= 10
-//             multiplicative steps, the reference's own re-seeding period (kfunc.c:225);
-//   larger    left tail ascending, right tail descending, 704 tables per sweep, after a
-//             64-point probe of log p has skipped the far tails whose terms are below
-//             q * 2^-86 (they cannot change a double-precision sum that is >= ~q).
-// Where the reference updates p multiplicatively across what are separate lanes / directions
-// here, the values differ from it at the 1e-13 relative level (parity bar: 1e-6).
-__device__ inline double bv_fisher_two_sided_wave(int n11, int n12, int n21, int n22, int lane) {
+// The pmf is unimodal, so the tables with p < lo are exactly those left of L* and right of R*:
+//   two = sum_{p(i) < lo} p(i) + [p(L*) < hi] p(L*) + [p(R*) < hi] p(R*),
+// with L* / R* the lowest / highest lane of a ballot.
+// Regimes:
+//   a row margin <= 12   product form, no log-factorials (the usual all-sites CVG case);
+//   R <= 64 tables       one table per lane;
+//   more                 rounds of 64 tables over [imin, imax]; beyond 256 tables a 64-point probe of
+//                        log p on either side first skips the far tails whose terms are below
+//                        q * 2^-86 (they cannot change a double-precision sum that is >= q).
+__device__ inline double bv_fisher_two_sided_wave(int n11, int n12, int n21, int n22, int lane, const BvLnTab &T) {
     const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
     const int imax = (n_1 < n1_) ? n_1 : n1_;
     int imin = n1_ + n_1 - n;
     if (imin < 0) imin = 0;
     if (imin == imax) return 1.;
-    const int INF = 0x7fffffff;
     {
         // ---- a row margin of at most 12 reads (the usual case for the all-sites CVG test: a hom-ref
         // site carries only a handful of non-reference reads).  With m = that row's total and j = how
-        // many of them sit in column 1, the table probability is a product of m small ratios
+        // many of them sit in column 1, the table probability is a ratio of two products of m terms
         //     p(j) = C(m, j) * (n_1)_j * (n_2)_{m-j} / (n)_m        ((x)_k: falling factorial)
-        // -- exact to ~1e-15 and ~3x cheaper than four log-factorials and an exp per table.  The
-        // tables are walked in j instead of n11; the two-sided sum is symmetric under that relabelling.
+        // -- exact to ~1e-15.  The tables are walked in j instead of n11; the two-sided sum is
+        // symmetric under that relabelling.  At most 13 tables: they sit in the first row of lanes.
         const int n2_ = n21 + n22, n_2 = n - n_1;
         const bool alt_row = n2_ <= n1_;
         const int m = alt_row ? n2_ : n1_, jobs = alt_row ? n21 : n11;
@@ -334,47 +379,50 @@ __device__ inline double bv_fisher_two_sided_wave(int n11, int n12, int n21, int
             const int jmin = max(0, m - n_2), jmax = min(m, n_1);  // jmin < jmax because imin < imax
             const int j = jmin + lane;
             const bool have = j <= jmax;
-            double p = 1.0;
+            double pn = 1.0, pd = 1.0;
             for (int t = 0; t < m; ++t) {
                 const double num = (t < j) ? (double)(n_1 - t) * (double)(m - t) : (double)(n_2 - (t - j));
                 const double den = (t < j) ? (double)(n - t) * (double)(t + 1) : (double)(n - t);
-                p *= num / den;
+                pn *= num;
+                pd *= den;
             }
-            if (!have) p = 0.;
+            const double p = have ? pn / pd : 0.;
             const double q = bv_readlane_f64(p, jobs - jmin);
             if (q == 0.0) return 0.0;
             const double lo = 0.99999999 * q, hi = 1.00000001 * q;
             const bool viol = have && !(p < lo);
-            const int Ls = bv_wave_min_i32(viol ? j : INF), Rs = bv_wave_max_i32(viol ? j : -1);
-            double left = bv_wave_sum((have && j < Ls) ? p : 0.);
-            double right = bv_wave_sum((have && j > Rs) ? p : 0.);
-            const double pL = bv_readlane_f64(p, Ls - jmin), pR = bv_readlane_f64(p, Rs - jmin);
-            if (pL < hi) left += pL;
-            if (pR < hi) right += pR;
-            const double two = left + right;
+            const unsigned long long vm = __ballot(viol);  // never empty: the observed table is in it
+            double v = viol ? 0. : p;                        // lanes 0..15 hold everything
+            v += bv_dpp_f64<BV_DPP_ROW_SHR(1), 0xf>(v);
+            v += bv_dpp_f64<BV_DPP_ROW_SHR(2), 0xf>(v);
+            v += bv_dpp_f64<BV_DPP_ROW_SHR(4), 0xf>(v);
+            v += bv_dpp_f64<BV_DPP_ROW_SHR(8), 0xf>(v);
+            double two = bv_readlane_f64(v, 15);
+            const double pL = bv_readlane_f64(p, (int)__builtin_ctzll(vm)), pR = bv_readlane_f64(p, 63 - (int)__builtin_clzll(vm));
+            if (pL < hi) two += pL;
+            if (pR < hi) two += pR;
             return two > 1. ? 1. : two;
         }
     }
     BvHyper h;
-    bv_hyper_init(h, n1_, n_1, n, lane);
+    bv_hyper_init(h, T, n1_, n_1, n);
     const int R = imax - imin + 1;
 
     if (R <= BV_WAVE) {
         // ---- one table per lane; q is the value of the lane that holds the observed table
         const int i = imin + lane;
         const bool have = i <= imax;
-        const double p = have ? bv_hyper_p(h, have ? i : imin) : 0.;
+        const double pe = bv_hyper_p(h, have ? i : imax);
+        const double p = have ? pe : 0.;
         const double q = bv_readlane_f64(p, n11 - imin);
         if (q == 0.0) return 0.0;  // kfunc.c:260-289
         const double lo = 0.99999999 * q, hi = 1.00000001 * q;
         const bool viol = have && !(p < lo);
-        const int Ls = bv_wave_min_i32(viol ? i : INF), Rs = bv_wave_max_i32(viol ? i : -1);
-        double left = bv_wave_sum((have && i < Ls) ? p : 0.);
-        double right = bv_wave_sum((have && i > Rs) ? p : 0.);
-        const double pL = bv_readlane_f64(p, Ls - imin), pR = bv_readlane_f64(p, Rs - imin);
-        if (pL < hi) left += pL;
-        if (pR < hi) right += pR;
-        double two = left + right;
+        const unsigned long long vm = __ballot(viol);
+        double two = bv_wave_sum(viol ? 0. : p);
+        const double pL = bv_readlane_f64(p, (int)__builtin_ctzll(vm)), pR = bv_readlane_f64(p, 63 - (int)__builtin_clzll(vm));
+        if (pL < hi) two += pL;
+        if (pR < hi) two += pR;
         return two > 1. ? 1. : two;
     }
 
@@ -382,142 +430,55 @@ __device__ inline double bv_fisher_two_sided_wave(int n11, int n12, int n21, int
     const double q = exp(logq);
     if (q == 0.0) return 0.0;  // kfunc.c:260-289
     const double lo = 0.99999999 * q, hi = 1.00000001 * q;
-
-    if (imax / 11 - imin / 11 < BV_WAVE) {
-        // ---- one ascending sweep covers every table: block b = imin/11 + lane
-        const int b = imin / 11 + lane;
-        const int start = max(b * 11, imin), end = min(b * 11 + 10, imax);
-        const bool have = start <= end;
-        double before = 0., after = 0., pf = 0., pl = 0.;  // sums around / values at the block's violations
-        int vf = INF, vl = -1;
-        if (have) {
-            double p = bv_hyper_p(h, start);
-            for (int i = start;; ++i) {
-                if (p < lo) {
-                    if (vl < 0) before += p; else after += p;
-                } else {
-                    if (vf == INF) { vf = i; pf = p; }
-                    vl = i; pl = p;
-                    after = 0.;
-                }
-                if (i == end) break;
-                p *= (double)(n1_ - i) / (i + 1) * (n_1 - i) / (i + 1 + h.n22off);  // kfunc.c:226-231
-            }
-        }
-        const int Ls = bv_wave_min_i32(vf), Rs = bv_wave_max_i32(vl);
-        // left: whole blocks before L*, plus the part of L*'s block before it
-        double left = bv_wave_sum(have ? ((end < Ls) ? before : ((vf == Ls) ? before : 0.)) : 0.);
-        // right: whole blocks after R*, plus the part of R*'s block after it
-        double right = bv_wave_sum(have ? ((start > Rs) ? before : ((vl == Rs) ? after : 0.)) : 0.);
-        const double pL = bv_wave_sum(vf == Ls ? pf : 0.), pR = bv_wave_sum(vl == Rs ? pl : 0.);
-        if (pL < hi) left += pL;
-        if (pR < hi) right += pR;
-        double two = left + right;
-        return two > 1. ? 1. : two;
-    }
-
-    // ---- many tables: skip the far tails, then sweep towards the observed table
-    const double cut = logq - 60.0;  // exp(-60) ~ 2^-86.6
+    const int INF = 0x7fffffff;
     int wl = imin, wr = imax;
-    {
-        // probes on [imin, n11]: tables before the last probe that is still below the cut are negligible
-        // (rising side, or between mode and n11 where p >= q): a prefix by unimodality
-        const int span = n11 - imin, step = span / 63 + 1;
-        const int i = imin + lane * step;
-        const bool below = (i <= n11) && (bv_hyper_logp(h, min(i, n11)) < cut);
-        const int last = bv_wave_max_i32(below ? i : -1);
-        if (last >= 0) wl = last;
-    }
-    {
-        const int span = imax - n11, step = span / 63 + 1;
-        const int i = imax - lane * step;
-        const bool below = (i >= n11) && (bv_hyper_logp(h, max(i, n11)) < cut);
-        const int first = bv_wave_min_i32(below ? i : INF);
-        if (first != INF) wr = first;
-    }
-    // left tail: ascending from wl; block b covers [11b, 11b+10]
-    double left = 0.;
-    {
-        int blk0 = wl / 11;
-        for (;;) {
-            const int b = blk0 + lane;
-            const int start = max(b * 11, wl), end = min(b * 11 + 10, imax);
-            double acc = 0., pv = 0.;
-            int viol = INF;
-            if (start <= end) {
-                double p = bv_hyper_p(h, start);
-                for (int i = start;; ++i) {
-                    if (p < lo) {
-                        acc += p;
-                    } else {
-                        viol = i;
-                        pv = p;
-                        break;
-                    }
-                    if (i == end) break;
-                    p *= (double)(n1_ - i) / (i + 1) * (n_1 - i) / (i + 1 + h.n22off);  // kfunc.c:226-231
-                }
-            }
-            const int first = bv_wave_min_i32(viol);
-            left += bv_wave_sum((start <= end && start <= first) ? acc : 0.);
-            if (first != INF) {
-                const double pb = bv_wave_sum(viol == first ? pv : 0.);
-                if (pb < hi) left += pb;
-                break;
-            }
-            blk0 += BV_WAVE;
-            if (blk0 * 11 > imax) break;
+    if (R > 4 * BV_WAVE) {
+        // ---- many tables: skip the far tails
+        const double cut = logq - 60.0;  // exp(-60) ~ 2^-86.6
+        {
+            // probes on [imin, n11]: tables before the last probe that is still below the cut are negligible
+            // (rising side, or between mode and n11 where p >= q): a prefix by unimodality
+            const int span = n11 - imin, step = span / 63 + 1;
+            const int i = imin + lane * step;
+            const bool below = (i <= n11) && (bv_hyper_logp(h, min(i, n11)) < cut);
+            const int last = bv_wave_max_i32(below ? i : -1);
+            if (last >= 0) wl = last;
+        }
+        {
+            const int span = imax - n11, step = span / 63 + 1;
+            const int i = imax - lane * step;
+            const bool below = (i >= n11) && (bv_hyper_logp(h, max(i, n11)) < cut);
+            const int first = bv_wave_min_i32(below ? i : INF);
+            if (first != INF) wr = first;
         }
     }
-    // right tail: descending from wr; block b covers [11b+1, 11b+11], seeded at its top
-    double right = 0.;
-    {
-        int blk0 = (wr - 1) / 11;  // wr >= n11 >= imin, and wr >= 1 here
-        if (wr < 1) blk0 = -1;
-        for (;;) {
-            const int b = blk0 - lane;
-            int start = min(b * 11 + 11, wr), end = max(b * 11 + 1, imin);
-            bool have = (b >= 0) && (start >= end);
-            if (b == -1 && imin == 0) {  // table 0 is its own seed (0 % 11 == 0)
-                start = 0;
-                end = 0;
-                have = true;
-            }
-            double acc = 0., pv = 0.;
-            int viol = -1;
-            if (have) {
-                double p = bv_hyper_p(h, start);
-                for (int j = start;; --j) {
-                    if (p < lo) {
-                        acc += p;
-                    } else {
-                        viol = j;
-                        pv = p;
-                        break;
-                    }
-                    if (j == end) break;
-                    p *= (double)j / (n1_ - (j - 1)) * (j + h.n22off) / (n_1 - (j - 1));  // kfunc.c:232-237
-                }
-            }
-            const int first = bv_wave_max_i32(viol);
-            right += bv_wave_sum((have && start >= first) ? acc : 0.);
-            if (first >= 0) {
-                const double pb = bv_wave_sum(viol == first ? pv : 0.);
-                if (pb < hi) right += pb;
-                break;
-            }
-            blk0 -= BV_WAVE;
-            if (blk0 < -1) break;
+    // ---- rounds of 64 tables, ascending over [wl, wr]
+    double tail = 0., pL = 0., pR = 0.;
+    bool seen = false;
+    for (int w = wl; w <= wr; w += BV_WAVE) {
+        const int i = w + lane;
+        const bool have = i <= wr;
+        const double pe = bv_hyper_p(h, have ? i : wr);
+        const double p = have ? pe : 0.;
+        const bool viol = have && !(p < lo);
+        tail += viol ? 0. : p;
+        const unsigned long long vm = __ballot(viol);
+        if (vm != 0ull) {
+            if (!seen) pL = bv_readlane_f64(p, (int)__builtin_ctzll(vm));
+            seen = true;
+            pR = bv_readlane_f64(p, 63 - (int)__builtin_clzll(vm));
         }
     }
-    double two = left + right;
+    double two = bv_wave_sum(tail);
+    if (pL < hi) two += pL;
+    if (pR < hi) two += pR;
     return two > 1. ? 1. : two;
 }
 
 // strand_bias tail, src/basetype.cpp:277-286
 __device__ inline void bv_strand_bias_wave(uint32_t ref_fwd, uint32_t ref_rev, uint32_t alt_fwd, uint32_t alt_rev,
-                                           int lane, double *fs_out, double *sor_out, uint32_t *flags) {
-    double fs = -10 * log10(bv_fisher_two_sided_wave((int)ref_fwd, (int)ref_rev, (int)alt_fwd, (int)alt_rev, lane));
+                                           int lane, const BvLnTab &T, double *fs_out, double *sor_out, uint32_t *flags) {
+    double fs = -10 * log10(bv_fisher_two_sided_wave((int)ref_fwd, (int)ref_rev, (int)alt_fwd, (int)alt_rev, lane, T));
     if (isinf(fs)) fs = 10000;
     else if (fs == 0) fs = 0.0;
     // basetype.cpp:286 multiplies `int`s; past 2^31 that is UB in the reference.  Its compiled
@@ -595,21 +556,30 @@ __device__ __forceinline__ double bv_int_abs_trunc(double d) {
 // k = 1..100 are the `while (iter_num--)` body (algorithm.h:235-251).  Each pass is one
 // fused sweep over the bins: e_step (algorithm.h:161-171), the m_step numerators
 // (algorithm.h:190-193), log-marginals and the convergence sum (algorithm.h:243-247).
-// Bin i lives in lane i % 64, slot i / 64; only the per-bin log-marginal of the previous pass
+// Bin i lives in lane i % 64, slot i / 64; only the per-bin marginal of the previous pass
 // is carried (in registers).  (A branch-free variant that kept three bins per lane in flight
 // for ILP, with the log-marginals in LDS, was measured 13 % SLOWER end to end: the solver wave
 // shares its SIMD with tally waves, so its instruction count matters more than its latency.)
-__device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n_cov, double *lr_out, int lane) {
+__device__ __forceinline__ int bv_em_wave_generic(const BvBins &B, double f[4], double n_cov, double *lr_out, int lane) {
     const double epsilon = (double)0.001f;  // `const float epsilon=0.001`, algorithm.h:213
     const int nslots = (B.nb + BV_WAVE - 1) / BV_WAVE;
-    double prev[BV_SLOTS];
+#ifdef BV_ABL_NO_EM  /* attribution builds only */
+    *lr_out = -f[0];
+    return 1;
+#endif
+    // The reference takes log(marginal) of every sample in every pass, but uses the values only (a) in
+    // the convergence term |int(llh_new - llh_old)| (algorithm.h:245, integer abs: zero unless the two logs
+    // differ by >= 1) and (b) from the LAST pass, as the log-likelihood sum.  So the previous pass's
+    // MARGINAL is carried instead of its log; a pass takes logs only for the bins whose marginal moved
+    // by a factor outside (0.37, 2.7) -- |delta log| < 0.995 otherwise, which truncates to 0 whatever the
+    // rounding of log() -- and the sum (b) is formed once after the loop.  NaN / 0 / inf marginals fail both
+    // comparisons and take the exact path.
+    double pm[BV_SLOTS];
 #pragma unroll
-    for (int s = 0; s < BV_SLOTS; ++s) prev[s] = 0.;
+    for (int s = 0; s < BV_SLOTS; ++s) pm[s] = 1.0;
     int iters = 0;
-    double lr = 0.;
     for (int k = 0; k <= 100; ++k) {
         double pf0 = 0., pf1 = 0., pf2 = 0., pf3 = 0., delta = 0.;
-        lr = 0.;
 #pragma unroll
         for (int s = 0; s < BV_SLOTS; ++s) {
             if (s < nslots) {
@@ -633,10 +603,10 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n
                     pf1 += c * (L1 * r);
                     pf2 += c * (L2 * r);
                     pf3 += c * (L3 * r);
-                    double llh = log(marg);
-                    delta += c * bv_int_abs_trunc(llh - prev[s]);
-                    lr += c * llh;
-                    prev[s] = llh;
+                    const double old = pm[s];
+                    if (k > 0 && !(marg < old * 2.7 && marg > old * 0.37))
+                        delta += c * bv_int_abs_trunc(log(marg) - log(old));
+                    pm[s] = marg;
                 }
             }
         }
@@ -648,6 +618,102 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], double n
         delta = bv_wave_sum(delta);
         ++iters;
         if (delta < epsilon) break;
+    }
+    // log-likelihood sum at the marginals of the last pass (algorithm.h:243, basetype.cpp:123-125)
+    double lr = 0.;
+#pragma unroll
+    for (int s = 0; s < BV_SLOTS; ++s) {
+        if (s < nslots) {
+            const int i = s * BV_WAVE + lane;
+            if (i < B.nb) lr += (double)B.cnt[bv_bin_at(B, i)] * log(pm[s]);
+        }
+    }
+    *lr_out = bv_wave_sum(lr);
+    return iters;
+}
+
+// The same EM when no call of the site has phred 0 and the start frequencies are not all zero (every
+// likelihood and marginal is then a positive finite number).  Bases outside the subset keep
+// frequency +0.0 through every pass in the reference as well (0 * x, 0 + x, 0 / n are exact), so their
+// terms are skipped rather than computed; the per-base sums of a pass are reduced together
+// (bv_wave_sum2/4); the convergence sum is only formed when some bin took the exact-log path; and
+// sum / n_cov is sum * (1 / n_cov) (<= 1 ulp; the parity bar is 1e-6).  `in_set`: bit b = base b.
+__device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], unsigned in_set, double n_cov, double *lr_out,
+                                          int lane) {
+    const double epsilon = (double)0.001f;
+    const int nslots = (B.nb + BV_WAVE - 1) / BV_WAVE;
+#ifdef BV_ABL_NO_EM
+    *lr_out = -f[0];
+    return 1;
+#endif
+    const double inv_n = 1.0 / n_cov;
+    const bool s0 = in_set & 1u, s1 = in_set & 2u, s2 = in_set & 4u, s3 = in_set & 8u;
+    const int nset = __popc(in_set);
+    double pm[BV_SLOTS];
+#pragma unroll
+    for (int s = 0; s < BV_SLOTS; ++s) pm[s] = 1.0;
+    int iters = 0;
+    for (int k = 0; k <= 100; ++k) {
+        double pf0 = 0., pf1 = 0., pf2 = 0., pf3 = 0., delta = 0.;
+#pragma unroll
+        for (int s = 0; s < BV_SLOTS; ++s) {
+            if (s < nslots) {
+                const int i = s * BV_WAVE + lane;
+                if (i < B.nb) {
+                    const int at = bv_bin_at(B, i);
+                    const uint32_t code = B.code[at];
+                    const double c = (double)B.cnt[at];
+                    const uint32_t b = code >> 7;
+                    const double hit = B.hit[code & 127u], miss = B.miss[code & 127u];
+                    double L0 = 0., L1 = 0., L2 = 0., L3 = 0., marg = 0.;
+                    if (s0) { L0 = (b == 0 ? hit : miss) * f[0]; marg += L0; }
+                    if (s1) { L1 = (b == 1 ? hit : miss) * f[1]; marg += L1; }
+                    if (s2) { L2 = (b == 2 ? hit : miss) * f[2]; marg += L2; }
+                    if (s3) { L3 = (b == 3 ? hit : miss) * f[3]; marg += L3; }
+                    const double r = c / marg;
+                    if (s0) pf0 += L0 * r;
+                    if (s1) pf1 += L1 * r;
+                    if (s2) pf2 += L2 * r;
+                    if (s3) pf3 += L3 * r;
+                    const double old = pm[s];
+                    if (k > 0 && !(marg < old * 2.7 && marg > old * 0.37))
+                        delta += c * bv_int_abs_trunc(log(marg) - log(old));
+                    pm[s] = marg;
+                }
+            }
+        }
+        if (nset == 1) {
+            const double t = bv_wave_sum(s0 ? pf0 : (s1 ? pf1 : (s2 ? pf2 : pf3)));
+            pf0 = pf1 = pf2 = pf3 = t;
+        } else if (nset == 2) {
+            // the two members, in base order
+            const double x = s0 ? pf0 : (s1 ? pf1 : pf2);
+            const double y = s3 ? pf3 : ((s2 && (s0 || s1)) ? pf2 : pf1);
+            double tx, ty;
+            bv_wave_sum2(x, y, tx, ty);
+            pf0 = tx;                                  // only read when s0
+            pf1 = s0 ? ty : tx;                        // s1: second member iff s0 is the first
+            pf2 = (s0 || s1) ? ty : tx;                // s2: second member iff an earlier base is in the set
+            pf3 = ty;                                  // s3 is always the second member
+        } else {
+            bv_wave_sum4(pf0, pf1, pf2, pf3, pf0, pf1, pf2, pf3);
+        }
+        f[0] = s0 ? pf0 * inv_n : 0.;
+        f[1] = s1 ? pf1 * inv_n : 0.;
+        f[2] = s2 ? pf2 * inv_n : 0.;
+        f[3] = s3 ? pf3 * inv_n : 0.;
+        if (k == 0) continue;
+        ++iters;
+        if (__ballot(delta != 0.) == 0ull) break;  // every bin's log-marginal moved by < 1: the sum is 0
+        if (bv_wave_sum(delta) < epsilon) break;
+    }
+    double lr = 0.;
+#pragma unroll
+    for (int s = 0; s < BV_SLOTS; ++s) {
+        if (s < nslots) {
+            const int i = s * BV_WAVE + lane;
+            if (i < B.nb) lr += (double)B.cnt[bv_bin_at(B, i)] * log(pm[s]);
+        }
     }
     *lr_out = bv_wave_sum(lr);
     return iters;
@@ -757,7 +823,9 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             double s = 0.;
             s += f[0]; s += f[1]; s += f[2]; s += f[3];
             double lr;
-            int it = bv_em_wave(B, f, n_cov, &lr, lane);
+            // phred-0 calls (1 - eps == 0) and all-zero starts make 0/0 in the reference: exact replay
+            int it = (q0_mask != 0u || s == 0.) ? bv_em_wave_generic(B, f, n_cov, &lr, lane)
+                                                : bv_em_wave(B, f, in_set, n_cov, &lr, lane);
             if (lane == 0) {
                 sh->f[par][c][0] = f[0]; sh->f[par][c][1] = f[1];
                 sh->f[par][c][2] = f[2]; sh->f[par][c][3] = f[3];

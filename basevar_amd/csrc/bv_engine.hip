@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "bv_kernels.h"
 
@@ -32,6 +33,7 @@ struct bv_engine {
     hipStream_t stream = nullptr;      // engine-owned stream
     hipStream_t last_stream = nullptr; // stream of the last submit
     BvTables *d_tables = nullptr;
+    double *d_lnfact = nullptr;
     uint32_t *d_var_list = nullptr;
     uint32_t *d_counters = nullptr;    // BV_CTR_* words (bv_kernels.h)
     uint32_t *h_counters = nullptr;    // pinned host mirror
@@ -162,6 +164,23 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         t.hit[qv] = 1.0 - epsilon;
         t.miss[qv] = epsilon / 3;
     }
+    // log-factorials for the Fisher test with the host libm -- kfunc.c:197-201 calls lgamma(n + 1) --
+    // for every depth a site of this engine can reach (deeper tables fall back to a series on the device)
+    {
+        size_t nfact = (size_t)(cfg->max_samples ? cfg->max_samples : 1u << 20) + 2;
+        if (nfact < (1u << 16)) nfact = 1u << 16;
+        if (nfact > (1u << 23)) nfact = 1u << 23;
+        std::vector<double> lf(nfact);
+        for (size_t k = 0; k < nfact; ++k) {
+            int sign;
+            lf[k] = lgamma_r((double)k + 1.0, &sign);
+        }
+        BV_TRY(hipMalloc(&e->d_lnfact, sizeof(double) * nfact));
+        BV_TRY(hipMemcpy(e->d_lnfact, lf.data(), sizeof(double) * nfact, hipMemcpyHostToDevice));
+        t.lnfact = e->d_lnfact;
+        t.lnfact_n = (uint32_t)nfact;
+        t.pad_ = 0;
+    }
     BV_TRY(hipMemcpy(e->d_tables, &t, sizeof(t), hipMemcpyHostToDevice));
 #undef BV_TRY
     *out = e;
@@ -176,6 +195,7 @@ int bv_engine_destroy(bv_engine *e) {
         for (auto &ev : tri)
             if (ev) (void)hipEventDestroy(ev);
     if (e->d_tables) (void)hipFree(e->d_tables);
+    if (e->d_lnfact) (void)hipFree(e->d_lnfact);
     if (e->d_var_list) (void)hipFree(e->d_var_list);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->h_counters) (void)hipHostFree(e->h_counters);

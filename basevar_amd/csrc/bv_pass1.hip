@@ -223,6 +223,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
         BvSolveArgs sa;
         sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
         sa.min_af = a.min_af; sa.flags = a.flags;
+    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
         for (uint32_t k = (uint32_t)s;; k += NSOLVE) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[BV_CTR_TIMEOUT]);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, 4) void bv_pass1_fused_ker
     BvSolveArgs sa;
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = a.flags;
+    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     // Tickets are drawn BV_FUSED_TICKET sites at a time: at ~70 M short-row sites/s one ticket per
     // site would run into the ~88 M/s ceiling of atomics on a single address (measured: throughput
     // flat from 6 to 11 waves per CU until the draws were chunked).

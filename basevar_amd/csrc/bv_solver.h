@@ -81,6 +81,7 @@ struct BvSolveArgs {
     uint32_t *counters;
     double min_af;
     uint32_t flags;
+    BvLnTab lnfact;  // log-factorial table (BvTables::lnfact)
 };
 
 #define BV_LDS __attribute__((address_space(3)))
@@ -136,18 +137,20 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
         uint32_t flags = BV_SITE_COVERED | (badq ? BV_SITE_BAD_QUAL : 0u);
 
         // ---- CVG strand bias: alt = every non-ref ACGT base (caller.cpp:1236-1245)
+        uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;
+        double c_fs = 0, c_sor = 0;
+        uint32_t c_flags = 0;
         if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
-            uint32_t rf = 0, rr = 0, af = 0, ar = 0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                if (b == ref) { rf += fwd[b]; rr += rev[b]; } else { af += fwd[b]; ar += rev[b]; }
+                if (b == ref) { c_rf += fwd[b]; c_rr += rev[b]; } else { c_af += fwd[b]; c_ar += rev[b]; }
             }
-            double fs, sor;
-            bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &flags);
+            bv_strand_bias_wave(c_rf, c_rr, c_af, c_ar, lane, a.lnfact, &c_fs, &c_sor, &c_flags);
+            flags |= c_flags;
             if (lane == 0) {
-                sv->res.cvg_sb[0] = rf; sv->res.cvg_sb[1] = rr; sv->res.cvg_sb[2] = af; sv->res.cvg_sb[3] = ar;
-                sv->res.cvg_fs = fs;
-                sv->res.cvg_sor = sor;
+                sv->res.cvg_sb[0] = c_rf; sv->res.cvg_sb[1] = c_rr; sv->res.cvg_sb[2] = c_af; sv->res.cvg_sb[3] = c_ar;
+                sv->res.cvg_fs = c_fs;
+                sv->res.cvg_sor = c_sor;
             }
         }
 
@@ -178,7 +181,11 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                 double r = (double)bv_sel4u(depth, L.first) / (double)total;
                 double qual;
                 if (L.m == 1 && total > 10 && r > 0.5) qual = 5000.0;
+#ifdef BV_ABL_NO_QUAL  /* attribution builds only (tools/ablate.sh) */
+                else qual = L.chi2;
+#else
                 else qual = bv_qual_from_chi2(L.chi2);
+#endif
                 double ad_sum = 0;
 #pragma unroll
                 for (int k = 0; k < BV_MAX_ALT; ++k) {
@@ -208,8 +215,16 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                     if (b == ref) { rf += fwd[b]; rr += rev[b]; }
                     else if ((alt_mask >> b) & 1u) { af += fwd[b]; ar += rev[b]; }
                 }
-                double fs, sor;
-                bv_strand_bias_wave(rf, rr, af, ar, lane, &fs, &sor, &flags);
+                double fs = 0, sor = 0;
+#ifndef BV_ABL_NO_VARFS
+                // same 2x2 table as the CVG test whenever the chosen ALTs are all the non-ref bases seen
+                if (!(a.flags & BV_FLAG_SKIP_FISHER) && rf == c_rf && rr == c_rr && af == c_af && ar == c_ar) {
+                    fs = c_fs;
+                    sor = c_sor;
+                } else {
+                    bv_strand_bias_wave(rf, rr, af, ar, lane, a.lnfact, &fs, &sor, &flags);
+                }
+#endif
                 if (lane == 0) {
                     sv->res.var_sb[0] = rf; sv->res.var_sb[1] = rr; sv->res.var_sb[2] = af; sv->res.var_sb[3] = ar;
                     sv->res.var_fs = fs;
@@ -217,6 +232,7 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                 }
             }
             // base-quality rank sum from the histogram this pass already holds (caller.cpp:1157)
+#ifndef BV_ABL_NO_BQ
             {
                 unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
                 unsigned long long below = 0, twoR = 0;
@@ -234,6 +250,7 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                 }
                 bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
             }
+#endif
         }
         if (lane == 0) {
 #pragma unroll

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
     BvSolveArgs sa;
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = 0;
+    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)sh.hist, (BV_LDS uint32_t *)nullptr, (BV_LDS uint32_t *)nullptr,
                              (BV_LDS BvSolverScratch *)&sh.sc, (BV_LDS const double *)sh.tab_hit,
                              (BV_LDS const double *)sh.tab_miss, lane);

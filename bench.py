@@ -166,8 +166,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BASEVAR_BENCH_FORCE_DIST=1: run the process group + record gather even with ONE rank, so that the
+    # RCCL code path (nccl backend, async gather ordered on the engine's stream) can be exercised on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("BASEVAR_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -205,8 +211,8 @@ def main():
     rec = basevar_amd.SITE_DTYPE.itemsize
     # record buffers: one per stream at N = 1; a ring of 3 per rank at N > 1 so that the gather of
     # batch i (RCCL, asynchronous) overlaps the kernels of batches i+1 and i+2
-    depth = 3 if world > 1 else ns
-    gloo_host = world > 1 and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
+    depth = 3 if dist_on else ns
+    gloo_host = dist_on and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
     outs = [torch.zeros(B * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
     houts = [torch.zeros(B * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None
     # Everything of engine k -- its kernels and the gather of its records -- is issued on that engine's OWN
@@ -215,7 +221,7 @@ def main():
     # torch's pooled streams either: two of them may share one hardware queue, and --streams 2 then
     # overlaps nothing.)
     streams = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in engs]
-    gatherer = RecordGatherer(B * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if world > 1 else None
+    gatherer = RecordGatherer(B * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if dist_on else None
     last_slot = [0]
 
     def step(i):
@@ -245,7 +251,7 @@ def main():
             with torch.cuda.stream(streams[0]):
                 gatherer.drain()
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -261,7 +267,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     gathered_ok = None
-    if rank == 0 and world > 1:
+    if rank == 0 and dist_on:
         # the gathered buffer holds world x B records in rank order: every record must be a covered site
         recs = torch.cat([p.cpu() for p in gatherer.parts(last_slot[0])]).numpy().view(basevar_amd.SITE_DTYPE)
         mine = outs[last_slot[0]].cpu().numpy().view(basevar_amd.SITE_DTYPE)
@@ -276,7 +282,7 @@ def main():
     nvar = eng.last_variant_count()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -366,7 +372,7 @@ def main():
         print(json.dumps(line), flush=True)
     for e in engs:
         e.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

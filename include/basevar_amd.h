@@ -151,7 +151,8 @@ typedef struct bv_group_result {
 typedef struct bv_engine_config {
     int32_t device;        /* HIP device ordinal                                        */
     uint32_t max_sites;    /* largest n_sites per submit (sizes scratch)                */
-    uint32_t max_samples;  /* largest n_samples (host-staging only; 0 = no staging)     */
+    uint32_t max_samples;  /* largest n_samples: sizes the host staging area (0 = no staging) and the
+                              log-factorial table of the strand-bias test (0 = 1 Mi entries)   */
     uint32_t flags;        /* BV_FLAG_* bits, normally 0                                */
     double min_af;         /* BaseType ctor arg 2 (basetype.cpp:30): already the        */
                            /* float-rounded value of caller.cpp:122; see bv_min_af()    */

@@ -28,3 +28,20 @@ def test_bench_two_ranks_gloo_one_device():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["unit"] == "sites/s"
     assert d["config"]["gathered_records_ok"] is True
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_bench_rccl_backend_single_rank():
+    """The backend the driver's N > 1 runs use ("nccl" = RCCL), forced on with ONE rank: process-group
+    init bound to the device, the asynchronous gather issued on the engine's own HIP stream (wrapped as a
+    torch ExternalStream), Work.wait() ordering before buffer reuse, barrier and all_reduce of the timing."""
+    env = dict(os.environ, BASEVAR_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("BASEVAR_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "7", "--warmup", "2", "--samples",
+           "20000", "--batch-sites", "2048", "--no-cpu-baseline", "--streams", "2"]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["gathered_records_ok"] is True and d["value"] > 0
