@@ -77,30 +77,39 @@ __device__ __forceinline__ uint32_t bv_mask_tail_dword(uint32_t w, int keep) {
 struct BvChunkSet {
     bv_u32x4 vb[BV_TALLY_U], vq[BV_TALLY_U];
 };
-__device__ __forceinline__ void bv_chunks_load(BvChunkSet &c, const bv_u32x4 *b4, const bv_u32x4 *q4, uint32_t base,
+// FULL: every chunk of the set lies wholly inside the row (wave-uniform fact) -- unguarded loads off a
+// scalar base (row pointer + set offset in SGPRs, lane offset in one VGPR, the chunk's 1 KiB step in
+// the instruction's immediate) and no tail masking.  !FULL: the row's last, partial set.
+template <bool FULL>
+__device__ __forceinline__ void bv_chunks_load(BvChunkSet &c, const uint8_t *bs_row, const uint8_t *q_row, uint32_t base,
                                                uint32_t n_chunks, int lane) {
+    const uint8_t *pb = bs_row + (size_t)base * 16u, *pq = q_row + (size_t)base * 16u;  // uniform
+    const uint32_t voff = (uint32_t)lane * 16u;
 #pragma unroll
     for (int u = 0; u < BV_TALLY_U; ++u) {
-        uint32_t idx = base + u * BV_WAVE + lane;
-        if (idx < n_chunks) {
-            c.vb[u] = __builtin_nontemporal_load(b4 + idx);
-            c.vq[u] = __builtin_nontemporal_load(q4 + idx);
+        const uint32_t off = voff + (uint32_t)u * (BV_WAVE * 16u);
+        if (FULL || base + u * BV_WAVE + lane < n_chunks) {
+            c.vb[u] = __builtin_nontemporal_load(reinterpret_cast<const bv_u32x4 *>(pb + off));
+            c.vq[u] = __builtin_nontemporal_load(reinterpret_cast<const bv_u32x4 *>(pq + off));
         } else {
             c.vb[u] = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
             c.vq[u] = bv_u32x4{0u, 0u, 0u, 0u};
         }
     }
 }
+template <bool FULL>
 __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, uint32_t n_chunks, int tail, int lane,
                                                 uint32_t *hist, uint32_t one) {
 #pragma unroll
     for (int u = 0; u < BV_TALLY_U; ++u) {
-        uint32_t idx = base + u * BV_WAVE + lane;
-        if (tail && idx == n_chunks - 1) {
-            c.vb[u].x = bv_mask_tail_dword(c.vb[u].x, tail);
-            c.vb[u].y = bv_mask_tail_dword(c.vb[u].y, tail - 4);
-            c.vb[u].z = bv_mask_tail_dword(c.vb[u].z, tail - 8);
-            c.vb[u].w = bv_mask_tail_dword(c.vb[u].w, tail - 12);
+        if (!FULL) {
+            uint32_t idx = base + u * BV_WAVE + lane;
+            if (tail && idx == n_chunks - 1) {
+                c.vb[u].x = bv_mask_tail_dword(c.vb[u].x, tail);
+                c.vb[u].y = bv_mask_tail_dword(c.vb[u].y, tail - 4);
+                c.vb[u].z = bv_mask_tail_dword(c.vb[u].z, tail - 8);
+                c.vb[u].w = bv_mask_tail_dword(c.vb[u].w, tail - 12);
+            }
         }
         bv_tally_dword(c.vb[u].x, c.vq[u].x, hist, one);
         bv_tally_dword(c.vb[u].y, c.vq[u].y, hist, one);
@@ -108,12 +117,23 @@ __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, ui
         bv_tally_dword(c.vb[u].w, c.vq[u].w, hist, one);
     }
 }
+// set at `base`: nothing to do past the row's end; FULL form when the set ends inside the row
+#define BV_SET_LOAD(C, BASE)                                                                  \
+    do {                                                                                      \
+        const uint32_t b_ = (BASE);                                                           \
+        if (b_ + BLK <= n_full) bv_chunks_load<true>(C, bs_row, q_row, b_, n_chunks, lane);   \
+        else if (b_ < n_chunks) bv_chunks_load<false>(C, bs_row, q_row, b_, n_chunks, lane);  \
+    } while (0)
+#define BV_SET_TALLY(C, BASE)                                                                 \
+    do {                                                                                      \
+        const uint32_t b_ = (BASE);                                                           \
+        if (b_ + BLK <= n_full) bv_chunks_tally<true>(C, b_, n_chunks, tail, lane, hist, one);\
+        else if (b_ < n_chunks) bv_chunks_tally<false>(C, b_, n_chunks, tail, lane, hist, one);\
+    } while (0)
 template <int NTALLY>
 __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const uint8_t *q_row, uint32_t n_samples,
                                                   uint32_t *hist, int t, int lane) {
-    const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(bs_row);
-    const bv_u32x4 *q4 = reinterpret_cast<const bv_u32x4 *>(q_row);
-    const uint32_t n_chunks = (n_samples + 15u) >> 4;
+    const uint32_t n_chunks = (n_samples + 15u) >> 4, n_full = n_samples >> 4;
     const int tail = (int)(n_samples & 15u);
     constexpr uint32_t BLK = BV_WAVE * BV_TALLY_U;  // chunks per wave-iteration (4 KiB of each plane)
     constexpr uint32_t STRIDE = BLK * NTALLY;       // the row's blocks go round-robin over the tally waves
@@ -121,14 +141,16 @@ __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const u
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));  // opaque: not re-materialised per cell
     BvChunkSet A, B;
     uint32_t base = (uint32_t)t * BLK;
-    bv_chunks_load(A, b4, q4, base, n_chunks, lane);
+    BV_SET_LOAD(A, base);
     for (; base < n_chunks; base += 2 * STRIDE) {
-        bv_chunks_load(B, b4, q4, base + STRIDE, n_chunks, lane);
-        bv_chunks_tally(A, base, n_chunks, tail, lane, hist, one);
-        bv_chunks_load(A, b4, q4, base + 2 * STRIDE, n_chunks, lane);
-        bv_chunks_tally(B, base + STRIDE, n_chunks, tail, lane, hist, one);
+        BV_SET_LOAD(B, base + STRIDE);
+        BV_SET_TALLY(A, base);
+        BV_SET_LOAD(A, base + 2 * STRIDE);
+        BV_SET_TALLY(B, base + STRIDE);
     }
 }
+#undef BV_SET_LOAD
+#undef BV_SET_TALLY
 
 // ------------------------------------------------------------------------------ kernel
 // Every spin is bounded (~1 s): a protocol bug must end the kernel with counters[3] set
