@@ -163,6 +163,35 @@ __device__ __forceinline__ void bv_wave_sum4(double a, double b, double c, doubl
     sb = bv_readlane_f64_c(v, 47);
     sd = bv_readlane_f64_c(v, 63);
 }
+// Eight u32 wave totals with one scan: 32-lane fold, 16-lane fold, 8-lane fold, then a 3-step scan
+// inside groups of 8 lanes (26 VALU instead of 8 x 13).
+__device__ __forceinline__ uint32_t bv_fold32_u32(uint32_t a, uint32_t b) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    return r[0] + r[1];
+}
+__device__ __forceinline__ uint32_t bv_fold16_u32(uint32_t p, uint32_t q) {
+    auto r = __builtin_amdgcn_permlane16_swap(p, q, false, false);
+    return r[0] + r[1];
+}
+#define BV_DPP_ROW_ROR(n) (0x120 + (n))
+__device__ __forceinline__ void bv_wave_sum8_u32(const uint32_t v[8], uint32_t out[8], int lane) {
+    uint32_t t0 = bv_fold16_u32(bv_fold32_u32(v[0], v[1]), bv_fold32_u32(v[2], v[3]));  // rows: v0, v2, v1, v3
+    uint32_t t1 = bv_fold16_u32(bv_fold32_u32(v[4], v[5]), bv_fold32_u32(v[6], v[7]));  // rows: v4, v6, v5, v7
+    t0 += (uint32_t)bv_dpp_i32<BV_DPP_ROW_ROR(8), 0xf>(0, (int)t0);  // both halves of a row: its 8 pair sums
+    t1 += (uint32_t)bv_dpp_i32<BV_DPP_ROW_ROR(8), 0xf>(0, (int)t1);
+    uint32_t w = (lane & 8) ? t1 : t0;
+    w += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(1), 0xf>(0, (int)w);
+    w += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(2), 0xf>(0, (int)w);
+    w += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(4), 0xf>(0, (int)w);
+    out[0] = (uint32_t)__builtin_amdgcn_readlane((int)w, 7);
+    out[4] = (uint32_t)__builtin_amdgcn_readlane((int)w, 15);
+    out[2] = (uint32_t)__builtin_amdgcn_readlane((int)w, 23);
+    out[6] = (uint32_t)__builtin_amdgcn_readlane((int)w, 31);
+    out[1] = (uint32_t)__builtin_amdgcn_readlane((int)w, 39);
+    out[5] = (uint32_t)__builtin_amdgcn_readlane((int)w, 47);
+    out[3] = (uint32_t)__builtin_amdgcn_readlane((int)w, 55);
+    out[7] = (uint32_t)__builtin_amdgcn_readlane((int)w, 63);
+}
 // min / max: same scan shape with the matching identity
 __device__ __forceinline__ int bv_wave_min_i32(int v) {
     const int I = 0x7fffffff;

@@ -267,6 +267,9 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
 // For short rows (N <~ 50 k samples: <= 100 KB of stream per site) the solve, not the stream,
 // dominates a site, so every wave should be a solver: one independent wave per workgroup tallies
 // its own site and solves it, persistent with the same ticket counter.  No hand-off, no flags.
+// (Measured and dropped: touching one byte per 128-byte line of the wave's NEXT row before the solve,
+// to turn the next row's first HBM latency into L2 hits -- 15 % slower: 64 uncoalesced line requests
+// per instruction cost more than the latency they hide.)
 #define BV_FUSED_TICKET 4
 #define BV_FUSED_WAVES 4
 struct __attribute__((aligned(16))) BvPass1FusedShared {

@@ -220,12 +220,13 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         if (GROUPS) {
             for (uint32_t g = wave; g < a.n_groups; g += NW) {
                 const uint32_t *h = hg + g * 512u;
-                uint32_t nb = 0, gdepth[4], gtotal = 0;
+                uint32_t nb = 0, gdepth[4], gtotal = 0, q0_mask = 0;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int b = r >> 1;
                     const int q = ((r & 1) << 6) | lane;
                     uint32_t c = h[(b << 7) | q];
+                    if (!(r & 1) && __builtin_amdgcn_readfirstlane((int)c) != 0) q0_mask |= 1u << b;  // phred-0 calls of base b
                     uint32_t cs = bv_wave_sum_u32(c);
                     if (r & 1) gdepth[b] += cs; else gdepth[b] = cs;
                     bool valid = (c != 0) && (q < BV_NQ_VALID);
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     BvBins B;
                     B.code = sh.bin_code[wave]; B.cnt = sh.bin_cnt[wave]; B.skip_mask = 0u;
                     B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.nb = (int)nb;
-                    bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.lrt[wave], wave, lane, L);
+                    bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.lrt[wave], wave, lane, L, q0_mask);
                 }
                 if (lane == 0) {
                     bv_group_result gr;

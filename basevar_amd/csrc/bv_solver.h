@@ -66,8 +66,13 @@ __device__ __forceinline__ void bv_prologue_wave(const uint32_t *hist, uint32_t 
             }
             nb += (uint32_t)__popcll(m);
         }
-        fwd[b] = bv_wave_sum_u32(facc[b]);
-        rev[b] = bv_wave_sum_u32(racc[b]);
+    }
+    {
+        const uint32_t v[8] = {facc[0], facc[1], facc[2], facc[3], racc[0], racc[1], racc[2], racc[3]};
+        uint32_t t[8];
+        bv_wave_sum8_u32(v, t, lane);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { fwd[b] = t[b]; rev[b] = t[4 + b]; }
     }
     *nb_out = nb;
     *badq_out = (__ballot(bad) != 0ull) ? 1u : 0u;
