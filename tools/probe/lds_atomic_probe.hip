@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void k(const uint32_t *idx, uint32_t *out, int
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 int main() {
-    const int grid = 256 * 4, iters = 2000;
+    const int gridmax = 256 * 4, iters = 2000;
+    const int grid = gridmax;
     uint32_t *idx, *out;
     CHECK(hipMalloc(&idx, grid * 256 * 16 * 4)); CHECK(hipMalloc(&out, grid * 256 * 4));
     uint32_t *h = (uint32_t *)malloc(grid * 256 * 16 * 4);
@@ -41,21 +42,21 @@ int main() {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const char *names[4] = {"ds_add_u32 (no rtn)", "ds_write_b32", "ds_add_rtn_u32", "ds_read_b32"};
     const int mods[4] = {65536, 5243 /* 8 % */, 1311 /* 2 % */, 0};
-    for (int mode = 0; mode < 4; ++mode)
+    for (int wg = 1; wg <= 4; wg *= 2)
+    for (int mode = 0; mode < 2; ++mode)
         for (int m = 0; m < 4; ++m) {
             float ms = 0;
+            const int g = 256 * wg;
             for (int rep = 0; rep < 2; ++rep) {
                 CHECK(hipEventRecord(e0));
-                if (mode == 0) k<0><<<grid, 256>>>(idx, out, iters, mods[m]);
-                if (mode == 1) k<1><<<grid, 256>>>(idx, out, iters, mods[m]);
-                if (mode == 2) k<2><<<grid, 256>>>(idx, out, iters, mods[m]);
-                if (mode == 3) k<3><<<grid, 256>>>(idx, out, iters, mods[m]);
+                if (mode == 0) k<0><<<g, 256>>>(idx, out, iters, mods[m]);
+                if (mode == 1) k<1><<<g, 256>>>(idx, out, iters, mods[m]);
                 CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
                 CHECK(hipEventElapsedTime(&ms, e0, e1));
             }
             // per CU: 16 waves x iters x 16 instructions
-            double instr_per_cu = 16.0 * iters * 16;
-            printf("%-20s active %5.1f %%: %.3f ms  -> %.1f ns = %.1f cycles(2.4GHz) per wave-instruction per CU\n", names[mode],
+            double instr_per_cu = 4.0 * wg * iters * 16;
+            printf("%2d waves/CU %-20s active %5.1f %%: %.3f ms  -> %.1f ns = %.1f cycles(2.4GHz) per wave-instruction per CU\n", 4 * wg, names[mode],
                    100.0 * mods[m] / 65536, ms, ms * 1e6 / instr_per_cu, ms * 1e6 / instr_per_cu * 2.4);
         }
     return 0;
