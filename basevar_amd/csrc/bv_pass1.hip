@@ -324,7 +324,9 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
 // (Measured and dropped: touching one byte per 128-byte line of the wave's NEXT row before the solve,
 // to turn the next row's first HBM latency into L2 hits -- 15 % slower: 64 uncoalesced line requests
 // per instruction cost more than the latency they hide.)
+#ifndef BV_FUSED_TICKET
 #define BV_FUSED_TICKET 4
+#endif
 #define BV_FUSED_WAVES 4
 struct __attribute__((aligned(16))) BvPass1FusedShared {
     uint32_t hist[BV_FUSED_WAVES][BV_H2_WORDS];  // one per wave; also holds that wave's bins (ALIAS mode)

@@ -13,6 +13,9 @@
 // the group-id vector is shared by all sites and stays in L2.
 #include "bv_kernels.h"
 
+#ifndef BV_P2_U64
+#define BV_P2_U64 4
+#endif
 #define BV_RPR_WIN 1024  /* read-position ranks per LDS window; longer reads take extra sweeps */
 
 template <int NW>
@@ -82,7 +85,8 @@ __device__ __forceinline__ void bv_p2_sweep(BvP2Ctx &cx, const BvPass2Args &a, u
     const uint32_t n_chunks = (a.n_samples + 15u) >> 4;
     const int tail = (int)(a.n_samples & 15u);
     const bv_u32x4 zero = bv_u32x4{0u, 0u, 0u, 0u};
-    constexpr int U = 2;
+    // chunks per thread and iteration: short rows (one wave per site) are latency-bound -> more loads in flight
+    constexpr int U = (NT == 64) ? BV_P2_U64 : 2;
     for (uint32_t base = 0; base < n_chunks; base += NT * U) {
         bv_u32x4 vb[U], vm[U], vr0[U], vr1[U], vq[U], vg[U];
 #pragma unroll
@@ -163,8 +167,11 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         }
 
         // ---- clear histograms
-        for (int i = tid; i < 2 * 256; i += NT) sh.hm[i] = 0u;
-        for (int i = tid; i < 2 * BV_RPR_WIN; i += NT) sh.hr[i] = 0u;
+        {
+            // hm and hr are adjacent and 16-byte aligned: clear them with 128-bit stores
+            uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
+            for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
+        }
         if (GROUPS)
             for (uint32_t i = tid; i < a.n_groups * 512u; i += NT) hg[i] = 0u;
         __syncthreads();
@@ -195,7 +202,9 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
             unsigned long long below = 0, twoR = 0;
             for (uint32_t win_lo = 0;; win_lo += BV_RPR_WIN) {
                 if (wave == (1 % NW)) {
-                    for (int w = 0; w < BV_RPR_WIN / 64; ++w)
+                    // ranks beyond the row's largest classified rank hold nothing: stop at its 64-wide block
+                    const int nblk = (maxr < win_lo + BV_RPR_WIN) ? (int)((maxr - win_lo) >> 6) + 1 : BV_RPR_WIN / 64;
+                    for (int w = 0; w < nblk; ++w)
                         twoR += bv_ranksum_window(sh.hr[w * 64 + lane], sh.hr[BV_RPR_WIN + w * 64 + lane], n1 + n2,
                                                   below, lane);
                 }
