@@ -184,9 +184,10 @@ __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, ui
         if (b_ + BLK <= n_full) bv_chunks_tally<true>(C, b_, n_chunks, tail, lane, hist, one);\
         else if (b_ < n_chunks) bv_chunks_tally<false>(C, b_, n_chunks, tail, lane, hist, one);\
     } while (0)
-template <int NTALLY>
+// PRE: the row's first set is already in (or on its way into) A -- see bv_row_preload.
+template <int NTALLY, bool PRE = false>
 __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const uint8_t *q_row, uint32_t n_samples,
-                                                  uint32_t *hist, int t, int lane) {
+                                                  uint32_t *hist, int t, int lane, BvChunkSet *pre = nullptr) {
     const uint32_t n_chunks = (n_samples + 15u) >> 4, n_full = n_samples >> 4;
     const int tail = (int)(n_samples & 15u);
     constexpr uint32_t BLK = BV_WAVE * BV_TALLY_U;  // chunks per wave-iteration (4 KiB of each plane)
@@ -195,13 +196,21 @@ __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const u
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));  // opaque: not re-materialised per cell
     BvChunkSet A, B;
     uint32_t base = (uint32_t)t * BLK;
-    BV_SET_LOAD(A, base);
+    if (PRE) A = *pre;
+    else BV_SET_LOAD(A, base);
     for (; base < n_chunks; base += 2 * STRIDE) {
         BV_SET_LOAD(B, base + STRIDE);
         BV_SET_TALLY(A, base);
         BV_SET_LOAD(A, base + 2 * STRIDE);
         BV_SET_TALLY(B, base + STRIDE);
     }
+}
+// issue the loads of a row's first set (the caller keeps the registers alive across other work)
+__device__ __forceinline__ void bv_row_preload(BvChunkSet &A, const uint8_t *bs_row, const uint8_t *q_row,
+                                               uint32_t n_samples, int lane) {
+    const uint32_t n_chunks = (n_samples + 15u) >> 4, n_full = n_samples >> 4;
+    constexpr uint32_t BLK = BV_WAVE * BV_TALLY_U;
+    BV_SET_LOAD(A, 0u);
 }
 #undef BV_SET_LOAD
 #undef BV_SET_TALLY
@@ -328,15 +337,21 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
 #define BV_FUSED_TICKET 4
 #endif
 #define BV_FUSED_WAVES 4
+#ifndef BV_FUSED_PRELOAD
+#define BV_FUSED_PRELOAD 1
+#endif
+#ifndef BV_FUSED_OCC
+#define BV_FUSED_OCC 3 /* waves per SIMD the register budget is set for (170 VGPRs) */
+#endif
 struct __attribute__((aligned(16))) BvPass1FusedShared {
     uint32_t hist[BV_FUSED_WAVES][BV_H2_WORDS];  // one per wave; also holds that wave's bins (ALIAS mode)
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
     BvSolverScratch sc[BV_FUSED_WAVES];
 };
 
-// Four INDEPENDENT waves per workgroup (they share only the phred tables): ~9 KiB of LDS per wave
-// -> 16 waves per CU, the VGPR limit.
-__global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, 4) void bv_pass1_fused_kernel(BvPass1Args a) {
+// Four INDEPENDENT waves per workgroup (they share only the phred tables), 3 workgroups per CU.
+// (4 per CU at 128 VGPRs was measured too: +4 % without the preload below, 13 % slower with it -- spills.)
+__global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass1_fused_kernel(BvPass1Args a) {
     __shared__ BvPass1FusedShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *hist = sh.hist[wave];
@@ -359,13 +374,34 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, 4) void bv_pass1_fused_ker
     // flat from 6 to 11 waves per CU until the draws were chunked).
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);
+#if BV_FUSED_PRELOAD
+    // The wave streams nothing while it solves, and its next row would start with a full HBM latency
+    // (PMC: 48 % of the wave time in s_waitcnt on row loads).  So the first 4 KiB set of the NEXT row is
+    // requested before the solve and kept in 32 VGPRs across it -- affordable at 3 waves per SIMD.
+    BvChunkSet P;
+    {
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        if (s0 < a.n_sites) bv_row_preload(P, a.bs + (size_t)s0 * a.pitch, a.q + (size_t)s0 * a.pitch, a.n_samples, lane);
+    }
+#endif
     for (;;) {
         const uint32_t site0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
         if (site0 >= a.n_sites) break;
         if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);  // in flight under this work
         const uint32_t site1 = min(site0 + (uint32_t)BV_FUSED_TICKET, a.n_sites);
         for (uint32_t site = site0; site < site1; ++site) {
+#if BV_FUSED_PRELOAD
+            bv_tally_row_wave<1, true>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, hist, 0,
+                                       lane, &P);
+            {
+                uint32_t nsite = site + 1;
+                if (nsite == site1) nsite = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+                if (nsite < a.n_sites)
+                    bv_row_preload(P, a.bs + (size_t)nsite * a.pitch, a.q + (size_t)nsite * a.pitch, a.n_samples, lane);
+            }
+#else
             bv_tally_row_wave<1>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, hist, 0, lane);
+#endif
             bv_lrt_sync<0>();
             bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)hist, (BV_LDS uint32_t *)nullptr,
                                      (BV_LDS uint32_t *)nullptr, (BV_LDS BvSolverScratch *)&sh.sc[wave],

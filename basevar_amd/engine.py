@@ -77,9 +77,9 @@ class BaseTypeBatch:
 class BaseTypeEngine:
     """One engine per GPU / host thread (mirrors one BaseType per ThreadPool worker)."""
 
-    def __init__(self, max_sites, min_af_value, device=0, flags=0):
+    def __init__(self, max_sites, min_af_value, device=0, flags=0, max_samples=0):
         self._lib = _capi.load()
-        cfg = _capi.EngineConfig(int(device), int(max_sites), 0, int(flags), float(min_af_value))
+        cfg = _capi.EngineConfig(int(device), int(max_sites), int(max_samples), int(flags), float(min_af_value))
         h = C.c_void_p()
         rc = self._lib.bv_engine_create(C.byref(cfg), C.byref(h))
         if rc != 0:

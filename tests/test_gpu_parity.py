@@ -396,3 +396,58 @@ def test_sample_axis_tiles_long_read_ranks_are_flagged(bv):
     flagged = (t.sites["status"] & 0x40) != 0
     assert flagged[3] and flagged.sum() == 1 and np.isnan(t.sites["rpr_ranksum"][3])
     assert not np.isnan(t.sites["mq_ranksum"][3])
+
+
+def _strand_table_slab(tables, n_samples):
+    """One site per (ref_fwd, ref_rev, alt_fwd, alt_rev[, other_fwd, other_rev]) table: ref A, alt C, a third
+    base G for the optional pair (it makes the all-sites CVG table differ from the VCF one)."""
+    S = len(tables)
+    bs = np.full((S, n_samples), 8, np.uint8)
+    q = np.zeros((S, n_samples), np.uint8)
+    for i, t in enumerate(tables):
+        t = tuple(t) + (0, 0)
+        cells = [0] * t[0] + [4] * t[1] + [1] * t[2] + [5] * t[3] + [2] * t[4] + [6] * t[5]
+        assert len(cells) <= n_samples
+        bs[i, :len(cells)] = cells
+        q[i, :len(cells)] = 30
+    rng = np.random.default_rng(5)
+    return {"base_strand": bs, "qual": q, "mapq": rng.integers(0, 61, (S, n_samples)).astype(np.uint8),
+            "rpr": rng.integers(1, 151, (S, n_samples)).astype(np.uint16), "ref_base": np.zeros(S, np.uint8),
+            "n_samples": n_samples}
+
+
+FISHER_TABLES = [
+    (5, 3, 2, 1), (500, 480, 6, 6), (100000, 90000, 3, 2), (7, 5, 0, 12),        # row margin <= 12: product form
+    (500, 480, 7, 6), (300, 280, 40, 20), (300, 280, 33, 30), (40, 23, 30, 33),  # <= 64 tables: one per lane
+    (300, 280, 50, 30), (1000, 900, 120, 130), (90, 100, 80, 110),               # rounds of 64, whole range
+    (3000, 2900, 200, 150), (20000, 19000, 5000, 4000), (60000, 60000, 30000, 31000),  # probes + rounds
+    (1000, 0, 0, 1000), (0, 1000, 1000, 0), (30000, 100, 100, 30000),            # p underflows / vanishing
+    (10, 10, 10, 10), (50000, 50000, 50000, 50000), (1, 0, 0, 1), (64, 0, 0, 64),  # symmetric: ties at L* / R*
+    (0, 0, 5, 5), (9, 9, 0, 0), (1, 1, 1, 1),                                    # degenerate margins
+    (300, 280, 40, 20, 3, 1), (3000, 2900, 200, 150, 1, 0), (500, 480, 6, 6, 0, 2),  # CVG table != VCF table
+]
+
+
+def test_fisher_regimes_by_construction(bv, restatement):
+    """Strand-bias tables built cell by cell to hit every regime of the device's Fisher test (product form,
+    one table per lane, rounds, probed tails), ties and degenerate margins -- FS / SOR of both flavours."""
+    slab = _strand_table_slab(FISHER_TABLES, 200000)
+    maf = restatement.min_af(200000)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(run_engine(bv, slab, maf), exp, gexp, margins)
+    for i, t in enumerate(FISHER_TABLES):
+        t6 = tuple(t) + (0, 0)
+        assert tuple(exp["cvg_sb"][i]) == (t6[0], t6[1], t6[2] + t6[4], t6[3] + t6[5])
+
+
+def test_fisher_beyond_the_log_factorial_table(bv, restatement):
+    """Depths past the engine's lgamma table (sized by max_samples) use the device's series instead."""
+    slab = _strand_table_slab([(60000, 60000, 30000, 31000), (90000, 80000, 7, 3), (70000, 69000, 300, 280)], 200000)
+    maf = restatement.min_af(200000)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    eng = bv.BaseTypeEngine(max_sites=3, min_af_value=maf, device=0, max_samples=1000)  # table: 65536 entries
+    try:
+        got = eng.lrt(slab)
+    finally:
+        eng.close()
+    check(got, exp, gexp, margins)
