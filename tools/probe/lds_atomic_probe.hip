@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 tools/probe/lds_atomic_probe.hip -o /tmp/lds_atomic_probe  (run on the GPU box)
 // micro-benchmark: LDS instruction throughput per CU for the tally's access pattern
 #include <hip/hip_runtime.h>
 #include <cstdio>

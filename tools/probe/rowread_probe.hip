@@ -1,3 +1,4 @@
+// build: hipcc --offload-arch=gfx950 -O3 tools/probe/rowread_probe.hip -o /tmp/rowread_probe  (run on the GPU box)
 // micro-benchmark: HBM read bandwidth when every wave streams whole rows of L bytes from each of two planes
 // (the short-row access pattern of pass 1), rows handed out by a ticket counter.
 #include <hip/hip_runtime.h>
