@@ -439,6 +439,7 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
         case 1: return bv_launch_pass1_cfg<3, 1>(a, stream);
         case 2: return bv_launch_pass1_cfg<3, 2>(a, stream);  // measured: 15-30 % slower than <3,1>
         case 5: return bv_launch_pass1_cfg<2, 1>(a, stream);  // measured:  4 % slower than <3,1>
+        // (<7,1> and <5,1>, i.e. fewer solver waves per CU, were measured too: 6 % slower than <3,1>)
         case 9: return bv_launch_pass1_fused(a, stream);
         default: break;
     }
