@@ -261,3 +261,26 @@ def test_bv_call_end_to_end(tmp_path, restatement):
     assert exact >= 0.9 * len(exp_vcf)   # the vast majority is byte-identical
     hdr = [l for l in open(vcf).read().split("\n") if l.startswith("#")]
     assert hdr[-1].split("\t")[9:] == ids and any(l.startswith("##INFO=<ID=AA_AF") for l in hdr)
+
+
+@pytest.mark.gpu
+def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path):
+    """BASELINE configs[0] plumbing: the reference's own test command (tests/data/work.log.sh:1 -- 2 x range.bam,
+    ce.fa.gz, CHROMOSOME_I:900-1200, --mapq=10 --min-af=0.05) through bv_pileup -> bv_call (GPU engine).
+    The real `basevar basetype` binary printed 5 VCF records and 207 CVG rows for it."""
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "basevar_amd", "csrc"), "../lib/bv_pileup"], check=True)
+    call = cxx(os.path.join(ROOT, "basevar_amd", "host", "bv_call.cpp"), str(tmp_path / "bv_call"), ["-lz"])
+    bf = str(tmp_path / "range.bf.gz")
+    bam = os.path.join(data, "range.bam")
+    subprocess.check_call([os.path.join(ROOT, "basevar_amd", "lib", "bv_pileup"), "-R", os.path.join(data, "ce.fa.gz"), "--regions",
+                           "CHROMOSOME_I:900-1200", "--mapq", "10", "-I", bam, "-I", bam, "-o", bf])
+    vcf, cvg = str(tmp_path / "vz.vcf"), str(tmp_path / "t.cvg")
+    subprocess.check_call([call, "--batchfiles", bf, "--output-vcf", vcf, "--output-cvg", cvg, "--min-af", "0.05"])
+    vrec = [l for l in open(vcf).read().split("\n") if l and not l.startswith("#")]
+    crow = [l for l in open(cvg).read().split("\n") if l and not l.startswith("#")]
+    assert len(crow) == 207 and len(vrec) == 5
+    assert open(vcf).read().split("\n#CHROM")[1].split("\n")[0].endswith("FORMAT\tERS225193\tERS225193")
+    for l in vrec:
+        f = l.split("\t")
+        assert f[0] == "CHROMOSOME_I" and 900 <= int(f[1]) <= 1200 and len(f) == 11
