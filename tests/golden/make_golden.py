@@ -103,6 +103,64 @@ def deep_sor_slab():
             "ref_base": np.array([s[0] for s in sites], np.uint8)}
 
 
+def real_bam_slab():
+    """Real sequencing data: the reference's own 100-BAM test set (tests/data/140k_thalassemia_brca_bam, work.log.sh:8),
+    piled up by basevar_amd/lib/bv_pileup over chr11:5246595-5248428 and the first 6 kb of the chr17 region, covered
+    positions only.  hg19 is not shipped with the reference, so REF is the majority call of the position (ties: lowest
+    base code) -- most sites hom-ref, the rest real SNVs/errors -- and every 37th site gets REF 'N'.  Pop-groups come from
+    the set's sample_group.info."""
+    import gzip
+    import subprocess
+    import tempfile
+    bdir = "/root/reference/tests/data/140k_thalassemia_brca_bam"
+    tool = os.path.join(ROOT, "basevar_amd", "lib", "bv_pileup")
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "basevar_amd", "csrc"), "../lib/bv_pileup"], check=True)
+    bams = [os.path.join(bdir, l.split()[0]) for l in open(os.path.join(bdir, "bam100.list")) if l.strip()]
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    rows = []
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = os.path.join(tmp, "nn.fa.gz")
+        with gzip.open(fa, "wt", compresslevel=1) as f:
+            for name, L in (("chr11", 5250000), ("chr17", 41210000)):
+                f.write(">%s\n" % name + ("N" * 60 + "\n") * (L // 60 + 1))
+        ids = None
+        for region in ("chr11:5246595-5248428", "chr17:41197764-41203763"):
+            out = os.path.join(tmp, "o.bf")
+            cmd = [tool, "-R", fa, "--regions", region, "--mapq", "10", "-o", out]
+            for b in bams:
+                cmd += ["-I", b]
+            subprocess.run(cmd, check=True, capture_output=True)
+            lines = open(out).read().splitlines()
+            ids = lines[1].split("=", 1)[1].split(",")
+            rows += [l.split("\t") for l in lines[3:] if int(l.split("\t")[3]) > 0]
+    n = len(ids)
+    S = len(rows)
+    pitch = (n + 15) // 16 * 16  # row pitch of the planes: a multiple of 16 bytes
+    bs = np.full((S, pitch), N, np.uint8); q = np.zeros((S, pitch), np.uint8); mq = np.zeros((S, pitch), np.uint8)
+    rp = np.zeros((S, pitch), np.uint16); ref = np.zeros(S, np.uint8)
+    for s, r in enumerate(rows):
+        toks, quals, strands = r[5].split(" "), r[6].split(" "), r[8].split(" ")
+        mqs, ranks = r[4].split(" "), r[7].split(" ")
+        cnt = [0, 0, 0, 0]
+        for i, t in enumerate(toks):
+            if t[0] == "N":
+                continue
+            if t[0] in code:
+                bs[s, i] = code[t[0]] | (REV if strands[i] == "-" else 0)
+                cnt[code[t[0]]] += 1
+            else:
+                bs[s, i] = INS if t[0] == "+" else DEL
+            q[s, i] = ord(quals[i]) - 33
+            mq[s, i] = int(mqs[i])
+            rp[s, i] = int(ranks[i])
+        ref[s] = 4 if s % 37 == 36 else int(np.argmax(cnt))
+    s2g = dict(l.split()[:2] for l in open(os.path.join(bdir, "sample_group.info")) if l.strip())
+    gnames = sorted(set(s2g.values()))
+    gid = np.array([gnames.index(s2g[i]) if i in s2g else 0xFF for i in ids], np.uint8)
+    return {"n_sites": S, "n_samples": n, "pitch": pitch, "n_groups": len(gnames), "base_strand": bs, "qual": q, "mapq": mq,
+            "rpr": rp, "ref_base": ref, "group_id": gid}
+
+
 FIXTURES = {
     # name: (slab factory, user min_af)
     "edge16": (edge_slab, 0.01),
@@ -110,6 +168,7 @@ FIXTURES = {
     "dense_64x500": (lambda: make_slab(64, 500, seed=11, coverage=0.6, n_groups=2, ref_n_frac=0.05), 0.01),
     "nipt_96x4000": (lambda: make_slab(96, 4000, seed=12, coverage=0.08, n_groups=2), 0.01),
     "ragged_40x1003": (lambda: make_slab(40, 1003, seed=13, coverage=0.25, n_groups=3, pitch=1008), 0.01),
+    "real_100bam": (real_bam_slab, 0.05),   # --min-af=0.05 as in the set's work.log.sh
     "lowq_48x800": (lambda: make_slab(48, 800, seed=14, coverage=0.4, qual_mean=12.0, qual_sd=8.0, qual_min=1,
                                       qual_max=60), 0.01),
 }
