@@ -136,7 +136,7 @@ __device__ __forceinline__ double bv_fold16_f64(double p, double q) {
     auto rh = __builtin_amdgcn_permlane16_swap(phi, qhi, false, false);
     return __hiloint2double((int)rh[0], (int)rl[0]) + __hiloint2double((int)rh[1], (int)rl[1]);
 }
-__device__ __forceinline__ double bv_readlane_f64_c(double v, int srclane) {
+__device__ __forceinline__ double bv_readlane_f64(double v, int srclane) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
     return __hiloint2double(hi, lo);
@@ -148,8 +148,8 @@ __device__ __forceinline__ void bv_wave_sum2(double a, double b, double &sa, dou
     v += bv_dpp_f64<BV_DPP_ROW_SHR(4), 0xf>(v);
     v += bv_dpp_f64<BV_DPP_ROW_SHR(8), 0xf>(v);
     v += bv_dpp_f64<BV_DPP_BCAST15, 0xa>(v);
-    sa = bv_readlane_f64_c(v, 31);
-    sb = bv_readlane_f64_c(v, 63);
+    sa = bv_readlane_f64(v, 31);
+    sb = bv_readlane_f64(v, 63);
 }
 __device__ __forceinline__ void bv_wave_sum4(double a, double b, double c, double d, double &sa, double &sb, double &sc,
                                              double &sd) {
@@ -158,10 +158,10 @@ __device__ __forceinline__ void bv_wave_sum4(double a, double b, double c, doubl
     v += bv_dpp_f64<BV_DPP_ROW_SHR(2), 0xf>(v);
     v += bv_dpp_f64<BV_DPP_ROW_SHR(4), 0xf>(v);
     v += bv_dpp_f64<BV_DPP_ROW_SHR(8), 0xf>(v);
-    sa = bv_readlane_f64_c(v, 15);
-    sc = bv_readlane_f64_c(v, 31);
-    sb = bv_readlane_f64_c(v, 47);
-    sd = bv_readlane_f64_c(v, 63);
+    sa = bv_readlane_f64(v, 15);
+    sc = bv_readlane_f64(v, 31);
+    sb = bv_readlane_f64(v, 47);
+    sd = bv_readlane_f64(v, 63);
 }
 // Eight u32 wave totals with one scan: 32-lane fold, 16-lane fold, 8-lane fold, then a 3-step scan
 // inside groups of 8 lanes (26 VALU instead of 8 x 13).
@@ -343,11 +343,6 @@ __device__ __forceinline__ double bv_lnfact_series(int n) {
 __device__ __forceinline__ double bv_lnfact(const BvLnTab &T, int n) {
     if (n < T.n) return T.t[n];
     return bv_lnfact_series(n);
-}
-__device__ __forceinline__ double bv_readlane_f64(double v, int srclane) {
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), srclane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), srclane);
-    return __hiloint2double(hi, lo);
 }
 
 // One 2x2 table family: margins fixed, n11 = i varies over [imin, imax].

@@ -6,8 +6,10 @@
 //   tally waves  stream one site (one slab row) after another, the row's 4 KiB blocks dealt
 //                round-robin to the NTALLY waves: 16-byte coalesced, non-temporal loads of the
 //                two byte planes along the sample axis (2 B/cell, each byte read exactly once),
-//                software-pipelined (16 KiB in flight per wave), covered cells tallied with LDS
-//                atomics into a (strand, base, phred) histogram -- 8 KiB, one of a small ring.
+//                software-pipelined (two sets of 4 KiB per plane, 16 KiB in flight per wave), covered
+//                cells tallied with LDS atomics into a (strand, base, phred) histogram -- 8 KiB, one
+//                of a small ring.  Sets that lie wholly inside the row take an unguarded fast path;
+//                each 16-byte chunk is hand-scheduled (bv_tally_chunk).
 //   solver wave  takes a finished histogram and runs the whole reference solver on it
 //                (cites below), writes the site's 208-byte record, re-zeroes the histogram
 //                and hands it back.
