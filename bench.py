@@ -6,8 +6,9 @@
 Workload (BASELINE.json configs[2], the configuration the metric and the north-star target
 are quoted on): synthetic NIPT-scale pileup, 100,000 samples per site, generated on the
 device.  The 1 M-site job does not fit HBM at once (5 B/cell = 500 GB),
-so it is processed in HBM-resident batches (default 32,768 sites = 16.4 GB of planes; the 1 M
-sites are 31 such steps): ONE STEP = one pass of the whole hot path
+so it is processed in HBM-resident batches (default 131,072 sites = 65.6 GB of planes; the 1 M
+sites are 8 such steps; two distinct batches are resident, 131 GB of the 288 GB; a launch carries ~0.09 ms
+of fill/drain, which is why big batches are the default): ONE STEP = one pass of the whole hot path
 (pass 1: tally + EM/LRT/AF/QUAL/strand bias/BaseQRankSum for every site; pass 2: MQ and
 ReadPos rank sums for the variant sites) over one batch of --batch-sites sites, followed
 (N > 1) by the gather of the batch's result records to rank 0 (RCCL over xGMI).
@@ -39,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=100000, help="samples per site (row length)")
-    ap.add_argument("--batch-sites", type=int, default=32768, help="sites per step and per GPU")
+    ap.add_argument("--batch-sites", type=int, default=131072, help="sites per step and per GPU")
     ap.add_argument("--coverage", type=float, default=0.08)
     ap.add_argument("--distinct-batches", type=int, default=2)
     ap.add_argument("--no-rank-planes", action="store_true", help="omit mapq/rpr planes (pass 2 skipped)")

@@ -18,7 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def find(tag, kind, pattern):
-    return glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, kind), "**", pattern), recursive=True)
+    """newest matching file only: gpurun merges every call's output into the same local directory"""
+    hits = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, kind), "**", pattern), recursive=True)
+    return sorted(hits, key=os.path.getmtime)[-1:]
 
 
 def main():
