@@ -264,7 +264,7 @@ def test_bv_call_end_to_end(tmp_path, restatement):
 
 
 @pytest.mark.gpu
-def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path):
+def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement):
     """BASELINE configs[0] plumbing: the reference's own test command (tests/data/work.log.sh:1 -- 2 x range.bam,
     ce.fa.gz, CHROMOSOME_I:900-1200, --mapq=10 --min-af=0.05) through bv_pileup -> bv_call (GPU engine).
     The real `basevar basetype` binary printed 5 VCF records and 207 CVG rows for it."""
@@ -284,3 +284,18 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path):
     for l in vrec:
         f = l.split("\t")
         assert f[0] == "CHROMOSOME_I" and 900 <= int(f[1]) <= 1200 and len(f) == 11
+    # every line against the line derived from the oracle's record of that position
+    sites = []
+    for l in gzip.open(bf, "rt").read().splitlines()[3:]:
+        c = l.split("\t")
+        sites.append({"chrom": c[0], "pos": int(c[1]), "ref": c[2], "mapqs": [int(x) for x in c[4].split(" ")], "bases": c[5].split(" "),
+                      "quals": c[6].split(" "), "ranks": [int(x) for x in c[7].split(" ")], "strands": c[8].split(" ")})
+    kept = [s_ for s_ in sites if any(t != "N" for t in s_["bases"])]
+    pad = 16  # row pitch of the planes
+    slab = sites_to_slab(kept, pad)
+    slab["n_samples"] = 2
+    exp, _, _ = restatement.run_with_margins(slab, restatement.min_af(2, 0.05))
+    exp_cvg = [x for x in (expected_cvg(s_, r) for s_, r in zip(kept, exp)) if x]
+    exp_vcf = [x for x in (expected_vcf(s_, r, None, []) for s_, r in zip(kept, exp)) if x]
+    assert crow == exp_cvg
+    assert vrec == exp_vcf
