@@ -39,7 +39,7 @@ struct BvP2Ctx {
     uint32_t maxr;     // per-lane running max of classified ranks
 };
 
-template <bool RANKS, bool MAPQ, bool GROUPS>
+template <bool RANKS, bool MAPQ, bool GROUPS, int RW = BV_RPR_WIN>
 __device__ __forceinline__ void bv_p2_dword(BvP2Ctx &cx, uint32_t w, uint32_t mq, uint32_t r01, uint32_t r23,
                                             uint32_t qq, uint32_t gg) {
 #pragma unroll
@@ -54,7 +54,7 @@ __device__ __forceinline__ void bv_p2_dword(BvP2Ctx &cx, uint32_t w, uint32_t mq
                     uint32_t r = ((j < 2 ? r01 : r23) >> (16 * (j & 1))) & 0xFFFFu;
                     cx.maxr = max(cx.maxr, r);
                     uint32_t rr = r - cx.win_lo;
-                    if (rr < (uint32_t)BV_RPR_WIN) atomicAdd(&cx.hr[cls * BV_RPR_WIN + rr], 1u);
+                    if (rr < (uint32_t)RW) atomicAdd(&cx.hr[cls * RW + rr], 1u);
                 }
             }
             if (GROUPS) {
@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t bv_p2_mask_tail(uint32_t w, int keep) {
 
 // one sweep over the row; the first sweep (MAPQ/GROUPS as configured) fills everything,
 // later sweeps (rank window > 0) only re-tally read-position ranks
-template <int NT, bool RANKS, bool MAPQ, bool GROUPS>
+template <int NT, bool RANKS, bool MAPQ, bool GROUPS, int RW = BV_RPR_WIN>
 __device__ __forceinline__ void bv_p2_sweep(BvP2Ctx &cx, const BvPass2Args &a, uint32_t site, int tid) {
     const size_t row = (size_t)site * a.pitch;
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
@@ -116,10 +116,10 @@ __device__ __forceinline__ void bv_p2_sweep(BvP2Ctx &cx, const BvPass2Args &a, u
                 vb[u].z = bv_p2_mask_tail(vb[u].z, tail - 8);
                 vb[u].w = bv_p2_mask_tail(vb[u].w, tail - 12);
             }
-            bv_p2_dword<RANKS, MAPQ, GROUPS>(cx, vb[u].x, vm[u].x, vr0[u].x, vr0[u].y, vq[u].x, vg[u].x);
-            bv_p2_dword<RANKS, MAPQ, GROUPS>(cx, vb[u].y, vm[u].y, vr0[u].z, vr0[u].w, vq[u].y, vg[u].y);
-            bv_p2_dword<RANKS, MAPQ, GROUPS>(cx, vb[u].z, vm[u].z, vr1[u].x, vr1[u].y, vq[u].z, vg[u].z);
-            bv_p2_dword<RANKS, MAPQ, GROUPS>(cx, vb[u].w, vm[u].w, vr1[u].z, vr1[u].w, vq[u].w, vg[u].w);
+            bv_p2_dword<RANKS, MAPQ, GROUPS, RW>(cx, vb[u].x, vm[u].x, vr0[u].x, vr0[u].y, vq[u].x, vg[u].x);
+            bv_p2_dword<RANKS, MAPQ, GROUPS, RW>(cx, vb[u].y, vm[u].y, vr0[u].z, vr0[u].w, vq[u].y, vg[u].y);
+            bv_p2_dword<RANKS, MAPQ, GROUPS, RW>(cx, vb[u].z, vm[u].z, vr1[u].x, vr1[u].y, vq[u].z, vg[u].z);
+            bv_p2_dword<RANKS, MAPQ, GROUPS, RW>(cx, vb[u].w, vm[u].w, vr1[u].z, vr1[u].w, vq[u].w, vg[u].w);
         }
     }
 }
@@ -277,6 +277,87 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     }
 }
 
+// ------------------------------------------------------------------------------ short rows, no pop-groups
+// One workgroup launch per variant site costs more than the site itself when a row is a few tens of KB
+// (10 k samples: 40 KB).  Here the grid is persistent: four independent waves per workgroup, each with its
+// own 4 KiB of histograms (mapq 2 x 256, read-position ranks 2 x 256 per sweep), walk the variant list
+// with a fixed stride.  Same arithmetic as bv_pass2_kernel<64, true, false>.
+#define BV_P2S_WAVES 4
+#define BV_P2S_RW 256
+struct __attribute__((aligned(16))) BvPass2ShortShared {
+    uint32_t h[BV_P2S_WAVES][2 * 256 + 2 * BV_P2S_RW];  // per wave: hm[2][256] then hr[2][BV_P2S_RW]
+};
+__global__ __launch_bounds__(BV_WAVE *BV_P2S_WAVES, 4) void bv_pass2_short_kernel(BvPass2Args a) {
+    __shared__ BvPass2ShortShared sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *hm = sh.h[wave], *hr = sh.h[wave] + 2 * 256;
+    const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
+    const uint32_t stride = gridDim.x * BV_P2S_WAVES;
+    for (uint32_t v = blockIdx.x * BV_P2S_WAVES + wave; v < n_var; v += stride) {
+        const uint32_t site = a.var_list[v];
+        const bv_site_result *res = &a.out[site];
+        int ref = a.ref_base[site];
+        if (ref > 4) ref = 4;
+        const int n_alt = res->n_alt;
+        uint32_t depth[4] = {res->depth[0], res->depth[1], res->depth[2], res->depth[3]};
+        uint32_t lut = 0xAAu;  // every base "neither"
+        unsigned long long n1 = 0, n2 = 0;
+        if (ref < 4) { lut &= ~(3u << (2 * ref)); n1 = bv_sel4u(depth, ref); }
+#pragma unroll
+        for (int k = 0; k < BV_MAX_ALT; ++k) {
+            if (k < n_alt) {
+                const int b = res->alt[k] & 3;
+                lut = (lut & ~(3u << (2 * b))) | (1u << (2 * b));
+                n2 += bv_sel4u(depth, b);
+            }
+        }
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(hm);
+#pragma unroll
+            for (int i = 0; i < (2 * 256 + 2 * BV_P2S_RW) / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+        }
+        bv_lrt_sync<0>();
+        BvP2Ctx cx;
+        cx.hm = hm; cx.hr = hr; cx.hg = nullptr;
+        cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
+        bv_p2_sweep<BV_WAVE, true, true, false, BV_P2S_RW>(cx, a, site, lane);
+        const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
+        bv_lrt_sync<0>();
+        {   // MQRankSum
+            unsigned long long below = 0, twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hm[w * 64 + lane], hm[256 + w * 64 + lane], n1 + n2, below, lane);
+            const double ph = bv_ranksum_phred(twoR, n1, n2);
+            if (lane == 0) a.out[site].mq_ranksum = ph;
+        }
+        {   // ReadPosRankSum; extra sweeps of the rank plane for ranks >= BV_P2S_RW
+            unsigned long long below = 0, twoR = 0;
+            for (uint32_t win_lo = 0;; win_lo += BV_P2S_RW) {
+                const int nblk = (maxr < win_lo + BV_P2S_RW) ? (int)((maxr - win_lo) >> 6) + 1 : BV_P2S_RW / 64;
+                for (int w = 0; w < nblk; ++w)
+                    twoR += bv_ranksum_window(hr[w * 64 + lane], hr[BV_P2S_RW + w * 64 + lane], n1 + n2, below, lane);
+                if (maxr < win_lo + BV_P2S_RW) break;
+                bv_lrt_sync<0>();
+                {
+                    uint4 *z = reinterpret_cast<uint4 *>(hr);
+#pragma unroll
+                    for (int i = 0; i < 2 * BV_P2S_RW / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+                }
+                bv_lrt_sync<0>();
+                cx.win_lo = win_lo + BV_P2S_RW;
+                bv_p2_sweep<BV_WAVE, true, false, false, BV_P2S_RW>(cx, a, site, lane);
+                bv_lrt_sync<0>();
+            }
+            const double ph = bv_ranksum_phred(twoR, n1, n2);
+            if (lane == 0) {
+                a.out[site].rpr_ranksum = ph;
+                atomicOr(&a.out[site].status, BV_SITE_RANKSUM);
+            }
+        }
+        bv_lrt_sync<0>();
+    }
+}
+
 size_t bv_pass2_lds_bytes(uint32_t n_groups) { return (size_t)n_groups * 512u * sizeof(uint32_t); }
 
 template <int NT>
@@ -295,6 +376,15 @@ static void bv_launch_pass2_nt(const BvPass2Args &a, hipStream_t stream) {
 }
 
 void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream) {
+    const bool ranks = a.mapq != nullptr && a.rpr != nullptr;
+    const bool groups = a.n_groups > 0 && a.group_id != nullptr && a.gout != nullptr;
+    if (a.n_samples <= 16384u && ranks && !groups) {
+        uint32_t grid = 256u * 4u;  // 16 KiB of LDS and <= 128 VGPRs: 4 workgroups per CU
+        const uint32_t need = (a.n_sites + BV_P2S_WAVES - 1) / BV_P2S_WAVES;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL(bv_pass2_short_kernel, dim3(grid), dim3(BV_WAVE * BV_P2S_WAVES), 0, stream, a);
+        return;
+    }
     if (a.n_samples <= 16384u) bv_launch_pass2_nt<64>(a, stream);
     else bv_launch_pass2_nt<256>(a, stream);
 }

@@ -70,6 +70,8 @@ private:
             uint8_t h[18];
             const size_t r = std::fread(h, 1, sizeof h, f_);
             if (r == 0) return false;
+            if (r >= 4 && std::memcmp(h, "CRAM", 4) == 0)
+                throw std::runtime_error("[ERROR] " + path_ + " is a CRAM file: only BAM is read here (samtools view -b converts)");
             if (r != sizeof h || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
                 throw std::runtime_error("[ERROR] not a BGZF file: " + path_);
             const unsigned xlen = h[10] | (h[11] << 8);

@@ -155,3 +155,18 @@ def test_reference_100_bam_set_reproduces_the_real_binarys_record_count(tool, tm
         if region.startswith("chr11"):  # full text against the independent derivation on the short region
             assert text == bam_py.batchfile_text(bams, fa, "chr11", 5246595, 5248428, 10)
     assert (covered, with_call) == (71985, 71984)
+
+
+def test_cram_and_garbage_inputs_fail_with_a_message(tool, tmp_path):
+    fa = os.path.join(DATA, "ce.fa.gz")
+    cram = str(tmp_path / "x.cram")
+    open(cram, "wb").write(b"CRAM\x03\x00" + b"\0" * 64)
+    p = subprocess.run([tool, "-R", fa, "--regions", "CHROMOSOME_I:1-10", "-I", cram, "-o", str(tmp_path / "o.bf")], capture_output=True, text=True)
+    assert p.returncode != 0 and "CRAM" in p.stderr
+    junk = str(tmp_path / "junk.bam")
+    open(junk, "wb").write(b"hello world, not a bam file at all")
+    p = subprocess.run([tool, "-R", fa, "--regions", "CHROMOSOME_I:1-10", "-I", junk, "-o", str(tmp_path / "o.bf")], capture_output=True, text=True)
+    assert p.returncode != 0 and "BGZF" in p.stderr
+    p = subprocess.run([tool, "-R", fa, "--regions", "NOPE:1-10", "-I", os.path.join(DATA, "range.bam"), "-o", str(tmp_path / "o.bf")],
+                       capture_output=True, text=True)
+    assert p.returncode != 0 and "not found" in p.stderr
