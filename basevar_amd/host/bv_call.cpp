@@ -8,9 +8,11 @@
 //   bv_call --batchfiles a.bf.gz,b.bf.gz --output-vcf out.vcf --output-cvg out.cvg
 //           [--pop-group FILE] [--min-af 0.01] [--batch-sites 4096] [--device 0]
 //           [--reference ref.fa --contig NAME:LENGTH ...]
+//   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END [--mapq 10] ...   (same outputs)
 //
-// Batchfiles may be bgzip/gzip-compressed or plain (zlib reads all three).  Pileup / batchfile
-// creation from BAM (f2) is not part of this tool: it consumes the reference's own batchfiles.
+// Batchfiles may be bgzip/gzip-compressed or plain (zlib reads all three).  With BAM inputs the pileup
+// (pileup.hpp) feeds the engine directly: the same cells the batchfile rows would carry,
+// without the text round trip.
 #include <zlib.h>
 
 #include <cstdio>
@@ -22,6 +24,7 @@
 #include <vector>
 
 #include "basetype_gpu.hpp"
+#include "pileup.hpp"
 #include "vcf_emit.hpp"
 
 namespace {
@@ -57,8 +60,9 @@ struct GzReader {
 }  // namespace
 
 int main(int argc, char **argv) {
-    std::vector<std::string> batchfiles;
-    std::string out_vcf, out_cvg, pop_group_file, reference = ".";
+    std::vector<std::string> batchfiles, bams;
+    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list;
+    int mapq_thd = 10;
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
     uint32_t batch_sites = 4096;
@@ -73,22 +77,41 @@ int main(int argc, char **argv) {
         else if (a == "--min-af") user_min_af = std::stof(next());
         else if (a == "--batch-sites") batch_sites = (uint32_t)std::stoul(next());
         else if (a == "--device") device = std::stoi(next());
-        else if (a == "--reference") reference = next();
+        else if (a == "--reference" || a == "-R") reference = next();
+        else if (a == "-I" || a == "--input") bams.push_back(next());
+        else if (a == "-L" || a == "--align-file-list") bam_list = next();
+        else if (a == "-r" || a == "--regions") regions = next();
+        else if (a == "-q" || a == "--mapq") mapq_thd = std::stoi(next());
         else if (a == "--contig") {
             std::vector<std::string> p; bvamd::split(next(), p, ":");
             if (p.size() != 2) die("--contig wants NAME:LENGTH");
             contigs.push_back({p[0], (uint32_t)std::stoul(p[1])});
         } else die("unknown argument " + a);
     }
-    if (batchfiles.empty() || out_vcf.empty() || out_cvg.empty())
-        die("usage: bv_call --batchfiles a,b,... --output-vcf FILE --output-cvg FILE [--pop-group FILE] [--min-af F]");
+    if (!bam_list.empty()) {
+        std::ifstream f(bam_list);
+        if (!f) die("[ERROR] cannot open " + bam_list);
+        std::string line;
+        while (std::getline(f, line)) {
+            if (line.empty() || line[0] == '#') continue;
+            const size_t e = line.find_first_of(" \t");
+            bams.push_back(e == std::string::npos ? line : line.substr(0, e));
+        }
+    }
+    const bool from_bam = !bams.empty();
+    if ((batchfiles.empty() && !from_bam) || out_vcf.empty() || out_cvg.empty() || (from_bam && (regions.empty() || reference == ".")))
+        die("usage: bv_call (--batchfiles a,b,... | -I a.bam [-I ...] -R ref.fa --regions CHR:BEG-END [--mapq Q]) --output-vcf FILE "
+            "--output-cvg FILE [--pop-group FILE] [--min-af F]");
 
     // ---- headers: sample ids in batchfile order (caller.cpp:637-665)
     std::vector<GzReader> readers(batchfiles.size());
     std::vector<std::string> sample_ids;
     std::vector<std::string> first_row(batchfiles.size());
     std::vector<bool> have_row(batchfiles.size(), false);
-    for (size_t b = 0; b < batchfiles.size(); ++b) {
+    try {
+        for (const auto &b : bams) sample_ids.push_back(bvamd::BamFile(b, false).sample_name());
+    } catch (const std::exception &ex) { die(ex.what()); }
+    for (size_t b = 0; b < batchfiles.size() && !from_bam; ++b) {
         if (!readers[b].open(batchfiles[b])) die("[ERROR] " + batchfiles[b] + " open failure.");
         std::string line;
         while (readers[b].getline(line)) {
@@ -98,6 +121,7 @@ int main(int argc, char **argv) {
     }
     const size_t n_sample = sample_ids.size();
     if (n_sample == 0) die("[ERROR] no ##SampleIDs= header found in the batchfiles");
+    if (from_bam) batchfiles.clear();
 
     // ---- pop groups (caller.cpp:372-410): sample -> group, later rows override; groups iterate by name
     std::map<std::string, std::vector<size_t>> groups_idx;
@@ -163,9 +187,34 @@ int main(int argc, char **argv) {
         slab.clear();
     };
 
+    if (from_bam) {
+        // ---- pileup -> BatchInfo -> slab, in the reference's 500 kb steps (caller.cpp:826-846)
+        try {
+            const size_t colon = regions.rfind(':'), dash = regions.rfind('-');
+            if (colon == std::string::npos || dash == std::string::npos || dash < colon) die("--regions wants CHR:BEG-END");
+            const std::string ref_id = regions.substr(0, colon);
+            const uint32_t beg = (uint32_t)std::stoul(regions.substr(colon + 1, dash - colon - 1));
+            const uint32_t end = (uint32_t)std::stoul(regions.substr(dash + 1));
+            const std::string fa_seq = bvamd::load_fasta_sequence(reference, ref_id);
+            if (beg < 1 || end < beg || end > fa_seq.size()) die("[ERROR] region outside " + ref_id);
+            for (uint32_t sb = beg; sb < end + 1; sb += 500000u) {
+                const uint32_t se = sb + 500000u - 1 > end ? end : sb + 500000u - 1;
+                bvamd::PosMapVector v;
+                bvamd::fetch_base_in_region(bams, fa_seq, mapq_thd, std::make_tuple(ref_id, sb, se), v);
+                for (uint32_t pos = sb; pos <= se; ++pos) {
+                    bvamd::BatchInfo bi;
+                    if (!bvamd::batchinfo_at(v, fa_seq, ref_id, pos, bi)) continue;
+                    slab.add_site(bi);
+                    pending.push_back(std::move(bi));
+                    if (pending.size() == batch_sites) flush();
+                }
+            }
+        } catch (const std::exception &ex) { die(ex.what()); }
+    }
+
     // ---- one row from every batchfile per position (caller.cpp:586-611)
     std::vector<std::string> rows(batchfiles.size());
-    for (;;) {
+    for (; !from_bam;) {
         bool eof = false;
         for (size_t b = 0; b < batchfiles.size(); ++b) {
             if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }

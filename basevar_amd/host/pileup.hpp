@@ -229,6 +229,41 @@ inline void write_records(const PosMapVector &v, const std::string &fa_seq, cons
     }
 }
 
+// The same cells as one row of write_records(), but as the BatchInfo that _basevar_caller would parse back from
+// that row (src/basetype_caller.cpp:688-736) -- for hosts that go from the pileup straight to the engine without
+// the batchfile text.  False when no sample covers the position (the reference skips such rows, :718).
+inline bool batchinfo_at(const PosMapVector &v, const std::string &fa_seq, const std::string &ref_id, uint32_t pos, BatchInfo &bi) {
+    const size_t sn = v.size();
+    bi = BatchInfo();
+    bi.n = sn;
+    bi.ref_id = ref_id;
+    bi.ref_pos = pos;
+    bi.ref_base = std::string(1, fa_seq[pos - 1]);
+    bi.align_bases.reserve(sn); bi.align_base_quals.reserve(sn); bi.mapqs.reserve(sn);
+    bi.map_strands.reserve(sn); bi.base_pos_ranks.reserve(sn);
+    for (size_t i = 0; i < sn; ++i) {
+        auto it = v[i].find(pos);
+        if (it != v[i].end()) {
+            const AlignBaseInfo &a = it->second;
+            ++bi.depth;
+            bi.mapqs.push_back(a.mapq);
+            if (a.ref_base.size() == a.read_base.size()) bi.align_bases.push_back(a.read_base);
+            else if (a.ref_base.size() < a.read_base.size()) bi.align_bases.push_back("+" + a.read_base);
+            else bi.align_bases.push_back("-" + a.ref_base);
+            bi.align_base_quals.push_back(a.read_base_qual);
+            bi.base_pos_ranks.push_back(a.rpr);
+            bi.map_strands.push_back(a.map_strand);
+        } else {
+            bi.mapqs.push_back(0);
+            bi.align_bases.push_back("N");
+            bi.align_base_quals.push_back('!');
+            bi.base_pos_ranks.push_back(0);
+            bi.map_strands.push_back('.');
+        }
+    }
+    return bi.depth > 0;
+}
+
 // __create_a_batchfile, src/basetype_caller.cpp:800-874: header + rows of the whole region, walked in
 // 500 kb sub-regions; `sink(text)` receives the text piecewise.  Returns has_data.
 template <typename Sink>

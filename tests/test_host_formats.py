@@ -299,3 +299,10 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
     exp_vcf = [x for x in (expected_vcf(s_, r, None, []) for s_, r in zip(kept, exp)) if x]
     assert crow == exp_cvg
     assert vrec == exp_vcf
+    # BAM inputs handed to bv_call directly (pileup -> engine without the batchfile text): same records
+    vcf2, cvg2 = str(tmp_path / "vz2.vcf"), str(tmp_path / "t2.cvg")
+    subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions", "CHROMOSOME_I:900-1200",
+                           "--mapq", "10", "--output-vcf", vcf2, "--output-cvg", cvg2, "--min-af", "0.05", "--batch-sites", "64"])
+    assert [l for l in open(vcf2).read().split("\n") if l and not l.startswith("##")] == \
+        [l for l in open(vcf).read().split("\n") if l and not l.startswith("##")]
+    assert open(cvg2).read() == open(cvg).read()
