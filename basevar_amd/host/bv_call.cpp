@@ -62,7 +62,7 @@ struct GzReader {
 int main(int argc, char **argv) {
     std::vector<std::string> batchfiles, bams;
     std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list;
-    int mapq_thd = 10;
+    int mapq_thd = 10, threads = 1;
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
     uint32_t batch_sites = 4096;
@@ -82,6 +82,7 @@ int main(int argc, char **argv) {
         else if (a == "-L" || a == "--align-file-list") bam_list = next();
         else if (a == "-r" || a == "--regions") regions = next();
         else if (a == "-q" || a == "--mapq") mapq_thd = std::stoi(next());
+        else if (a == "-t" || a == "--thread") threads = std::stoi(next());
         else if (a == "--contig") {
             std::vector<std::string> p; bvamd::split(next(), p, ":");
             if (p.size() != 2) die("--contig wants NAME:LENGTH");
@@ -200,7 +201,7 @@ int main(int argc, char **argv) {
             for (uint32_t sb = beg; sb < end + 1; sb += 500000u) {
                 const uint32_t se = sb + 500000u - 1 > end ? end : sb + 500000u - 1;
                 bvamd::PosMapVector v;
-                bvamd::fetch_base_in_region(bams, fa_seq, mapq_thd, std::make_tuple(ref_id, sb, se), v);
+                bvamd::fetch_base_in_region(bams, fa_seq, mapq_thd, std::make_tuple(ref_id, sb, se), v, true, threads);
                 for (uint32_t pos = sb; pos <= se; ++pos) {
                     bvamd::BatchInfo bi;
                     if (!bvamd::batchinfo_at(v, fa_seq, ref_id, pos, bi)) continue;

@@ -19,8 +19,13 @@
 
 #include <zlib.h>
 
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -159,35 +164,59 @@ inline void seek_position(const std::vector<BamAlignment> &reads, const std::str
     }
 }
 
-// __fetch_base_in_region, src/basetype_caller.cpp:876-939.  Returns is_empty.
-inline bool fetch_base_in_region(const std::vector<std::string> &batch_align_files, const std::string &fa_seq, int mapq_thd,
-                                 const GenomeRegionTuple &region, PosMapVector &out, bool use_index = true) {
+// __fetch_base_in_region, src/basetype_caller.cpp:876-939.  Returns is_empty.  The samples are independent
+// (one BAM, one PosMap each), so `n_threads` > 1 deals them to worker threads; the result does not depend on it.
+inline void pileup_one_sample(const std::string &path, const std::string &fa_seq, int mapq_thd, const GenomeRegionTuple &region,
+                              bool use_index, PosMap &sample_posinfo_map) {
     static const uint32_t REG_EXPEND_SIZE = 200;
     const std::string &ref_id = std::get<0>(region);
     const uint32_t reg_start = std::get<1>(region), reg_end = std::get<2>(region);
     const uint32_t exp_reg_start = reg_start > REG_EXPEND_SIZE ? reg_start - REG_EXPEND_SIZE : 1;
     const uint32_t exp_reg_end = reg_end + REG_EXPEND_SIZE;
-    bool is_empty = true;
-    for (const auto &path : batch_align_files) {
-        BamFile bf(path, use_index);
-        PosMap sample_posinfo_map;
-        // "chr:beg-end", 1-based inclusive == [beg - 1, end) 0-based
-        if (bf.fetch(bf.tid_of(ref_id), (int64_t)exp_reg_start - 1, (int64_t)exp_reg_end)) {
-            std::vector<BamAlignment> sample_target_reads;
-            BamAlignment al;
-            while (bf.next(al) >= 0) {
-                if (al.mapq() < mapq_thd || al.is_duplicate() || al.is_qc_fail()) continue;
-                const int64_t map_ref_start = al.map_ref_start_pos() + 1;  // 1-based
-                const int64_t map_ref_end = al.map_ref_end_pos();          // 1-based
-                if ((int64_t)reg_start > map_ref_end) continue;
-                if ((int64_t)reg_end < map_ref_start) break;
-                sample_target_reads.push_back(al);
-            }
-            if (!sample_target_reads.empty()) seek_position(sample_target_reads, fa_seq, region, sample_posinfo_map);
+    BamFile bf(path, use_index);
+    // "chr:beg-end", 1-based inclusive == [beg - 1, end) 0-based
+    if (bf.fetch(bf.tid_of(ref_id), (int64_t)exp_reg_start - 1, (int64_t)exp_reg_end)) {
+        std::vector<BamAlignment> sample_target_reads;
+        BamAlignment al;
+        while (bf.next(al) >= 0) {
+            if (al.mapq() < mapq_thd || al.is_duplicate() || al.is_qc_fail()) continue;
+            const int64_t map_ref_start = al.map_ref_start_pos() + 1;  // 1-based
+            const int64_t map_ref_end = al.map_ref_end_pos();          // 1-based
+            if ((int64_t)reg_start > map_ref_end) continue;
+            if ((int64_t)reg_end < map_ref_start) break;
+            sample_target_reads.push_back(al);
         }
-        if (is_empty && !sample_posinfo_map.empty()) is_empty = false;
-        out.push_back(sample_posinfo_map);
+        if (!sample_target_reads.empty()) seek_position(sample_target_reads, fa_seq, region, sample_posinfo_map);
     }
+}
+inline bool fetch_base_in_region(const std::vector<std::string> &batch_align_files, const std::string &fa_seq, int mapq_thd,
+                                 const GenomeRegionTuple &region, PosMapVector &out, bool use_index = true, int n_threads = 1) {
+    const size_t base = out.size(), n = batch_align_files.size();
+    out.resize(base + n);
+    if (n_threads <= 1 || n < 2) {
+        for (size_t i = 0; i < n; ++i) pileup_one_sample(batch_align_files[i], fa_seq, mapq_thd, region, use_index, out[base + i]);
+    } else {
+        std::atomic<size_t> next(0);
+        std::mutex mu;
+        std::string err;
+        auto work = [&]() {
+            for (size_t i; (i = next.fetch_add(1)) < n;) {
+                try {
+                    pileup_one_sample(batch_align_files[i], fa_seq, mapq_thd, region, use_index, out[base + i]);
+                } catch (const std::exception &ex) {
+                    std::lock_guard<std::mutex> g(mu);
+                    if (err.empty()) err = ex.what();
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
+        for (auto &t : pool) t.join();
+        if (!err.empty()) throw std::runtime_error(err);
+    }
+    bool is_empty = true;
+    for (size_t i = 0; i < n; ++i)
+        if (!out[base + i].empty()) is_empty = false;
     return is_empty;
 }
 
@@ -196,36 +225,37 @@ inline void write_records(const PosMapVector &v, const std::string &fa_seq, cons
     const std::string &ref_id = std::get<0>(region);
     const uint32_t reg_start = std::get<1>(region), reg_end = std::get<2>(region);
     const size_t sn = v.size();
-    std::vector<int> mapq, ranks;
-    std::vector<std::string> bases;
-    std::vector<char> quals, strands;
+    // the five per-sample columns are built as text directly (same characters as ngslib::join over the vectors
+    // of :1040-1045, without an ostringstream per item)
+    std::string mapq, bases, quals, ranks, strands;
     for (uint32_t pos = reg_start; pos < reg_end + 1; ++pos) {
         uint32_t depth = 0;
         mapq.clear(); ranks.clear(); bases.clear(); quals.clear(); strands.clear();
         for (size_t i = 0; i < sn; ++i) {
+            if (i) { mapq += ' '; bases += ' '; quals += ' '; ranks += ' '; strands += ' '; }
             auto it = v[i].find(pos);
             if (it != v[i].end()) {
                 ++depth;
                 const AlignBaseInfo &a = it->second;
                 if (a.ref_id != ref_id || a.ref_pos != pos) throw std::runtime_error("[ERROR] reference id or position not match.");
-                mapq.push_back(a.mapq);
-                if (a.ref_base.size() == a.read_base.size()) bases.push_back(a.read_base);
-                else if (a.ref_base.size() < a.read_base.size()) bases.push_back("+" + a.read_base);
-                else bases.push_back("-" + a.ref_base);
-                quals.push_back(a.read_base_qual);
-                ranks.push_back(a.rpr);
-                strands.push_back(a.map_strand);
+                mapq += std::to_string(a.mapq);
+                if (a.ref_base.size() == a.read_base.size()) bases += a.read_base;
+                else if (a.ref_base.size() < a.read_base.size()) { bases += '+'; bases += a.read_base; }
+                else { bases += '-'; bases += a.ref_base; }
+                quals += a.read_base_qual;
+                ranks += std::to_string(a.rpr);
+                strands += a.map_strand;
             } else {
-                mapq.push_back(0);
-                bases.push_back("N");
-                quals.push_back('!');
-                ranks.push_back(0);
-                strands.push_back('.');
+                mapq += '0';
+                bases += 'N';
+                quals += '!';
+                ranks += '0';
+                strands += '.';
             }
         }
-        out += ref_id + "\t" + std::to_string(pos) + "\t" + fa_seq[pos - 1] + "\t" + std::to_string(depth) + "\t" +
-               join(mapq, " ") + "\t" + join(bases, " ") + "\t" + join(quals, " ") + "\t" + join(ranks, " ") + "\t" +
-               join(strands, " ") + "\n";
+        out += ref_id; out += '\t'; out += std::to_string(pos); out += '\t'; out += fa_seq[pos - 1]; out += '\t';
+        out += std::to_string(depth); out += '\t'; out += mapq; out += '\t'; out += bases; out += '\t'; out += quals;
+        out += '\t'; out += ranks; out += '\t'; out += strands; out += '\n';
     }
 }
 
@@ -269,7 +299,7 @@ inline bool batchinfo_at(const PosMapVector &v, const std::string &fa_seq, const
 template <typename Sink>
 inline bool create_a_batchfile(const std::vector<std::string> &batch_align_files, const std::vector<std::string> &batch_sample_ids,
                                const std::string &fa_seq, const GenomeRegionTuple &region, int mapq_thd, Sink sink,
-                               bool use_index = true) {
+                               bool use_index = true, int n_threads = 1) {
     static const uint32_t STEP_REGION_LEN = 500000;
     const std::string &ref_id = std::get<0>(region);
     const uint32_t reg_beg = std::get<1>(region), reg_end = std::get<2>(region);
@@ -281,11 +311,17 @@ inline bool create_a_batchfile(const std::vector<std::string> &batch_align_files
         PosMapVector v;
         v.reserve(batch_align_files.size());
         const GenomeRegionTuple sub = std::make_tuple(ref_id, sub_beg, sub_end);
-        const bool is_empty = fetch_base_in_region(batch_align_files, fa_seq, mapq_thd, sub, v, use_index);
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool is_empty = fetch_base_in_region(batch_align_files, fa_seq, mapq_thd, sub, v, use_index, n_threads);
         if (!is_empty) has_data = true;
+        const auto t1 = std::chrono::steady_clock::now();
         std::string rows;
         write_records(v, fa_seq, sub, rows);
         sink(rows);
+        if (std::getenv("BV_PILEUP_TIMING"))
+            std::fprintf(stderr, "[timing] %u-%u: pileup %.2f s, rows %.2f s\n", sub_beg, sub_end,
+                         std::chrono::duration<double>(t1 - t0).count(),
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     }
     return has_data;
 }
