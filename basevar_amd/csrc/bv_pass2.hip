@@ -45,7 +45,7 @@ __device__ __forceinline__ void bv_p2_dword(BvP2Ctx &cx, uint32_t w, uint32_t mq
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint32_t c = (w >> (8 * j)) & 0xFFu;
-        if (!(c & BV_CELL_NOCALL)) {
+        if (c < 8u) {  // a call byte is 0..7; N / indel tokens (8..10) and anything else count as "no call", as in pass 1
             uint32_t b = c & 3u;
             if (RANKS) {
                 uint32_t cls = (cx.lut >> (2 * b)) & 3u;

@@ -451,3 +451,20 @@ def test_fisher_beyond_the_log_factorial_table(bv, restatement):
     finally:
         eng.close()
     check(got, exp, gexp, margins)
+
+
+def test_garbage_bytes_are_no_calls_everywhere(bv, restatement):
+    """Call bytes outside 0..10 are not produced by any packer; the engine must treat them as 'no call' in both passes
+    instead of half-counting them: the records equal those of the same slab with the garbage replaced by 'N'."""
+    slab = make_slab(64, 3000, seed=77, coverage=0.3, n_groups=2)
+    rng = np.random.default_rng(3)
+    dirty = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in slab.items()}
+    m = rng.random(slab["base_strand"].shape) < 0.05
+    dirty["base_strand"][m] = rng.integers(11, 256, int(m.sum())).astype(np.uint8)
+    clean = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in slab.items()}
+    clean["base_strand"][m] = 8
+    maf = restatement.min_af(3000)
+    a = run_engine(bv, dirty, maf)
+    b = run_engine(bv, clean, maf)
+    assert a.sites.tobytes() == b.sites.tobytes()
+    assert a.groups.tobytes() == b.groups.tobytes()
