@@ -270,19 +270,27 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
     if (wave < NTALLY) {
         // ------------------------------------------------ tally waves (wave 0 leads)
         // (s_setprio(3) for this role was measured: 2 % slower, so priorities stay equal.)
-        uint32_t next = 0;
-        if (wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], 1u);
+        // Tickets are drawn `chunk` sites at a time: 1 for long rows (a reserved site is tens of microseconds of
+        // work, so reserving more would lengthen the drain), 4 for short rows (one atomic per site on a single
+        // address saturates at ~85 M/s).
+        const uint32_t chunk = a.n_samples > 16384u ? 1u : 4u;
+        uint32_t next = 0, cur = 0, end = 0;
+        if (wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
         for (uint32_t k = 0;; ++k) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             uint32_t site;
             if (wave == 0) {
-                site = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-                if (site >= a.n_sites) site = 0xFFFFFFFFu;
+                if (cur == end) {
+                    cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+                    end = cur + chunk;
+                    if (cur < a.n_sites && lane == 0)
+                        next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);  // in flight under these rows' stream
+                }
+                site = cur < a.n_sites ? cur : 0xFFFFFFFFu;
+                ++cur;
                 bv_wait_flag(&sh.drained[buf], gen, &a.counters[BV_CTR_TIMEOUT]);  // the solver has re-zeroed this slot
                 if (lane == 0) sh.site_of[buf] = site;
                 bv_set_flag(&sh.published[buf], gen + 1u);
-                if (site != 0xFFFFFFFFu && lane == 0)
-                    next = atomicAdd(&a.counters[BV_CTR_TICKET], 1u);  // in flight under this row's stream
             } else {
                 bv_wait_flag(&sh.published[buf], gen + 1u, &a.counters[BV_CTR_TIMEOUT]);
                 site = sh.site_of[buf];
@@ -429,7 +437,9 @@ template <int NTALLY, int NSOLVE>
 static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
     // never more than there are sites.
-    uint32_t grid = 256u * (16u / (NTALLY + NSOLVE));
+    constexpr uint32_t by_vgpr = 16u / (NTALLY + NSOLVE);
+    constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + 2, NSOLVE>));
+    uint32_t grid = 256u * (by_vgpr < by_lds ? by_vgpr : by_lds);
     if (grid > a.n_sites) grid = a.n_sites;
     hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
 }
@@ -442,6 +452,8 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
         case 2: return bv_launch_pass1_cfg<3, 2>(a, stream);  // measured: 15-30 % slower than <3,1>
         case 5: return bv_launch_pass1_cfg<2, 1>(a, stream);  // measured:  4 % slower than <3,1>
         // (<7,1> and <5,1>, i.e. fewer solver waves per CU, were measured too: 6 % slower than <3,1>)
+        // (solver-heavy shapes for short rows -- <1,3>, <1,2>, <2,2> at 10 k samples -- were measured as well:
+        //  24-90 % slower than the fused kernel, one tally wave cannot feed several solvers)
         case 9: return bv_launch_pass1_fused(a, stream);
         default: break;
     }
