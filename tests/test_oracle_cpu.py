@@ -110,3 +110,40 @@ def test_min_af_is_float_rounded(restatement):
     assert restatement.min_af(100000) == 0.0010000000474974513  # SURVEY trap #2
     assert restatement.min_af(100) == float(np.float32(0.01))
     assert restatement.min_af(1000000) == float(np.float32(100.0) / np.float32(1000000.0))
+
+
+def test_special_functions_against_scipy(restatement):
+    """Third, independent pin of the special functions the path takes from htslib/kfunc.c (kf_gammaq, kf_erfc,
+    kt_fisher_exact) and of the Wilcoxon z-test: the restatement (and, where the build container has it, the compiled
+    reference behind known_answers.json) against scipy's implementations of the same published functions."""
+    import json
+    from scipy import special, stats
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    for x, df, ref_val in ka["chi2_test"]:
+        if x < 0:
+            continue
+        want = special.gammaincc(df / 2.0, x / 2.0)  # chi-square survival function, algorithm.h:44-46
+        assert ref_val == pytest.approx(want, rel=1e-9, abs=1e-300)
+        assert restatement.chi2_test(x, df) == pytest.approx(want, rel=1e-9, abs=1e-300)
+    for x, ref_val in ka["norm_dist"]:
+        want = 0.5 * special.erfc(x / np.sqrt(2.0))  # algorithm.h:48-50
+        assert ref_val == pytest.approx(want, rel=1e-6, abs=1e-300)  # AS66 is a 1e-7-class approximation
+        assert restatement.norm_dist(x) == pytest.approx(want, rel=1e-6, abs=1e-300)
+    tables = [t for t, _ in ka["fisher_exact_test"]] + [[3, 1, 1, 3], [12, 0, 0, 9], [100, 200, 150, 90], [7, 5, 0, 12]]
+    refv = {tuple(t): v for t, v in ka["fisher_exact_test"]}
+    for t in tables:
+        want = stats.fisher_exact([[t[0], t[1]], [t[2], t[3]]], alternative="two-sided")[1]
+        got = restatement.fisher(*t)
+        assert got == pytest.approx(want, rel=1e-7, abs=1e-300), t
+        if tuple(t) in refv:
+            assert refv[tuple(t)] == pytest.approx(want, rel=1e-7, abs=1e-300), t
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        a = rng.integers(0, 60, int(rng.integers(3, 40))).astype(float)
+        b = rng.integers(10, 70, int(rng.integers(3, 40))).astype(float)
+        # algorithm.h:76-136: normal approximation without tie or continuity correction, two-sided
+        n1, n2 = len(a), len(b)
+        ranks = stats.rankdata(-np.concatenate([a, b]))  # descending, average ranks
+        z = (ranks[:n1].sum() - n1 * (n1 + n2 + 1) / 2.0) / np.sqrt(n1 * n2 * (n1 + n2 + 1) / 12.0)
+        want = 2 * 0.5 * special.erfc(abs(z) / np.sqrt(2.0))
+        assert restatement.wilcoxon(list(a), list(b)) == pytest.approx(want, rel=1e-6, abs=1e-300)
