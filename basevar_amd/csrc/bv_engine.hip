@@ -58,6 +58,18 @@ struct bv_engine {
     size_t tile_state_bytes = 0, tile_maxr_bytes = 0;
     uint32_t tile_sites = 0, tile_groups = 0, tile_stride = 0, tile_samples_total = 0, tile_samples_seen = 0;
     bool tile_ranks = false, tile_open = false;
+    // host tiles: two staging buffers filled by a copy stream, so the PCIe copy of tile k+1 runs under the
+    // kernels of tile k
+    hipStream_t copy_stream = nullptr;
+    void *tstage[2] = {nullptr, nullptr};
+    size_t tstage_bytes[2] = {0, 0};
+    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    bool tstage_used[2] = {false, false};
+    unsigned tile_k = 0;
+    // joined-rows realisation of the tile mode: resident planes [tile_sites][j_pitch]
+    bool tile_join = false;
+    uint8_t *j_buf = nullptr;
+    size_t j_bytes = 0, j_pitch = 0, j_o_q = 0, j_o_mq = 0, j_o_rp = 0, j_o_gid = 0;
     mutable std::mutex mu;
     std::string err;
 };
@@ -202,8 +214,60 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->stage) (void)hipFree(e->stage);
     if (e->tile_state) (void)hipFree(e->tile_state);
     if (e->tile_maxr) (void)hipFree(e->tile_maxr);
+    if (e->j_buf) (void)hipFree(e->j_buf);
+    for (int k = 0; k < 2; ++k) {
+        if (e->tstage[k]) (void)hipFree(e->tstage[k]);
+        if (e->ev_copied[k]) (void)hipEventDestroy(e->ev_copied[k]);
+        if (e->ev_free[k]) (void)hipEventDestroy(e->ev_free[k]);
+    }
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+    return BV_OK;
+}
+
+// The two passes over device-resident planes + the copies back (records to a host caller, counters).
+static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
+                         const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
+                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st) {
+    const size_t S = n_sites, G = n_groups;
+    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
+    if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
+
+    BvPass1Args a1;
+    a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
+    a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
+    a1.var_list = e->d_var_list; a1.counters = e->d_counters;
+    if (e->ring_count == bv_engine::kRing) {
+        int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
+        if (rc != BV_OK) return rc;
+    }
+    const int slot = e->ring_head;
+    e->ring_head = (e->ring_head + 1) % bv_engine::kRing;
+    e->ring_count += 1;
+    e->last_slot = slot;
+    hipEvent_t *ev = e->ring[slot];
+    BV_HIP(e, hipEventRecord(ev[0], st));
+    bv_launch_pass1(a1, st);
+    BV_HIP(e, hipGetLastError());
+    BV_HIP(e, hipEventRecord(ev[1], st));
+
+    BvPass2Args a2;
+    a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
+    a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
+    a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
+    a2.var_list = e->d_var_list; a2.counters = e->d_counters;
+    bv_launch_pass2(a2, st);
+    BV_HIP(e, hipGetLastError());
+    BV_HIP(e, hipEventRecord(ev[2], st));
+
+    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS, hipMemcpyDeviceToHost, st));
+    if (e->host_out) {
+        BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
+        if (e->host_gout && e->host_gout_bytes)
+            BV_HIP(e, hipMemcpyAsync(e->host_gout, e->stage_gout, e->host_gout_bytes, hipMemcpyDeviceToHost, st));
+    }
+    e->submitted = true;
     return BV_OK;
 }
 
@@ -276,44 +340,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         e->host_out = nullptr; e->host_gout = nullptr;
     }
 
-    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
-    if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
-
-    BvPass1Args a1;
-    a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = slab->n_sites;
-    a1.n_samples = slab->n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
-    a1.var_list = e->d_var_list; a1.counters = e->d_counters;
-    if (e->ring_count == bv_engine::kRing) {
-        int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
-        if (rc != BV_OK) return rc;
-    }
-    const int slot = e->ring_head;
-    e->ring_head = (e->ring_head + 1) % bv_engine::kRing;
-    e->ring_count += 1;
-    e->last_slot = slot;
-    hipEvent_t *ev = e->ring[slot];
-    BV_HIP(e, hipEventRecord(ev[0], st));
-    bv_launch_pass1(a1, st);
-    BV_HIP(e, hipGetLastError());
-    BV_HIP(e, hipEventRecord(ev[1], st));
-
-    BvPass2Args a2;
-    a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
-    a2.n_sites = slab->n_sites; a2.n_samples = slab->n_samples; a2.n_groups = slab->n_groups;
-    a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
-    a2.var_list = e->d_var_list; a2.counters = e->d_counters;
-    bv_launch_pass2(a2, st);
-    BV_HIP(e, hipGetLastError());
-    BV_HIP(e, hipEventRecord(ev[2], st));
-
-    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS, hipMemcpyDeviceToHost, st));
-    if (e->host_out) {
-        BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
-        if (e->host_gout && e->host_gout_bytes)
-            BV_HIP(e, hipMemcpyAsync(e->host_gout, e->stage_gout, e->host_gout_bytes, hipMemcpyDeviceToHost, st));
-    }
-    e->submitted = true;
-    return BV_OK;
+    return launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st);
 }
 
 // ---------------------------------------------------------------- sample-axis tile mode
@@ -335,6 +362,40 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
     if (n_sites > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_tiles_begin: n_sites exceeds cfg.max_sites");
     if (n_groups > BV_MAX_GROUPS) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: n_groups exceeds BV_MAX_GROUPS");
     BV_HIP(e, hipSetDevice(e->cfg.device));
+    e->tile_join = false;
+    if (!(e->cfg.flags & BV_FLAG_TILE_STATE)) {
+        // joined rows: [n_sites][pitch] planes resident in HBM, if they fit next to what is already there
+        const size_t pitch = ((size_t)n_samples_total + 255) & ~(size_t)255, plane = (size_t)n_sites * pitch;
+        const size_t o_q = plane, o_mq = 2 * plane, o_rp = o_mq + (with_ranks ? plane : 0), o_gid = o_rp + (with_ranks ? 2 * plane : 0),
+                     need = o_gid + pitch;
+        bool ok = need <= e->j_bytes;
+        if (!ok) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= (free_b + e->j_bytes) / 10 * 9) {
+                if (e->j_buf) BV_HIP(e, hipFree(e->j_buf));
+                e->j_buf = nullptr;
+                e->j_bytes = 0;
+                if (hipMalloc(&e->j_buf, need) == hipSuccess) {
+                    e->j_bytes = need;
+                    ok = true;
+                } else {
+                    (void)hipGetLastError();
+                    e->j_buf = nullptr;
+                }
+            }
+        }
+        if (ok) {
+            e->j_pitch = pitch; e->j_o_q = o_q; e->j_o_mq = o_mq; e->j_o_rp = o_rp; e->j_o_gid = o_gid;
+            BV_HIP(e, hipMemset(e->j_buf, 0x08, plane));           // every cell 'N' until its tile arrives
+            BV_HIP(e, hipMemset(e->j_buf + o_gid, 0xFF, pitch));   // no pop-group
+            e->tile_sites = n_sites; e->tile_groups = n_groups; e->tile_stride = 0;
+            e->tile_samples_total = n_samples_total; e->tile_samples_seen = 0;
+            e->tile_ranks = with_ranks != 0;
+            e->tile_join = true;
+            e->tile_open = true;
+            return BV_OK;
+        }
+    }
     const uint32_t stride = 7168u + n_groups * 512u;  // H1 2048 + Hm 1024 + Hr 4096 + Hg 512/group (bv_tiles.hip)
     const size_t bytes = (size_t)n_sites * stride * sizeof(uint32_t), mbytes = (size_t)n_sites * sizeof(uint32_t);
     if (bytes > e->tile_state_bytes) {
@@ -376,22 +437,55 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     const uint8_t *bs = t->base_strand, *q = t->qual, *mq = e->tile_ranks ? t->mapq : nullptr, *gid = e->tile_groups ? t->group_id : nullptr;
     const uint16_t *rp = e->tile_ranks ? t->rpr : nullptr;
     const size_t S = t->n_sites, P = t->pitch;
+    int slot = -1;
     if (t->mem_kind == BV_MEM_HOST) {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         size_t o_bs = 0, o_q = o_bs + up(S * P), o_mq = o_q + up(S * P), o_rp = o_mq + (mq ? up(S * P) : 0),
                o_gid = o_rp + (rp ? up(S * P * 2) : 0), total = o_gid + (gid ? up(P) : 0);
-        int rc = ensure_stage(e, total);
-        if (rc != BV_OK) return rc;
-        uint8_t *base = static_cast<uint8_t *>(e->stage);
-        BV_HIP(e, hipMemcpyAsync(base + o_bs, bs, S * P, hipMemcpyHostToDevice, st));
-        BV_HIP(e, hipMemcpyAsync(base + o_q, q, S * P, hipMemcpyHostToDevice, st));
-        if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, st));
-        if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, st));
-        if (gid) BV_HIP(e, hipMemcpyAsync(base + o_gid, gid, t->n_samples, hipMemcpyHostToDevice, st));
+        if (!e->copy_stream) {
+            BV_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+            for (int k = 0; k < 2; ++k) {
+                BV_HIP(e, hipEventCreateWithFlags(&e->ev_copied[k], hipEventDisableTiming));
+                BV_HIP(e, hipEventCreateWithFlags(&e->ev_free[k], hipEventDisableTiming));
+            }
+        }
+        slot = (int)(e->tile_k++ & 1u);
+        if (total > e->tstage_bytes[slot]) {
+            if (e->tstage[slot]) BV_HIP(e, hipFree(e->tstage[slot]));  // synchronises with work that still uses it
+            e->tstage[slot] = nullptr;
+            e->tstage_bytes[slot] = 0;
+            BV_HIP(e, hipMalloc(&e->tstage[slot], total));
+            e->tstage_bytes[slot] = total;
+            e->tstage_used[slot] = false;
+        }
+        // the buffer is free again once the kernels of the tile that used it last have run
+        if (e->tstage_used[slot]) BV_HIP(e, hipStreamWaitEvent(e->copy_stream, e->ev_free[slot], 0));
+        uint8_t *base = static_cast<uint8_t *>(e->tstage[slot]);
+        hipStream_t cs = e->copy_stream;
+        BV_HIP(e, hipMemcpyAsync(base + o_bs, bs, S * P, hipMemcpyHostToDevice, cs));
+        BV_HIP(e, hipMemcpyAsync(base + o_q, q, S * P, hipMemcpyHostToDevice, cs));
+        if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, cs));
+        if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, cs));
+        if (gid) BV_HIP(e, hipMemcpyAsync(base + o_gid, gid, t->n_samples, hipMemcpyHostToDevice, cs));
+        BV_HIP(e, hipEventRecord(e->ev_copied[slot], cs));
+        BV_HIP(e, hipStreamWaitEvent(st, e->ev_copied[slot], 0));
         bs = base + o_bs; q = base + o_q;
         mq = mq ? base + o_mq : nullptr;
         rp = rp ? reinterpret_cast<const uint16_t *>(base + o_rp) : nullptr;
         gid = gid ? base + o_gid : nullptr;
+    }
+    if (e->tile_join) {
+        const uint64_t lo = e->tile_samples_seen, JP = e->j_pitch;
+        const uint32_t w = t->n_samples, rows = t->n_sites;
+        bv_launch_tile_scatter(e->j_buf, JP, lo, bs, P, w, rows, st);
+        bv_launch_tile_scatter(e->j_buf + e->j_o_q, JP, lo, q, P, w, rows, st);
+        if (mq) bv_launch_tile_scatter(e->j_buf + e->j_o_mq, JP, lo, mq, P, w, rows, st);
+        if (rp) bv_launch_tile_scatter(e->j_buf + e->j_o_rp, 2 * JP, 2 * lo, reinterpret_cast<const uint8_t *>(rp), 2 * P, 2 * w, rows, st);
+        BV_HIP(e, hipGetLastError());
+        if (gid) BV_HIP(e, hipMemcpyAsync(e->j_buf + e->j_o_gid + lo, gid, w, hipMemcpyDeviceToDevice, st));
+        if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }
+        e->tile_samples_seen += t->n_samples;
+        return BV_OK;
     }
     BvTileArgs a;
     a.bs = bs; a.q = q; a.mapq = mq; a.rpr = rp; a.group_id = gid; a.pitch = P; a.n_sites = t->n_sites;
@@ -399,6 +493,7 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     a.maxr = e->tile_maxr;
     bv_launch_tile_tally(a, st);
     BV_HIP(e, hipGetLastError());
+    if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }
     e->tile_samples_seen += t->n_samples;
     return BV_OK;
 }
@@ -433,6 +528,13 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
         e->host_gout_bytes = S * G * sizeof(bv_group_result);
     }
     BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
+    if (e->tile_join) {
+        e->tile_open = false;
+        return launch_passes(e, e->j_buf, e->j_buf + e->j_o_q, e->tile_ranks ? e->j_buf + e->j_o_mq : nullptr,
+                             e->tile_ranks ? reinterpret_cast<const uint16_t *>(e->j_buf + e->j_o_rp) : nullptr, dref,
+                             G ? e->j_buf + e->j_o_gid : nullptr, e->j_pitch, e->tile_sites, e->tile_samples_total, e->tile_groups,
+                             dout, dgout, st);
+    }
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
     BvTileFinishArgs f;
     f.state = e->tile_state; f.maxr = e->tile_maxr; f.ref_base = dref; f.n_sites = e->tile_sites; f.n_groups = e->tile_groups;

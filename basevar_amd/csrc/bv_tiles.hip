@@ -17,8 +17,9 @@
 //
 // Tally: one LANE per site (a narrow tile row is only a few 16-byte chunks), covered cells go to the
 // site's state with global atomics -- lanes of a wave hit different sites, so no two lanes of an
-// instruction collide.  The tile path is PCIe- or ingest-bound by two orders of magnitude
-// (DESIGN.md), so this kernel is written for correctness and simplicity, not for the HBM roofline.
+// instruction collide.  This per-site-state realisation is the FALLBACK of the tile mode (measured:
+// ~95 GB/s of tile bytes, i.e. not above the PCIe rate); by default the engine joins the tiles into
+// rows resident in HBM (bv_tile_scatter_kernel below) and runs the ordinary two passes on them.
 #include "bv_solver.h"
 
 #define BV_TS_H1 0u
@@ -200,6 +201,30 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
         }
         bv_lrt_sync<0>();
     }
+}
+
+// Joined-rows mode: a tile's columns go to their place in the resident [n_sites][n_samples_total] planes.
+// UNIT bytes per thread (8 when offsets, pitches and width allow it, else 1).
+template <typename UNIT>
+__global__ __launch_bounds__(256) void bv_tile_scatter_kernel(uint8_t *dst, uint64_t dst_pitch, uint64_t col_off, const uint8_t *src,
+                                                              uint64_t src_pitch, uint32_t units_per_row, uint32_t n_rows) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t row = i / units_per_row, u = i % units_per_row;
+    if (row >= n_rows) return;
+    const UNIT v = *reinterpret_cast<const UNIT *>(src + row * src_pitch + u * sizeof(UNIT));
+    *reinterpret_cast<UNIT *>(dst + row * dst_pitch + col_off + u * sizeof(UNIT)) = v;
+}
+void bv_launch_tile_scatter(uint8_t *dst, uint64_t dst_pitch, uint64_t col_off, const uint8_t *src, uint64_t src_pitch,
+                            uint32_t width_bytes, uint32_t n_rows, hipStream_t stream) {
+    const bool wide = ((dst_pitch | col_off | src_pitch | width_bytes | (uint64_t)(uintptr_t)dst | (uint64_t)(uintptr_t)src) & 7u) == 0;
+    const uint32_t unit = wide ? 8u : 1u, upr = width_bytes / unit;
+    const uint64_t total = (uint64_t)upr * n_rows;
+    const uint32_t grid = (uint32_t)((total + 255u) / 256u);
+    if (grid == 0) return;
+    if (wide)
+        hipLaunchKernelGGL(bv_tile_scatter_kernel<uint64_t>, dim3(grid), dim3(256), 0, stream, dst, dst_pitch, col_off, src, src_pitch, upr, n_rows);
+    else
+        hipLaunchKernelGGL(bv_tile_scatter_kernel<uint8_t>, dim3(grid), dim3(256), 0, stream, dst, dst_pitch, col_off, src, src_pitch, upr, n_rows);
 }
 
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream) {

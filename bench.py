@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines/HIP streams used round-robin for consecutive batches (tails of one batch overlap the next)")
+    ap.add_argument("--with-tile-mode", action="store_true",
+                    help="also time BASELINE config #5's shape: sample-axis tiles (--tile-width samples each) accumulated in "
+                         "HBM, from device-resident tiles and from pinned host memory over PCIe (never `value`)")
+    ap.add_argument("--tile-width", type=int, default=200, help="samples per tile (the reference's --batch-count)")
+    ap.add_argument("--tile-sites", type=int, default=16384, help="sites per tile job (at most --batch-sites)")
     ap.add_argument("--with-host-path", action="store_true",
                     help="also time the PCIe-inclusive path: pinned host planes staged by the engine (never `value`)")
     return ap.parse_args()
@@ -353,6 +358,49 @@ def main():
             dt = (time.perf_counter() - t0) / 3
             line["pcie_inclusive"] = {"value": hb / dt, "unit": "sites/s", "batch_sites": hb,
                                       "host_GBps": hb * pitch * (5 if ranks else 2) / dt / 1e9}
+        if world == 1 and args.with_tile_mode:
+            # the reference's own on-disk shape: one tile = one batchfile's worth of samples for every site
+            import ctypes as C
+            from basevar_amd import _capi
+            St = min(B, args.tile_sites)
+            W = args.tile_width
+            Wp = (W + 15) // 16 * 16
+            n_tiles = N // W
+            res = min(n_tiles, 64)  # distinct tiles kept resident (cycled): 64 x St x Wp x 5 B
+            bs0, q0, mq0, rp0, ref0 = batches[0]
+
+            def cut(t, lo, dt):
+                o = torch.zeros((St, Wp), dtype=dt, device=dev)
+                o[:, :W] = t[:St, lo:lo + W]
+                return o
+            dtiles = [(cut(bs0, k * W, torch.uint8), cut(q0, k * W, torch.uint8), cut(mq0, k * W, torch.uint8),
+                       cut(rp0, k * W, torch.int16)) for k in range(res)]
+            htiles = [tuple(x.cpu().pin_memory() for x in t) for t in dtiles]
+            tout = torch.zeros(St * rec, dtype=torch.uint8, device=dev)
+            lib = eng._lib
+
+            def tile_job(tiles, kind):
+                rc = lib.bv_engine_tiles_begin(eng._h, St, n_tiles * W, 0, 1)
+                assert rc == 0, eng._err()
+                for k in range(n_tiles):
+                    tb, tq, tm, tr = tiles[k % res]
+                    t = _capi.Slab(St, W, Wp, tb.data_ptr(), tq.data_ptr(), tm.data_ptr(), tr.data_ptr(), None, None, 0, kind)
+                    rc = lib.bv_engine_tiles_add(eng._h, C.byref(t), None)
+                    assert rc == 0, eng._err()
+                rc = lib.bv_engine_tiles_finish(eng._h, ref0.data_ptr(), tout.data_ptr(), None, _capi.BV_MEM_DEVICE, None)
+                assert rc == 0, eng._err()
+                eng.wait()
+            tm = {}
+            for name, tiles, kind in (("device", dtiles, _capi.BV_MEM_DEVICE), ("host", htiles, _capi.BV_MEM_HOST)):
+                tile_job(tiles, kind)
+                t0 = time.perf_counter()
+                tile_job(tiles, kind)
+                tm[name] = time.perf_counter() - t0
+            cells = float(St) * n_tiles * W
+            line["tile_mode"] = {"sites": St, "samples": n_tiles * W, "tile_width": W, "tiles": n_tiles,
+                                 "device_resident": {"value": St / tm["device"], "unit": "sites/s", "GBps": 5 * cells / tm["device"] / 1e9},
+                                 "host_pinned_pcie": {"value": St / tm["host"], "unit": "sites/s", "GBps": 5 * St * n_tiles * Wp / tm["host"] / 1e9}}
+            del dtiles, htiles
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, cpu_rec, cpu_idx = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)

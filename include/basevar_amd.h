@@ -147,6 +147,8 @@ typedef struct bv_group_result {
 #define BV_FLAG_TALLY_ONLY 0x1u
 #define BV_FLAG_SKIP_FISHER 0x2u /* diagnostic: strand-bias Fisher tests return p = 1 */
 #define BV_FLAG_SKIP_LRT 0x4u    /* diagnostic: no EM / LRT (no site is called variant) */
+#define BV_FLAG_TILE_STATE 0x8u  /* tile mode: always accumulate per-site tallies (the fallback for jobs whose
+                                    joined planes do not fit the HBM) instead of joining the tiles into rows */
 
 typedef struct bv_engine_config {
     int32_t device;        /* HIP device ordinal                                        */
@@ -205,8 +207,13 @@ int bv_engine_wait(bv_engine *e);
  *     bv_engine_tiles_add(e, tile, stream)      for every tile; tile->n_sites must match;
  *                                               tile->group_id covers the tile's samples
  *     bv_engine_tiles_finish(e, ref_base, out, gout, mem_kind, stream)   then bv_engine_wait()
- * Results equal those of one bv_engine_submit on the joined rows, except that read-position
- * ranks >= 1024 are not supported in this mode (BV_SITE_RPR_RANGE, rpr_ranksum = NaN). */
+ * Two realisations, chosen at bv_engine_tiles_begin:
+ *   joined rows (default)  the tiles are copied into one [n_sites][n_samples_total] slab kept in HBM
+ *                          (5 B per cell: 82 GB for 16 Ki sites x 1 M samples) and finish() runs the ordinary
+ *                          two passes on it -- results are those of bv_engine_submit on the joined rows, bit for bit;
+ *   per-site tallies       when that slab does not fit (or with BV_FLAG_TILE_STATE): additive per-site state
+ *                          (~30 KB per site), global atomics; equal results except that read-position ranks
+ *                          >= 1024 are not supported there (BV_SITE_RPR_RANGE, rpr_ranksum = NaN). */
 int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_total, uint32_t n_groups,
                           int with_ranks);
 int bv_engine_tiles_add(bv_engine *e, const bv_slab *tile, void *stream);

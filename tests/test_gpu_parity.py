@@ -366,19 +366,22 @@ def test_two_engines_on_two_host_threads(bv, restatement):
         check(got, exp, gexp, margins)
 
 
+@pytest.mark.parametrize("flags", [0, 0x8], ids=["joined_rows", "per_site_tallies"])
 @pytest.mark.parametrize("n,width,groups,ranks", [(1000, 200, 2, True), (3001, 200, 0, True), (700, 64, 3, False),
-                                                  (5000, 5000, 2, True), (257, 16, 1, True)])
-def test_sample_axis_tiles_equal_rows(bv, restatement, n, width, groups, ranks):
+                                                  (5000, 5000, 2, True), (257, 16, 1, True), (1003, 7, 2, True)])
+def test_sample_axis_tiles_equal_rows(bv, restatement, n, width, groups, ranks, flags):
     """BASELINE config #5 mechanism: column tiles of `width` samples accumulated in HBM give the same
     records as the joined rows (and the oracle)."""
     slab = make_slab(96, n, seed=900 + n, coverage=0.4, n_groups=groups, site_offset=9, ref_n_frac=0.05)
     if not ranks:
         slab.pop("mapq"); slab.pop("rpr")
     maf = bv.min_af(n)
-    eng = bv.BaseTypeEngine(max_sites=96, min_af_value=maf, device=0)
+    eng = bv.BaseTypeEngine(max_sites=96, min_af_value=maf, device=0, flags=flags)
     rows = eng.lrt(slab)
     tiles = eng.lrt_tiles(slab, width)
     eng.close()
+    if flags == 0:  # the joined realisation runs the row kernels on the joined planes: same bytes out
+        assert rows.sites.tobytes() == tiles.sites.tobytes()
     exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=4)
     check(tiles, exp, gexp, margins, check_ranks=ranks)
     # and bit-identical to the row mode wherever the arithmetic is order-free (integers)
@@ -386,11 +389,20 @@ def test_sample_axis_tiles_equal_rows(bv, restatement, n, width, groups, ranks):
         assert np.array_equal(rows.sites[f], tiles.sites[f]), f
 
 
-def test_sample_axis_tiles_long_read_ranks_are_flagged(bv):
+def test_sample_axis_tiles_long_read_ranks(bv, restatement):
+    """Ranks >= 1024: exact in the default (joined-rows) realisation of the tile mode, flagged in the per-site-tally
+    fallback (BV_FLAG_TILE_STATE), whose layout cannot hold them."""
     slab = make_slab(16, 400, seed=950, coverage=0.6, class_af=[(0.4, 0.0)])
     cov = slab["base_strand"] < 8
     slab["rpr"][3, np.nonzero(cov[3])[0][:2]] = 2000
-    eng = bv.BaseTypeEngine(max_sites=16, min_af_value=bv.min_af(400), device=0)
+    maf = bv.min_af(400)
+    eng = bv.BaseTypeEngine(max_sites=16, min_af_value=maf, device=0)
+    t = eng.lrt_tiles(slab, 100)
+    eng.close()
+    exp, gexp, margins = restatement.run_with_margins(slab, maf)
+    check(t, exp, gexp, margins)
+    assert ((t.sites["status"] & 0x40) == 0).all()
+    eng = bv.BaseTypeEngine(max_sites=16, min_af_value=maf, device=0, flags=0x8)
     t = eng.lrt_tiles(slab, 100)
     eng.close()
     flagged = (t.sites["status"] & 0x40) != 0
