@@ -269,7 +269,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
     // on the site's record, so results stay bit-reproducible.
     if (wave < NTALLY) {
         // ------------------------------------------------ tally waves (wave 0 leads)
-        // (s_setprio(3) for this role was measured: 2 % slower, so priorities stay equal.)
+        // (s_setprio(1) / s_setprio(3) for this role were measured, twice: 0.5-2 % slower; priorities stay equal.)
         // Tickets are drawn `chunk` sites at a time: 1 for long rows (a reserved site is tens of microseconds of
         // work, so reserving more would lengthen the drain), 4 for short rows (one atomic per site on a single
         // address saturates at ~85 M/s).
