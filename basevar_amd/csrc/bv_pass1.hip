@@ -33,6 +33,9 @@
 
 #include "bv_solver.h"
 
+#ifndef BV_RING_EXTRA
+#define BV_RING_EXTRA 2
+#endif
 template <int NBUF, int NSOLVE>
 struct __attribute__((aligned(16))) BvPass1Shared {
     uint32_t hist[NBUF][BV_H2_WORDS];  // ring of histograms [(rev<<2)|base][phred byte]
@@ -243,7 +246,7 @@ __device__ __forceinline__ void bv_add_flag(uint32_t *flag, int lane) {
 template <int NTALLY, int NSOLVE>
 __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel(BvPass1Args a) {
     constexpr int NT = BV_WAVE * (NTALLY + NSOLVE);
-    constexpr int NBUF = NSOLVE + 2;  // the tally may run two sites ahead of a slow (variant-site) solve
+    constexpr int NBUF = NSOLVE + BV_RING_EXTRA;  // the tally may run BV_RING_EXTRA sites ahead of a slow (variant-site) solve
     __shared__ BvPass1Shared<NBUF, NSOLVE> sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -438,7 +441,7 @@ static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
     // never more than there are sites.
     constexpr uint32_t by_vgpr = 16u / (NTALLY + NSOLVE);
-    constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + 2, NSOLVE>));
+    constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + BV_RING_EXTRA, NSOLVE>));
     uint32_t grid = 256u * (by_vgpr < by_lds ? by_vgpr : by_lds);
     if (grid > a.n_sites) grid = a.n_sites;
     hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
