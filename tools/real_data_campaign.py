@@ -77,10 +77,13 @@ def run():
     d = np.load(SLAB)
     ref = oracle.Reference(); res = oracle.Restatement()
     tot = bad_tot = amb_tot = 0
-    for mode in ("consensus", "refN", "ref_shift"):
+    for mode in ("consensus", "refN", "ref_shift", "refN_nogroups"):
         for user_af in (0.05, 0.01):
             slab = {k: d[k] for k in ("base_strand", "qual", "mapq", "rpr", "ref_base", "group_id")}
             slab["n_samples"] = int(d["n_samples"]); slab["n_groups"] = int(d["n_groups"])
+            if mode == "refN_nogroups":  # without pop-groups short rows take the persistent pass-2 kernel
+                slab.pop("group_id"); slab["n_groups"] = 0
+                slab["ref_base"] = np.full_like(d["ref_base"], 4)
             if mode == "refN":
                 slab["ref_base"] = np.full_like(d["ref_base"], 4)
             if mode == "ref_shift":
@@ -98,7 +101,7 @@ def run():
             bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
             bad = {f: i for f, i in bad.items() if i.size}
             nv = int(((exp["status"] & 2) != 0).sum())
-            print("real data %-10s min_af %.2f: %d sites (%d variant), mismatching fields %d, tie-excused %d" % (
+            print("real data %-13s min_af %.2f: %d sites (%d variant), mismatching fields %d, tie-excused %d" % (
                 mode, user_af, len(exp), nv, sum(len(v) for v in bad.values()), len(exc)))
             if bad:
                 print(describe(bad, got.sites, exp)[:2000])
