@@ -326,6 +326,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "bv_pass1_kernel", "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": p1_avg_s * 1e3, "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
+                # BASELINE.md section 3's whole-path figure: S*N*(2 + 3 f_var) bytes over both kernels' time
+                # (pass 2 also re-reads the call byte of variant rows: its own traffic is 4 B/cell)
+                "whole_path_GBps": (2.0 + 3.0 * nvar / B) * B * N / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9,
+                "whole_path_frac": (2.0 + 3.0 * nvar / B) * B * N / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
             },
         }
         if world == 1:

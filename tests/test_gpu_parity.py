@@ -119,13 +119,14 @@ def test_high_depth_all_covered(bv, restatement):
     check(got, exp, gexp)
 
 
-def test_long_read_position_ranks(bv, restatement):
-    """Ranks beyond the 1024-wide LDS window take extra sweeps."""
-    slab = make_slab(32, 3000, seed=43, coverage=0.5, class_af=[(0.3, 0.0), (0.2, 0.1)])
+@pytest.mark.parametrize("n,groups", [(3000, 0), (3000, 2), (20000, 0)], ids=["short_rows", "short_rows_groups", "long_rows"])
+def test_long_read_position_ranks(bv, restatement, n, groups):
+    """Ranks beyond the LDS rank window (256 wide in the short-row kernel, 1024 in the others) take extra sweeps."""
+    slab = make_slab(32, n, seed=43, coverage=0.5, class_af=[(0.3, 0.0), (0.2, 0.1)], n_groups=groups)
     rng = np.random.default_rng(5)
     slab["rpr"] = np.where(slab["base_strand"] < 8, rng.integers(1, 5000, size=slab["rpr"].shape), 0).astype(np.uint16)
     slab["rpr"][3, :] = np.where(slab["base_strand"][3] < 8, 65535 - (np.arange(slab["rpr"].shape[1]) % 7), 0)
-    maf = bv.min_af(3000)
+    maf = bv.min_af(n)
     got = run_engine(bv, slab, maf)
     exp, gexp = restatement.run(slab, maf, n_threads=4)
     check(got, exp, gexp)
