@@ -481,3 +481,41 @@ def test_garbage_bytes_are_no_calls_everywhere(bv, restatement):
     b = run_engine(bv, clean, maf)
     assert a.sites.tobytes() == b.sites.tobytes()
     assert a.groups.tobytes() == b.groups.tobytes()
+
+
+def test_tile_job_interleaved_with_row_submits_and_abandoned_jobs(bv, restatement):
+    """A tile job may stay open across ordinary submits of the same engine (separate buffers), a new begin() discards an
+    unfinished job, and destroying an engine with an open job is harmless."""
+    import ctypes as C
+    from basevar_amd import _capi
+    a = make_slab(40, 1200, seed=501, coverage=0.3)
+    b = make_slab(24, 900, seed=502, coverage=0.5, n_groups=2)
+    maf = bv.min_af(1200)
+    eng = bv.BaseTypeEngine(max_sites=64, min_af_value=maf, device=0)
+    lib = eng._lib
+    assert lib.bv_engine_tiles_begin(eng._h, 40, 1200, 0, 1) == 0          # job 1: abandoned below
+    assert lib.bv_engine_tiles_begin(eng._h, 40, 1200, 0, 1) == 0          # job 2
+    keep = []
+
+    def add(lo, w):
+        pitch = (w + 15) // 16 * 16
+        t = {}
+        for k, dt, fill in (("base_strand", np.uint8, 8), ("qual", np.uint8, 0), ("mapq", np.uint8, 0), ("rpr", np.uint16, 0)):
+            x = np.full((40, pitch), fill, dt); x[:, :w] = a[k][:, lo:lo + w]; t[k] = x
+        keep.append(t)
+        s = _capi.Slab(40, w, pitch, t["base_strand"].ctypes.data, t["qual"].ctypes.data, t["mapq"].ctypes.data, t["rpr"].ctypes.data,
+                       None, None, 0, _capi.BV_MEM_HOST)
+        assert lib.bv_engine_tiles_add(eng._h, C.byref(s), None) == 0, eng._err()
+    add(0, 500)
+    rows_b = eng.lrt(b)                                                     # an ordinary submit in the middle
+    add(500, 700)
+    out = np.zeros(40, dtype=_capi.SITE_DTYPE)
+    ref = np.ascontiguousarray(a["ref_base"])
+    assert lib.bv_engine_tiles_finish(eng._h, ref.ctypes.data, out.ctypes.data, None, _capi.BV_MEM_HOST, None) == 0, eng._err()
+    eng.wait()
+    rows_a = eng.lrt(a)
+    assert out.tobytes() == rows_a.sites.tobytes()
+    exp_b, gexp_b, m_b = restatement.run_with_margins(b, maf)
+    check(rows_b, exp_b, gexp_b, m_b)
+    assert lib.bv_engine_tiles_begin(eng._h, 40, 1200, 0, 1) == 0          # left open
+    eng.close()
