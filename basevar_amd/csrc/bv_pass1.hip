@@ -384,7 +384,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     // Tickets are drawn BV_FUSED_TICKET sites at a time: at ~70 M short-row sites/s one ticket per
     // site would run into the ~88 M/s ceiling of atomics on a single address (measured: throughput
-    // flat from 6 to 11 waves per CU until the draws were chunked).
+    // flat from 6 to 11 waves per CU until the draws were chunked).  (Drawing single sites over the last one or
+    // two rounds of the grid, to shorten the drain, was measured too: +-0 and -10 % -- the atomics pile up.)
     uint32_t next = 0;
     if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);
 #if BV_FUSED_PRELOAD
