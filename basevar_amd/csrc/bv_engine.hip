@@ -477,10 +477,19 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     if (e->tile_join) {
         const uint64_t lo = e->tile_samples_seen, JP = e->j_pitch;
         const uint32_t w = t->n_samples, rows = t->n_sites;
-        bv_launch_tile_scatter(e->j_buf, JP, lo, bs, P, w, rows, st);
-        bv_launch_tile_scatter(e->j_buf + e->j_o_q, JP, lo, q, P, w, rows, st);
-        if (mq) bv_launch_tile_scatter(e->j_buf + e->j_o_mq, JP, lo, mq, P, w, rows, st);
-        if (rp) bv_launch_tile_scatter(e->j_buf + e->j_o_rp, 2 * JP, 2 * lo, reinterpret_cast<const uint8_t *>(rp), 2 * P, 2 * w, rows, st);
+        BvTileScatterArgs sc;
+        sc.n_rows = rows;
+        sc.n_planes = 0;
+        auto plane = [&](uint8_t *dst, const uint8_t *src, uint64_t scale) {
+            BvTileScatterPlane &p = sc.plane[sc.n_planes++];
+            p.dst = dst; p.src = src; p.dst_pitch = scale * JP; p.src_pitch = scale * P; p.col_off = scale * lo;
+            p.width_bytes = (uint32_t)(scale * w); p.pad_ = 0;
+        };
+        plane(e->j_buf, bs, 1);
+        plane(e->j_buf + e->j_o_q, q, 1);
+        if (mq) plane(e->j_buf + e->j_o_mq, mq, 1);
+        if (rp) plane(e->j_buf + e->j_o_rp, reinterpret_cast<const uint8_t *>(rp), 2);
+        bv_launch_tile_scatter(sc, st);
         BV_HIP(e, hipGetLastError());
         if (gid) BV_HIP(e, hipMemcpyAsync(e->j_buf + e->j_o_gid + lo, gid, w, hipMemcpyDeviceToDevice, st));
         if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }

@@ -79,9 +79,19 @@ struct BvTileFinishArgs {
 };
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream);
 void bv_launch_tile_finish(const BvTileFinishArgs &a, hipStream_t stream);
-// copies `width_bytes` bytes of each of n_rows rows from src (row pitch src_pitch) to dst + col_off (row pitch dst_pitch)
-void bv_launch_tile_scatter(uint8_t *dst, uint64_t dst_pitch, uint64_t col_off, const uint8_t *src, uint64_t src_pitch,
-                            uint32_t width_bytes, uint32_t n_rows, hipStream_t stream);
+// joined-rows tile mode: `width_bytes` bytes of each of n_rows rows go from src (row pitch src_pitch) to
+// dst + col_off (row pitch dst_pitch), for up to five planes in one launch
+struct BvTileScatterPlane {
+    uint8_t *dst;
+    const uint8_t *src;
+    uint64_t dst_pitch, src_pitch, col_off;
+    uint32_t width_bytes, pad_;
+};
+struct BvTileScatterArgs {
+    BvTileScatterPlane plane[5];
+    uint32_t n_planes, n_rows;
+};
+void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream);
 
 // host-callable launchers (defined next to the kernels)
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);

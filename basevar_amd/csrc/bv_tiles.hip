@@ -204,27 +204,33 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
 }
 
 // Joined-rows mode: a tile's columns go to their place in the resident [n_sites][n_samples_total] planes.
-// UNIT bytes per thread (8 when offsets, pitches and width allow it, else 1).
+// One launch moves all the planes of a tile (blockIdx.y = plane); 8 bytes per thread when every offset, pitch
+// and width of the tile allows it, else 1.
 template <typename UNIT>
-__global__ __launch_bounds__(256) void bv_tile_scatter_kernel(uint8_t *dst, uint64_t dst_pitch, uint64_t col_off, const uint8_t *src,
-                                                              uint64_t src_pitch, uint32_t units_per_row, uint32_t n_rows) {
+__global__ __launch_bounds__(256) void bv_tile_scatter_kernel(BvTileScatterArgs a) {
+    const BvTileScatterPlane p = a.plane[blockIdx.y];
+    const uint32_t upr = p.width_bytes / (uint32_t)sizeof(UNIT);
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t row = i / units_per_row, u = i % units_per_row;
-    if (row >= n_rows) return;
-    const UNIT v = *reinterpret_cast<const UNIT *>(src + row * src_pitch + u * sizeof(UNIT));
-    *reinterpret_cast<UNIT *>(dst + row * dst_pitch + col_off + u * sizeof(UNIT)) = v;
+    if (upr == 0) return;
+    const uint64_t row = i / upr, u = i % upr;
+    if (row >= a.n_rows) return;
+    const UNIT v = *reinterpret_cast<const UNIT *>(p.src + row * p.src_pitch + u * sizeof(UNIT));
+    *reinterpret_cast<UNIT *>(p.dst + row * p.dst_pitch + p.col_off + u * sizeof(UNIT)) = v;
 }
-void bv_launch_tile_scatter(uint8_t *dst, uint64_t dst_pitch, uint64_t col_off, const uint8_t *src, uint64_t src_pitch,
-                            uint32_t width_bytes, uint32_t n_rows, hipStream_t stream) {
-    const bool wide = ((dst_pitch | col_off | src_pitch | width_bytes | (uint64_t)(uintptr_t)dst | (uint64_t)(uintptr_t)src) & 7u) == 0;
-    const uint32_t unit = wide ? 8u : 1u, upr = width_bytes / unit;
-    const uint64_t total = (uint64_t)upr * n_rows;
-    const uint32_t grid = (uint32_t)((total + 255u) / 256u);
-    if (grid == 0) return;
-    if (wide)
-        hipLaunchKernelGGL(bv_tile_scatter_kernel<uint64_t>, dim3(grid), dim3(256), 0, stream, dst, dst_pitch, col_off, src, src_pitch, upr, n_rows);
-    else
-        hipLaunchKernelGGL(bv_tile_scatter_kernel<uint8_t>, dim3(grid), dim3(256), 0, stream, dst, dst_pitch, col_off, src, src_pitch, upr, n_rows);
+void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream) {
+    bool wide = true;
+    uint32_t max_w = 0;
+    for (uint32_t k = 0; k < a.n_planes; ++k) {
+        const BvTileScatterPlane &p = a.plane[k];
+        if ((p.dst_pitch | p.col_off | p.src_pitch | p.width_bytes | (uint64_t)(uintptr_t)p.dst | (uint64_t)(uintptr_t)p.src) & 7u) wide = false;
+        if (p.width_bytes > max_w) max_w = p.width_bytes;
+    }
+    if (a.n_planes == 0 || max_w == 0 || a.n_rows == 0) return;
+    const uint32_t unit = wide ? 8u : 1u;
+    const uint64_t total = (uint64_t)(max_w / unit) * a.n_rows;
+    const dim3 grid((uint32_t)((total + 255u) / 256u), a.n_planes);
+    if (wide) hipLaunchKernelGGL(bv_tile_scatter_kernel<uint64_t>, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(bv_tile_scatter_kernel<uint8_t>, grid, dim3(256), 0, stream, a);
 }
 
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream) {
