@@ -430,7 +430,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass
 
 static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
     uint32_t per_cu = (a.flags >> 12) & 0xFu;  // tuning knob: resident workgroups per CU (0 = default)
-    if (per_cu == 0) per_cu = 4u;             // ~38 KiB of LDS per 4-wave workgroup, 128 VGPRs -> 4 per CU
+    if (per_cu == 0) per_cu = (uint32_t)BV_FUSED_OCC;  // ~38 KiB of LDS and 4 x 168 VGPRs per workgroup -> 3 resident per CU
     uint32_t grid = 256u * per_cu;
     const uint32_t need = (a.n_sites + BV_FUSED_TICKET * BV_FUSED_WAVES - 1) / (BV_FUSED_TICKET * BV_FUSED_WAVES);
     if (grid > need) grid = need > 0 ? need : 1;
