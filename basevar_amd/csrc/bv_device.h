@@ -848,8 +848,12 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             s += f[0]; s += f[1]; s += f[2]; s += f[3];
             double lr;
             // phred-0 calls (1 - eps == 0) and all-zero starts make 0/0 in the reference: exact replay
+#ifdef BV_EXP_NO_GENERIC_EM  /* code-size experiment only: wrong for phred-0 sites */
+            int it = bv_em_wave(B, f, in_set, n_cov, &lr, lane);
+#else
             int it = (q0_mask != 0u || s == 0.) ? bv_em_wave_generic(B, f, n_cov, &lr, lane)
                                                 : bv_em_wave(B, f, in_set, n_cov, &lr, lane);
+#endif
             if (lane == 0) {
                 sh->f[par][c][0] = f[0]; sh->f[par][c][1] = f[1];
                 sh->f[par][c][2] = f[2]; sh->f[par][c][3] = f[3];

@@ -141,22 +141,13 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
     } else {
         uint32_t flags = BV_SITE_COVERED | (badq ? BV_SITE_BAD_QUAL : 0u);
 
-        // ---- CVG strand bias: alt = every non-ref ACGT base (caller.cpp:1236-1245)
+        // ---- CVG strand-bias table: alt = every non-ref ACGT base (caller.cpp:1236-1245).  The two Fisher tests of a
+        // site (this one and the VCF one, caller.cpp:1164) run further down through ONE call site: the test is
+        // ~45 KB of code, and a second inlined copy was a third of the kernel (162 KB against a 64 KB I-cache).
         uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;
-        double c_fs = 0, c_sor = 0;
-        uint32_t c_flags = 0;
-        if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b == ref) { c_rf += fwd[b]; c_rr += rev[b]; } else { c_af += fwd[b]; c_ar += rev[b]; }
-            }
-            bv_strand_bias_wave(c_rf, c_rr, c_af, c_ar, lane, a.lnfact, &c_fs, &c_sor, &c_flags);
-            flags |= c_flags;
-            if (lane == 0) {
-                sv->res.cvg_sb[0] = c_rf; sv->res.cvg_sb[1] = c_rr; sv->res.cvg_sb[2] = c_af; sv->res.cvg_sb[3] = c_ar;
-                sv->res.cvg_fs = c_fs;
-                sv->res.cvg_sor = c_sor;
-            }
+        for (int b = 0; b < 4; ++b) {
+            if (b == ref) { c_rf += fwd[b]; c_rr += rev[b]; } else { c_af += fwd[b]; c_ar += rev[b]; }
         }
 
         // ---- lrt() over ACGT (basetype.h:115)
@@ -171,6 +162,8 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
         if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
 
         double bq_ranksum = qnan;
+        uint32_t v_rf = 0, v_rr = 0, v_af = 0, v_ar = 0;
+        bool have_var = false;
         if (L.n_alt > 0) {
             flags |= BV_SITE_VARIANT;
             uint32_t alt_mask = 0, ad_sum_u = 0;
@@ -212,30 +205,13 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                     sv->res.qd = qd;
                 }
             }
-            // VCF strand bias w.r.t. the chosen ALTs (caller.cpp:1164)
-            {
-                uint32_t rf = 0, rr = 0, af = 0, ar = 0;
+            // VCF strand-bias table w.r.t. the chosen ALTs (caller.cpp:1164)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    if (b == ref) { rf += fwd[b]; rr += rev[b]; }
-                    else if ((alt_mask >> b) & 1u) { af += fwd[b]; ar += rev[b]; }
-                }
-                double fs = 0, sor = 0;
-#ifndef BV_ABL_NO_VARFS
-                // same 2x2 table as the CVG test whenever the chosen ALTs are all the non-ref bases seen
-                if (!(a.flags & BV_FLAG_SKIP_FISHER) && rf == c_rf && rr == c_rr && af == c_af && ar == c_ar) {
-                    fs = c_fs;
-                    sor = c_sor;
-                } else {
-                    bv_strand_bias_wave(rf, rr, af, ar, lane, a.lnfact, &fs, &sor, &flags);
-                }
-#endif
-                if (lane == 0) {
-                    sv->res.var_sb[0] = rf; sv->res.var_sb[1] = rr; sv->res.var_sb[2] = af; sv->res.var_sb[3] = ar;
-                    sv->res.var_fs = fs;
-                    sv->res.var_sor = sor;
-                }
+            for (int b = 0; b < 4; ++b) {
+                if (b == ref) { v_rf += fwd[b]; v_rr += rev[b]; }
+                else if ((alt_mask >> b) & 1u) { v_af += fwd[b]; v_ar += rev[b]; }
             }
+            have_var = true;
             // base-quality rank sum from the histogram this pass already holds (caller.cpp:1157)
 #ifndef BV_ABL_NO_BQ
             {
@@ -256,6 +232,35 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                 bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
             }
 #endif
+        }
+        // ---- strand bias: FS / SOR of the CVG table, then of the VCF table unless it is the same 2x2 table (it is
+        // whenever the chosen ALTs are all the non-ref bases seen)
+        if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
+            const bool same = have_var && v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar;
+#ifdef BV_ABL_NO_VARFS
+            const int ntab = 1;
+#else
+            const int ntab = (have_var && !same) ? 2 : 1;
+#endif
+            double c_fs = 0, c_sor = 0, v_fs = 0, v_sor = 0;
+#pragma unroll 1
+            for (int t = 0; t < ntab; ++t) {
+                double fs, sor;
+                bv_strand_bias_wave(t ? v_rf : c_rf, t ? v_rr : c_rr, t ? v_af : c_af, t ? v_ar : c_ar, lane, a.lnfact, &fs, &sor,
+                                    &flags);
+                if (t) { v_fs = fs; v_sor = sor; } else { c_fs = fs; c_sor = sor; }
+            }
+            if (same) { v_fs = c_fs; v_sor = c_sor; }
+            if (lane == 0) {
+                sv->res.cvg_sb[0] = c_rf; sv->res.cvg_sb[1] = c_rr; sv->res.cvg_sb[2] = c_af; sv->res.cvg_sb[3] = c_ar;
+                sv->res.cvg_fs = c_fs;
+                sv->res.cvg_sor = c_sor;
+                if (have_var) {
+                    sv->res.var_sb[0] = v_rf; sv->res.var_sb[1] = v_rr; sv->res.var_sb[2] = v_af; sv->res.var_sb[3] = v_ar;
+                    sv->res.var_fs = v_fs;
+                    sv->res.var_sor = v_sor;
+                }
+            }
         }
         if (lane == 0) {
 #pragma unroll
