@@ -169,6 +169,9 @@ FIXTURES = {
     "nipt_96x4000": (lambda: make_slab(96, 4000, seed=12, coverage=0.08, n_groups=2), 0.01),
     "ragged_40x1003": (lambda: make_slab(40, 1003, seed=13, coverage=0.25, n_groups=3, pitch=1008), 0.01),
     "real_100bam": (real_bam_slab, 0.05),   # --min-af=0.05 as in the set's work.log.sh
+    # the headline row lengths, records from the real reference (the other fixtures stop at 4,000 samples)
+    "nipt_20x100000": (lambda: make_slab(20, 100000, seed=15, coverage=0.08, n_groups=2), 0.01),
+    "deep_6x1000000": (lambda: make_slab(6, 1000000, seed=16, coverage=0.05, site_offset=14), 0.01),
     "lowq_48x800": (lambda: make_slab(48, 800, seed=14, coverage=0.4, qual_mean=12.0, qual_sd=8.0, qual_min=1,
                                       qual_max=60), 0.01),
 }
