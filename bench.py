@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines/HIP streams used round-robin for consecutive batches (tails of one batch overlap the next)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="diagnostic: G pop-groups (random membership, ~15 % of the samples in none): adds the per-group calls of pass 2")
     ap.add_argument("--with-tile-mode", action="store_true",
                     help="also time BASELINE config #5's shape: sample-axis tiles (--tile-width samples each) accumulated in "
                          "HBM, from device-resident tiles and from pinned host memory over PCIe (never `value`)")
@@ -230,6 +232,14 @@ def main():
     gatherer = RecordGatherer(B * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if dist_on else None
     last_slot = [0]
 
+    G = max(0, min(args.groups, 32))
+    gid = gouts = None
+    if G:
+        gen = torch.Generator(device="cpu").manual_seed(args.seed & 0xFFFF)
+        g = torch.randint(0, G + 1, (pitch,), generator=gen, dtype=torch.int64)
+        gid = torch.where(g == G, torch.full_like(g, 255), g).to(torch.uint8).to(dev)
+        gouts = [torch.zeros(B * G * basevar_amd.GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(depth)]
+
     def step(i):
         bs, q, mq, rp, ref = batches[i % nb]
         k = i % ns
@@ -242,6 +252,7 @@ def main():
                 gatherer.before_reuse(slot)
             engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                 mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
+                                group_id=gid.data_ptr() if G else 0, n_groups=G, gout=gouts[slot].data_ptr() if G else 0,
                                 stream=streams[k].cuda_stream)
             if gatherer is not None:
                 if gloo_host:
