@@ -16,6 +16,9 @@
 #ifndef BV_P2_U64
 #define BV_P2_U64 4
 #endif
+#ifndef BV_P2_WIDE_GROUPS
+#define BV_P2_WIDE_GROUPS 2 /* from this many pop-groups on, short rows also take the four-wave kernel: one wave per group */
+#endif
 #define BV_RPR_WIN 1024  /* read-position ranks per LDS window; longer reads take extra sweeps */
 
 template <int NW>
@@ -385,6 +388,6 @@ void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream) {
         hipLaunchKernelGGL(bv_pass2_short_kernel, dim3(grid), dim3(BV_WAVE * BV_P2S_WAVES), 0, stream, a);
         return;
     }
-    if (a.n_samples <= 16384u) bv_launch_pass2_nt<64>(a, stream);
+    if (a.n_samples <= 16384u && !(groups && a.n_groups >= BV_P2_WIDE_GROUPS)) bv_launch_pass2_nt<64>(a, stream);
     else bv_launch_pass2_nt<256>(a, stream);
 }
