@@ -223,10 +223,13 @@ __device__ __forceinline__ void bv_row_preload(BvChunkSet &A, const uint8_t *bs_
 // ------------------------------------------------------------------------------ kernel
 // Every spin is bounded (~1 s): a protocol bug must end the kernel with counters[3] set
 // (reported by bv_engine_wait) instead of hanging the GPU.
+#ifndef BV_SPIN_SLEEP
+#define BV_SPIN_SLEEP 16 /* x64 cycles between polls of a hand-off flag (4, 16, 64 measured: 4.09, 4.05, 4.04 ms) */
+#endif
 __device__ __forceinline__ void bv_wait_flag(const uint32_t *flag, uint32_t want, uint32_t *err) {
     uint32_t spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(BV_SPIN_SLEEP);
         if (++spins > (1u << 23)) {
             atomicOr(err, 1u);
             break;
