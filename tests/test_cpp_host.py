@@ -2,6 +2,7 @@
 refuses to run without a GPU, and on a GPU reproduces the oracle on the sites it packed."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -52,3 +53,10 @@ def test_cpp_wrapper_matches_oracle(tmp_path, restatement):
     bad = compare_sites(got, exp)
     assert not bad, describe(bad, got, exp)
     assert ((exp["status"] & 2) != 0).sum() >= 5
+
+
+@pytest.mark.gpu
+def test_python_example_runs():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "python_example.py")], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert p.stdout.count("site ") == 3 and "alts ['C']" in p.stdout
