@@ -8,7 +8,8 @@
 //   bv_call --batchfiles a.bf.gz,b.bf.gz --output-vcf out.vcf --output-cvg out.cvg
 //           [--pop-group FILE] [--min-af 0.01] [--batch-sites 4096] [--device 0]
 //           [--reference ref.fa --contig NAME:LENGTH ...]
-//   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END [--mapq 10] ...   (same outputs)
+//   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END[,CHR:BEG-END...] [--mapq 10]
+//           [--thread T] ...   (same outputs)
 //
 // Batchfiles may be bgzip/gzip-compressed or plain (zlib reads all three).  With BAM inputs the pileup
 // (pileup.hpp) feeds the engine directly: the same cells the batchfile rows would carry,
@@ -191,23 +192,29 @@ int main(int argc, char **argv) {
     if (from_bam) {
         // ---- pileup -> BatchInfo -> slab, in the reference's 500 kb steps (caller.cpp:826-846)
         try {
-            const size_t colon = regions.rfind(':'), dash = regions.rfind('-');
-            if (colon == std::string::npos || dash == std::string::npos || dash < colon) die("--regions wants CHR:BEG-END");
-            const std::string ref_id = regions.substr(0, colon);
-            const uint32_t beg = (uint32_t)std::stoul(regions.substr(colon + 1, dash - colon - 1));
-            const uint32_t end = (uint32_t)std::stoul(regions.substr(dash + 1));
-            const std::string fa_seq = bvamd::load_fasta_sequence(reference, ref_id);
-            if (beg < 1 || end < beg || end > fa_seq.size()) die("[ERROR] region outside " + ref_id);
-            for (uint32_t sb = beg; sb < end + 1; sb += 500000u) {
-                const uint32_t se = sb + 500000u - 1 > end ? end : sb + 500000u - 1;
-                bvamd::PosMapVector v;
-                bvamd::fetch_base_in_region(bams, fa_seq, mapq_thd, std::make_tuple(ref_id, sb, se), v, true, threads);
-                for (uint32_t pos = sb; pos <= se; ++pos) {
-                    bvamd::BatchInfo bi;
-                    if (!bvamd::batchinfo_at(v, fa_seq, ref_id, pos, bi)) continue;
-                    slab.add_site(bi);
-                    pending.push_back(std::move(bi));
-                    if (pending.size() == batch_sites) flush();
+            // "-r chr:beg-end[,chr:beg-end ...]" (caller.cpp:311-356); regions are called in the order given
+            std::vector<std::string> region_list;
+            bvamd::split(regions, region_list, ",");
+            std::string fa_seq, fa_of;
+            for (const std::string &rg : region_list) {
+                const size_t colon = rg.rfind(':'), dash = rg.rfind('-');
+                if (colon == std::string::npos || dash == std::string::npos || dash < colon) die("--regions wants CHR:BEG-END[,CHR:BEG-END...]");
+                const std::string ref_id = rg.substr(0, colon);
+                const uint32_t beg = (uint32_t)std::stoul(rg.substr(colon + 1, dash - colon - 1));
+                const uint32_t end = (uint32_t)std::stoul(rg.substr(dash + 1));
+                if (fa_of != ref_id) { fa_seq = bvamd::load_fasta_sequence(reference, ref_id); fa_of = ref_id; }
+                if (beg < 1 || end < beg || end > fa_seq.size()) die("[ERROR] region outside " + ref_id);
+                for (uint32_t sb = beg; sb < end + 1; sb += 500000u) {
+                    const uint32_t se = sb + 500000u - 1 > end ? end : sb + 500000u - 1;
+                    bvamd::PosMapVector v;
+                    bvamd::fetch_base_in_region(bams, fa_seq, mapq_thd, std::make_tuple(ref_id, sb, se), v, true, threads);
+                    for (uint32_t pos = sb; pos <= se; ++pos) {
+                        bvamd::BatchInfo bi;
+                        if (!bvamd::batchinfo_at(v, fa_seq, ref_id, pos, bi)) continue;
+                        slab.add_site(bi);
+                        pending.push_back(std::move(bi));
+                        if (pending.size() == batch_sites) flush();
+                    }
                 }
             }
         } catch (const std::exception &ex) { die(ex.what()); }

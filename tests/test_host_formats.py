@@ -306,3 +306,12 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
     assert [l for l in open(vcf2).read().split("\n") if l and not l.startswith("##")] == \
         [l for l in open(vcf).read().split("\n") if l and not l.startswith("##")]
     assert open(cvg2).read() == open(cvg).read()
+    # several regions in one call: the records of each, in the order given
+    vcf3, cvg3 = str(tmp_path / "vz3.vcf"), str(tmp_path / "t3.cvg")
+    subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions",
+                           "CHROMOSOME_I:1051-1200,CHROMOSOME_I:900-1050", "--mapq", "10", "--output-vcf", vcf3, "--output-cvg", cvg3,
+                           "--min-af", "0.05", "--thread", "2"])
+    rows3 = [l for l in open(cvg3).read().split("\n") if l and not l.startswith("#")]
+    lo = [l for l in crow if int(l.split("\t")[1]) <= 1050]
+    hi = [l for l in crow if int(l.split("\t")[1]) > 1050]
+    assert rows3 == hi + lo
