@@ -32,6 +32,12 @@ struct bv_engine {
     bv_engine_config cfg;
     hipStream_t stream = nullptr;      // engine-owned stream
     hipStream_t last_stream = nullptr; // stream of the last submit
+    std::vector<hipStream_t> used_streams;  // every stream that carried work since the last bv_engine_wait
+    hipEvent_t ev_done = nullptr;      // end of the last submit: a submit on ANOTHER stream waits for it (shared scratch)
+    bool ev_done_set = false;
+    uint32_t n_cu = 256;               // hipDeviceProp_t::multiProcessorCount
+    uint8_t *d_gid = nullptr;          // engine-owned copy of group_id, padded to 16 bytes with BV_NO_GROUP
+    size_t d_gid_bytes = 0;
     BvTables *d_tables = nullptr;
     double *d_lnfact = nullptr;
     uint32_t *d_var_list = nullptr;
@@ -115,6 +121,41 @@ int drain_timings(bv_engine *e, bool block) {
 }
 }  // namespace
 
+
+namespace {
+// The engine's scratch (variant list, counters, staging) is shared by its submits, so work of one engine is
+// serialised even when the caller alternates streams: a submit on a stream other than the previous one first
+// waits for the end of the previous submit.  Every stream used is remembered for bv_engine_wait.
+int use_stream(bv_engine *e, hipStream_t st) {
+    bool seen = false;
+    for (hipStream_t u : e->used_streams) seen |= (u == st);
+    if (!seen) e->used_streams.push_back(st);
+    if (e->ev_done_set && st != e->last_stream) BV_HIP(e, hipStreamWaitEvent(st, e->ev_done, 0));
+    e->last_stream = st;
+    return BV_OK;
+}
+int mark_done(bv_engine *e, hipStream_t st) {
+    BV_HIP(e, hipEventRecord(e->ev_done, st));
+    e->ev_done_set = true;
+    return BV_OK;
+}
+// group ids as the kernels read them: 16-byte chunks up to round_up(n_samples, 16) -- the ABI promises only
+// [n_samples] bytes of any alignment, so the engine keeps its own padded copy (n_samples bytes per submit)
+int stage_group_ids(bv_engine *e, const uint8_t *gid, uint32_t n_samples, bool host, hipStream_t st, const uint8_t **out) {
+    const size_t need = (((size_t)n_samples + 255) & ~(size_t)255) + 256;
+    if (need > e->d_gid_bytes) {
+        if (e->d_gid) BV_HIP(e, hipFree(e->d_gid));
+        e->d_gid = nullptr; e->d_gid_bytes = 0;
+        BV_HIP(e, hipMalloc(&e->d_gid, need));
+        e->d_gid_bytes = need;
+    }
+    BV_HIP(e, hipMemsetAsync(e->d_gid, 0xFF, need, st));
+    BV_HIP(e, hipMemcpyAsync(e->d_gid, gid, n_samples, host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
+    *out = e->d_gid;
+    return BV_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char *bv_version(void) { return "basevar_amd 0.1 abi1 gfx950"; }
@@ -159,7 +200,9 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         }                                                                                             \
     } while (0)
     BV_TRY(hipSetDevice(cfg->device));
+    e->n_cu = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     BV_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    BV_TRY(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     for (auto &tri : e->ring)
         for (auto &ev : tri) BV_TRY(hipEventCreate(&ev));
     BV_TRY(hipMalloc(&e->d_tables, sizeof(BvTables)));
@@ -167,6 +210,7 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
     BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS));
     BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * BV_CTR_WORDS));
     std::memset(e->h_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS);
+    BV_TRY(hipMemset(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS));
 
     // eps table with the host libm, exactly the reference's expression (basetype.cpp:47-48, :63)
     BvTables t;
@@ -203,6 +247,7 @@ int bv_engine_destroy(bv_engine *e) {
     if (!e) return BV_OK;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipStream_t st : e->used_streams) (void)hipStreamSynchronize(st);
     for (auto &tri : e->ring)
         for (auto &ev : tri)
             if (ev) (void)hipEventDestroy(ev);
@@ -210,6 +255,8 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_lnfact) (void)hipFree(e->d_lnfact);
     if (e->d_var_list) (void)hipFree(e->d_var_list);
     if (e->d_counters) (void)hipFree(e->d_counters);
+    if (e->d_gid) (void)hipFree(e->d_gid);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->stage) (void)hipFree(e->stage);
     if (e->tile_state) (void)hipFree(e->tile_state);
@@ -231,13 +278,13 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
                          bv_site_result *dout, bv_group_result *dgout, hipStream_t st) {
     const size_t S = n_sites, G = n_groups;
-    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
+    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));  // not the sticky error counters
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
 
     BvPass1Args a1;
     a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
     a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
-    a1.var_list = e->d_var_list; a1.counters = e->d_counters;
+    a1.var_list = e->d_var_list; a1.counters = e->d_counters; a1.n_cu = e->n_cu;
     if (e->ring_count == bv_engine::kRing) {
         int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
         if (rc != BV_OK) return rc;
@@ -256,7 +303,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
     a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
-    a2.var_list = e->d_var_list; a2.counters = e->d_counters;
+    a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu;
     bv_launch_pass2(a2, st);
     BV_HIP(e, hipGetLastError());
     BV_HIP(e, hipEventRecord(ev[2], st));
@@ -268,7 +315,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             BV_HIP(e, hipMemcpyAsync(e->host_gout, e->stage_gout, e->host_gout_bytes, hipMemcpyDeviceToHost, st));
     }
     e->submitted = true;
-    return BV_OK;
+    return mark_done(e, st);
 }
 
 int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_group_result *gout, void *stream_) {
@@ -288,13 +335,15 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     if (slab->n_groups > 0 && (!slab->group_id || !gout))
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: n_groups > 0 needs group_id and gout");
     auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
-    if (misaligned(slab->base_strand) || misaligned(slab->qual) || misaligned(slab->mapq) || misaligned(slab->rpr) ||
-        (slab->n_groups && misaligned(slab->group_id)))
+    if (misaligned(slab->base_strand) || misaligned(slab->qual) || misaligned(slab->mapq) || misaligned(slab->rpr))
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: planes must be 16-byte aligned");
 
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
-    e->last_stream = st;
+    {
+        int rc = use_stream(e, st);
+        if (rc != BV_OK) return rc;
+    }
 
     const uint8_t *bs = slab->base_strand, *q = slab->qual, *mq = slab->mapq, *refb = slab->ref_base,
                   *gid = slab->group_id;
@@ -306,7 +355,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         // stage host planes into one device allocation (grown on demand)
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
         size_t o_bs = 0, o_q = o_bs + up(S * P), o_mq = o_q + up(S * P), o_rp = o_mq + (mq ? up(S * P) : 0),
-               o_ref = o_rp + (rp ? up(S * P * 2) : 0), o_gid = o_ref + up(S), o_out = o_gid + (G ? up(P) : 0),
+               o_ref = o_rp + (rp ? up(S * P * 2) : 0), o_gid = o_ref + up(S), o_out = o_gid,
                o_gout = o_out + up(S * sizeof(bv_site_result)), total = o_gout + up(S * G * sizeof(bv_group_result));
         if (total > e->stage_bytes) {
             if (e->stage) BV_HIP(e, hipFree(e->stage));
@@ -321,15 +370,10 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, st));
         if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, st));
         BV_HIP(e, hipMemcpyAsync(base + o_ref, refb, S, hipMemcpyHostToDevice, st));
-        if (G) {
-            BV_HIP(e, hipMemsetAsync(base + o_gid, 0xFF, up(P), st));
-            BV_HIP(e, hipMemcpyAsync(base + o_gid, gid, slab->n_samples, hipMemcpyHostToDevice, st));
-        }
         bs = base + o_bs; q = base + o_q;
         mq = mq ? base + o_mq : nullptr;
         rp = rp ? reinterpret_cast<const uint16_t *>(base + o_rp) : nullptr;
         refb = base + o_ref;
-        gid = G ? base + o_gid : nullptr;
         dout = reinterpret_cast<bv_site_result *>(base + o_out);
         dgout = G ? reinterpret_cast<bv_group_result *>(base + o_gout) : nullptr;
         e->stage_out = dout; e->stage_gout = dgout;
@@ -338,6 +382,10 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         e->host_gout_bytes = S * G * sizeof(bv_group_result);
     } else {
         e->host_out = nullptr; e->host_gout = nullptr;
+    }
+    if (G) {
+        int rc = stage_group_ids(e, slab->group_id, slab->n_samples, slab->mem_kind == BV_MEM_HOST, st, &gid);
+        if (rc != BV_OK) return rc;
     }
 
     return launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st);
@@ -433,7 +481,10 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: more samples than announced");
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
-    e->last_stream = st;
+    {
+        int rc = use_stream(e, st);
+        if (rc != BV_OK) return rc;
+    }
     const uint8_t *bs = t->base_strand, *q = t->qual, *mq = e->tile_ranks ? t->mapq : nullptr, *gid = e->tile_groups ? t->group_id : nullptr;
     const uint16_t *rp = e->tile_ranks ? t->rpr : nullptr;
     const size_t S = t->n_sites, P = t->pitch;
@@ -494,7 +545,7 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
         if (gid) BV_HIP(e, hipMemcpyAsync(e->j_buf + e->j_o_gid + lo, gid, w, hipMemcpyDeviceToDevice, st));
         if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }
         e->tile_samples_seen += t->n_samples;
-        return BV_OK;
+        return mark_done(e, st);
     }
     BvTileArgs a;
     a.bs = bs; a.q = q; a.mapq = mq; a.rpr = rp; a.group_id = gid; a.pitch = P; a.n_sites = t->n_sites;
@@ -504,7 +555,7 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     BV_HIP(e, hipGetLastError());
     if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }
     e->tile_samples_seen += t->n_samples;
-    return BV_OK;
+    return mark_done(e, st);
 }
 
 int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result *out, bv_group_result *gout,
@@ -514,7 +565,10 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     if (e->tile_groups && !gout) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_finish: job has groups, gout is NULL");
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
-    e->last_stream = st;
+    {
+        int rc = use_stream(e, st);
+        if (rc != BV_OK) return rc;
+    }
     const size_t S = e->tile_sites, G = e->tile_groups;
     const uint8_t *dref = ref_base;
     bv_site_result *dout = out;
@@ -536,7 +590,6 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
         e->host_out_bytes = S * sizeof(bv_site_result);
         e->host_gout_bytes = S * G * sizeof(bv_group_result);
     }
-    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS, st));
     if (e->tile_join) {
         e->tile_open = false;
         return launch_passes(e, e->j_buf, e->j_buf + e->j_o_q, e->tile_ranks ? e->j_buf + e->j_o_mq : nullptr,
@@ -544,6 +597,7 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
                              G ? e->j_buf + e->j_o_gid : nullptr, e->j_pitch, e->tile_sites, e->tile_samples_total, e->tile_groups,
                              dout, dgout, st);
     }
+    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
     BvTileFinishArgs f;
     f.state = e->tile_state; f.maxr = e->tile_maxr; f.ref_base = dref; f.n_sites = e->tile_sites; f.n_groups = e->tile_groups;
@@ -559,7 +613,8 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     }
     e->tile_open = false;
     e->submitted = true;
-    return BV_OK;
+    e->last_slot = -1;  // no pass-1/pass-2 event triplet for this realisation: bv_engine_kernel_ms has nothing to report
+    return mark_done(e, st);
 }
 
 void *bv_engine_stream(bv_engine *e) { return e ? (void *)e->stream : nullptr; }
@@ -568,14 +623,25 @@ int bv_engine_wait(bv_engine *e) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_wait: null engine");
     if (!e->submitted) return BV_OK;
     BV_HIP(e, hipSetDevice(e->cfg.device));
-    BV_HIP(e, hipStreamSynchronize(e->last_stream));
-    if (e->h_counters[BV_CTR_TIMEOUT] != 0)
+    // every stream that carried a submit since the last wait (submits of one engine are serialised through ev_done,
+    // so the counters mirrored by the LAST submit are final once all of them have drained)
+    for (hipStream_t st : e->used_streams) BV_HIP(e, hipStreamSynchronize(st));
+    e->used_streams.clear();
+    e->used_streams.push_back(e->last_stream);
+    const uint32_t timed_out = e->h_counters[BV_CTR_TIMEOUT], zero_freq = e->h_counters[BV_CTR_ZEROFREQ];
+    if (timed_out != 0 || zero_freq != 0) {
+        // the error counters are sticky on the device (they accumulate over submits): reported once, then cleared
+        BV_HIP(e, hipMemsetAsync(e->d_counters + BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, 0,
+                                 sizeof(uint32_t) * (BV_CTR_WORDS - BV_CTR_PER_LAUNCH * BV_CTR_STRIDE), e->last_stream));
+        BV_HIP(e, hipStreamSynchronize(e->last_stream));
+        e->h_counters[BV_CTR_TIMEOUT] = e->h_counters[BV_CTR_ZEROFREQ] = 0;
+    }
+    if (timed_out != 0)
         return fail(e, BV_ERR_HIP, "pass 1: an intra-workgroup hand-off timed out (internal error; results invalid)");
-    if (e->h_counters[BV_CTR_ZEROFREQ] > 0) {
+    if (zero_freq > 0) {
         char buf[160];
         std::snprintf(buf, sizeof buf,
-                      "The sum of frequence of active bases must always > 0 (%u site(s); see BV_SITE_ZERO_FREQ)",
-                      e->h_counters[BV_CTR_ZEROFREQ]);
+                      "The sum of frequence of active bases must always > 0 (%u site(s); see BV_SITE_ZERO_FREQ)", zero_freq);
         return fail(e, BV_ERR_SITE, buf);  // message of src/basetype.cpp:114
     }
     return BV_OK;
@@ -583,6 +649,8 @@ int bv_engine_wait(bv_engine *e) {
 
 int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms) {
     if (!e || !e->submitted) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_kernel_ms: nothing submitted");
+    if (e->last_slot < 0)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_kernel_ms: the last job recorded no pass timings (per-site-tally tile job)");
     float a = 0.f, b = 0.f;
     hipEvent_t *t = e->ring[e->last_slot];
     BV_HIP(e, hipEventSynchronize(t[2]));

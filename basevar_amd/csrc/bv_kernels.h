@@ -7,11 +7,17 @@
 // Device counters, each on a 128-byte line of its own (they are hit by atomics from every
 // workgroup; sharing one line would serialise them at the memory-side atomic unit).
 #define BV_CTR_STRIDE 32u                  /* words */
+// The first BV_CTR_PER_LAUNCH lines are zeroed before every launch; the error counters behind them are STICKY:
+// they accumulate over submits and are cleared only by bv_engine_wait, so that a time-out or a zero-frequency
+// site of an earlier batch of a pipelined sequence of submits is still reported.
 #define BV_CTR_VARIANTS (0u * BV_CTR_STRIDE)  /* number of BV_SITE_VARIANT sites = length of var_list */
-#define BV_CTR_ZEROFREQ (1u * BV_CTR_STRIDE)  /* sites with BV_SITE_ZERO_FREQ                         */
-#define BV_CTR_TICKET (2u * BV_CTR_STRIDE)    /* pass-1 site ticket counter                           */
-#define BV_CTR_TIMEOUT (3u * BV_CTR_STRIDE)   /* pass-1 pipeline time-out flag                        */
-#define BV_CTR_WORDS (4u * BV_CTR_STRIDE)
+#define BV_CTR_TICKET (1u * BV_CTR_STRIDE)    /* pass-1 site ticket counter                           */
+#define BV_CTR_CANDS (2u * BV_CTR_STRIDE)     /* short rows: number of candidate sites = length of cand_list */
+#define BV_CTR_TICKET2 (3u * BV_CTR_STRIDE)   /* short rows: ticket counter of the candidate solver   */
+#define BV_CTR_PER_LAUNCH 4u                  /* lines zeroed per launch                              */
+#define BV_CTR_ZEROFREQ (4u * BV_CTR_STRIDE)  /* sticky: sites with BV_SITE_ZERO_FREQ                 */
+#define BV_CTR_TIMEOUT (5u * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag                */
+#define BV_CTR_WORDS (6u * BV_CTR_STRIDE)
 
 struct BvPass1Args {
     const uint8_t *bs;        // [n_sites][pitch]
@@ -25,7 +31,8 @@ struct BvPass1Args {
     const BvTables *tables;
     bv_site_result *out;      // [n_sites]
     uint32_t *var_list;       // [n_sites]  indices of BV_SITE_VARIANT sites (unordered)
-    uint32_t *counters;       // BV_CTR_* words, all zeroed before the launch
+    uint32_t *counters;       // BV_CTR_* words; VARIANTS and TICKET zeroed before the launch
+    uint32_t n_cu;            // compute units of the device (hipDeviceProp_t::multiProcessorCount): sizes persistent grids
 };
 
 struct BvPass2Args {
@@ -45,6 +52,7 @@ struct BvPass2Args {
     bv_group_result *gout;    // [n_sites][n_groups] or NULL
     const uint32_t *var_list;
     const uint32_t *counters;
+    uint32_t n_cu;
 };
 
 // sample-axis tile mode (bv_tiles.hip)

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass
 static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
     uint32_t per_cu = (a.flags >> 12) & 0xFu;  // tuning knob: resident workgroups per CU (0 = default)
     if (per_cu == 0) per_cu = (uint32_t)BV_FUSED_OCC;  // ~38 KiB of LDS and 4 x 168 VGPRs per workgroup -> 3 resident per CU
-    uint32_t grid = 256u * per_cu;
+    uint32_t grid = (a.n_cu ? a.n_cu : 256u) * per_cu;
     const uint32_t need = (a.n_sites + BV_FUSED_TICKET * BV_FUSED_WAVES - 1) / (BV_FUSED_TICKET * BV_FUSED_WAVES);
     if (grid > need) grid = need > 0 ? need : 1;
     hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_FUSED_WAVES), 0, stream, a);
@@ -446,7 +446,7 @@ static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     // never more than there are sites.
     constexpr uint32_t by_vgpr = 16u / (NTALLY + NSOLVE);
     constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + BV_RING_EXTRA, NSOLVE>));
-    uint32_t grid = 256u * (by_vgpr < by_lds ? by_vgpr : by_lds);
+    uint32_t grid = (a.n_cu ? a.n_cu : 256u) * (by_vgpr < by_lds ? by_vgpr : by_lds);
     if (grid > a.n_sites) grid = a.n_sites;
     hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
 }

@@ -62,7 +62,7 @@ __device__ __forceinline__ void bv_p2_dword(BvP2Ctx &cx, uint32_t w, uint32_t mq
             }
             if (GROUPS) {
                 uint32_t g = (gg >> (8 * j)) & 0xFFu;
-                if (g < cx.n_groups) atomicAdd(&cx.hg[((g * 4u + b) << 7) | ((qq >> (8 * j)) & 0x7Fu)], 1u);
+                if (g < cx.n_groups) atomicAdd(&cx.hg[((g * 4u + b) << 7) | min((qq >> (8 * j)) & 0xFFu, 127u)], 1u);  // phred >= 128: invalid bin 127 (in the depth, in no valid bin -- as in pass 1)
             }
         }
     }
@@ -382,7 +382,7 @@ void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream) {
     const bool ranks = a.mapq != nullptr && a.rpr != nullptr;
     const bool groups = a.n_groups > 0 && a.group_id != nullptr && a.gout != nullptr;
     if (a.n_samples <= 16384u && ranks && !groups) {
-        uint32_t grid = 256u * 4u;  // 16 KiB of LDS and <= 128 VGPRs: 4 workgroups per CU
+        uint32_t grid = (a.n_cu ? a.n_cu : 256u) * 4u;  // 16 KiB of LDS and <= 128 VGPRs: 4 workgroups per CU
         const uint32_t need = (a.n_sites + BV_P2S_WAVES - 1) / BV_P2S_WAVES;
         if (grid > need) grid = need;
         hipLaunchKernelGGL(bv_pass2_short_kernel, dim3(grid), dim3(BV_WAVE * BV_P2S_WAVES), 0, stream, a);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void bv_tile_tally_kernel(BvTileArgs a) {
             }
             if (a.n_groups) {
                 const uint32_t g = a.group_id[smp];
-                if (g < a.n_groups) atomicAdd(&S[BV_TS_HG + (((g * 4u + b) << 7) | (q & 127u))], 1u);
+                if (g < a.n_groups) atomicAdd(&S[BV_TS_HG + (((g * 4u + b) << 7) | min(q, 127u))], 1u);
             }
         }
     }

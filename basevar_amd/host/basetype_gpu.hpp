@@ -68,7 +68,13 @@ public:
                     throw std::runtime_error("[ERROR] Why dose the size of aligned base is not 1? Check: " + tok);
                 const int c = base_code(fb);
                 if (c == BV_BASE_OTHER) {
-                    cell = BV_CELL_N;  // non-ACGT single characters never reach the path (bam_record.h:28-31)
+                    // A single character outside ACGTN+- : the reference would count it in total_depth and give it
+                    // an all-eps/3 likelihood row (src/basetype.cpp:58-64).  Its own pileup never writes one
+                    // (bam_record.h:28-31, caller.cpp:1060-1077) and the slab has no code for it, so such a token is
+                    // refused loudly instead of being dropped silently.
+                    throw std::runtime_error(std::string("[ERROR] base character '") + fb +
+                                             "' is outside ACGTN+-: not representable in the slab (the reference would "
+                                             "count it in the depth)");
                 } else {
                     const char s = bi.map_strands[i];
                     if (s != '+' && s != '-')  // src/basetype.cpp:272

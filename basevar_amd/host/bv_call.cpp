@@ -6,7 +6,7 @@
 // _get_popgroup_info does (src/basetype_caller.cpp:372-410).
 //
 //   bv_call --batchfiles a.bf.gz,b.bf.gz --output-vcf out.vcf --output-cvg out.cvg
-//           [--pop-group FILE] [--min-af 0.01] [--batch-sites 4096] [--device 0]
+//           [--pop-group FILE] [--min-af 0.01] [--batch-sites N (default: min(4096, 2^26 / samples))] [--device 0]
 //           [--reference ref.fa --contig NAME:LENGTH ...]
 //   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END[,CHR:BEG-END...] [--mapq 10]
 //           [--thread T] ...   (same outputs)
@@ -14,6 +14,7 @@
 // Batchfiles may be bgzip/gzip-compressed or plain (zlib reads all three).  With BAM inputs the pileup
 // (pileup.hpp) feeds the engine directly: the same cells the batchfile rows would carry,
 // without the text round trip.
+#include <algorithm>
 #include <zlib.h>
 
 #include <cstdio>
@@ -66,7 +67,7 @@ int main(int argc, char **argv) {
     int mapq_thd = 10, threads = 1;
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
-    uint32_t batch_sites = 4096;
+    uint32_t batch_sites = 0;  // 0 = from a cell budget once the sample count is known
     int device = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -100,6 +101,7 @@ int main(int argc, char **argv) {
             bams.push_back(e == std::string::npos ? line : line.substr(0, e));
         }
     }
+    if (!(user_min_af > 0.f)) die("[ERROR] --min-af must be > 0");  // the reference refuses it too (caller.cpp:73)
     const bool from_bam = !bams.empty();
     if ((batchfiles.empty() && !from_bam) || out_vcf.empty() || out_cvg.empty() || (from_bam && (regions.empty() || reference == ".")))
         die("usage: bv_call (--batchfiles a,b,... | -I a.bam [-I ...] -R ref.fa --regions CHR:BEG-END [--mapq Q]) --output-vcf FILE "
@@ -165,6 +167,12 @@ int main(int argc, char **argv) {
     std::fwrite(hc.data(), 1, hc.size(), CVG);
 
     // ---- engine
+    // pending sites keep their BatchInfo text (~42 B per cell) next to the 5 B/cell slab until they are emitted:
+    // bound a batch by cells (2^26 cells ~ 3 GB of host memory), not by a site count that ignores the row length
+    if (batch_sites == 0) {
+        const size_t by_cells = ((size_t)1 << 26) / std::max<size_t>(n_sample, 1);
+        batch_sites = (uint32_t)std::min<size_t>(4096, std::max<size_t>(by_cells, 1));
+    }
     bvamd::BaseTypeEngine engine(batch_sites, (uint32_t)n_sample, user_min_af, device);
     bvamd::SlabBuilder slab((uint32_t)n_sample);
     if (!group_names.empty()) slab.set_groups(group_id, (uint32_t)group_names.size());

@@ -60,7 +60,32 @@ def parse():
     ap.add_argument("--tile-sites", type=int, default=16384, help="sites per tile job (at most --batch-sites)")
     ap.add_argument("--with-host-path", action="store_true",
                     help="also time the PCIe-inclusive path: pinned host planes staged by the engine (never `value`)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch-sites per GPU per step (default); strong: --batch-sites is the WHOLE job's batch "
+                         "per step and every rank takes its contiguous 1/N of it (the fixed 1 M-site job of BASELINE "
+                         "configs[3] = 8 steps of 131072 sites whatever N)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) without a torch.distributed environment: start the N ranks ourselves,
+    the way the driver does, as a CHILD process tree (`python -m torch.distributed.run ...`), relay rank 0's JSON
+    line (the children inherit stdout/stderr) and exit with the launcher's code.  Called before this process has
+    touched torch.cuda or HIP, and it never execs: the parent only waits.  (Reference analogue: the in-process
+    fan-out of _variants_discovery, src/basetype_caller.cpp:469-525.)"""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env["BASEVAR_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        print("[bench] the %d-rank launch failed (exit code %d); see the ranks' messages above" % (args.gpus, rc),
+              file=sys.stderr)
+    sys.exit(rc if rc != 0 else 0)
 
 
 def cpu_baseline(torch, planes, n_samples, maf, want_sites):
@@ -154,6 +179,8 @@ def parity_on_sample(gpu, cpu):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -162,9 +189,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (
-                args.gpus, args.gpus))
+        sys.exit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with --nproc-per-node %d, or without a "
+                 "torch.distributed environment (it then starts its own ranks)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the engine has no CPU path")
     # BASEVAR_BENCH_BACKEND=gloo + BASEVAR_BENCH_ONE_DEVICE=1 let the multi-rank plumbing be exercised
@@ -192,6 +218,10 @@ def main():
 
     N = args.samples
     B = args.batch_sites
+    if args.scaling == "strong":
+        if args.batch_sites % world:
+            sys.exit("bench.py --scaling strong: --batch-sites must be a multiple of the number of ranks")
+        B = args.batch_sites // world  # this rank's contiguous share of the job's batch
     pitch = (N + 255) // 256 * 256
     maf = basevar_amd.min_af(N)
     nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
@@ -322,14 +352,20 @@ def main():
         line = {
             "metric": "genomic sites/sec through basetype caller at N samples",
             "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
-                            "HBM-resident batches of %d sites per GPU per step (1M-site job = %d such steps)" % (
-                                N, args.coverage, B, (1000000 + B - 1) // B),
+                            "HBM-resident batches of %d sites per GPU per step (%s; 1M-site job = %d such steps)" % (
+                                N, args.coverage, B,
+                                "strong scaling: the job's %d-site batch split over the ranks" % (world * B)
+                                if args.scaling == "strong" else "weak scaling: per-GPU batch fixed",
+                                (1000000 + world * B - 1) // (world * B) if args.scaling == "strong" else (1000000 + B - 1) // B),
                 "samples": N, "batch_sites": B, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
                 "parallelism": "site-sharded x%d, gather of %d-byte records to rank 0" % (world, rec),
+                "job_batch_sites": world * B, "backend": (backend if dist_on else None),
+                "rccl_ranks": (dist.get_world_size() if dist_on and backend == "nccl" else 0),
+                "dist_world_size": (dist.get_world_size() if dist_on else 1),
                 "variant_sites_last_batch": nvar, "gathered_records_ok": gathered_ok,
             },
             "roofline": {

@@ -1,5 +1,6 @@
-"""bench.py launched exactly as the driver does for N > 1 (torch.distributed.run, one process per
-rank), here with 2 ranks.  On the single-GPU box both ranks share cuda:0 and use the gloo backend
+"""bench.py with 2 ranks, started both ways: as the driver does for N > 1 (torch.distributed.run, one
+process per rank) and self-launched (`python bench.py --gpus 2` without a torch.distributed environment
+starts its own ranks as child processes before touching the GPU).  On the single-GPU box both ranks share cuda:0 and use the gloo backend
 (RCCL refuses two ranks on one device), which still exercises rank/env handling, per-rank site
 ranges, the ordered gather of records to rank 0, max-over-ranks timing and the JSON contract."""
 import json
@@ -31,6 +32,42 @@ def test_bench_two_ranks_gloo_one_device():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_self_launch_two_ranks(scaling):
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the parent starts the two ranks itself."""
+    env = dict(os.environ, BASEVAR_BENCH_BACKEND="gloo", BASEVAR_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--samples",
+           "20000", "--batch-sites", "2048", "--no-cpu-baseline", "--scaling", scaling]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["config"]["gathered_records_ok"] is True
+    assert d["config"]["dist_world_size"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["batch_sites"] == (1024 if scaling == "strong" else 2048)
+    assert d["config"]["job_batch_sites"] == (2048 if scaling == "strong" else 4096)
+
+
+def test_bench_self_launch_fails_in_the_children_without_a_gpu():
+    """On a GPU-less box `python bench.py --gpus 2` must get as far as starting its ranks: the failure is the
+    ranks' "needs a GPU" check, relayed with a non-zero exit code -- not an argument check in the parent."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by test_bench_self_launch_two_ranks")
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs a GPU") == 2, p.stderr[-2000:]   # both ranks got to the GPU check
+    assert "2-rank launch failed" in p.stderr and "must be launched with" not in p.stderr
+
+
+@pytest.mark.gpu
 def test_bench_rccl_backend_single_rank():
     """The backend the driver's N > 1 runs use ("nccl" = RCCL), forced on with ONE rank: process-group
     init bound to the device, the asynchronous gather issued on the engine's own HIP stream (wrapped as a
@@ -45,3 +82,4 @@ def test_bench_rccl_backend_single_rank():
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["gathered_records_ok"] is True and d["value"] > 0
+    assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
