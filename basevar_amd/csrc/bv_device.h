@@ -42,6 +42,8 @@ struct BvTables {
     const double *lnfact;  // lnfact[k] = lgamma(k + 1) (host glibc), k < lnfact_n; device memory
     uint32_t lnfact_n;
     uint32_t pad_;
+    double loghit[BV_QBINS];   // log(hit[q]), log(miss[q]) with the host's log(): the per-sample log-marginals of a
+    double logmiss[BV_QBINS];  // single-base subset (algorithm.h:243 with f == 1), see bv_lrt
 };
 
 // ------------------------------------------------------------------ wave reductions
@@ -561,6 +563,8 @@ struct BvBins {
                            // stored in the unused upper halves of the histogram rows, bv_pass1.hip)
     const double *hit;     // LDS copy of BvTables::hit  (1 - eps)
     const double *miss;    // LDS copy of BvTables::miss (eps / 3)
+    const double *loghit;  // BvTables::loghit / logmiss (device memory, L2-resident), or NULL: single-base subsets then
+    const double *logmiss; // run the iterative EM like every other subset
     int nb;                // number of bins (wave-uniform)
 };
 
@@ -756,6 +760,8 @@ struct BvLrtShared {
     double f[2][4][4];  // [level parity][combination][base]
     double lr[2][4];
     int iters[2][4];
+    double single[4];   // closed-form log-likelihoods of the four single-base subsets (wave mode; kept here, not in
+                        // registers: the solver runs at the 128-VGPR limit)
 };
 
 struct BvLrtOut {
@@ -828,6 +834,7 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
 
     double fr0 = 0., fr1 = 0., fr2 = 0., fr3 = 0.;  // active_bases_freq
     double lr_alt = 0., chi = 0.;
+    bool have_single = false;  // sh->single[] holds the closed-form log-likelihoods of the single-base subsets
     int par = 0;
     // n == m0: F_m over the full active set (basetype.cpp:144); n < m0: the loop of :151-169,
     // whose bound is the ORIGINAL size while the subsets are drawn from the current set.
@@ -847,13 +854,61 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             double s = 0.;
             s += f[0]; s += f[1]; s += f[2]; s += f[3];
             double lr;
-            // phred-0 calls (1 - eps == 0) and all-zero starts make 0/0 in the reference: exact replay
+            int it;
+            if (NW == 0 && B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
+                // A single-base subset {b} with every likelihood positive: the reference's EM needs no arithmetic.  Its
+                // first e_step gives every sample the posterior L/L == 1.0 for b, the m_step f_b == n/n == 1.0, and from
+                // then on every marginal is the likelihood itself (lh * 1.0), so the reported log-likelihood is
+                //     sum_i log(lh_i[b]) = sum_bins c * (bin's base == b ? log(1 - eps_q) : log(eps_q / 3))
+                // with the host's log() of the host's table values -- the reference's own per-sample terms.  One sweep
+                // yields the sums of all four bases: lr_b = sum c * logmiss + sum_{bins of b} c * (loghit - logmiss).
+                // The loop runs twice when the start frequency is below 1/e (the first delta is |int(-log f_init)|
+                // per sample, algorithm.h:245), else once.
+                if (!have_single) {
+                    double a_ = 0., g0 = 0., g1 = 0., g2 = 0., g3 = 0.;
+                    const int nslots = (B.nb + BV_WAVE - 1) / BV_WAVE;
+#pragma unroll
+                    for (int sl = 0; sl < BV_SLOTS; ++sl) {
+                        if (sl < nslots) {
+                            const int i = sl * BV_WAVE + lane;
+                            if (i < B.nb) {
+                                const int at = bv_bin_at(B, i);
+                                const uint32_t code = B.code[at];
+                                const double cc = (double)B.cnt[at];
+                                const double lm = B.logmiss[code & 127u], dh = B.loghit[code & 127u] - lm;
+                                const uint32_t bb = code >> 7;
+                                a_ += cc * lm;
+                                g0 += (bb == 0) ? cc * dh : 0.;
+                                g1 += (bb == 1) ? cc * dh : 0.;
+                                g2 += (bb == 2) ? cc * dh : 0.;
+                                g3 += (bb == 3) ? cc * dh : 0.;
+                            }
+                        }
+                    }
+                    a_ = bv_wave_sum(a_);
+                    bv_wave_sum4(g0, g1, g2, g3, g0, g1, g2, g3);
+                    if (lane == 0) {
+                        sh->single[0] = a_ + g0; sh->single[1] = a_ + g1;
+                        sh->single[2] = a_ + g2; sh->single[3] = a_ + g3;
+                    }
+                    bv_lrt_sync<NW>();
+                    have_single = true;
+                }
+                const int b1 = __builtin_ctz(in_set);
+                lr = sh->single[b1];
+                const double f_init = bv_sel4(f[0], f[1], f[2], f[3], b1);
+                it = (f_init < 0.36787944117144233) ? 2 : 1;
+                f[0] = (b1 == 0) ? 1.0 : 0.; f[1] = (b1 == 1) ? 1.0 : 0.;
+                f[2] = (b1 == 2) ? 1.0 : 0.; f[3] = (b1 == 3) ? 1.0 : 0.;
+            } else {
+                // phred-0 calls (1 - eps == 0) and all-zero starts make 0/0 in the reference: exact replay
 #ifdef BV_EXP_NO_GENERIC_EM  /* code-size experiment only: wrong for phred-0 sites */
-            int it = bv_em_wave(B, f, in_set, n_cov, &lr, lane);
+                it = bv_em_wave(B, f, in_set, n_cov, &lr, lane);
 #else
-            int it = (q0_mask != 0u || s == 0.) ? bv_em_wave_generic(B, f, n_cov, &lr, lane)
+                it = (q0_mask != 0u || s == 0.) ? bv_em_wave_generic(B, f, n_cov, &lr, lane)
                                                 : bv_em_wave(B, f, in_set, n_cov, &lr, lane);
 #endif
+            }
             if (lane == 0) {
                 sh->f[par][c][0] = f[0]; sh->f[par][c][1] = f[1];
                 sh->f[par][c][2] = f[2]; sh->f[par][c][3] = f[3];

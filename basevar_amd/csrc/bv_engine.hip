@@ -44,10 +44,13 @@ struct bv_engine {
     uint32_t *d_counters = nullptr;    // BV_CTR_* words (bv_kernels.h)
     uint32_t *h_counters = nullptr;    // pinned host mirror
     static constexpr int kRing = 256;
-    hipEvent_t ring[kRing][3] = {};    // per-submit event triplets
+    hipEvent_t ring[kRing][4] = {};    // per-submit events: start, end of pass 1, end of pass 2, [3] end of the streaming kernel of pass 1
     int ring_head = 0, ring_count = 0; // pending (not yet accumulated) triplets
     int last_slot = -1;
-    double acc1_ms = 0., acc2_ms = 0.;
+    double acc1_ms = 0., acc2_ms = 0., acc_stream_ms = 0.;
+    // short rows (bv_pass1_short.hip): HBM scratch between the streaming kernel and the solve kernel
+    BvSiteSummary *d_summ = nullptr;
+    uint32_t *d_bins = nullptr, *d_cand_list = nullptr;
     uint32_t acc_n = 0;
     bool submitted = false;
     // host-slab staging (BV_MEM_HOST)
@@ -109,11 +112,13 @@ int drain_timings(bv_engine *e, bool block) {
         } else if (hipEventQuery(t[2]) != hipSuccess) {
             break;
         }
-        float a = 0.f, b = 0.f;
+        float a = 0.f, b = 0.f, c = 0.f;
         BV_HIP(e, hipEventElapsedTime(&a, t[0], t[1]));
         BV_HIP(e, hipEventElapsedTime(&b, t[1], t[2]));
+        BV_HIP(e, hipEventElapsedTime(&c, t[0], t[3]));
         e->acc1_ms += a;
         e->acc2_ms += b;
+        e->acc_stream_ms += c;
         e->acc_n += 1;
         e->ring_count -= 1;
     }
@@ -219,6 +224,10 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         double epsilon = exp((double)qv * MLN10TO10);
         t.hit[qv] = 1.0 - epsilon;
         t.miss[qv] = epsilon / 3;
+        // log of the two likelihood values with the host libm (algorithm.h:243 takes log of exactly these when a
+        // subset holds one base); log(0) = -inf at phred 0 is never read (such sites take the iterative path)
+        t.loghit[qv] = log(t.hit[qv]);
+        t.logmiss[qv] = log(t.miss[qv]);
     }
     // log-factorials for the Fisher test with the host libm -- kfunc.c:197-201 calls lgamma(n + 1) --
     // for every depth a site of this engine can reach (deeper tables fall back to a series on the device)
@@ -256,6 +265,9 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_var_list) (void)hipFree(e->d_var_list);
     if (e->d_counters) (void)hipFree(e->d_counters);
     if (e->d_gid) (void)hipFree(e->d_gid);
+    if (e->d_summ) (void)hipFree(e->d_summ);
+    if (e->d_bins) (void)hipFree(e->d_bins);
+    if (e->d_cand_list) (void)hipFree(e->d_cand_list);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     if (e->stage) (void)hipFree(e->stage);
@@ -294,9 +306,35 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     e->ring_count += 1;
     e->last_slot = slot;
     hipEvent_t *ev = e->ring[slot];
+    // Short rows take the two-kernel form of pass 1 (bv_pass1_short.hip); bits 8-11 of the flags force a kernel for
+    // tuning runs (9: the one-kernel short-row form; 1, 2, 5: a long-row workgroup shape).
+    const uint32_t shape = (e->cfg.flags >> 8) & 0xFu;
+    const bool two_kernel = (shape == 0 && n_samples <= BV_SHORT_ROW_MAX) || shape == 10;
+    if (two_kernel && n_samples > 65535u)
+        return fail(e, BV_ERR_INVALID_ARG, "the two-kernel short-row pass 1 holds bin counts in 16 bits: n_samples <= 65535");
     BV_HIP(e, hipEventRecord(ev[0], st));
-    bv_launch_pass1(a1, st);
-    BV_HIP(e, hipGetLastError());
+    if (two_kernel) {
+        if (!e->d_summ) {
+            // scratch between the two kernels, sized once for cfg.max_sites: 48 B + 2 KiB + 4 B per site
+            BV_HIP(e, hipMalloc(&e->d_summ, sizeof(BvSiteSummary) * (size_t)e->cfg.max_sites));
+            BV_HIP(e, hipMalloc(&e->d_bins, sizeof(uint32_t) * BV_S_BIN_STRIDE * (size_t)e->cfg.max_sites));
+            BV_HIP(e, hipMalloc(&e->d_cand_list, sizeof(uint32_t) * (size_t)e->cfg.max_sites));
+        }
+        BvP1ShortArgs s1;
+        s1.bs = bs; s1.q = q; s1.ref_base = refb; s1.pitch = P; s1.n_sites = n_sites; s1.n_samples = n_samples;
+        s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout;
+        s1.var_list = e->d_var_list; s1.counters = e->d_counters; s1.summ = e->d_summ; s1.bins = e->d_bins;
+        s1.cand_list = e->d_cand_list;
+        bv_launch_p1s_stream(s1, st);
+        BV_HIP(e, hipGetLastError());
+        BV_HIP(e, hipEventRecord(ev[3], st));
+        bv_launch_p1s_solve(s1, st);
+        BV_HIP(e, hipGetLastError());
+    } else {
+        bv_launch_pass1(a1, st);
+        BV_HIP(e, hipGetLastError());
+        BV_HIP(e, hipEventRecord(ev[3], st));
+    }
     BV_HIP(e, hipEventRecord(ev[1], st));
 
     BvPass2Args a2;
@@ -337,6 +375,8 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
     if (misaligned(slab->base_strand) || misaligned(slab->qual) || misaligned(slab->mapq) || misaligned(slab->rpr))
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: planes must be 16-byte aligned");
+    if (slab->mem_kind != BV_MEM_HOST && misaligned(out))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: device record buffers must be 16-byte aligned");
 
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
@@ -666,7 +706,7 @@ int bv_engine_timing_reset(bv_engine *e) {
     BV_HIP(e, hipSetDevice(e->cfg.device));
     int rc = drain_timings(e, true);
     if (rc != BV_OK) return rc;
-    e->acc1_ms = e->acc2_ms = 0.;
+    e->acc1_ms = e->acc2_ms = e->acc_stream_ms = 0.;
     e->acc_n = 0;
     return BV_OK;
 }
@@ -676,6 +716,19 @@ int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_tot
     BV_HIP(e, hipSetDevice(e->cfg.device));
     int rc = drain_timings(e, true);
     if (rc != BV_OK) return rc;
+    if (pass1_total_ms) *pass1_total_ms = e->acc1_ms;
+    if (pass2_total_ms) *pass2_total_ms = e->acc2_ms;
+    if (n_submits) *n_submits = e->acc_n;
+    return BV_OK;
+}
+
+int bv_engine_timing_get_ex(bv_engine *e, double *stream_total_ms, double *pass1_total_ms, double *pass2_total_ms,
+                            uint32_t *n_submits) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_timing_get_ex: null engine");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    int rc = drain_timings(e, true);
+    if (rc != BV_OK) return rc;
+    if (stream_total_ms) *stream_total_ms = e->acc_stream_ms;
     if (pass1_total_ms) *pass1_total_ms = e->acc1_ms;
     if (pass2_total_ms) *pass2_total_ms = e->acc2_ms;
     if (n_submits) *n_submits = e->acc_n;

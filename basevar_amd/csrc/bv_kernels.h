@@ -55,6 +55,34 @@ struct BvPass2Args {
     uint32_t n_cu;
 };
 
+// short rows (bv_pass1_short.hip): pass 1 as a streaming kernel + a solve kernel that meet in HBM scratch
+#define BV_SHORT_ROW_MAX 49152u /* measured crossover with the long-row kernel (one row shared by several tally waves) */
+#define BV_S_BIN_STRIDE 512u /* words per site in the bins scratch: every non-empty (base, phred < 128) bin */
+struct __attribute__((aligned(16))) BvSiteSummary {  // 48 bytes per site
+    uint32_t fwd[4], rev[4];  // covered calls per base, forward / reverse strand
+    uint32_t nb;              // exported bins (candidate sites only)
+    uint32_t flags;           // BV_SUM_*
+    uint32_t pad_[2];
+};
+#define BV_SUM_Q0_MASK 0xFu /* bit b: base b has a phred-0 call           */
+#define BV_SUM_BADQ 0x10u   /* a covered cell had phred > 93               */
+#define BV_SUM_CAND 0x20u   /* solved by a whole wave from its bins        */
+struct BvP1ShortArgs {
+    const uint8_t *bs, *q, *ref_base;
+    uint64_t pitch;
+    uint32_t n_sites, n_samples, flags, n_cu;
+    double min_af;
+    const BvTables *tables;
+    bv_site_result *out;
+    uint32_t *var_list;
+    uint32_t *counters;
+    BvSiteSummary *summ;   // [n_sites]
+    uint32_t *bins;        // [n_sites][BV_S_BIN_STRIDE]  (code << 16 | count), candidate sites only
+    uint32_t *cand_list;   // [n_sites]
+};
+void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream);
+void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream);
+
 // sample-axis tile mode (bv_tiles.hip)
 struct BvTileArgs {
     const uint8_t *bs;        // [n_sites][pitch] tile planes (device)

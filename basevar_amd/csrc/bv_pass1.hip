@@ -32,6 +32,7 @@
 #include "bv_kernels.h"
 
 #include "bv_solver.h"
+#include "bv_tally.h"
 
 #ifndef BV_RING_EXTRA
 #define BV_RING_EXTRA 2
@@ -46,90 +47,6 @@ struct __attribute__((aligned(16))) BvPass1Shared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];  // LDS copy of BvTables
     BvSolverShared sv[NSOLVE];
 };
-
-// ------------------------------------------------------------------------------ tally
-// One cell = one byte of each plane.  v_perm_b32 glues the call byte and the phred byte into
-// X = call << 8 | phred; covered calls are 0..7, so X < 0x800 is the coverage test and X
-// is directly the histogram word index: 3 VALU + 1 ds_add_u32 per cell, and no phred byte can
-// index outside its 256-wide row.
-template <int J>
-__device__ __forceinline__ uint32_t bv_cell_index(uint32_t w, uint32_t qq) {
-    // selector bytes: result byte0 = qq.byte[J] (S1 is bytes 0-3), byte1 = w.byte[J] (S0 is 4-7)
-    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
-    return __builtin_amdgcn_perm(w, qq, SEL);
-}
-// One 16-byte chunk = 16 cells of this lane.  All 16 word addresses are formed first, unpredicated
-// (independent VALU work that pipelines), and only then come the 16 predicated ds_add_u32: a per-cell
-// perm -> cmp -> exec -> address -> ds_add chain cannot overlap with its neighbours because every
-// link goes through VCC / EXEC.
-typedef __attribute__((address_space(3))) uint32_t bv_lds_u32;
-__device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x4 &vq, uint32_t *hist, uint32_t one) {
-    uint32_t x[16];
-    x[0] = bv_cell_index<0>(vb.x, vq.x); x[1] = bv_cell_index<1>(vb.x, vq.x);
-    x[2] = bv_cell_index<2>(vb.x, vq.x); x[3] = bv_cell_index<3>(vb.x, vq.x);
-    x[4] = bv_cell_index<0>(vb.y, vq.y); x[5] = bv_cell_index<1>(vb.y, vq.y);
-    x[6] = bv_cell_index<2>(vb.y, vq.y); x[7] = bv_cell_index<3>(vb.y, vq.y);
-    x[8] = bv_cell_index<0>(vb.z, vq.z); x[9] = bv_cell_index<1>(vb.z, vq.z);
-    x[10] = bv_cell_index<2>(vb.z, vq.z); x[11] = bv_cell_index<3>(vb.z, vq.z);
-    x[12] = bv_cell_index<0>(vb.w, vq.w); x[13] = bv_cell_index<1>(vb.w, vq.w);
-    x[14] = bv_cell_index<2>(vb.w, vq.w); x[15] = bv_cell_index<3>(vb.w, vq.w);
-    // 32-bit LDS byte addresses
-    const uint32_t hbase = (uint32_t)(uintptr_t)(bv_lds_u32 *)hist;
-    uint32_t ad[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) ad[j] = hbase + (x[j] << 2);
-    // 16 coverage masks into 16 SGPR pairs (independent VALU compares), then EXEC := mask, ds_add_u32 for
-    // each cell: pure SALU + LDS issue, no VALU in the chain, no branches.  Hand-scheduled because the
-    // compiler either re-serialises the chains through VCC or branches around every add.  (LDS
-    // operations of one wave execute in order, so the histogram reads that follow need no extra wait.)
-    unsigned long long m[16], sv;
-    asm volatile(
-        "v_cmp_gt_u32_e64 %[m0], %[lim], %[x0]\n\t"
-        "v_cmp_gt_u32_e64 %[m1], %[lim], %[x1]\n\t"
-        "v_cmp_gt_u32_e64 %[m2], %[lim], %[x2]\n\t"
-        "v_cmp_gt_u32_e64 %[m3], %[lim], %[x3]\n\t"
-        "v_cmp_gt_u32_e64 %[m4], %[lim], %[x4]\n\t"
-        "v_cmp_gt_u32_e64 %[m5], %[lim], %[x5]\n\t"
-        "v_cmp_gt_u32_e64 %[m6], %[lim], %[x6]\n\t"
-        "v_cmp_gt_u32_e64 %[m7], %[lim], %[x7]\n\t"
-        "v_cmp_gt_u32_e64 %[m8], %[lim], %[x8]\n\t"
-        "v_cmp_gt_u32_e64 %[m9], %[lim], %[x9]\n\t"
-        "v_cmp_gt_u32_e64 %[m10], %[lim], %[x10]\n\t"
-        "v_cmp_gt_u32_e64 %[m11], %[lim], %[x11]\n\t"
-        "v_cmp_gt_u32_e64 %[m12], %[lim], %[x12]\n\t"
-        "v_cmp_gt_u32_e64 %[m13], %[lim], %[x13]\n\t"
-        "v_cmp_gt_u32_e64 %[m14], %[lim], %[x14]\n\t"
-        "v_cmp_gt_u32_e64 %[m15], %[lim], %[x15]\n\t"
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_and_b64 exec, %[sv], %[m0]\n\tds_add_u32 %[a0], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m1]\n\tds_add_u32 %[a1], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m2]\n\tds_add_u32 %[a2], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m3]\n\tds_add_u32 %[a3], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m4]\n\tds_add_u32 %[a4], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m5]\n\tds_add_u32 %[a5], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m6]\n\tds_add_u32 %[a6], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m7]\n\tds_add_u32 %[a7], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m8]\n\tds_add_u32 %[a8], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m9]\n\tds_add_u32 %[a9], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m10]\n\tds_add_u32 %[a10], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m11]\n\tds_add_u32 %[a11], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m12]\n\tds_add_u32 %[a12], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m13]\n\tds_add_u32 %[a13], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m14]\n\tds_add_u32 %[a14], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m15]\n\tds_add_u32 %[a15], %[one]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [m2] "=&s"(m[2]), [m3] "=&s"(m[3]), [m4] "=&s"(m[4]), [m5] "=&s"(m[5]), [m6] "=&s"(m[6]), [m7] "=&s"(m[7]), [m8] "=&s"(m[8]), [m9] "=&s"(m[9]), [m10] "=&s"(m[10]), [m11] "=&s"(m[11]), [m12] "=&s"(m[12]), [m13] "=&s"(m[13]), [m14] "=&s"(m[14]), [m15] "=&s"(m[15]), [sv] "=&s"(sv)
-        : [x0] "v"(x[0]), [a0] "v"(ad[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]), [one] "v"(one), [lim] "s"(0x800u)
-        : "memory", "scc");
-}
-
-// cells at or beyond n_samples in the row's last chunk are forced to 'N'
-__device__ __forceinline__ uint32_t bv_mask_tail_dword(uint32_t w, int keep) {
-    if (keep >= 4) return w;
-    if (keep <= 0) return 0x08080808u;
-    uint32_t low = (1u << (8 * keep)) - 1u;
-    return (w & low) | (0x08080808u & ~low);
-}
 
 // One wave streams one row, software-pipelined: two register sets of U chunks per plane, the
 // loads of the next set are in flight (16 KiB per wave) while the current set is tallied.
@@ -325,6 +242,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
         sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
         sa.min_af = a.min_af; sa.flags = a.flags;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
+    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
         for (uint32_t k = (uint32_t)s;; k += NSOLVE) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[BV_CTR_TIMEOUT]);
@@ -385,6 +303,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = a.flags;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
+    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     // Tickets are drawn BV_FUSED_TICKET sites at a time: at ~70 M short-row sites/s one ticket per
     // site would run into the ~88 M/s ceiling of atomics on a single address (measured: throughput
     // flat from 6 to 11 waves per CU until the draws were chunked).  (Drawing single sites over the last one or

@@ -1,0 +1,506 @@
+// bv_pass1_short.hip -- pass 1 for short rows (<= 49,152 samples per site): a streaming kernel and a solve kernel.
+//
+// On short rows the solve, not the stream, used to set the pace of pass 1: one wave tallied a row and then solved it,
+// and while it solved nothing of its own was in flight (40-51 % of the HBM peak at 10 k samples).  Here the two
+// halves are separate kernels that meet in a small HBM scratch:
+//
+//   bv_p1s_stream_kernel   every wave owns a contiguous range of sites and streams their rows as ONE sequence of
+//                          1 KiB + 1 KiB slots (64 lanes x 16 bytes of the call plane and of the phred plane) through
+//                          a private ring in LDS filled by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no wait until
+//                          the slot is consumed, K slots in flight per wave ACROSS row boundaries -- the next rows are
+//                          already on their way while a row's totals are formed).  Per site it leaves a 48-byte
+//                          summary (strand x base totals, flags); only sites that need the EM -- more than one active
+//                          base, a non-reference base, a phred-0 call, a deep strand table -- also export their
+//                          compacted (base, phred) bins and go on the candidate list.
+//   bv_p1s_solve_kernel    (a) every non-candidate site (hom-ref, or uncovered) is finished ONE LANE PER SITE: the
+//                          work there is scalar per site (depths, one small Fisher test), and a whole wave per
+//                          site repeated it 64 times over;  (b) every candidate gets a whole wave and the full
+//                          solver of bv_solver.h on its bins (EM / LRT / QUAL / both Fisher tests / BaseQ rank sum).
+//
+// Reference functions realised: those of bv_pass1.hip (src/basetype.cpp:22-295, src/algorithm.h:44-255,
+// htslib/kfunc.c:39-143,197-313); results are bit-identical to the one-kernel form for candidates (same bins, same
+// order, same solver) and equal to ~1e-13 relative for the per-lane Fisher test, which walks the tables exactly as
+// kt_fisher_exact does (kfunc.c:291-307, incremental hypergeo_acc with its re-seeding every 11 tables).
+//
+// HBM-bound by design (2 B per cell, each byte read once); no MFMA (categorical tallies).
+#include "bv_kernels.h"
+
+#include "bv_solver.h"
+#include "bv_tally.h"
+
+#define BV_S_HROWQ 128                       /* phred axis of the short-row histogram */
+#define BV_S_HWORDS (BV_ROWS * BV_S_HROWQ)   /* 1024 words = 4 KiB */
+#define BV_S_OVF 8                           /* + per-row counts of covered cells with phred >= 128 (invalid input) */
+#define BV_S_SLOT_WORDS 512                  /* one slot: 1 KiB of calls, then 1 KiB of phreds */
+#define BV_S_SIMPLE_MAX_TABLES 32            /* a non-candidate site's strand table has at most this many Fisher tables */
+
+// ------------------------------------------------------------------------------ LDS-DMA
+// 64 lanes x 16 bytes from base + voff into LDS at lds_dst + lane * 16; counted on vmcnt like any load.
+__device__ __forceinline__ void bv_glds16(uint32_t lds_dst, const uint8_t *base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(base)
+                 : "memory");
+}
+__device__ __forceinline__ const uint8_t *bv_uniform_ptr(const uint8_t *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+// ------------------------------------------------------------------------------ streaming kernel
+template <int NW, int K>
+struct __attribute__((aligned(16))) BvP1sStreamShared {
+    uint32_t hist[NW][BV_S_HWORDS + BV_S_OVF + 8];     // per wave: [(rev<<2)|base][phred < 128], then the overflow rows
+    uint32_t ring[NW][K][BV_S_SLOT_WORDS];             // per wave: K slots
+};
+
+// One slot of one row: tally its 64 x 16 cells into the wave's histogram.
+template <bool LAST>
+__device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint32_t chunk, uint32_t n_chunks, int tail,
+                                                  uint32_t *hist, uint32_t one) {
+    if (LAST) {
+        // the row's last slot: lanes past the row were not loaded (their LDS bytes are stale), and the last chunk may be partial
+        if (chunk >= n_chunks) {
+            vb = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+            vq = bv_u32x4{0u, 0u, 0u, 0u};
+        } else if (tail && chunk == n_chunks - 1) {
+            vb.x = bv_mask_tail_dword(vb.x, tail);
+            vb.y = bv_mask_tail_dword(vb.y, tail - 4);
+            vb.z = bv_mask_tail_dword(vb.z, tail - 8);
+            vb.w = bv_mask_tail_dword(vb.w, tail - 12);
+        }
+    }
+    // A phred byte >= 128 (invalid input) would carry into its neighbour under the shift below: such a slot takes the
+    // exact cell-by-cell path (wave-uniform branch; never taken on valid data).
+    const uint32_t hi = (vq.x | vq.y | vq.z | vq.w) & 0x80808080u;
+    if (__builtin_expect(__ballot(hi != 0u) != 0ull, 0)) {
+        const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w}, wq[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll 1
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t c = (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu, p = (wq[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            if (c < 8u) atomicAdd(p < 128u ? &hist[(c << 7) | p] : &hist[BV_S_HWORDS + c], 1u);
+        }
+        return;
+    }
+    // X = call << 8 | phred << 1 = twice the word index of the 8 x 128 histogram; call < 8 <=> X < 0x800
+    vq.x <<= 1; vq.y <<= 1; vq.z <<= 1; vq.w <<= 1;
+    bv_tally_chunk<1>(vb, vq, hist, one);
+}
+
+#ifndef BV_P1S_NW
+#define BV_P1S_NW 4
+#endif
+template <int NW, int K>
+__global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArgs a) {
+    __shared__ BvP1sStreamShared<NW, K> sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *hist = sh.hist[wave];
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(bv_lds_u32 *)sh.ring[wave][0]);
+    const uint32_t *ring = sh.ring[wave][0];
+    {
+        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+        for (int i = 0; i < (BV_S_HWORDS + BV_S_OVF + 8) / 4 / BV_WAVE + 1; ++i)
+            if (i * BV_WAVE + lane < (BV_S_HWORDS + BV_S_OVF + 8) / 4) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+    }
+    // this wave's contiguous site range
+    const uint64_t n_waves = (uint64_t)gridDim.x * NW, gw = (uint64_t)blockIdx.x * NW + (uint64_t)wave;
+    const uint32_t s0 = (uint32_t)((uint64_t)a.n_sites * gw / n_waves), s1 = (uint32_t)((uint64_t)a.n_sites * (gw + 1) / n_waves);
+    if (s0 >= s1) return;
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 63u) >> 6;
+    const int tail = (int)(a.n_samples & 15u);
+    const uint32_t voff = (uint32_t)lane * 16u;
+    const uint32_t last_valid = n_chunks - (n_slots - 1u) * 64u;  // lanes of a row's last slot that lie inside the row
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+
+    // prefetch cursor: the next slot to request
+    uint32_t p_site = s0, p_j = 0, ring_w = 0, inflight = 0;
+    auto issue = [&]() {
+        if (p_site < s1) {
+            const size_t off = (size_t)p_site * a.pitch + (size_t)p_j * 1024u;
+            const uint8_t *pb = bv_uniform_ptr(a.bs + off), *pq = bv_uniform_ptr(a.q + off);
+            const uint32_t dst = ring_lds + ring_w * (BV_S_SLOT_WORDS * 4u);
+            if (p_j + 1u < n_slots || (uint32_t)lane < last_valid) {  // lanes past the row's end load nothing
+                bv_glds16(dst, pb, voff);
+                bv_glds16(dst + 1024u, pq, voff);
+            }
+            ring_w = (ring_w + 1u == (uint32_t)K) ? 0u : ring_w + 1u;
+            ++inflight;
+            if (++p_j == n_slots) { p_j = 0; ++p_site; }
+        }
+    };
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) issue();
+
+    uint32_t ring_r = 0;
+    uint32_t cand = 0, n_cand = 0;  // lane k: the k-th candidate site of this wave since the last flush
+    uint32_t refv = 0;              // lane i: ref_base of site blk0 + i
+    uint32_t blk0 = s0;
+#pragma unroll 1
+    for (uint32_t site = s0; site < s1; ++site) {
+        if (site == blk0) {
+            // reference bases of the next 64 sites (the wait for this load also drains the ring: once per 64 sites)
+            refv = (site + (uint32_t)lane < s1) ? (uint32_t)a.ref_base[site + (uint32_t)lane] : 4u;
+            // pass the value through an asm statement: the compiler waits for the load HERE, not (with vmcnt(0), draining the
+            // ring) in front of every later use of the register
+            asm volatile("" : "+v"(refv)::"memory");
+        }
+#pragma unroll 1
+        for (uint32_t j = 0; j < n_slots; ++j) {
+            // the oldest slot in flight has landed once at most 2 (K - 1) younger loads are outstanding
+            if (inflight == (uint32_t)K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (K - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(ring + ring_r * BV_S_SLOT_WORDS + lane * 4);
+            const bv_u32x4 vq = *reinterpret_cast<const bv_u32x4 *>(ring + ring_r * BV_S_SLOT_WORDS + 256 + lane * 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers: the slot may be refilled
+            ring_r = (ring_r + 1u == (uint32_t)K) ? 0u : ring_r + 1u;
+            --inflight;
+            issue();
+            const uint32_t chunk = j * 64u + (uint32_t)lane;
+            if (j + 1u == n_slots) bv_p1s_tally_slot<true>(vb, vq, chunk, n_chunks, tail, hist, one);
+            else bv_p1s_tally_slot<false>(vb, vq, chunk, n_chunks, tail, hist, one);
+        }
+        bv_lrt_sync<0>();
+
+        // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
+        uint32_t c[4][2], facc[4], racc[4];
+        bool bad = false;
+        uint32_t q0_mask = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int qr = 0; qr < 2; ++qr) {
+                const int q = (qr << 6) | lane;
+                const uint32_t f = hist[(b << 7) | q], v = hist[((b | 4) << 7) | q];
+                c[b][qr] = f + v;
+                if (qr == 0) { facc[b] = f; racc[b] = v; } else { facc[b] += f; racc[b] += v; }
+                if (qr == 1) bad |= (c[b][qr] != 0u) && (q >= BV_NQ_VALID);
+            }
+            if (__builtin_amdgcn_readfirstlane((int)c[b][0]) != 0) q0_mask |= 1u << b;
+        }
+        uint32_t fwd[4], rev[4];
+        {
+            const uint32_t v[8] = {facc[0], facc[1], facc[2], facc[3], racc[0], racc[1], racc[2], racc[3]};
+            uint32_t t[8];
+            bv_wave_sum8_u32(v, t, lane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { fwd[b] = t[b]; rev[b] = t[4 + b]; }
+        }
+        uint32_t badq = (__ballot(bad) != 0ull) ? 1u : 0u;
+        {
+            uint32_t ovf_any = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t of = hist[BV_S_HWORDS + b], orv = hist[BV_S_HWORDS + 4 + b];
+                fwd[b] += of; rev[b] += orv;
+                ovf_any |= of | orv;
+            }
+            if (ovf_any) badq = 1u;
+        }
+        uint32_t depth[4], total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { depth[b] = fwd[b] + rev[b]; total += depth[b]; }
+
+        // ---- candidate or not.  Not a candidate: nothing covered, or exactly one active base (basetype.cpp:135-139), it is
+        // the reference base, none of its calls has phred 0, and the all-sites strand table is shallow.
+        bool is_cand = false;
+        if (total != 0u && !(a.flags & BV_FLAG_TALLY_ONLY)) {
+            const int bsel = lane & 3;
+            const bool act = (double)bv_sel4u(depth, bsel) / (int)total >= a.min_af;  // basetype.cpp:137, one base per lane
+            const uint32_t act_mask = (uint32_t)(__ballot(act) & 0xFull);
+            int ref = __builtin_amdgcn_readlane((int)refv, (int)(site - blk0));
+            if (ref > 4) ref = 4;
+            const bool one_ref = act_mask != 0u && (act_mask & (act_mask - 1u)) == 0u && ref < 4 && act_mask == (1u << ref);
+            is_cand = !one_ref || (q0_mask & act_mask) != 0u;
+            if (!is_cand) {
+                // Fisher tables of (ref_fwd, ref_rev, alt_fwd, alt_rev): imax - imin + 1 (kfunc.c:253-257)
+                const uint32_t rf = bv_sel4u(fwd, ref), rr = bv_sel4u(rev, ref);
+                const uint32_t af = fwd[0] + fwd[1] + fwd[2] + fwd[3] - rf, ar = rev[0] + rev[1] + rev[2] + rev[3] - rr;
+                const int n1_ = (int)(rf + rr), n_1 = (int)(rf + af), n = (int)total;
+                const int imax = n_1 < n1_ ? n_1 : n1_;
+                int imin = n1_ + n_1 - n;
+                if (imin < 0) imin = 0;
+                (void)ar;
+                is_cand = (imax - imin + 1) > BV_S_SIMPLE_MAX_TABLES;
+            }
+        }
+        uint32_t nb = 0;
+        if (is_cand) {
+            // every non-empty (base, phred < 128) bin, in (base, phred) order -- the order of bv_prologue_wave
+            uint32_t *dst = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                for (int qr = 0; qr < 2; ++qr) {
+                    const int q = (qr << 6) | lane;
+                    const bool valid = c[b][qr] != 0u;
+                    const unsigned long long m = __ballot(valid);
+                    const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (valid) dst[pos] = ((((uint32_t)b << 7) | (uint32_t)q) << 16) | c[b][qr];
+                    nb += (uint32_t)__popcll(m);
+                }
+            }
+            cand = ((uint32_t)lane == n_cand) ? site : cand;
+            ++n_cand;
+        }
+        {
+            // 48-byte summary: 12 lanes, one dword each
+            const uint32_t fl = q0_mask | (badq ? BV_SUM_BADQ : 0u) | (is_cand ? BV_SUM_CAND : 0u);
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                w = (lane == b) ? fwd[b] : w;
+                w = (lane == 4 + b) ? rev[b] : w;
+            }
+            w = (lane == 8) ? nb : w;
+            w = (lane == 9) ? fl : w;
+            if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
+        }
+        // ---- hand the histogram back, zeroed
+        {
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+            for (int i = 0; i < BV_S_HWORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+            if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        bv_lrt_sync<0>();
+        if (site + 1u == blk0 + 64u) blk0 += 64u;
+        if (n_cand == 64u || (site + 1u == s1 && n_cand != 0u)) {
+            // flush this wave's candidates: one atomic reserves their places in the list
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_CANDS], n_cand);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((uint32_t)lane < n_cand) a.cand_list[base + (uint32_t)lane] = cand;
+            n_cand = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ per-lane Fisher test
+// kt_fisher_exact (two-sided), htslib/kfunc.c:245-313, one table family per LANE: the walk of kfunc.c:291-307 with its
+// incremental hypergeo_acc (kfunc.c:220-243: multiplicative update, re-seeded from log-factorials whenever n11 % 11 == 0
+// or the table's n22 is 0).  log(k!) comes from the engine's table of the host's lgamma (the reference's own values).
+struct BvHgAcc {
+    int n11, n1_, n_1, n;
+    double p;
+};
+__device__ __forceinline__ double bv_lbinom_lane(const BvLnTab &T, int n, int k) {
+    if (k == 0 || n == k) return 0;
+    return bv_lnfact(T, n) - bv_lnfact(T, k) - bv_lnfact(T, n - k);
+}
+__device__ __forceinline__ double bv_hypergeo_lane(const BvLnTab &T, int n11, int n1_, int n_1, int n) {
+    return exp(bv_lbinom_lane(T, n1_, n11) + bv_lbinom_lane(T, n - n1_, n_1 - n11) - bv_lbinom_lane(T, n, n_1));
+}
+__device__ __forceinline__ double bv_hgacc_step(const BvLnTab &T, int n11, BvHgAcc &x) {  // hypergeo_acc(n11, 0, 0, 0, aux)
+    if (n11 % 11 && n11 + x.n - x.n1_ - x.n_1) {
+        if (n11 == x.n11 + 1) {
+            x.p *= (double)(x.n1_ - x.n11) / n11 * (x.n_1 - x.n11) / (n11 + x.n - x.n1_ - x.n_1);
+            x.n11 = n11;
+            return x.p;
+        }
+        if (n11 == x.n11 - 1) {
+            x.p *= (double)x.n11 / (x.n1_ - n11) * (x.n11 + x.n - x.n1_ - x.n_1) / (x.n_1 - n11);
+            x.n11 = n11;
+            return x.p;
+        }
+    }
+    x.n11 = n11;
+    x.p = bv_hypergeo_lane(T, x.n11, x.n1_, x.n_1, x.n);
+    return x.p;
+}
+__device__ inline double bv_fisher_two_sided_lane(int n11, int n12, int n21, int n22, const BvLnTab &T) {
+    const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
+    const int max = (n_1 < n1_) ? n_1 : n1_;
+    int min = n1_ + n_1 - n;
+    if (min < 0) min = 0;
+    if (min == max) return 1.;
+    BvHgAcc x;
+    x.n11 = n11; x.n1_ = n1_; x.n_1 = n_1; x.n = n;
+    x.p = bv_hypergeo_lane(T, n11, n1_, n_1, n);
+    const double q = x.p;
+    if (q == 0.0) return 0.0;  // kfunc.c:260-289: two = 0
+    double p, left, right;
+    int i, j;
+    p = bv_hgacc_step(T, min, x);
+    for (left = 0., i = min + 1; p < 0.99999999 * q && i <= max; ++i) { left += p; p = bv_hgacc_step(T, i, x); }
+    if (p < 1.00000001 * q) left += p;
+    p = bv_hgacc_step(T, max, x);
+    for (right = 0., j = max - 1; p < 0.99999999 * q && j >= 0; --j) { right += p; p = bv_hgacc_step(T, j, x); }
+    if (p < 1.00000001 * q) right += p;
+    double two = left + right;
+    if (two > 1.) two = 1.;
+    return two;
+}
+
+// ------------------------------------------------------------------------------ solve kernel
+#define BV_P1S_SOLVE_NW 4
+struct __attribute__((aligned(16))) BvP1sSolveShared {
+    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    uint32_t bin_code[BV_P1S_SOLVE_NW][BV_SLOTS * BV_WAVE];
+    uint32_t bin_cnt[BV_P1S_SOLVE_NW][BV_SLOTS * BV_WAVE];
+    uint32_t hq[BV_P1S_SOLVE_NW][4 * 128];  // merged-strand (base, phred) counts of the wave's site
+    BvSolverScratch sc[BV_P1S_SOLVE_NW];
+};
+
+__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kernel(BvP1ShortArgs a) {
+    __shared__ BvP1sSolveShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE_NW) {
+        sh.tab_hit[i] = a.tables->hit[i];
+        sh.tab_miss[i] = a.tables->miss[i];
+    }
+    __syncthreads();  // the only workgroup-wide barrier: from here the waves never meet
+    BvSolveArgs sa;
+    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
+    sa.min_af = a.min_af; sa.flags = a.flags;
+    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
+    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+
+    // ---- (a) non-candidate sites, one lane per site
+    const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;
+    const double qnan = __builtin_nan("");
+    for (uint32_t blk = gw; (uint64_t)blk * 64u < a.n_sites; blk += n_waves) {
+        const uint32_t site = blk * 64u + (uint32_t)lane;
+        if (site >= a.n_sites) continue;
+        const uint4 *sp = reinterpret_cast<const uint4 *>(&a.summ[site]);
+        const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+        if (s2.y & BV_SUM_CAND) continue;
+        const uint32_t fwd[4] = {s0.x, s0.y, s0.z, s0.w}, rev[4] = {s1.x, s1.y, s1.z, s1.w};
+        bv_site_result r;
+        {
+            uint32_t *w = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(r) / 4); ++i) w[i] = 0u;
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { r.depth[b] = fwd[b] + rev[b]; total += r.depth[b]; }
+        r.total_depth = total;
+        if (a.flags & BV_FLAG_TALLY_ONLY) {
+            // diagnostic: depths only
+        } else if (total == 0) {
+            r.mq_ranksum = r.rpr_ranksum = r.bq_ranksum = qnan;  // caller.cpp:718 / basetype.cpp:132
+        } else {
+            int ref = a.ref_base[site];
+            if (ref > 4) ref = 4;
+            uint32_t flags = BV_SITE_COVERED | ((s2.y & BV_SUM_BADQ) ? BV_SITE_BAD_QUAL : 0u);
+            uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;  // caller.cpp:1236-1245
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                if (b == ref) { c_rf += fwd[b]; c_rr += rev[b]; } else { c_af += fwd[b]; c_ar += rev[b]; }
+            }
+            if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
+                // strand_bias tail, src/basetype.cpp:277-286 (see bv_strand_bias_wave for the SOR overflow note)
+                double fs = -10 * log10(bv_fisher_two_sided_lane((int)c_rf, (int)c_rr, (int)c_af, (int)c_ar, sa.lnfact));
+                if (isinf(fs)) fs = 10000;
+                else if (fs == 0) fs = 0.0;
+                const int den = (int)(c_rr * c_af), num = (int)(c_rf * c_ar);
+                if ((unsigned long long)c_rr * c_af > 0x7fffffffull || (unsigned long long)c_rf * c_ar > 0x7fffffffull)
+                    flags |= BV_SITE_SOR_OVERFLOW;
+                r.cvg_fs = fs;
+                r.cvg_sor = (c_rr != 0u && c_af != 0u) ? (double)num / (double)den : 10000;
+                r.cvg_sb[0] = c_rf; r.cvg_sb[1] = c_rr; r.cvg_sb[2] = c_af; r.cvg_sb[3] = c_ar;
+            }
+            r.status = flags;
+            // lrt() with one active base, the reference base: no ALT, chi2 0, one EM run of one iteration (bv_lrt)
+            const bool lrt_ran = !(a.flags & BV_FLAG_SKIP_LRT);
+            r.em_iters = lrt_ran ? 1 : 0;
+            r.n_em = lrt_ran ? 1 : 0;
+            r.mq_ranksum = r.rpr_ranksum = r.bq_ranksum = qnan;
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(&a.out[site]);
+        const uint4 *src = reinterpret_cast<const uint4 *>(&r);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(r) / 16); ++i) dst[i] = src[i];
+    }
+
+    // ---- (b) candidates, one wave per site
+    const uint32_t n_cand = a.counters[BV_CTR_CANDS];
+    uint32_t *bin_code = sh.bin_code[wave], *bin_cnt = sh.bin_cnt[wave], *hq = sh.hq[wave];
+    BvSolverScratch *sv = &sh.sc[wave];
+    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+    uint32_t vlist = 0, n_vlist = 0;  // lane k: the k-th variant site of this wave since the last flush
+    auto flush_variants = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_VARIANTS], n_vlist);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint32_t)lane < n_vlist) a.var_list[base + (uint32_t)lane] = vlist;
+        n_vlist = 0;
+    };
+    // Candidates are dealt round-robin, not drawn from a ticket counter: a single-address atomic serves ~88 M draws/s,
+    // and at ~25 k candidates per 100 k sites the draws alone took 0.28 ms (measured) -- longer than the solves.
+    for (uint32_t t = gw; t < n_cand; t += n_waves) {
+        const uint32_t site = a.cand_list[t];
+        const BvSiteSummary sm = a.summ[site];
+        BvSiteSums S;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
+        S.q0_mask = sm.flags & BV_SUM_Q0_MASK;
+        S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
+        if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&sv->res)[lane] = 0u;
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(hq);
+#pragma unroll
+            for (int i = 0; i < 4 * 128 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+        }
+        bv_lrt_sync<0>();
+        // exported bins -> merged counts for the rank sum (all of them) and the EM's bins (phred <= 93), order kept
+        const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+        uint32_t nb = 0;
+        for (uint32_t i0 = 0; i0 < sm.nb; i0 += BV_WAVE) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const bool have = i < sm.nb;
+            const uint32_t w = have ? src[i] : 0u;
+            const uint32_t code = w >> 16, cnt = w & 0xFFFFu;
+            if (have) hq[code] = cnt;
+            const bool valid = have && (code & 127u) < BV_NQ_VALID;
+            const unsigned long long m = __ballot(valid);
+            const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (valid) { bin_code[pos] = code; bin_cnt[pos] = cnt; }
+            nb += (uint32_t)__popcll(m);
+        }
+        S.nb = nb;
+        bv_lrt_sync<0>();
+        BvHqMerged H{hq};
+        if (bv_site_solve<false, BvHqMerged, true>(sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
+            vlist = ((uint32_t)lane == n_vlist) ? site : vlist;
+            if (++n_vlist == 64u) flush_variants();
+        }
+        bv_lrt_sync<0>();
+    }
+    if (n_vlist) flush_variants();
+}
+
+// ------------------------------------------------------------------------------ launchers
+template <int NW, int K>
+static void bv_launch_p1s_stream_cfg(const BvP1ShortArgs &a, hipStream_t stream, uint32_t wg_per_cu) {
+    const uint32_t cu = a.n_cu ? a.n_cu : 256u;
+    uint32_t grid = cu * wg_per_cu;
+    const uint32_t need = (a.n_sites + NW - 1) / NW;  // at least one site per wave
+    if (grid > need) grid = need > 0 ? need : 1;
+    hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
+}
+void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
+    // bits 12-15 of the flags select a ring depth / residency for tuning runs (0 = default)
+    switch ((a.flags >> 12) & 0xFu) {
+        case 1: return bv_launch_p1s_stream_cfg<4, 3>(a, stream, 4);   // 16 waves/CU, 2 slots in flight each
+        case 2: return bv_launch_p1s_stream_cfg<4, 6>(a, stream, 2);   //  8 waves/CU, 5 slots in flight each
+        case 3: return bv_launch_p1s_stream_cfg<4, 8>(a, stream, 2);   //  8 waves/CU, 7 slots in flight each
+        case 4: return bv_launch_p1s_stream_cfg<2, 4>(a, stream, 6);   // 12 waves/CU in 2-wave workgroups
+        case 5: return bv_launch_p1s_stream_cfg<4, 4>(a, stream, 3);   // 12 waves/CU, 3 slots in flight each
+        default: break;
+    }
+    bv_launch_p1s_stream_cfg<4, 4>(a, stream, 2);                      // 8 waves/CU, 3 slots (6 KiB) in flight each: measured best with K = 6 (0.70-0.73 of peak at 10 k samples); leaves LDS for the solve kernel of the previous batch
+}
+void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream) {
+    const uint32_t cu = a.n_cu ? a.n_cu : 256u;
+    uint32_t grid = cu * 3u;  // 3 waves per SIMD: the solver is VALU-bound, and at 4 (128 VGPRs) it spills
+    const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
+    if (grid > need) grid = need > 0 ? need : 1;
+    hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
+}

@@ -259,6 +259,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     BvBins B;
                     B.code = sh.bin_code[wave]; B.cnt = sh.bin_cnt[wave]; B.skip_mask = 0u;
                     B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.nb = (int)nb;
+                    B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss;
                     bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.lrt[wave], wave, lane, L, q0_mask);
                 }
                 if (lane == 0) {

@@ -87,47 +87,59 @@ struct BvSolveArgs {
     double min_af;
     uint32_t flags;
     BvLnTab lnfact;  // log-factorial table (BvTables::lnfact)
+    const double *loghit, *logmiss;  // BvTables::loghit / logmiss (device memory)
 };
 
 #define BV_LDS __attribute__((address_space(3)))
 
-// Everything the reference computes for one site, from its histogram, on one wave.
+// Merged-strand (base, phred) counts as the base-quality rank sum wants them: from the pass-1 histogram
+// (rows of 256 phred words, forward rows 0-3 and reverse rows 4-7), or from a [4][128] table (bv_pass1_short.hip).
+struct BvHqFromHist {
+    const uint32_t *hist;
+    __device__ __forceinline__ uint32_t operator()(int b, int q) const { return hist[(b << 8) | q] + hist[((b | 4) << 8) | q]; }
+};
+struct BvHqMerged {
+    const uint32_t *hq;
+    __device__ __forceinline__ uint32_t operator()(int b, int q) const { return hq[(b << 7) | q]; }
+};
+
+// What the tally of a site boils down to before the solve: strand x base totals, the number of compacted
+// (base, phred) bins, and two facts about the phred values seen.
+struct BvSiteSums {
+    uint32_t fwd[4], rev[4];
+    uint32_t nb;       // compacted bins
+    uint32_t badq;     // a covered cell had phred > 93
+    uint32_t q0_mask;  // bit b: base b has a phred-0 call
+};
+
+// Everything the reference computes for one site, on one wave, from the site's totals, its compacted bins
+// (bin_code / bin_cnt, layout given by ALIAS) and the merged (base, phred) counts `hq`.
 // Register-pressure note: this body sits inside the persistent loop of the kernel.  With
 // MachineLICM enabled, every libm polynomial constant of log/exp is hoisted out of that loop
-// and kept live around it -> 240 VGPRs, 2 waves/SIMD.  This file is therefore compiled with
+// and kept live around it -> 240 VGPRs, 2 waves/SIMD.  The kernel files are therefore compiled with
 // `-mllvm -disable-machine-licm` (see Makefile): 121 VGPRs, 4 waves/SIMD.  (A noinline call
 // is no way out: device functions are register-allocated without an occupancy target.)
-template <bool ALIAS>
-__device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
-                                                  BV_LDS uint32_t *bin_code_l, BV_LDS uint32_t *bin_cnt_l,
-                                                  BV_LDS BvSolverScratch *sv_l, BV_LDS const double *tab_hit_l,
-                                                  BV_LDS const double *tab_miss_l, int lane) {
-    uint32_t *hist = (uint32_t *)hist_l;
-    uint32_t *bin_code = ALIAS ? hist + BV_ALIAS_CODE_OFF : (uint32_t *)bin_code_l;
-    uint32_t *bin_cnt = ALIAS ? hist + BV_ALIAS_CNT_OFF : (uint32_t *)bin_cnt_l;
-    BvSolverScratch *sv = (BvSolverScratch *)sv_l;
-    const double *tab_hit = (const double *)tab_hit_l, *tab_miss = (const double *)tab_miss_l;
+// DEFER_LIST: the caller appends variant sites to var_list itself, in batches (one returning atomic per SITE on the single
+// counter address serialises at ~88 M/s: 0.23 ms per 20 k variant sites, measured in the short-row solve kernel).
+// Returns whether the site is a variant site.
+template <bool ALIAS, class HQ, bool DEFER_LIST = false>
+__device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, uint32_t *bin_code,
+                                              uint32_t *bin_cnt, const HQ &hq, BvSolverScratch *sv, const double *tab_hit,
+                                              const double *tab_miss, int lane) {
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
     uint32_t *res_words = reinterpret_cast<uint32_t *>(&sv->res);
-    if (lane < REC_WORDS) res_words[lane] = 0u;
-
-    uint32_t fwd[4], rev[4], depth[4], nb, badq, total = 0;
-    // phred-0 calls per base, read before ALIAS-mode bins can overwrite anything (they never touch
-    // phred < 128, but keep every histogram read of the prologue in one place)
-    uint32_t q0_mask = 0;
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-        if (hist[b << 8] + hist[(b | 4) << 8]) q0_mask |= 1u << b;
-    bv_prologue_wave<ALIAS>(hist, bin_code, bin_cnt, lane, fwd, rev, &nb, &badq);
+    uint32_t depth[4], total = 0;
+    const uint32_t *fwd = S.fwd, *rev = S.rev;
+    const uint32_t nb = S.nb, badq = S.badq, q0_mask = S.q0_mask;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         depth[b] = fwd[b] + rev[b];
         total += depth[b];
     }
-    bv_lrt_sync<0>();  // bin_code / bin_cnt / res zeroing visible to every lane
     int ref = a.ref_base[site];
     if (ref > 4) ref = 4;
     const double qnan = __builtin_nan("");
+    bool is_variant = false;
 
     if (a.flags & BV_FLAG_TALLY_ONLY) {  // diagnostic: streaming part only
         if (lane == 0) {
@@ -153,6 +165,7 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
         // ---- lrt() over ACGT (basetype.h:115)
         BvBins B;
         B.code = bin_code; B.cnt = bin_cnt; B.skip_mask = ALIAS ? ~127u : 0u; B.hit = tab_hit; B.miss = tab_miss;
+        B.loghit = a.loghit; B.logmiss = a.logmiss;
         B.nb = (int)nb;
         BvLrtOut L;
         // q0_mask: bases that hold a phred-0 call (1 - eps == 0) keep the generic EM path, because
@@ -212,7 +225,7 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                 else if ((alt_mask >> b) & 1u) { v_af += fwd[b]; v_ar += rev[b]; }
             }
             have_var = true;
-            // base-quality rank sum from the histogram this pass already holds (caller.cpp:1157)
+            // base-quality rank sum from the (base, phred) counts this pass already holds (caller.cpp:1157)
 #ifndef BV_ABL_NO_BQ
             {
                 unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
@@ -223,7 +236,7 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
                     uint32_t rv = 0, av = 0;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        uint32_t c = hist[(b << 8) | q] + hist[((b | 4) << 8) | q];
+                        uint32_t c = hq(b, q);
                         if (b == ref) rv += c;
                         else if ((alt_mask >> b) & 1u) av += c;
                     }
@@ -273,14 +286,42 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
             sv->res.mq_ranksum = qnan;
             sv->res.rpr_ranksum = qnan;
             sv->res.bq_ranksum = bq_ranksum;
-            if (L.n_alt > 0) {
+            if (!DEFER_LIST && L.n_alt > 0) {
                 uint32_t slot = atomicAdd(&a.counters[BV_CTR_VARIANTS], 1u);
                 a.var_list[slot] = site;
             }
             if (L.zero_freq) atomicAdd(&a.counters[BV_CTR_ZEROFREQ], 1u);
         }
+        is_variant = L.n_alt > 0;
     }
     bv_lrt_sync<0>();
     if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&a.out[site])[lane] = res_words[lane];
+    return is_variant;
 }
 
+// Tally histogram -> record: the prologue (totals + bins) and the solve, on one wave.
+template <bool ALIAS>
+__device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
+                                                  BV_LDS uint32_t *bin_code_l, BV_LDS uint32_t *bin_cnt_l,
+                                                  BV_LDS BvSolverScratch *sv_l, BV_LDS const double *tab_hit_l,
+                                                  BV_LDS const double *tab_miss_l, int lane) {
+    uint32_t *hist = (uint32_t *)hist_l;
+    uint32_t *bin_code = ALIAS ? hist + BV_ALIAS_CODE_OFF : (uint32_t *)bin_code_l;
+    uint32_t *bin_cnt = ALIAS ? hist + BV_ALIAS_CNT_OFF : (uint32_t *)bin_cnt_l;
+    BvSolverScratch *sv = (BvSolverScratch *)sv_l;
+    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+    uint32_t *res_words = reinterpret_cast<uint32_t *>(&sv->res);
+    if (lane < REC_WORDS) res_words[lane] = 0u;
+
+    BvSiteSums S;
+    // phred-0 calls per base, read before ALIAS-mode bins can overwrite anything (they never touch
+    // phred < 128, but keep every histogram read of the prologue in one place)
+    S.q0_mask = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (hist[b << 8] + hist[(b | 4) << 8]) S.q0_mask |= 1u << b;
+    bv_prologue_wave<ALIAS>(hist, bin_code, bin_cnt, lane, S.fwd, S.rev, &S.nb, &S.badq);
+    bv_lrt_sync<0>();  // bin_code / bin_cnt / res zeroing visible to every lane
+    BvHqFromHist hq{hist};
+    bv_site_solve<ALIAS>(a, site, S, bin_code, bin_cnt, hq, sv, (const double *)tab_hit_l, (const double *)tab_miss_l, lane);
+}

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = 0;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
+    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)sh.hist, (BV_LDS uint32_t *)nullptr, (BV_LDS uint32_t *)nullptr,
                              (BV_LDS BvSolverScratch *)&sh.sc, (BV_LDS const double *)sh.tab_hit,
                              (BV_LDS const double *)sh.tab_miss, lane);
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
         if (gtotal > 0) {
             BvBins B;
             B.code = sh.bin_code; B.cnt = sh.bin_cnt; B.skip_mask = 0u; B.hit = sh.tab_hit; B.miss = sh.tab_miss;
+            B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss;
             B.nb = (int)nb;
             bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.sc.lrt, 0, lane, L);
         }

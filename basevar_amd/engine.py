@@ -141,6 +141,14 @@ class BaseTypeEngine:
             raise RuntimeError("bv_engine_timing_get: " + self._err())
         return a.value, b.value, n.value
 
+    def timing_get_ex(self):
+        """(streaming-kernel ms, pass-1 ms, pass-2 ms, submits) since timing_reset(); on short rows pass 1 is the
+        streaming kernel plus the solve kernel, on long rows it is one kernel and the first two figures coincide."""
+        s, a, b, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        if self._lib.bv_engine_timing_get_ex(self._h, C.byref(s), C.byref(a), C.byref(b), C.byref(n)) != 0:
+            raise RuntimeError("bv_engine_timing_get_ex: " + self._err())
+        return s.value, a.value, b.value, n.value
+
     def last_variant_count(self):
         n = C.c_uint32()
         self._lib.bv_engine_last_variant_count(self._h, C.byref(n))

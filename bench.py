@@ -320,12 +320,12 @@ def main():
         mine = outs[last_slot[0]].cpu().numpy().view(basevar_amd.SITE_DTYPE)
         gathered_ok = bool(len(recs) == world * B and (recs["total_depth"] > 0).all() and
                            recs[:B].tobytes() == mine.tobytes())
-    p1_ms = p2_ms = 0.0
+    p1_ms = p2_ms = st_ms = 0.0
     nsub = 0
     for e in engs:
         e.wait()
-        a1, a2, n_ = e.timing_get()
-        p1_ms += a1; p2_ms += a2; nsub += n_
+        s_, a1, a2, n_ = e.timing_get_ex()
+        st_ms += s_; p1_ms += a1; p2_ms += a2; nsub += n_
     nvar = eng.last_variant_count()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -337,8 +337,14 @@ def main():
         sites_per_s = world * B * args.steps / elapsed
         p1_avg_s = p1_ms / max(nsub, 1) / 1e3
         p2_avg_s = p2_ms / max(nsub, 1) / 1e3
+        st_avg_s = st_ms / max(nsub, 1) / 1e3
         algo_bytes = 2.0 * B * N  # pass 1: u8 call + u8 phred per cell
-        achieved = algo_bytes / p1_avg_s / 1e9
+        # the dominant (HBM-bound) kernel: on short rows pass 1 is a streaming kernel + a solve kernel that reads no
+        # planes; on long rows it is one kernel (st_avg_s == p1_avg_s)
+        shape = (args.flags >> 8) & 0xF
+        two_kernel = (shape == 0 and N <= 49152) or shape == 10
+        kernel_name = "bv_p1s_stream_kernel" if two_kernel else ("bv_pass1_fused_kernel" if (shape == 9 or (shape == 0 and N <= 49152)) else "bv_pass1_kernel")
+        achieved = algo_bytes / st_avg_s / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -371,8 +377,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "bv_pass1_kernel", "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_launch_ms": p1_avg_s * 1e3, "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
+                "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_launch_ms": st_avg_s * 1e3, "pass1_avg_ms": p1_avg_s * 1e3,
+                "pass1_frac": algo_bytes / p1_avg_s / 1e9 / HBM_PEAK_GBS,  # all of pass 1 (streaming + solve kernels) over the same bytes
+                "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
                 # BASELINE.md section 3's whole-path figure: S*N*(2 + 3 f_var) bytes over both kernels' time
                 # (pass 2 also re-reads the call byte of variant rows: its own traffic is 4 B/cell)
                 "whole_path_GBps": (2.0 + 3.0 * nvar / B) * B * N / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9,

@@ -96,7 +96,8 @@ typedef struct bv_slab {
     const uint8_t *mapq;         /* [n_sites][pitch]  mapqs; may be NULL              */
     const uint16_t *rpr;         /* [n_sites][pitch]  base_pos_ranks; may be NULL     */
     const uint8_t *ref_base;     /* [n_sites] toupper(ref_base[0]) as BV_BASE_*; 4 = not ACGT  */
-    const uint8_t *group_id;     /* [n_samples] pop-group index or BV_NO_GROUP; may be NULL   */
+    const uint8_t *group_id;     /* [n_samples] pop-group index or BV_NO_GROUP; may be NULL; any alignment (the engine
+                                    keeps its own padded copy)                                */
     uint32_t n_groups;           /* 0 if no groups (caller.cpp:746)                   */
     uint32_t mem_kind;           /* bv_mem_kind                                       */
 } bv_slab;
@@ -180,7 +181,7 @@ int bv_engine_destroy(bv_engine *e);
  *   strand_bias (CVG and VCF flavours)            caller.cpp:1245, 1164
  *   3 x ref_vs_alt_ranksumtest                    caller.cpp:1151-1157
  *   per-group __gb() when slab->n_groups > 0      caller.cpp:756-759
- * `out`   : [n_sites] records, same mem_kind as the slab.
+ * `out`   : [n_sites] records, same mem_kind as the slab; a device buffer must be 16-byte aligned.
  * `gout`  : [n_sites][n_groups] records or NULL when n_groups == 0.
  * `stream`: hipStream_t to launch on, or NULL for the engine's own stream.  (NULL is also the handle of
  *           the legacy default stream: a caller that wants ordering with other work must pass an
@@ -193,8 +194,10 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
  * wrap it (torch.cuda.ExternalStream) and issue the RCCL gather of the records behind the kernels. */
 void *bv_engine_stream(bv_engine *e);
 
-/* Block until the last submit has finished.  Returns BV_ERR_SITE if any site set
- * BV_SITE_ZERO_FREQ (the reference would have thrown). */
+/* Block until every submit since the last wait has finished, on whatever streams they were issued (submits of one
+ * engine share its scratch and are therefore serialised, also across streams).  Returns BV_ERR_SITE if any site of any
+ * of those submits set BV_SITE_ZERO_FREQ (the reference would have thrown); the error counters are sticky across submits
+ * and cleared by this call. */
 int bv_engine_wait(bv_engine *e);
 
 /* ---- sample-axis tile mode -----------------------------------------------------
@@ -230,6 +233,11 @@ int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms);
  * to quote the average launch duration of each pass over the timed region. */
 int bv_engine_timing_reset(bv_engine *e);
 int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_total_ms, uint32_t *n_submits);
+/* The same with pass 1 split: on short rows (<= 49,152 samples) pass 1 is a streaming kernel (the HBM-bound one: tally of
+ * every row) followed by a solve kernel; `stream_total_ms` is the streaming kernel alone, `pass1_total_ms` both.  On
+ * long rows pass 1 is one kernel and the two figures coincide. */
+int bv_engine_timing_get_ex(bv_engine *e, double *stream_total_ms, double *pass1_total_ms, double *pass2_total_ms,
+                            uint32_t *n_submits);
 
 /* Number of BV_SITE_VARIANT sites found by the last submit (valid after wait). */
 int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant);
