@@ -60,7 +60,7 @@ class SynthParams(C.Structure):
 
 # every symbol include/basevar_amd.h declares
 EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_wait",
-           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_finish", "bv_engine_stream",
+           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
            "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
 
@@ -99,6 +99,9 @@ def load():
     L.bv_engine_tiles_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.bv_engine_tiles_add.restype = C.c_int
     L.bv_engine_tiles_add.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p]
+    L.bv_tile_packed_layout.restype = C.c_int
+    L.bv_tile_packed_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.bv_engine_tiles_finish.restype = C.c_int
     L.bv_engine_tiles_finish.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.bv_engine_stream.restype = C.c_void_p

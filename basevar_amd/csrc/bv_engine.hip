@@ -53,9 +53,19 @@ struct bv_engine {
     uint32_t *d_bins = nullptr, *d_cand_list = nullptr;
     uint32_t acc_n = 0;
     bool submitted = false;
-    // host-slab staging (BV_MEM_HOST)
-    void *stage = nullptr;
-    size_t stage_bytes = 0;
+    // Host buffers (BV_MEM_HOST slabs, tiles, record buffers) go through a ring of device staging buffers filled by a
+    // copy stream of their own: the PCIe copy of submit / tile k+1 runs under the kernels of k, and a buffer is reused
+    // only after the work that read it has finished (events).
+    static constexpr int kStage = 4;
+    struct StageSlot {
+        void *buf = nullptr;
+        size_t bytes = 0;
+        hipEvent_t copied = nullptr, freed = nullptr;
+        hipStream_t cs = nullptr;  // the copy stream that fills this slot
+        bool used = false;
+    };
+    StageSlot sring[kStage];
+    unsigned sring_next = 0;
     bv_site_result *stage_out = nullptr;
     bv_group_result *stage_gout = nullptr;
     bv_site_result *host_out = nullptr;
@@ -66,15 +76,9 @@ struct bv_engine {
     uint32_t *tile_maxr = nullptr;
     size_t tile_state_bytes = 0, tile_maxr_bytes = 0;
     uint32_t tile_sites = 0, tile_groups = 0, tile_stride = 0, tile_samples_total = 0, tile_samples_seen = 0;
+    uint32_t tile_rank_win = 1024, tile_hg_off = 0;
     bool tile_ranks = false, tile_open = false;
-    // host tiles: two staging buffers filled by a copy stream, so the PCIe copy of tile k+1 runs under the
-    // kernels of tile k
-    hipStream_t copy_stream = nullptr;
-    void *tstage[2] = {nullptr, nullptr};
-    size_t tstage_bytes[2] = {0, 0};
-    hipEvent_t ev_copied[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
-    bool tstage_used[2] = {false, false};
-    unsigned tile_k = 0;
+    hipStream_t copy_stream[2] = {nullptr, nullptr};  // alternate: the set-up of one copy hides under the transfer of the other
     // joined-rows realisation of the tile mode: resident planes [tile_sites][j_pitch]
     bool tile_join = false;
     uint8_t *j_buf = nullptr;
@@ -157,6 +161,92 @@ int stage_group_ids(bv_engine *e, const uint8_t *gid, uint32_t n_samples, bool h
     BV_HIP(e, hipMemsetAsync(e->d_gid, 0xFF, need, st));
     BV_HIP(e, hipMemcpyAsync(e->d_gid, gid, n_samples, host ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
     *out = e->d_gid;
+    return BV_OK;
+}
+// ---- staging ring
+int stage_acquire(bv_engine *e, size_t bytes, bv_engine::StageSlot **out) {
+    for (auto &cs : e->copy_stream)
+        if (!cs) BV_HIP(e, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    const unsigned k = e->sring_next++;
+    bv_engine::StageSlot &sl = e->sring[k % bv_engine::kStage];
+    sl.cs = e->copy_stream[k & 1u];
+    if (!sl.copied) {
+        BV_HIP(e, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+        BV_HIP(e, hipEventCreateWithFlags(&sl.freed, hipEventDisableTiming));
+    }
+    if (bytes > sl.bytes) {
+        if (sl.buf) BV_HIP(e, hipFree(sl.buf));  // synchronises with work that still uses it
+        sl.buf = nullptr; sl.bytes = 0; sl.used = false;
+        BV_HIP(e, hipMalloc(&sl.buf, bytes));
+        sl.bytes = bytes;
+    }
+    // the buffer is free again once the work that read it last has run
+    if (sl.used) BV_HIP(e, hipStreamWaitEvent(sl.cs, sl.freed, 0));
+    *out = &sl;
+    return BV_OK;
+}
+int stage_publish(bv_engine *e, bv_engine::StageSlot *sl, hipStream_t st) {  // the copies are queued: `st` may read after them
+    BV_HIP(e, hipEventRecord(sl->copied, sl->cs));
+    BV_HIP(e, hipStreamWaitEvent(st, sl->copied, 0));
+    return BV_OK;
+}
+int stage_release(bv_engine *e, bv_engine::StageSlot *sl, hipStream_t st) {  // everything queued on `st` so far is the last reader
+    BV_HIP(e, hipEventRecord(sl->freed, st));
+    sl->used = true;
+    return BV_OK;
+}
+// Host planes that lie in ONE allocation, one after the other (a packed tile, see bv_tile_packed_layout), go over the
+// link as one copy: the per-copy cost of five 2-3 MB copies per tile was a quarter of the tile's transfer time.
+struct HostSpan {
+    const uint8_t *lo = nullptr, *hi = nullptr;
+    void add(const void *p, size_t n) {
+        if (!p || !n) return;
+        const uint8_t *a = static_cast<const uint8_t *>(p);
+        if (!lo || a < lo) lo = a;
+        if (!hi || a + n > hi) hi = a + n;
+    }
+    size_t bytes() const { return (size_t)(hi - lo); }
+};
+struct HostPlane {
+    const void *src;     // host pointer (may be NULL: plane absent)
+    size_t bytes;
+    const uint8_t *dev;  // out: where the plane lives in the staging buffer
+};
+// Queue the host->device copies of `n` planes into a fresh staging slot (+ `extra` bytes of device scratch behind them).
+int stage_host_planes(bv_engine *e, HostPlane *pl, int n, size_t extra, bv_engine::StageSlot **slot_out, uint8_t **extra_dev) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    HostSpan sp;
+    size_t sum = 0;
+    bool aligned = true;
+    for (int i = 0; i < n; ++i) {
+        if (!pl[i].src || !pl[i].bytes) continue;
+        sp.add(pl[i].src, pl[i].bytes);
+        sum += up(pl[i].bytes);
+    }
+    for (int i = 0; i < n; ++i)
+        if (pl[i].src && pl[i].bytes && ((static_cast<const uint8_t *>(pl[i].src) - sp.lo) & 15)) aligned = false;
+    const bool one_copy = sp.lo && aligned && sp.bytes() <= sum + 4096;  // the planes tile one allocation (small gaps allowed)
+    const size_t planes_bytes = one_copy ? up(sp.bytes()) : sum;
+    bv_engine::StageSlot *sl = nullptr;
+    int rc = stage_acquire(e, planes_bytes + up(extra), &sl);
+    if (rc != BV_OK) return rc;
+    uint8_t *base = static_cast<uint8_t *>(sl->buf);
+    if (one_copy) {
+        BV_HIP(e, hipMemcpyAsync(base, sp.lo, sp.bytes(), hipMemcpyHostToDevice, sl->cs));
+        for (int i = 0; i < n; ++i)
+            pl[i].dev = (pl[i].src && pl[i].bytes) ? base + (static_cast<const uint8_t *>(pl[i].src) - sp.lo) : nullptr;
+    } else {
+        size_t off = 0;
+        for (int i = 0; i < n; ++i) {
+            pl[i].dev = nullptr;
+            if (!pl[i].src || !pl[i].bytes) continue;
+            BV_HIP(e, hipMemcpyAsync(base + off, pl[i].src, pl[i].bytes, hipMemcpyHostToDevice, sl->cs));
+            pl[i].dev = base + off;
+            off += up(pl[i].bytes);
+        }
+    }
+    *slot_out = sl;
+    if (extra_dev) *extra_dev = base + planes_bytes;
     return BV_OK;
 }
 }  // namespace
@@ -270,16 +360,18 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_cand_list) (void)hipFree(e->d_cand_list);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
-    if (e->stage) (void)hipFree(e->stage);
+    for (auto &sl : e->sring) {
+        if (sl.buf) (void)hipFree(sl.buf);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+        if (sl.freed) (void)hipEventDestroy(sl.freed);
+    }
     if (e->tile_state) (void)hipFree(e->tile_state);
     if (e->tile_maxr) (void)hipFree(e->tile_maxr);
     if (e->j_buf) (void)hipFree(e->j_buf);
-    for (int k = 0; k < 2; ++k) {
-        if (e->tstage[k]) (void)hipFree(e->tstage[k]);
-        if (e->ev_copied[k]) (void)hipEventDestroy(e->ev_copied[k]);
-        if (e->ev_free[k]) (void)hipEventDestroy(e->ev_free[k]);
-    }
-    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    for (hipStream_t cs : e->copy_stream)
+        if (cs) (void)hipStreamSynchronize(cs);
+    for (hipStream_t cs : e->copy_stream)
+        if (cs) (void)hipStreamDestroy(cs);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return BV_OK;
@@ -391,31 +483,23 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     bv_site_result *dout = out;
     bv_group_result *dgout = gout;
     const size_t S = slab->n_sites, P = slab->pitch, G = slab->n_groups;
+    bv_engine::StageSlot *slot = nullptr;
     if (slab->mem_kind == BV_MEM_HOST) {
-        // stage host planes into one device allocation (grown on demand)
+        // host planes -> a staging slot, copied by the copy stream (under the kernels of the previous submit)
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        size_t o_bs = 0, o_q = o_bs + up(S * P), o_mq = o_q + up(S * P), o_rp = o_mq + (mq ? up(S * P) : 0),
-               o_ref = o_rp + (rp ? up(S * P * 2) : 0), o_gid = o_ref + up(S), o_out = o_gid,
-               o_gout = o_out + up(S * sizeof(bv_site_result)), total = o_gout + up(S * G * sizeof(bv_group_result));
-        if (total > e->stage_bytes) {
-            if (e->stage) BV_HIP(e, hipFree(e->stage));
-            e->stage = nullptr;
-            e->stage_bytes = 0;
-            BV_HIP(e, hipMalloc(&e->stage, total));
-            e->stage_bytes = total;
-        }
-        uint8_t *base = static_cast<uint8_t *>(e->stage);
-        BV_HIP(e, hipMemcpyAsync(base + o_bs, bs, S * P, hipMemcpyHostToDevice, st));
-        BV_HIP(e, hipMemcpyAsync(base + o_q, q, S * P, hipMemcpyHostToDevice, st));
-        if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, st));
-        if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, st));
-        BV_HIP(e, hipMemcpyAsync(base + o_ref, refb, S, hipMemcpyHostToDevice, st));
-        bs = base + o_bs; q = base + o_q;
-        mq = mq ? base + o_mq : nullptr;
-        rp = rp ? reinterpret_cast<const uint16_t *>(base + o_rp) : nullptr;
-        refb = base + o_ref;
-        dout = reinterpret_cast<bv_site_result *>(base + o_out);
-        dgout = G ? reinterpret_cast<bv_group_result *>(base + o_gout) : nullptr;
+        HostPlane pl[5] = {{bs, S * P, nullptr}, {q, S * P, nullptr}, {mq, mq ? S * P : 0, nullptr},
+                           {rp, rp ? S * P * 2 : 0, nullptr}, {refb, S, nullptr}};
+        const size_t out_b = up(S * sizeof(bv_site_result)), gout_b = up(S * G * sizeof(bv_group_result));
+        uint8_t *extra = nullptr;
+        int rc = stage_host_planes(e, pl, 5, out_b + gout_b, &slot, &extra);
+        if (rc != BV_OK) return rc;
+        rc = stage_publish(e, slot, st);
+        if (rc != BV_OK) return rc;
+        bs = pl[0].dev; q = pl[1].dev; mq = pl[2].dev;
+        rp = reinterpret_cast<const uint16_t *>(pl[3].dev);
+        refb = pl[4].dev;
+        dout = reinterpret_cast<bv_site_result *>(extra);
+        dgout = G ? reinterpret_cast<bv_group_result *>(extra + out_b) : nullptr;
         e->stage_out = dout; e->stage_gout = dgout;
         e->host_out = out; e->host_gout = gout;
         e->host_out_bytes = S * sizeof(bv_site_result);
@@ -428,22 +512,12 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         if (rc != BV_OK) return rc;
     }
 
-    return launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st);
+    int rc = launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st);
+    if (rc == BV_OK && slot) rc = stage_release(e, slot, st);  // planes read, records copied back: the slot may be refilled
+    return rc;
 }
 
 // ---------------------------------------------------------------- sample-axis tile mode
-namespace {
-int ensure_stage(bv_engine *e, size_t bytes) {
-    if (bytes <= e->stage_bytes) return BV_OK;
-    if (e->stage) BV_HIP(e, hipFree(e->stage));  // synchronises with work that still uses it
-    e->stage = nullptr;
-    e->stage_bytes = 0;
-    BV_HIP(e, hipMalloc(&e->stage, bytes));
-    e->stage_bytes = bytes;
-    return BV_OK;
-}
-}  // namespace
-
 int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_total, uint32_t n_groups, int with_ranks) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: null engine");
     if (n_sites == 0 || n_samples_total == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: empty job");
@@ -484,7 +558,10 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
             return BV_OK;
         }
     }
-    const uint32_t stride = 7168u + n_groups * 512u;  // H1 2048 + Hm 1024 + Hr 4096 + Hg 512/group (bv_tiles.hip)
+    // H1 2048 + Hm 1024 + Hr 4 x W + Hg 512/group (bv_tiles.hip); W = 1024 ranks, or what the caller announced
+    const uint32_t rank_win = with_ranks > 1 ? (uint32_t)((with_ranks + 1023) / 1024 * 1024) : 1024u;
+    const uint32_t hg_off = 3072u + 4u * rank_win, stride = hg_off + n_groups * 512u;
+    e->tile_rank_win = rank_win; e->tile_hg_off = hg_off;
     const size_t bytes = (size_t)n_sites * stride * sizeof(uint32_t), mbytes = (size_t)n_sites * sizeof(uint32_t);
     if (bytes > e->tile_state_bytes) {
         if (e->tile_state) BV_HIP(e, hipFree(e->tile_state));
@@ -509,6 +586,23 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
     return BV_OK;
 }
 
+int bv_tile_packed_layout(uint32_t n_sites, uint32_t width, int with_ranks, int with_groups, uint64_t *pitch,
+                          uint64_t offsets[5], uint64_t *total_bytes) {
+    if (!n_sites || !width || !pitch || !offsets || !total_bytes)
+        return fail(nullptr, BV_ERR_INVALID_ARG, "bv_tile_packed_layout: bad argument");
+    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+    const uint64_t P = ((uint64_t)width + 15) / 16 * 16, plane = up((uint64_t)n_sites * P);
+    uint64_t at = 0;
+    offsets[0] = at; at += plane;
+    offsets[1] = at; at += plane;
+    offsets[2] = with_ranks ? at : 0; at += with_ranks ? plane : 0;
+    offsets[3] = with_ranks ? at : 0; at += with_ranks ? up((uint64_t)n_sites * P * 2) : 0;
+    offsets[4] = with_groups ? at : 0; at += with_groups ? up(P) : 0;
+    *pitch = P;
+    *total_bytes = at;
+    return BV_OK;
+}
+
 int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     if (!e || !t) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: null argument");
     if (!e->tile_open) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: call bv_engine_tiles_begin first");
@@ -528,72 +622,54 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     const uint8_t *bs = t->base_strand, *q = t->qual, *mq = e->tile_ranks ? t->mapq : nullptr, *gid = e->tile_groups ? t->group_id : nullptr;
     const uint16_t *rp = e->tile_ranks ? t->rpr : nullptr;
     const size_t S = t->n_sites, P = t->pitch;
-    int slot = -1;
+    bv_engine::StageSlot *slot = nullptr;
     if (t->mem_kind == BV_MEM_HOST) {
-        auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        size_t o_bs = 0, o_q = o_bs + up(S * P), o_mq = o_q + up(S * P), o_rp = o_mq + (mq ? up(S * P) : 0),
-               o_gid = o_rp + (rp ? up(S * P * 2) : 0), total = o_gid + (gid ? up(P) : 0);
-        if (!e->copy_stream) {
-            BV_HIP(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
-            for (int k = 0; k < 2; ++k) {
-                BV_HIP(e, hipEventCreateWithFlags(&e->ev_copied[k], hipEventDisableTiming));
-                BV_HIP(e, hipEventCreateWithFlags(&e->ev_free[k], hipEventDisableTiming));
-            }
-        }
-        slot = (int)(e->tile_k++ & 1u);
-        if (total > e->tstage_bytes[slot]) {
-            if (e->tstage[slot]) BV_HIP(e, hipFree(e->tstage[slot]));  // synchronises with work that still uses it
-            e->tstage[slot] = nullptr;
-            e->tstage_bytes[slot] = 0;
-            BV_HIP(e, hipMalloc(&e->tstage[slot], total));
-            e->tstage_bytes[slot] = total;
-            e->tstage_used[slot] = false;
-        }
-        // the buffer is free again once the kernels of the tile that used it last have run
-        if (e->tstage_used[slot]) BV_HIP(e, hipStreamWaitEvent(e->copy_stream, e->ev_free[slot], 0));
-        uint8_t *base = static_cast<uint8_t *>(e->tstage[slot]);
-        hipStream_t cs = e->copy_stream;
-        BV_HIP(e, hipMemcpyAsync(base + o_bs, bs, S * P, hipMemcpyHostToDevice, cs));
-        BV_HIP(e, hipMemcpyAsync(base + o_q, q, S * P, hipMemcpyHostToDevice, cs));
-        if (mq) BV_HIP(e, hipMemcpyAsync(base + o_mq, mq, S * P, hipMemcpyHostToDevice, cs));
-        if (rp) BV_HIP(e, hipMemcpyAsync(base + o_rp, rp, S * P * 2, hipMemcpyHostToDevice, cs));
-        if (gid) BV_HIP(e, hipMemcpyAsync(base + o_gid, gid, t->n_samples, hipMemcpyHostToDevice, cs));
-        BV_HIP(e, hipEventRecord(e->ev_copied[slot], cs));
-        BV_HIP(e, hipStreamWaitEvent(st, e->ev_copied[slot], 0));
-        bs = base + o_bs; q = base + o_q;
-        mq = mq ? base + o_mq : nullptr;
-        rp = rp ? reinterpret_cast<const uint16_t *>(base + o_rp) : nullptr;
-        gid = gid ? base + o_gid : nullptr;
+        HostPlane pl[5] = {{bs, S * P, nullptr}, {q, S * P, nullptr}, {mq, mq ? S * P : 0, nullptr},
+                           {rp, rp ? S * P * 2 : 0, nullptr}, {gid, gid ? (size_t)t->n_samples : 0, nullptr}};
+        int rc = stage_host_planes(e, pl, 5, 0, &slot, nullptr);
+        if (rc != BV_OK) return rc;
+        rc = stage_publish(e, slot, st);
+        if (rc != BV_OK) return rc;
+        bs = pl[0].dev; q = pl[1].dev; mq = pl[2].dev;
+        rp = reinterpret_cast<const uint16_t *>(pl[3].dev);
+        gid = pl[4].dev;
     }
     if (e->tile_join) {
         const uint64_t lo = e->tile_samples_seen, JP = e->j_pitch;
         const uint32_t w = t->n_samples, rows = t->n_sites;
         BvTileScatterArgs sc;
-        sc.n_rows = rows;
+        sc.max_rows = rows;
         sc.n_planes = 0;
-        auto plane = [&](uint8_t *dst, const uint8_t *src, uint64_t scale) {
+        auto plane = [&](uint8_t *dst, const uint8_t *src, uint64_t scale, uint32_t n_rows) {
             BvTileScatterPlane &p = sc.plane[sc.n_planes++];
             p.dst = dst; p.src = src; p.dst_pitch = scale * JP; p.src_pitch = scale * P; p.col_off = scale * lo;
-            p.width_bytes = (uint32_t)(scale * w); p.pad_ = 0;
+            p.width_bytes = (uint32_t)(scale * w); p.n_rows = n_rows;
         };
-        plane(e->j_buf, bs, 1);
-        plane(e->j_buf + e->j_o_q, q, 1);
-        if (mq) plane(e->j_buf + e->j_o_mq, mq, 1);
-        if (rp) plane(e->j_buf + e->j_o_rp, reinterpret_cast<const uint8_t *>(rp), 2);
+        plane(e->j_buf, bs, 1, rows);
+        plane(e->j_buf + e->j_o_q, q, 1, rows);
+        if (mq) plane(e->j_buf + e->j_o_mq, mq, 1, rows);
+        if (rp) plane(e->j_buf + e->j_o_rp, reinterpret_cast<const uint8_t *>(rp), 2, rows);
+        if (gid) plane(e->j_buf + e->j_o_gid, gid, 1, 1);  // one row: the tile's group ids, in the same launch
         bv_launch_tile_scatter(sc, st);
         BV_HIP(e, hipGetLastError());
-        if (gid) BV_HIP(e, hipMemcpyAsync(e->j_buf + e->j_o_gid + lo, gid, w, hipMemcpyDeviceToDevice, st));
-        if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }
+        if (slot) {
+            int rc = stage_release(e, slot, st);
+            if (rc != BV_OK) return rc;
+        }
         e->tile_samples_seen += t->n_samples;
         return mark_done(e, st);
     }
     BvTileArgs a;
     a.bs = bs; a.q = q; a.mapq = mq; a.rpr = rp; a.group_id = gid; a.pitch = P; a.n_sites = t->n_sites;
     a.width = t->n_samples; a.n_groups = e->tile_groups; a.stride = e->tile_stride; a.state = e->tile_state;
+    a.rank_win = e->tile_rank_win; a.hg_off = e->tile_hg_off;
     a.maxr = e->tile_maxr;
     bv_launch_tile_tally(a, st);
     BV_HIP(e, hipGetLastError());
-    if (slot >= 0) { BV_HIP(e, hipEventRecord(e->ev_free[slot], st)); e->tstage_used[slot] = true; }
+    if (slot) {
+        int rc = stage_release(e, slot, st);
+        if (rc != BV_OK) return rc;
+    }
     e->tile_samples_seen += t->n_samples;
     return mark_done(e, st);
 }
@@ -614,17 +690,19 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     bv_site_result *dout = out;
     bv_group_result *dgout = gout;
     e->host_out = nullptr; e->host_gout = nullptr;
+    bv_engine::StageSlot *slot = nullptr;
     if (mem_kind == BV_MEM_HOST) {
         auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-        size_t o_ref = 0, o_out = up(S), o_gout = o_out + up(S * sizeof(bv_site_result)),
-               total = o_gout + up(S * G * sizeof(bv_group_result));
-        int rc = ensure_stage(e, total);
+        HostPlane pl[1] = {{ref_base, S, nullptr}};
+        const size_t out_b = up(S * sizeof(bv_site_result)), gout_b = up(S * G * sizeof(bv_group_result));
+        uint8_t *extra = nullptr;
+        int rc = stage_host_planes(e, pl, 1, out_b + gout_b, &slot, &extra);
         if (rc != BV_OK) return rc;
-        uint8_t *base = static_cast<uint8_t *>(e->stage);
-        BV_HIP(e, hipMemcpyAsync(base + o_ref, ref_base, S, hipMemcpyHostToDevice, st));
-        dref = base + o_ref;
-        dout = reinterpret_cast<bv_site_result *>(base + o_out);
-        dgout = G ? reinterpret_cast<bv_group_result *>(base + o_gout) : nullptr;
+        rc = stage_publish(e, slot, st);
+        if (rc != BV_OK) return rc;
+        dref = pl[0].dev;
+        dout = reinterpret_cast<bv_site_result *>(extra);
+        dgout = G ? reinterpret_cast<bv_group_result *>(extra + out_b) : nullptr;
         e->stage_out = dout; e->stage_gout = dgout;
         e->host_out = out; e->host_gout = gout;
         e->host_out_bytes = S * sizeof(bv_site_result);
@@ -632,16 +710,19 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     }
     if (e->tile_join) {
         e->tile_open = false;
-        return launch_passes(e, e->j_buf, e->j_buf + e->j_o_q, e->tile_ranks ? e->j_buf + e->j_o_mq : nullptr,
-                             e->tile_ranks ? reinterpret_cast<const uint16_t *>(e->j_buf + e->j_o_rp) : nullptr, dref,
-                             G ? e->j_buf + e->j_o_gid : nullptr, e->j_pitch, e->tile_sites, e->tile_samples_total, e->tile_groups,
-                             dout, dgout, st);
+        int rc = launch_passes(e, e->j_buf, e->j_buf + e->j_o_q, e->tile_ranks ? e->j_buf + e->j_o_mq : nullptr,
+                               e->tile_ranks ? reinterpret_cast<const uint16_t *>(e->j_buf + e->j_o_rp) : nullptr, dref,
+                               G ? e->j_buf + e->j_o_gid : nullptr, e->j_pitch, e->tile_sites, e->tile_samples_total, e->tile_groups,
+                               dout, dgout, st);
+        if (rc == BV_OK && slot) rc = stage_release(e, slot, st);
+        return rc;
     }
     BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
     BvTileFinishArgs f;
     f.state = e->tile_state; f.maxr = e->tile_maxr; f.ref_base = dref; f.n_sites = e->tile_sites; f.n_groups = e->tile_groups;
     f.stride = e->tile_stride; f.have_ranks = e->tile_ranks ? 1u : 0u; f.min_af = e->cfg.min_af; f.tables = e->d_tables;
+    f.rank_win = e->tile_rank_win; f.hg_off = e->tile_hg_off;
     f.out = dout; f.gout = dgout; f.var_list = e->d_var_list; f.counters = e->d_counters;
     bv_launch_tile_finish(f, st);
     BV_HIP(e, hipGetLastError());
@@ -654,6 +735,10 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     e->tile_open = false;
     e->submitted = true;
     e->last_slot = -1;  // no pass-1/pass-2 event triplet for this realisation: bv_engine_kernel_ms has nothing to report
+    if (slot) {
+        int rc = stage_release(e, slot, st);
+        if (rc != BV_OK) return rc;
+    }
     return mark_done(e, st);
 }
 

@@ -95,6 +95,8 @@ struct BvTileArgs {
     uint32_t width;           // samples in this tile
     uint32_t n_groups;
     uint32_t stride;          // state words per site
+    uint32_t rank_win;        // read-position ranks 0 .. rank_win - 1 are tallied (multiple of 1024)
+    uint32_t hg_off;          // word offset of the pop-group tallies in a site's state
     uint32_t *state;          // [n_sites][stride]
     uint32_t *maxr;           // [n_sites] largest read-position rank seen
 };
@@ -106,6 +108,7 @@ struct BvTileFinishArgs {
     uint32_t n_groups;
     uint32_t stride;
     uint32_t have_ranks;
+    uint32_t rank_win, hg_off;
     double min_af;
     const BvTables *tables;
     bv_site_result *out;
@@ -121,11 +124,11 @@ struct BvTileScatterPlane {
     uint8_t *dst;
     const uint8_t *src;
     uint64_t dst_pitch, src_pitch, col_off;
-    uint32_t width_bytes, pad_;
+    uint32_t width_bytes, n_rows;
 };
 struct BvTileScatterArgs {
     BvTileScatterPlane plane[5];
-    uint32_t n_planes, n_rows;
+    uint32_t n_planes, max_rows;
 };
 void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream);
 

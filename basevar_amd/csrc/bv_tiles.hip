@@ -8,56 +8,62 @@
 // at the end.  State per site (u32 words):
 //     H1 [ (rev<<2|base) << 8 | phred ]        2048   same layout as the LDS histogram of pass 1
 //     Hm [ base << 8  | mapq ]                 1024   mapq tally per called base
-//     Hr [ base << 10 | rank ]                 4096   read-position ranks 0..1023 per called base
+//     Hr [ base * W + rank ]                   4 x W  read-position ranks 0..W-1 per called base; W = 1024 unless the job
+//                                                     announced longer reads (bv_engine_tiles_begin, with_ranks > 1)
 //     Hg [ (group*4 + base) << 7 | phred ]     512 per pop-group
 // Keeping Hm/Hr per BASE (not per REF/ALT class) is what makes a single sweep enough: the alt set
 // is only known after the last tile, and any (ref, alts) partition can be read off per-base tallies.
-// Ranks >= 1024 cannot be tallied exactly in this layout: such sites get BV_SITE_RPR_RANGE and a
-// NaN ReadPosRankSum (use the row mode, whose pass 2 sweeps rank windows, for long reads).
+// A rank at or beyond W cannot be tallied: such a site gets BV_SITE_RPR_RANGE and a NaN ReadPosRankSum (announce
+// the read length at bv_engine_tiles_begin, or use the joined-rows realisation, whose pass 2 sweeps rank windows).
 //
-// Tally: one LANE per site (a narrow tile row is only a few 16-byte chunks), covered cells go to the
-// site's state with global atomics -- lanes of a wave hit different sites, so no two lanes of an
-// instruction collide.  This per-site-state realisation is the FALLBACK of the tile mode (measured:
-// ~95 GB/s of tile bytes, i.e. not above the PCIe rate); by default the engine joins the tiles into
-// rows resident in HBM (bv_tile_scatter_kernel below) and runs the ordinary two passes on them.
+// Tally: one thread per 16-byte chunk of the tile (coalesced loads), covered cells go to the site's state with
+// global atomics.  This per-site-state realisation is the FALLBACK of the tile mode (for jobs whose joined planes do
+// not fit the HBM even in site chunks); by default the engine joins the tiles into rows resident in HBM
+// (bv_tile_scatter_kernel below) and runs the ordinary two passes on them.
 #include "bv_solver.h"
 
 #define BV_TS_H1 0u
 #define BV_TS_HM 2048u
-#define BV_TS_HR 3072u
-#define BV_TS_HG 7168u
-#define BV_TS_RPR_WIN 1024u
+#define BV_TS_HR 3072u /* [4][rank_win] words; the pop-group tallies follow at hg_off = 3072 + 4 * rank_win */
 
+// One thread per 16-byte chunk of the tile, chunks numbered row after row: consecutive lanes read consecutive chunks of a
+// row (coalesced 16-byte loads of all four planes) and add their covered cells to the row's state with global atomics.
 __global__ __launch_bounds__(256) void bv_tile_tally_kernel(BvTileArgs a) {
-    const uint32_t site = blockIdx.x * blockDim.x + threadIdx.x;
-    if (site >= a.n_sites) return;
-    uint32_t *S = a.state + (size_t)site * a.stride;
-    const size_t row = (size_t)site * a.pitch;
     const uint32_t n_chunks = (a.width + 15u) >> 4;
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (uint64_t)a.n_sites * n_chunks) return;
+    const uint32_t site = (uint32_t)(g / n_chunks), ch = (uint32_t)(g % n_chunks);
+    uint32_t *S = a.state + (size_t)site * a.stride;
+    const size_t at = (size_t)site * a.pitch + (size_t)ch * 16u;
+    const bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(a.bs + at);
+    const bv_u32x4 vq = *reinterpret_cast<const bv_u32x4 *>(a.q + at);
+    bv_u32x4 vm = bv_u32x4{0u, 0u, 0u, 0u}, vr0 = vm, vr1 = vm;
+    if (a.mapq) {
+        vm = *reinterpret_cast<const bv_u32x4 *>(a.mapq + at);
+        vr0 = *reinterpret_cast<const bv_u32x4 *>(a.rpr + at);        // uint16 plane: elements at .. at + 7
+        vr1 = *reinterpret_cast<const bv_u32x4 *>(a.rpr + at + 8);    //               elements at + 8 .. at + 15
+    }
+    const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w}, wq[4] = {vq.x, vq.y, vq.z, vq.w}, wm[4] = {vm.x, vm.y, vm.z, vm.w};
+    const uint32_t wr[8] = {vr0.x, vr0.y, vr0.z, vr0.w, vr1.x, vr1.y, vr1.z, vr1.w};
     uint32_t maxr = 0;
-    for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-        const bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(a.bs + row + (size_t)ch * 16u);
-        const bv_u32x4 vq = *reinterpret_cast<const bv_u32x4 *>(a.q + row + (size_t)ch * 16u);
-        const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w}, wq[4] = {vq.x, vq.y, vq.z, vq.w};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t smp = ch * 16u + j;
-            const uint32_t c = (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            if (smp >= a.width || (c & BV_CELL_NOCALL) || c > 7u) continue;
-            const uint32_t q = (wq[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const uint32_t b = c & 3u;
-            atomicAdd(&S[BV_TS_H1 + ((c << 8) | q)], 1u);
-            if (a.mapq) {
-                const uint32_t mq = a.mapq[row + smp];
-                const uint32_t r = a.rpr[row + smp];
-                atomicAdd(&S[BV_TS_HM + ((b << 8) | mq)], 1u);
-                maxr = max(maxr, r);
-                if (r < BV_TS_RPR_WIN) atomicAdd(&S[BV_TS_HR + ((b << 10) | r)], 1u);
-            }
-            if (a.n_groups) {
-                const uint32_t g = a.group_id[smp];
-                if (g < a.n_groups) atomicAdd(&S[BV_TS_HG + (((g * 4u + b) << 7) | min(q, 127u))], 1u);
-            }
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t smp = ch * 16u + j;
+        const uint32_t c = (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        if (smp >= a.width || c > 7u) continue;
+        const uint32_t q = (wq[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const uint32_t b = c & 3u;
+        atomicAdd(&S[BV_TS_H1 + ((c << 8) | q)], 1u);
+        if (a.mapq) {
+            const uint32_t mq = (wm[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t r = (wr[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            atomicAdd(&S[BV_TS_HM + ((b << 8) | mq)], 1u);
+            maxr = max(maxr, r);
+            if (r < a.rank_win) atomicAdd(&S[BV_TS_HR + b * a.rank_win + r], 1u);
+        }
+        if (a.n_groups) {
+            const uint32_t gi = a.group_id[smp];
+            if (gi < a.n_groups) atomicAdd(&S[a.hg_off + (((gi * 4u + b) << 7) | min(q, 127u))], 1u);
         }
     }
     if (a.mapq && maxr) atomicMax(&a.maxr[site], maxr);
@@ -133,15 +139,16 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
         }
         const double mq_ph = bv_ranksum_phred(twoR, n1, n2);
         double rp_ph = __builtin_nan("");
-        const bool in_range = a.maxr[site] < BV_TS_RPR_WIN;
+        const uint32_t maxr = a.maxr[site];
+        const bool in_range = maxr < a.rank_win;
         if (in_range) {
             below = 0; twoR = 0;
-            for (int w = 0; w < (int)BV_TS_RPR_WIN / 64; ++w) {
-                const int v = w * 64 + lane;
+            for (uint32_t w = 0; w * 64u <= maxr; ++w) {  // ranks beyond the site's largest hold nothing
+                const uint32_t v = w * 64u + (uint32_t)lane;
                 uint32_t rv = 0, av = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const uint32_t c = S[BV_TS_HR + ((b << 10) | v)];
+                    const uint32_t c = (v < a.rank_win) ? S[BV_TS_HR + (uint32_t)b * a.rank_win + v] : 0u;
                     if (b == ref) rv += c;
                     else if ((alt_mask >> b) & 1u) av += c;
                 }
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
 
     // per-group calls (caller.cpp:756-759): lrt([REF] + alts) on each group's tallies
     for (uint32_t g = 0; g < a.n_groups; ++g) {
-        const uint32_t *h = S + BV_TS_HG + g * 512u;
+        const uint32_t *h = S + a.hg_off + g * 512u;
         uint32_t nb = 0, gdepth[4], gtotal = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -215,28 +222,39 @@ __global__ __launch_bounds__(256) void bv_tile_scatter_kernel(BvTileScatterArgs 
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (upr == 0) return;
     const uint64_t row = i / upr, u = i % upr;
-    if (row >= a.n_rows) return;
+    if (row >= p.n_rows) return;
     const UNIT v = *reinterpret_cast<const UNIT *>(p.src + row * p.src_pitch + u * sizeof(UNIT));
     *reinterpret_cast<UNIT *>(p.dst + row * p.dst_pitch + p.col_off + u * sizeof(UNIT)) = v;
 }
 void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream) {
-    bool wide = true;
-    uint32_t max_w = 0;
+    // planes whose addresses, pitches and width are all multiples of 8 move 8 bytes per thread, the others 1
+    BvTileScatterArgs w8, w1;
+    w8.n_planes = w1.n_planes = 0;
+    w8.max_rows = w1.max_rows = 0;
+    uint32_t mw8 = 0, mw1 = 0;
     for (uint32_t k = 0; k < a.n_planes; ++k) {
         const BvTileScatterPlane &p = a.plane[k];
-        if ((p.dst_pitch | p.col_off | p.src_pitch | p.width_bytes | (uint64_t)(uintptr_t)p.dst | (uint64_t)(uintptr_t)p.src) & 7u) wide = false;
-        if (p.width_bytes > max_w) max_w = p.width_bytes;
+        if (p.width_bytes == 0 || p.n_rows == 0) continue;
+        const bool wide = !((p.dst_pitch | p.col_off | p.src_pitch | p.width_bytes | (uint64_t)(uintptr_t)p.dst | (uint64_t)(uintptr_t)p.src) & 7u);
+        BvTileScatterArgs &t = wide ? w8 : w1;
+        t.plane[t.n_planes++] = p;
+        if (p.n_rows > t.max_rows) t.max_rows = p.n_rows;
+        uint32_t &mw = wide ? mw8 : mw1;
+        if (p.width_bytes > mw) mw = p.width_bytes;
     }
-    if (a.n_planes == 0 || max_w == 0 || a.n_rows == 0) return;
-    const uint32_t unit = wide ? 8u : 1u;
-    const uint64_t total = (uint64_t)(max_w / unit) * a.n_rows;
-    const dim3 grid((uint32_t)((total + 255u) / 256u), a.n_planes);
-    if (wide) hipLaunchKernelGGL(bv_tile_scatter_kernel<uint64_t>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(bv_tile_scatter_kernel<uint8_t>, grid, dim3(256), 0, stream, a);
+    if (w8.n_planes) {
+        const uint64_t total = (uint64_t)(mw8 / 8u) * w8.max_rows;
+        hipLaunchKernelGGL(bv_tile_scatter_kernel<uint64_t>, dim3((uint32_t)((total + 255u) / 256u), w8.n_planes), dim3(256), 0, stream, w8);
+    }
+    if (w1.n_planes) {
+        const uint64_t total = (uint64_t)mw1 * w1.max_rows;
+        hipLaunchKernelGGL(bv_tile_scatter_kernel<uint8_t>, dim3((uint32_t)((total + 255u) / 256u), w1.n_planes), dim3(256), 0, stream, w1);
+    }
 }
 
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(bv_tile_tally_kernel, dim3((a.n_sites + 255u) / 256u), dim3(256), 0, stream, a);
+    const uint64_t total = (uint64_t)a.n_sites * ((a.width + 15u) >> 4);
+    hipLaunchKernelGGL(bv_tile_tally_kernel, dim3((uint32_t)((total + 255u) / 256u)), dim3(256), 0, stream, a);
 }
 void bv_launch_tile_finish(const BvTileFinishArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(bv_tile_finish_kernel, dim3(a.n_sites), dim3(BV_WAVE), 0, stream, a);

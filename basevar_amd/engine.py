@@ -155,9 +155,11 @@ class BaseTypeEngine:
         return n.value
 
     # ---- sample-axis tile mode (numpy tiles in host memory)
-    def lrt_tiles(self, slab, tile_width):
+    def lrt_tiles(self, slab, tile_width, max_rank=0):
         """Same result as lrt(slab), but the slab is fed as column tiles of `tile_width` samples
-        (the reference's `-B/--batch-count` batchfiles) that the engine accumulates in HBM."""
+        (the reference's `-B/--batch-count` batchfiles) that the engine accumulates in HBM.  Every tile is one packed
+        host allocation (bv_tile_packed_layout), so it crosses the link as one copy.  `max_rank`: an upper bound on the
+        read-position ranks, for the per-site-tally realisation (see bv_engine_tiles_begin)."""
         bs = np.ascontiguousarray(slab["base_strand"], dtype=np.uint8)
         S = bs.shape[0]
         N = int(slab.get("n_samples", bs.shape[1]))
@@ -167,32 +169,44 @@ class BaseTypeEngine:
         gid = slab.get("group_id")
         ng = int(slab.get("n_groups", 0)) if gid is not None else 0
         ref = np.ascontiguousarray(slab["ref_base"], dtype=np.uint8)
-        rc = self._lib.bv_engine_tiles_begin(self._h, S, N, ng, 1 if ranks else 0)
+        rc = self._lib.bv_engine_tiles_begin(self._h, S, N, ng, (max(2, int(max_rank)) if max_rank else 1) if ranks else 0)
         if rc != 0:
             raise RuntimeError("bv_engine_tiles_begin failed (%d): %s" % (rc, self._err()))
-        keep = []
+        keep = []  # the copies are asynchronous: every tile stays alive until the final wait
         for lo in range(0, N, tile_width):
             w = min(tile_width, N - lo)
-            pitch = (w + 15) // 16 * 16
+            pitch, total = C.c_uint64(), C.c_uint64()
+            offs = (C.c_uint64 * 5)()
+            rc = self._lib.bv_tile_packed_layout(S, w, 1 if ranks else 0, 1 if ng else 0, C.byref(pitch), offs, C.byref(total))
+            if rc != 0:
+                raise RuntimeError("bv_tile_packed_layout failed (%d)" % rc)
+            P = pitch.value
+            buf = np.zeros(total.value + 256, dtype=np.uint8)
+            base = buf.ctypes.data
+            pad = (-base) % 256  # 256-byte aligned start inside the numpy allocation
 
-            def tile(a, dt, fill):
-                t = np.full((S, pitch), fill, dtype=dt)
-                t[:, :w] = a[:, lo:lo + w]
-                return t
-            tb, tq = tile(bs, np.uint8, 8), tile(q, np.uint8, 0)
-            tm = tile(np.asarray(mq), np.uint8, 0) if ranks else None
-            tr = tile(np.asarray(rp), np.uint16, 0) if ranks else None
-            tg = None
+            def plane(k, dt, rows, fill):
+                n = rows * P * np.dtype(dt).itemsize
+                v = buf[pad + offs[k]: pad + offs[k] + n].view(dt).reshape(rows, P)
+                v[...] = fill
+                return v
+            tb = plane(0, np.uint8, S, 8); tb[:, :w] = bs[:, lo:lo + w]
+            tq = plane(1, np.uint8, S, 0); tq[:, :w] = q[:, lo:lo + w]
+            tm = tr = tg = None
+            if ranks:
+                tm = plane(2, np.uint8, S, 0); tm[:, :w] = np.asarray(mq)[:, lo:lo + w]
+                tr = plane(3, np.uint16, S, 0); tr[:, :w] = np.asarray(rp)[:, lo:lo + w]
             if ng:
-                tg = np.full(pitch, 0xFF, dtype=np.uint8)
-                tg[:w] = np.asarray(gid, dtype=np.uint8)[lo:lo + w]
-            keep.append((tb, tq, tm, tr, tg))
+                tg = plane(4, np.uint8, 1, 0xFF); tg[0, :w] = np.asarray(gid, dtype=np.uint8)[lo:lo + w]
+            keep.append(buf)
             p = lambda a: None if a is None else a.ctypes.data
-            t = _capi.Slab(S, w, pitch, p(tb), p(tq), p(tm), p(tr), None, p(tg), ng, _capi.BV_MEM_HOST)
+            t = _capi.Slab(S, w, P, p(tb), p(tq), p(tm), p(tr), None, p(tg), ng, _capi.BV_MEM_HOST)
             rc = self._lib.bv_engine_tiles_add(self._h, C.byref(t), None)
             if rc != 0:
                 raise RuntimeError("bv_engine_tiles_add failed (%d): %s" % (rc, self._err()))
-            self.wait()  # host tiles are staged through one buffer: keep it simple and safe here
+            if len(keep) >= 64:  # bound the host memory held by in-flight tiles
+                self.wait()
+                del keep[:-1]
         out = np.zeros(S, dtype=_capi.SITE_DTYPE)
         gout = np.zeros((S, ng), dtype=_capi.GROUP_DTYPE) if ng else None
         rc = self._lib.bv_engine_tiles_finish(self._h, ref.ctypes.data, out.ctypes.data,
@@ -225,6 +239,19 @@ class BaseTypeEngine:
         self.wait()
         ms1, ms2 = self.kernel_ms()
         return BaseTypeBatch(out, gout, self.last_variant_count(), ms1, ms2)
+
+
+def tile_packed_layout(n_sites, width, with_ranks=True, with_groups=False):
+    """(pitch, [offsets of base_strand, qual, mapq, rpr, group_id], total bytes) of a packed host tile: one allocation
+    that bv_engine_tiles_add sends over the link as one copy (include/basevar_amd.h)."""
+    lib = _capi.load()
+    pitch, total = C.c_uint64(), C.c_uint64()
+    offs = (C.c_uint64 * 5)()
+    rc = lib.bv_tile_packed_layout(n_sites, width, 1 if with_ranks else 0, 1 if with_groups else 0, C.byref(pitch), offs,
+                                   C.byref(total))
+    if rc != 0:
+        raise RuntimeError("bv_tile_packed_layout failed (%d)" % rc)
+    return pitch.value, [int(o) for o in offs], total.value
 
 
 def synth_fill(device, n_sites, n_samples, pitch, base_strand, qual, ref_base, mapq=0, rpr=0, seed=0xBA5E7A7,

@@ -434,7 +434,19 @@ def main():
                 return o
             dtiles = [(cut(bs0, k * W, torch.uint8), cut(q0, k * W, torch.uint8), cut(mq0, k * W, torch.uint8),
                        cut(rp0, k * W, torch.int16)) for k in range(res)]
-            htiles = [tuple(x.cpu().pin_memory() for x in t) for t in dtiles]
+            # host tiles: ONE pinned allocation per tile, planes at the offsets of bv_tile_packed_layout, so that a tile
+            # crosses the link as one copy
+            _, offs, tot = basevar_amd.tile_packed_layout(St, W, True, False)
+            htiles = []
+            for tb, tq, tm_, tr in dtiles:
+                buf = torch.zeros(tot, dtype=torch.uint8).pin_memory()
+                views = []
+                for o, src in zip(offs[:4], (tb, tq, tm_, tr)):
+                    nb_ = src.numel() * src.element_size()
+                    v = buf[o:o + nb_].view(src.dtype).view(src.shape)
+                    v.copy_(src)
+                    views.append(v)
+                htiles.append(tuple(views) + (buf,))
             tout = torch.zeros(St * rec, dtype=torch.uint8, device=dev)
             lib = eng._lib
 
@@ -442,7 +454,7 @@ def main():
                 rc = lib.bv_engine_tiles_begin(eng._h, St, n_tiles * W, 0, 1)
                 assert rc == 0, eng._err()
                 for k in range(n_tiles):
-                    tb, tq, tm, tr = tiles[k % res]
+                    tb, tq, tm, tr = tiles[k % res][:4]
                     t = _capi.Slab(St, W, Wp, tb.data_ptr(), tq.data_ptr(), tm.data_ptr(), tr.data_ptr(), None, None, 0, kind)
                     rc = lib.bv_engine_tiles_add(eng._h, C.byref(t), None)
                     assert rc == 0, eng._err()

@@ -217,8 +217,17 @@ int bv_engine_wait(bv_engine *e);
  *   per-site tallies       when that slab does not fit (or with BV_FLAG_TILE_STATE): additive per-site state
  *                          (~30 KB per site), global atomics; equal results except that read-position ranks
  *                          >= 1024 are not supported there (BV_SITE_RPR_RANGE, rpr_ranksum = NaN). */
+/* `with_ranks`: 0 = tiles carry no mapq/rpr planes; 1 = they do; a value > 1 also announces an upper bound on the
+ * read-position ranks (read length), which only the per-site-tally realisation needs: it keeps exact tallies of ranks
+ * below max(1024, with_ranks rounded up to 1024) and flags sites beyond that (BV_SITE_RPR_RANGE).  Host tiles go through
+ * a ring of staging buffers filled by a copy stream; a tile whose planes lie in one host allocation, one after the
+ * other (bv_tile_packed_layout), crosses the link as ONE copy. */
 int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_total, uint32_t n_groups,
                           int with_ranks);
+/* Layout of a packed host tile of `width` samples: pitch (cells per row, width rounded up to 16), the byte offsets of
+ * base_strand, qual, mapq, rpr, group_id in ONE allocation of *total_bytes (absent planes: offset 0), each 256-aligned. */
+int bv_tile_packed_layout(uint32_t n_sites, uint32_t width, int with_ranks, int with_groups, uint64_t *pitch,
+                          uint64_t offsets[5], uint64_t *total_bytes);
 int bv_engine_tiles_add(bv_engine *e, const bv_slab *tile, void *stream);
 int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result *out, bv_group_result *gout,
                            uint32_t mem_kind, void *stream);

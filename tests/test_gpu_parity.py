@@ -411,6 +411,69 @@ def test_sample_axis_tiles_long_read_ranks(bv, restatement):
     assert not np.isnan(t.sites["mq_ranksum"][3])
 
 
+@pytest.mark.parametrize("flags", [0, 0x8], ids=["joined_rows", "per_site_tallies"])
+def test_tile_job_at_one_million_samples_golden(bv, flags):
+    """BASELINE configs[4]'s row length under test: the six 1 M-sample rows of the real reference's golden file, fed as
+    5000 host tiles of 200 samples (the reference's --batch-count 200 batchfiles, caller.cpp:419-453, re-joined per site
+    at :589-601), both realisations of the tile mode, against the real reference's records."""
+    slab, maf, exp, gexp = load_fixture(os.path.join(GOLDEN, "deep_6x1000000.npz"))
+    eng = bv.BaseTypeEngine(max_sites=6, min_af_value=maf, device=0, flags=flags)
+    t = eng.lrt_tiles(slab, 200)
+    rows = eng.lrt(slab)
+    eng.close()
+    check(t, exp, gexp, check_chi2=False)
+    for f in ("depth", "total_depth", "cvg_sb", "var_sb", "n_alt", "alt"):
+        assert np.array_equal(rows.sites[f], t.sites[f]), f
+    if flags == 0:
+        assert rows.sites.tobytes() == t.sites.tobytes()
+
+
+@pytest.mark.parametrize("flags", [0, 0x8], ids=["joined_rows", "per_site_tallies"])
+def test_tile_job_64_sites_x_one_million_samples(bv, restatement, flags):
+    """A full-length tile job: 64 sites x 1,000,000 samples in 5000 host tiles of 200 samples with two pop-groups, both
+    realisations, against the real reference where oracle/_ref is present (the restatement otherwise) and against the
+    row mode on the same slab."""
+    n = 1000000
+    parts = [make_slab(8, n, seed=600 + k, coverage=0.05, n_groups=2, site_offset=8 * k) for k in range(8)]
+    slab = {k: np.concatenate([p[k] for p in parts]) for k in ("base_strand", "qual", "mapq", "rpr", "ref_base")}
+    slab.update(n_sites=64, n_samples=n, pitch=parts[0]["pitch"], n_groups=2, group_id=parts[0]["group_id"])
+    del parts
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=64, min_af_value=maf, device=0, flags=flags)
+    t = eng.lrt_tiles(slab, 200)
+    rows = eng.lrt(slab)
+    eng.close()
+    if oracle.ref_available():
+        exp, gexp = oracle.Reference().run(slab, maf, n_threads=32)
+        check(t, exp, gexp, check_chi2=False)
+    else:
+        exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=32)
+        check(t, exp, gexp, margins)
+    assert ((exp["status"] & 2) != 0).sum() >= 8
+    for f in ("depth", "total_depth", "cvg_sb", "var_sb", "n_alt", "alt"):
+        assert np.array_equal(rows.sites[f], t.sites[f]), f
+    if flags == 0:
+        assert rows.sites.tobytes() == t.sites.tobytes() and rows.groups.tobytes() == t.groups.tobytes()
+
+
+def test_per_site_tallies_with_an_announced_read_length(bv, restatement):
+    """Ranks beyond 1023 are exact in the per-site-tally realisation too once the job announces the read length."""
+    slab = make_slab(16, 400, seed=951, coverage=0.6, class_af=[(0.4, 0.0)])
+    cov = slab["base_strand"] < 8
+    slab["rpr"][3, np.nonzero(cov[3])[0][:5]] = [2000, 1024, 5000, 1023, 4095]
+    slab["rpr"][7, np.nonzero(cov[7])[0][:2]] = [9000, 3]
+    maf = bv.min_af(400)
+    eng = bv.BaseTypeEngine(max_sites=16, min_af_value=maf, device=0, flags=0x8)
+    t = eng.lrt_tiles(slab, 100, max_rank=6000)
+    eng.close()
+    exp, gexp, margins = restatement.run_with_margins(slab, maf)
+    flagged = (t.sites["status"] & 0x40) != 0
+    assert flagged[7] and flagged.sum() == 1 and np.isnan(t.sites["rpr_ranksum"][7])  # 9000 >= the announced 6000 (-> 6144)
+    keep = ~flagged
+    sub = type(t)(t.sites[keep], None, int(((t.sites["status"][keep] & 2) != 0).sum()), 0.0, 0.0)
+    check(sub, exp[keep], None, margins[keep])
+
+
 def _strand_table_slab(tables, n_samples):
     """One site per (ref_fwd, ref_rev, alt_fwd, alt_rev[, other_fwd, other_rev]) table: ref A, alt C, a third
     base G for the optional pair (it makes the all-sites CVG table differ from the VCF one)."""
