@@ -566,6 +566,8 @@ struct BvBins {
     const double *loghit;  // BvTables::loghit / logmiss (device memory, L2-resident), or NULL: single-base subsets then
     const double *logmiss; // run the iterative EM like every other subset
     int nb;                // number of bins (wave-uniform)
+    const uint16_t *ord;   // LDS: the site's covered cells in SAMPLE ORDER (call << 8 | phred), or NULL.  When given (shallow
+    int n_ord;             // sites), every EM of the LRT replays the reference's per-sample arithmetic literally (bv_em_ordered)
 };
 
 __device__ __forceinline__ int bv_bin_at(const BvBins &B, int i) { return i + (int)((uint32_t)i & B.skip_mask); }
@@ -747,6 +749,98 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], unsigned
     return iters;
 }
 
+// ------------------------------------------------------------------ shallow sites: the reference's own order
+// A histogram cannot see the ORDER of the samples, and when two allele subsets have mathematically equal likelihood
+// (two bases seen once each at the same phred ...) the reference's pick depends on it: its log-likelihood is a
+// sequential sum of per-sample terms (algorithm.h:24-41, basetype.cpp:123).  All such ties sit at shallow sites, so
+// sites with at most BV_ORD_MAX covered samples replay the reference literally: the covered cells are gathered in
+// sample order, one sample per lane, e_step / m_step as algorithm.h:148-198 (per-sample products, the marginal summed
+// over A, C, G, T in that order, four IEEE divisions, the m_step's sums taken over the samples in order, no fused
+// multiply-add), the convergence term and the final sum in sample order.  Only log() itself (ocml instead of glibc,
+// ulps) is not the reference's.
+#define BV_ORD_MAX 64
+
+// covered cells of one row in sample order -> ord[] (at most BV_ORD_MAX); returns how many the row holds.  With `gid`:
+// only the samples of pop-group `g` (gid: one byte per sample, readable in 16-byte chunks up to the row's last chunk).
+__device__ __noinline__ uint32_t bv_gather_ordered(const uint8_t *bs_row, const uint8_t *q_row, uint32_t n_samples, uint16_t *ord,
+                                                  int lane, const uint8_t *gid = nullptr, uint32_t g = 0) {
+    const uint32_t n_chunks = (n_samples + 15u) >> 4;
+    uint32_t count = 0;
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += BV_WAVE) {
+        const uint32_t chunk = c0 + (uint32_t)lane;
+        bv_u32x4 vb = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+        bv_u32x4 vg = bv_u32x4{0u, 0u, 0u, 0u};
+        if (chunk < n_chunks) {
+            vb = *reinterpret_cast<const bv_u32x4 *>(bs_row + (size_t)chunk * 16u);
+            if (gid) vg = *reinterpret_cast<const bv_u32x4 *>(gid + (size_t)chunk * 16u);
+        }
+        const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w}, wg[4] = {vg.x, vg.y, vg.z, vg.w};
+        uint32_t mask = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t c = (wb[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+            const bool mine = !gid || ((wg[k >> 2] >> (8 * (k & 3))) & 0xFFu) == g;
+            if (c < 8u && mine && chunk * 16u + (uint32_t)k < n_samples) mask |= 1u << k;
+        }
+        const uint32_t cnt = (uint32_t)__popc(mask);
+        const uint32_t incl = bv_wave_incl_scan_u32(cnt, lane);
+        uint32_t pos = count + incl - cnt;
+        while (mask) {
+            const int k = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            if (pos < (uint32_t)BV_ORD_MAX) {
+                const uint32_t c = (wb[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                ord[pos] = (uint16_t)((c << 8) | q_row[(size_t)chunk * 16u + (uint32_t)k]);
+            }
+            ++pos;
+        }
+        count += (uint32_t)bv_readlane63_i32((int)incl);
+    }
+    return count;
+}
+
+// EM, algorithm.h:210-255, literally, on n <= BV_ORD_MAX samples (lane i = sample i).  f: initial freqs in, final out.
+__device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const double *hit, const double *miss, double f[4],
+                                          double *lr_out, int lane) {
+    const double epsilon = (double)0.001f;
+    const bool have = lane < n;
+    const uint32_t w = have ? ord[lane] : 0u;
+    const uint32_t b = (w >> 8) & 3u, qi = min(w & 0xFFu, 127u);
+    const double hv = hit[qi], mv = miss[qi];
+    const double lh0 = b == 0 ? hv : mv, lh1 = b == 1 ? hv : mv, lh2 = b == 2 ? hv : mv, lh3 = b == 3 ? hv : mv;
+    double p0 = 0., p1 = 0., p2 = 0., p3 = 0., marg = 1.;
+    auto e_step = [&]() {  // algorithm.h:161-171
+        const double L0 = __dmul_rn(lh0, f[0]), L1 = __dmul_rn(lh1, f[1]), L2 = __dmul_rn(lh2, f[2]), L3 = __dmul_rn(lh3, f[3]);
+        marg = __dadd_rn(__dadd_rn(__dadd_rn(L0, L1), L2), L3);
+        p0 = __ddiv_rn(L0, marg); p1 = __ddiv_rn(L1, marg); p2 = __ddiv_rn(L2, marg); p3 = __ddiv_rn(L3, marg);
+    };
+    auto seq_sum = [&](double v) {  // sum over the samples in sample order, from 0.0 (algorithm.h:190-193, :29-33)
+        double s = 0.;
+        for (int i = 0; i < n; ++i) s = __dadd_rn(s, bv_readlane_f64(v, i));
+        return s;
+    };
+    auto m_step = [&]() {  // algorithm.h:184-198
+        const double dn = (double)n;
+        f[0] = __ddiv_rn(seq_sum(p0), dn); f[1] = __ddiv_rn(seq_sum(p1), dn);
+        f[2] = __ddiv_rn(seq_sum(p2), dn); f[3] = __ddiv_rn(seq_sum(p3), dn);
+    };
+    e_step();
+    double llh = log(marg);
+    m_step();
+    int iters = 0;
+    for (int it = 0; it < 100; ++it) {
+        e_step();
+        m_step();
+        const double now = log(marg);
+        const double d = have ? bv_int_abs_trunc(now - llh) : 0.;
+        llh = now;
+        ++iters;
+        if (seq_sum(d) < epsilon) break;
+    }
+    *lr_out = seq_sum(have ? llh : 0.);
+    return iters;
+}
+
 // ------------------------------------------------------------------ LRT
 // BaseType::lrt + _f, src/basetype.cpp:105-199.  The EM runs of one level (the n-subsets of
 // the current active set, Combinations order: external/combinations.h:55-69) are independent.
@@ -855,7 +949,9 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             s += f[0]; s += f[1]; s += f[2]; s += f[3];
             double lr;
             int it;
-            if (NW == 0 && B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
+            if (B.ord != nullptr && s != 0.) {
+                it = bv_em_ordered(B.ord, B.n_ord, B.hit, B.miss, f, &lr, lane);
+            } else if (NW == 0 && B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
                 // A single-base subset {b} with every likelihood positive: the reference's EM needs no arithmetic.  Its
                 // first e_step gives every sample the posterior L/L == 1.0 for b, the m_step f_b == n/n == 1.0, and from
                 // then on every marginal is the likelihood itself (lh * 1.0), so the reported log-likelihood is

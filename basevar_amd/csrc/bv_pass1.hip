@@ -243,6 +243,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
         sa.min_af = a.min_af; sa.flags = a.flags;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
         for (uint32_t k = (uint32_t)s;; k += NSOLVE) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[BV_CTR_TIMEOUT]);
@@ -304,6 +305,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass
     sa.min_af = a.min_af; sa.flags = a.flags;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
     // Tickets are drawn BV_FUSED_TICKET sites at a time: at ~70 M short-row sites/s one ticket per
     // site would run into the ~88 M/s ceiling of atomics on a single address (measured: throughput
     // flat from 6 to 11 waves per CU until the draws were chunked).  (Drawing single sites over the last one or

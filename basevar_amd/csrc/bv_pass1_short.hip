@@ -360,6 +360,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
     sa.min_af = a.min_af; sa.flags = a.flags;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
 
     // ---- (a) non-candidate sites, one lane per site
     const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;

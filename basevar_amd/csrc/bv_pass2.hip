@@ -30,6 +30,7 @@ struct __attribute__((aligned(16))) BvPass2Shared {
     uint32_t bin_cnt[NW][BV_SLOTS * BV_WAVE];
     BvLrtShared lrt[NW];
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    uint16_t ord[NW][BV_ORD_MAX];  // shallow pop-groups: the group's covered cells in sample order (bv_gather_ordered)
 };
 
 extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_groups][4][128]
@@ -259,7 +260,15 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     BvBins B;
                     B.code = sh.bin_code[wave]; B.cnt = sh.bin_cnt[wave]; B.skip_mask = 0u;
                     B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.nb = (int)nb;
-                    B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss;
+                    B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss; B.ord = nullptr; B.n_ord = 0;
+                    const int n_seen = (gdepth[0] != 0) + (gdepth[1] != 0) + (gdepth[2] != 0) + (gdepth[3] != 0);
+                    if (gtotal <= (uint32_t)BV_ORD_MAX && n_seen >= 2) {
+                        // a shallow group with more than one base: the reference's per-sample order decides ties (bv_em_ordered)
+                        const uint32_t got = bv_gather_ordered(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch,
+                                                               a.n_samples, sh.ord[wave], lane, a.group_id, g);
+                        bv_lrt_sync<0>();
+                        if (got == gtotal) { B.ord = sh.ord[wave]; B.n_ord = (int)gtotal; }
+                    }
                     bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.lrt[wave], wave, lane, L, q0_mask);
                 }
                 if (lane == 0) {

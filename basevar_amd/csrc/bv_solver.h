@@ -11,6 +11,7 @@
 struct BvSolverScratch {
     BvLrtShared lrt;
     bv_site_result res;  // staged record, stored with one coalesced write
+    uint16_t ord[BV_ORD_MAX];  // shallow sites: the covered cells in sample order (bv_gather_ordered)
 };
 struct BvSolverShared {
     uint32_t bin_code[BV_SLOTS * BV_WAVE];  // compacted non-empty (base<<7 | phred) bins
@@ -88,6 +89,11 @@ struct BvSolveArgs {
     uint32_t flags;
     BvLnTab lnfact;  // log-factorial table (BvTables::lnfact)
     const double *loghit, *logmiss;  // BvTables::loghit / logmiss (device memory)
+    // the planes the site's row lives in, for the ordered replay of shallow sites (bs == NULL: not available, e.g. the
+    // per-site-tally realisation of the tile mode)
+    const uint8_t *bs, *q;
+    uint64_t pitch;
+    uint32_t n_samples;
 };
 
 #define BV_LDS __attribute__((address_space(3)))
@@ -167,6 +173,14 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
         B.code = bin_code; B.cnt = bin_cnt; B.skip_mask = ALIAS ? ~127u : 0u; B.hit = tab_hit; B.miss = tab_miss;
         B.loghit = a.loghit; B.logmiss = a.logmiss;
         B.nb = (int)nb;
+        B.ord = nullptr; B.n_ord = 0;
+        if (a.bs != nullptr && total >= 2u && total <= (uint32_t)BV_ORD_MAX && !(a.flags & BV_FLAG_SKIP_LRT)) {
+            // shallow site: the reference's per-sample order decides ties -- replay it (bv_em_ordered)
+            const uint32_t got = bv_gather_ordered(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples,
+                                                   sv->ord, lane);
+            bv_lrt_sync<0>();
+            if (got == total) { B.ord = sv->ord; B.n_ord = (int)total; }
+        }
         BvLrtOut L;
         // q0_mask: bases that hold a phred-0 call (1 - eps == 0) keep the generic EM path, because
         // the reference's 0/0 there yields NaN frequencies that must be reproduced

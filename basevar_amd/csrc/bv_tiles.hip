@@ -99,6 +99,7 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
     sa.min_af = a.min_af; sa.flags = 0;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+    sa.bs = nullptr; sa.q = nullptr; sa.pitch = 0; sa.n_samples = 0;  // no rows here: ties of shallow sites stay order-blind
     bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)sh.hist, (BV_LDS uint32_t *)nullptr, (BV_LDS uint32_t *)nullptr,
                              (BV_LDS BvSolverScratch *)&sh.sc, (BV_LDS const double *)sh.tab_hit,
                              (BV_LDS const double *)sh.tab_miss, lane);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
         if (gtotal > 0) {
             BvBins B;
             B.code = sh.bin_code; B.cnt = sh.bin_cnt; B.skip_mask = 0u; B.hit = sh.tab_hit; B.miss = sh.tab_miss;
-            B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss;
+            B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss; B.ord = nullptr; B.n_ord = 0;
             B.nb = (int)nb;
             bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.sc.lrt, 0, lane, L);
         }

@@ -48,7 +48,9 @@ def check(got, exp, gexp, margins=None, **kw):
     bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
     bad = {f: idx for f, idx in bad.items() if idx.size}
     assert not bad, describe(bad, got.sites, exp)
-    assert len(excused) <= max(1, len(exp) // 200), "too many tie-excused sites: %d of %d" % (len(excused), len(exp))
+    # shallow sites and pop-groups replay the reference's per-sample order (bv_em_ordered), so a rounding-noise tie may only
+    # differ where log() itself differs by an ulp: observed ~1 site in 100,000 on tie-prone inputs
+    assert len(excused) <= max(1, len(exp) // 10000), "too many tie-excused sites: %d of %d" % (len(excused), len(exp))
     assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum())
     return len(excused)
 
@@ -329,12 +331,9 @@ def test_very_many_short_sites(bv, restatement):
     maf = bv.min_af(n)
     got = run_engine(bv, slab, maf)
     exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=8)
-    amb = ambiguous_sites(exp, margins)
-    bad = compare_sites(got.sites, exp)
-    bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
-    bad = {f: idx for f, idx in bad.items() if idx.size}
-    assert not bad, describe(bad, got.sites, exp)
-    assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum()) > 50000
+    n_excused = check(got, exp, gexp, margins)  # 300,000 tie-prone sites (depth ~32): at most 30 may hinge on a tie
+    assert n_excused <= 30
+    assert got.n_variant > 50000
 
 
 def test_two_engines_on_two_host_threads(bv, restatement):
