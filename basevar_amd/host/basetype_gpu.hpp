@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <stdexcept>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,22 @@ public:
         }
         ref_.push_back((uint8_t)base_code((char)std::toupper((unsigned char)(bi.ref_base.empty() ? 'N' : bi.ref_base[0]))));
     }
+
+    // One site straight from per-sample planes in the slab's own encoding (e.g. a row of a PileupTile, pileup.hpp).
+    void add_row(const uint8_t *cell, const uint8_t *phred, const uint8_t *mapq, const uint16_t *rank, uint8_t ref_code) {
+        const size_t off = bs_.size();
+        bs_.resize(off + pitch_, BV_CELL_N);
+        q_.resize(off + pitch_, 0);
+        mq_.resize(off + pitch_, 0);
+        rp_.resize(off + pitch_, 0);
+        std::memcpy(&bs_[off], cell, n_);
+        std::memcpy(&q_[off], phred, n_);
+        std::memcpy(&mq_[off], mapq, n_);
+        std::memcpy(&rp_[off], rank, (size_t)n_ * sizeof(uint16_t));
+        ref_.push_back(ref_code);
+    }
+    const uint8_t *cell_row(size_t site) const { return &bs_[site * pitch_]; }
+    const uint8_t *phred_row(size_t site) const { return &q_[site * pitch_]; }
 
     void set_groups(const std::vector<uint8_t> &group_id, uint32_t n_groups) {
         gid_ = group_id;

@@ -5,8 +5,15 @@
 // _variant_calling_unit (src/basetype_caller.cpp:529-635), with `--pop-group` handled as
 // _get_popgroup_info does (src/basetype_caller.cpp:372-410).
 //
+// Pipeline: the main thread produces batches of sites in genomic order (a slab + one SiteText per site -- not the
+// sites' BatchInfo text); `--gpus G` worker threads, one engine on one GPU each, take whichever batch is next; an
+// emitter thread writes the results in batch order.  It replaces the reference's fan-out of 100 kb sub-regions over a
+// thread pool and its ordered merge of per-task files (_variants_discovery + merge_file_by_line,
+// src/basetype_caller.cpp:469-525).
+//
 //   bv_call --batchfiles a.bf.gz,b.bf.gz --output-vcf out.vcf --output-cvg out.cvg
-//           [--pop-group FILE] [--min-af 0.01] [--batch-sites N (default: min(4096, 2^26 / samples))] [--device 0]
+//           [--pop-group FILE] [--min-af 0.01] [--batch-sites N (default: min(4096, 2^26 / samples))]
+//           [--gpus G] [--devices 0,1,... | --device 0]
 //           [--reference ref.fa --contig NAME:LENGTH ...]
 //   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END[,CHR:BEG-END...] [--mapq 10]
 //           [--thread T] ...   (same outputs)
@@ -21,8 +28,13 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "basetype_gpu.hpp"
@@ -54,6 +66,49 @@ struct GzReader {
     ~GzReader() { if (f) gzclose(f); }
 };
 
+// One batch of consecutive sites on its way through the pipeline.
+struct Batch {
+    uint64_t seq = 0;
+    bvamd::SlabBuilder slab;
+    std::vector<bvamd::SiteText> text;
+    bvamd::BaseTypeBatch result;
+    std::string error;
+    explicit Batch(uint32_t n_samples) : slab(n_samples) {}
+};
+typedef std::unique_ptr<Batch> BatchPtr;
+
+// Bounded hand-off queue (mutex + condition variables); close() lets the consumers drain and stop.
+class BatchQueue {
+public:
+    explicit BatchQueue(size_t cap) : cap_(cap) {}
+    void push(BatchPtr b) {
+        std::unique_lock<std::mutex> lk(mu_);
+        not_full_.wait(lk, [&] { return q_.size() < cap_; });
+        q_.push_back(std::move(b));
+        not_empty_.notify_one();
+    }
+    BatchPtr pop() {  // nullptr once closed and empty
+        std::unique_lock<std::mutex> lk(mu_);
+        not_empty_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return nullptr;
+        BatchPtr b = std::move(q_.front());
+        q_.pop_front();
+        not_full_.notify_one();
+        return b;
+    }
+    void close() {
+        std::lock_guard<std::mutex> lk(mu_);
+        closed_ = true;
+        not_empty_.notify_all();
+    }
+private:
+    size_t cap_;
+    std::deque<BatchPtr> q_;
+    bool closed_ = false;
+    std::mutex mu_;
+    std::condition_variable not_full_, not_empty_;
+};
+
 [[noreturn]] void die(const std::string &m) {
     std::cerr << m << std::endl;
     std::exit(1);
@@ -63,11 +118,11 @@ struct GzReader {
 
 int main(int argc, char **argv) {
     std::vector<std::string> batchfiles, bams;
-    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list;
-    int mapq_thd = 10, threads = 1;
+    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list, devices_arg;
+    int mapq_thd = 10, threads = 1, n_gpus = 1;
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
-    uint32_t batch_sites = 0;  // 0 = from a cell budget once the sample count is known
+    uint32_t batch_sites = 0;   // 0 = from a cell budget once the sample count is known
     int device = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -79,6 +134,8 @@ int main(int argc, char **argv) {
         else if (a == "--min-af") user_min_af = std::stof(next());
         else if (a == "--batch-sites") batch_sites = (uint32_t)std::stoul(next());
         else if (a == "--device") device = std::stoi(next());
+        else if (a == "--gpus") n_gpus = std::stoi(next());
+        else if (a == "--devices") devices_arg = next();
         else if (a == "--reference" || a == "-R") reference = next();
         else if (a == "-I" || a == "--input") bams.push_back(next());
         else if (a == "-L" || a == "--align-file-list") bam_list = next();
@@ -102,10 +159,20 @@ int main(int argc, char **argv) {
         }
     }
     if (!(user_min_af > 0.f)) die("[ERROR] --min-af must be > 0");  // the reference refuses it too (caller.cpp:73)
+    if (n_gpus < 1) die("[ERROR] --gpus must be >= 1");
+    // one engine per entry: --devices a,b,... (an ordinal may repeat: several engines on one GPU), else device, device+1, ...
+    std::vector<int> devices;
+    if (!devices_arg.empty()) {
+        std::vector<std::string> d; bvamd::split(devices_arg, d, ",");
+        for (const auto &x : d) devices.push_back(std::stoi(x));
+        if (n_gpus != 1 && (size_t)n_gpus != devices.size()) die("[ERROR] --gpus and --devices disagree");
+    } else {
+        for (int g = 0; g < n_gpus; ++g) devices.push_back(device + g);
+    }
     const bool from_bam = !bams.empty();
     if ((batchfiles.empty() && !from_bam) || out_vcf.empty() || out_cvg.empty() || (from_bam && (regions.empty() || reference == ".")))
         die("usage: bv_call (--batchfiles a,b,... | -I a.bam [-I ...] -R ref.fa --regions CHR:BEG-END [--mapq Q]) --output-vcf FILE "
-            "--output-cvg FILE [--pop-group FILE] [--min-af F]");
+            "--output-cvg FILE [--pop-group FILE] [--min-af F] [--gpus G]");
 
     // ---- headers: sample ids in batchfile order (caller.cpp:637-665)
     std::vector<GzReader> readers(batchfiles.size());
@@ -166,42 +233,86 @@ int main(int argc, char **argv) {
     std::fwrite(hv.data(), 1, hv.size(), VCF);
     std::fwrite(hc.data(), 1, hc.size(), CVG);
 
-    // ---- engine
-    // pending sites keep their BatchInfo text (~42 B per cell) next to the 5 B/cell slab until they are emitted:
-    // bound a batch by cells (2^26 cells ~ 3 GB of host memory), not by a site count that ignores the row length
+    // ---- batches are bounded by cells (2^26 cells = 5 x 64 MiB of planes), not by a site count that ignores the row
+    // length; per pending site the host keeps the slab row and a SiteText, nothing else
     if (batch_sites == 0) {
         const size_t by_cells = ((size_t)1 << 26) / std::max<size_t>(n_sample, 1);
         batch_sites = (uint32_t)std::min<size_t>(4096, std::max<size_t>(by_cells, 1));
     }
-    bvamd::BaseTypeEngine engine(batch_sites, (uint32_t)n_sample, user_min_af, device);
-    bvamd::SlabBuilder slab((uint32_t)n_sample);
-    if (!group_names.empty()) slab.set_groups(group_id, (uint32_t)group_names.size());
-    std::vector<bvamd::BatchInfo> pending;
-    size_t n_sites = 0, n_variants = 0;
 
-    auto flush = [&]() {
-        if (pending.empty()) return;
-        bvamd::BaseTypeBatch bt = engine.lrt(slab);
-        for (size_t i = 0; i < pending.size(); ++i) {
-            std::string c = bvamd::format_cvg_line(pending[i], bt.sites[i]);
-            std::fwrite(c.data(), 1, c.size(), CVG);
-            if (bt.has_variant(i)) {
-                std::string v = bvamd::format_vcf_line(pending[i], bt.sites[i],
-                                                       group_names.empty() ? nullptr : &bt.group(i, 0), group_names);
-                std::fwrite(v.data(), 1, v.size(), VCF);
-                ++n_variants;
+    // ---- the pipeline: producer (this thread) -> G engine workers -> emitter, results written in batch order
+    const size_t G = devices.size();
+    BatchQueue to_gpu(G + 1), to_emit(2 * G + 2);
+    std::mutex err_mu;
+    std::string first_error;
+    auto fail = [&](const std::string &m) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (first_error.empty()) first_error = m;
+    };
+    std::vector<std::thread> workers;
+    for (size_t g = 0; g < G; ++g)
+        workers.emplace_back([&, g]() {
+            std::unique_ptr<bvamd::BaseTypeEngine> engine;
+            try {
+                engine.reset(new bvamd::BaseTypeEngine(batch_sites, (uint32_t)n_sample, user_min_af, devices[g]));
+            } catch (const std::exception &ex) { fail(ex.what()); }
+            for (BatchPtr b; (b = to_gpu.pop());) {
+                if (engine) {
+                    try { b->result = engine->lrt(b->slab); } catch (const std::exception &ex) { b->error = ex.what(); }
+                } else {
+                    b->error = "no engine on device " + std::to_string(devices[g]);
+                }
+                to_emit.push(std::move(b));
+            }
+        });
+    size_t n_sites = 0, n_variants = 0;
+    std::thread emitter([&]() {
+        std::map<uint64_t, BatchPtr> waiting;  // finished out of order
+        uint64_t next_seq = 0;
+        for (BatchPtr b; (b = to_emit.pop());) {
+            waiting[b->seq] = std::move(b);
+            for (auto it = waiting.find(next_seq); it != waiting.end(); it = waiting.find(next_seq)) {
+                Batch &d = *it->second;
+                if (!d.error.empty()) fail(d.error);
+                else {
+                    for (size_t i = 0; i < d.text.size(); ++i) {
+                        const std::string c = bvamd::format_cvg_line(d.text[i], d.result.sites[i]);
+                        std::fwrite(c.data(), 1, c.size(), CVG);
+                        if (d.result.has_variant(i)) {
+                            const std::string v = bvamd::format_vcf_line(d.text[i], d.slab.cell_row(i), d.slab.phred_row(i), n_sample,
+                                                                         d.result.sites[i],
+                                                                         group_names.empty() ? nullptr : &d.result.group(i, 0), group_names);
+                            std::fwrite(v.data(), 1, v.size(), VCF);
+                            ++n_variants;
+                        }
+                    }
+                    n_sites += d.text.size();
+                }
+                waiting.erase(it);
+                ++next_seq;
             }
         }
-        n_sites += pending.size();
-        pending.clear();
-        slab.clear();
-    };
+    });
 
-    if (from_bam) {
-        // ---- pileup -> BatchInfo -> slab, in the reference's 500 kb steps (caller.cpp:826-846)
-        try {
-            // "-r chr:beg-end[,chr:beg-end ...]" (caller.cpp:311-356); regions are called in the order given
-            std::vector<std::string> region_list;
+    uint64_t seq = 0;
+    BatchPtr cur;
+    auto fresh = [&]() {
+        cur.reset(new Batch((uint32_t)n_sample));
+        if (!group_names.empty()) cur->slab.set_groups(group_id, (uint32_t)group_names.size());
+        cur->seq = seq++;
+    };
+    auto ship = [&]() {
+        if (cur && cur->slab.n_sites()) to_gpu.push(std::move(cur));
+        else if (cur) --seq;
+        cur.reset();
+    };
+    auto still_ok = [&]() { std::lock_guard<std::mutex> g(err_mu); return first_error.empty(); };
+
+    try {
+        if (from_bam) {
+            // ---- pileup windows -> slab rows, straight from the tile planes (no text round trip); a site is a position that
+            // at least one sample covers (the reference skips rows of total depth 0, caller.cpp:718)
+            std::vector<std::string> region_list;  // "-r chr:beg-end[,chr:beg-end ...]" (caller.cpp:311-356), in the order given
             bvamd::split(regions, region_list, ",");
             std::string fa_seq, fa_of;
             for (const std::string &rg : region_list) {
@@ -212,41 +323,53 @@ int main(int argc, char **argv) {
                 const uint32_t end = (uint32_t)std::stoul(rg.substr(dash + 1));
                 if (fa_of != ref_id) { fa_seq = bvamd::load_fasta_sequence(reference, ref_id); fa_of = ref_id; }
                 if (beg < 1 || end < beg || end > fa_seq.size()) die("[ERROR] region outside " + ref_id);
-                for (uint32_t sb = beg; sb < end + 1; sb += 500000u) {
-                    const uint32_t se = sb + 500000u - 1 > end ? end : sb + 500000u - 1;
-                    bvamd::PosMapVector v;
-                    bvamd::fetch_base_in_region(bams, fa_seq, mapq_thd, std::make_tuple(ref_id, sb, se), v, true, threads);
-                    for (uint32_t pos = sb; pos <= se; ++pos) {
-                        bvamd::BatchInfo bi;
-                        if (!bvamd::batchinfo_at(v, fa_seq, ref_id, pos, bi)) continue;
-                        slab.add_site(bi);
-                        pending.push_back(std::move(bi));
-                        if (pending.size() == batch_sites) flush();
+                bvamd::pileup_region(bams, fa_seq, ref_id, beg, end, mapq_thd, true, threads, [&](const bvamd::PileupTile &t) {
+                    size_t next_indel = 0;
+                    for (uint32_t pos = t.beg; pos <= t.end && still_ok(); ++pos) {
+                        if (t.depth[pos - t.beg] == 0) continue;
+                        if (!cur) fresh();
+                        const size_t k = t.at(pos, 0);
+                        const char rb = fa_seq[pos - 1];
+                        cur->slab.add_row(&t.cell[k], &t.qual[k], &t.mapq[k], &t.rank[k],
+                                          (uint8_t)bvamd::base_code((char)std::toupper((unsigned char)rb)));
+                        bvamd::SiteText st;
+                        st.ref_id = ref_id; st.ref_pos = pos; st.ref_base = std::string(1, rb);
+                        while (next_indel < t.indels.size() && t.indels[next_indel].pos < pos) ++next_indel;
+                        for (; next_indel < t.indels.size() && t.indels[next_indel].pos == pos; ++next_indel)
+                            st.indel_tokens.push_back(t.indels[next_indel].text);
+                        cur->text.push_back(std::move(st));
+                        if (cur->slab.n_sites() == batch_sites) ship();
                     }
-                }
+                });
             }
-        } catch (const std::exception &ex) { die(ex.what()); }
-    }
-
-    // ---- one row from every batchfile per position (caller.cpp:586-611)
-    std::vector<std::string> rows(batchfiles.size());
-    for (; !from_bam;) {
-        bool eof = false;
-        for (size_t b = 0; b < batchfiles.size(); ++b) {
-            if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }
-            else if (!readers[b].getline(rows[b])) { eof = true; break; }
+        } else {
+            // ---- one row from every batchfile per position (caller.cpp:586-611)
+            std::vector<std::string> rows(batchfiles.size());
+            for (; still_ok();) {
+                bool eof = false;
+                for (size_t b = 0; b < batchfiles.size(); ++b) {
+                    if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }
+                    else if (!readers[b].getline(rows[b])) { eof = true; break; }
+                }
+                if (eof) break;
+                bvamd::BatchInfo bi;
+                if (!bvamd::parse_site_rows(rows, n_sample, bi)) continue;  // total depth 0, caller.cpp:718
+                if (!cur) fresh();
+                cur->slab.add_site(bi);
+                cur->text.push_back(bvamd::site_text_of(bi));
+                if (cur->slab.n_sites() == batch_sites) ship();
+            }
         }
-        if (eof) break;
-        bvamd::BatchInfo bi;
-        if (!bvamd::parse_site_rows(rows, n_sample, bi)) continue;  // total depth 0, caller.cpp:718
-        slab.add_site(bi);
-        pending.push_back(std::move(bi));
-        if (pending.size() == batch_sites) flush();
-    }
-    flush();
+        ship();
+    } catch (const std::exception &ex) { fail(ex.what()); }
+    to_gpu.close();
+    for (auto &w : workers) w.join();
+    to_emit.close();
+    emitter.join();
     std::fclose(VCF);
     std::fclose(CVG);
+    if (!first_error.empty()) die(first_error);
     std::cout << "[INFO] bv_call: " << n_sites << " covered positions, " << n_variants << " VCF records, " << n_sample
-              << " samples, " << group_names.size() << " groups" << std::endl;
+              << " samples, " << group_names.size() << " groups, " << G << " engine(s)" << std::endl;
     return 0;
 }

@@ -4,7 +4,7 @@
 // `bv_call --batchfiles` (or the reference's own calling phase) consumes.  Host-only: no GPU involved.
 //
 //   bv_pileup -R ref.fa[.gz] --regions CHR:BEG-END [--mapq 10] -I a.bam [-I b.bam ...] [-L bam.list]
-//             [--filename-has-samplename] [--no-index] [--thread T] -o out.bf[.gz]
+//             [--filename-has-samplename] [--no-index] [--thread T] [--window POSITIONS] -o out.bf[.gz]
 //
 // Sample ids come from the first @RG SM tag of each BAM (BamHeader::get_sample_name) or, with
 // --filename-has-samplename, from the file name up to its first '.' (src/basetype_caller.cpp:262-294).
@@ -35,6 +35,7 @@ int main(int argc, char **argv) {
     std::string fasta, regions, out_path, bam_list;
     int mapq = 10;  // BaseTypeARGS default, src/basetype_utils.h
     int threads = 1;
+    uint32_t window = 0;  // positions per pileup window (0 = from a cell budget); the rows do not depend on it
     bool name_from_file = false, use_index = true;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -48,6 +49,7 @@ int main(int argc, char **argv) {
         else if (a == "--filename-has-samplename") name_from_file = true;
         else if (a == "--no-index") use_index = false;
         else if (a == "-t" || a == "--thread") threads = std::stoi(next());
+        else if (a == "--window") window = (uint32_t)std::stoul(next());
         else die("unknown argument " + a);
     }
     if (!bam_list.empty()) {  // get_firstcolumn_from_file, src/basetype_caller.cpp:114-117
@@ -96,7 +98,7 @@ int main(int argc, char **argv) {
             const bool ok = gz ? gzwrite(zf, s.data(), (unsigned)s.size()) == (int)s.size() : std::fwrite(s.data(), 1, s.size(), pf) == s.size();
             if (!ok) throw std::runtime_error("[ERROR] fail to write data");
         };
-        const bool has_data = bvamd::create_a_batchfile(bams, sample_ids, fa_seq, std::make_tuple(ref_id, beg, end), mapq, sink, use_index, threads);
+        const bool has_data = bvamd::create_a_batchfile(bams, sample_ids, fa_seq, std::make_tuple(ref_id, beg, end), mapq, sink, use_index, threads, window);
         if (gz) gzclose(zf); else std::fclose(pf);
         std::cerr << "[INFO] " << out_path << ": " << bams.size() << " samples, " << ref_id << ":" << beg << "-" << end
                   << (has_data ? "" : " (no covering reads)") << std::endl;

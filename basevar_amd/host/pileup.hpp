@@ -1,25 +1,36 @@
-// pileup.hpp -- the pileup that feeds the path: BAM alignments of
-// one batch of samples -> per-position, per-sample first-read-wins cells -> reference-format
-// batchfile rows.  Restates, step for step,
-//   __create_a_batchfile          src/basetype_caller.cpp:800-874   (500 kb sub-regions, header)
-//   __fetch_base_in_region        src/basetype_caller.cpp:876-939   (200 bp padding, read filter)
-//   __seek_position               src/basetype_caller.cpp:941-1024  (aligned pairs, indel anchoring)
-//   __write_record_to_batchfile   src/basetype_caller.cpp:1027-1101 (row text)
-//   BamRecord::get_aligned_pairs  src/bam_record.cpp:217-283
-// on top of bamio.hpp instead of htslib.  Quirks kept on purpose: an indel is anchored on the base to its
-// left and only recorded if no earlier pair of any read -- including the same read's own match at that
-// base -- already claimed the position (:1013-1019); the region test uses the un-anchored position
-// (:976-977); N / S / P / H operations contribute nothing (:1004-1007).
+// pileup.hpp -- the pileup that feeds the path: BAM alignments of many samples ->
+// first-read-wins cells, written STRAIGHT into dense position x sample planes in the engine's own cell encoding
+// (include/basevar_amd.h) -- the slab rows the engine takes, and what a batchfile row is printed from.
 //
-// PARITY STATUS: transcribed from the cited lines; unpinned by a run of the reference binary (htslib is
-// not buildable under this round's rules).  Checked against an independent Python derivation on the
-// reference's own BAM fixture and on synthetic BAMs (tests/test_pileup_cpu.py); the record counts of
-// SURVEY.md section 8c (real binary, 2 x range.bam: 5 VCF records, 207 CVG rows) are asserted end to end.
+// Design (not the reference's): the reference keeps, per sample and 500 kb step, a std::map<position, AlignBaseInfo>
+// of strings that it fills from a vector of per-base "aligned pair" records (src/basetype_caller.cpp:876-1024,
+// src/bam_record.cpp:217-283) and later looks up once per position and sample.  Here one pass over a read's CIGAR
+// claims cells directly in a PileupTile: four planes [position][sample] (call + strand, phred, mapq, read-position
+// rank) plus the few indel token texts, for a window of positions sized by a cell budget (so 10^5 samples work as well
+// as 10^2); samples are dealt to a thread pool, each worker writing only its samples' columns.  What a site needs
+// afterwards -- the slab row, the batchfile row, the VCF/CVG text -- is read from those planes.
+//
+// Behaviour kept identical to the reference's, quirks included (each cited where it is implemented):
+//   * reads are taken in file order and the FIRST claim of a (sample, position) wins        caller.cpp:1013-1019
+//   * mapq / duplicate / QC-fail filter, reads must overlap the step                         caller.cpp:900-912
+//   * the walk is bounded by the reference's own 500 kb step grid, tested on the UN-anchored position of an indel
+//     (an indel whose anchor base is the last base of a step is lost; one whose anchor lies before the step claims
+//     nothing that is ever printed)                                                          caller.cpp:826-846, 976-977
+//   * an indel is anchored on the base to its left and recorded only if nothing -- including the same read's own
+//     match at that base -- has claimed that position; its quality is int(mean read quality)  caller.cpp:982-1003
+//   * N / S / P / H operations claim nothing; S and P advance the query position             bam_record.cpp:258-270
+//
+// PARITY STATUS: unpinned by a run of the reference binary (htslib is not buildable here).  Checked against an
+// independent Python derivation on the reference's own BAM fixture and on synthetic BAMs (tests/test_pileup_cpu.py);
+// the record counts of SURVEY.md section 8c (real binary, 2 x range.bam: 5 VCF records, 207 CVG rows) are asserted
+// end to end.
 #pragma once
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <atomic>
+#include <iterator>
 #include <chrono>
 #include <cstdlib>
 #include <map>
@@ -29,6 +40,7 @@
 #include <tuple>
 #include <vector>
 
+#include "../../include/basevar_amd.h"
 #include "bamio.hpp"
 #include "batchfile.hpp"
 
@@ -65,264 +77,239 @@ inline std::string load_fasta_sequence(const std::string &path, const std::strin
     return seq;
 }
 
-// AlignBaseInfo, src/basetype_caller.h (the value of PosMap)
-struct AlignBaseInfo {
-    std::string ref_id;
-    uint32_t ref_pos = 0;
-    std::string ref_base, read_base;
-    char read_base_qual = '!';
-    int rpr = 0;
-    int mapq = 0;
-    char map_strand = '.';
-};
-typedef std::map<uint32_t, AlignBaseInfo> PosMap;
-typedef std::vector<PosMap> PosMapVector;
 typedef std::tuple<std::string, uint32_t, uint32_t> GenomeRegionTuple;  // [chr, start, end], 1-based
 
-// ReadAlignedPair + BamRecord::get_aligned_pairs, src/bam_record.h:33-41, src/bam_record.cpp:217-283
-struct ReadAlignedPair {
-    int op;
-    int64_t ref_pos;
-    std::string ref_base;
-    uint32_t qpos;
-    std::string read_base, read_qual;
+static const uint32_t PILEUP_STEP = 500000;   // the reference's sub-region length, caller.cpp:826
+static const uint32_t PILEUP_PAD = 200;       // REG_EXPEND_SIZE, caller.cpp:883
+
+// Dense first-read-wins cells of a window of positions [beg, end] (1-based, inclusive) for n samples.
+// Row = position, column = sample; a cell is claimed <=> its rank is non-zero (ranks start at 1).
+struct PileupTile {
+    std::string ref_id;
+    uint32_t beg = 0, end = 0;
+    size_t n_samples = 0, pitch = 0;
+    std::vector<uint8_t> cell;    // BV_CELL_*: base | strand for A/C/G/T; N / + / - tokens carry the strand bit too
+    std::vector<uint8_t> qual;    // phred (quality character - 33)
+    std::vector<uint8_t> mapq;
+    std::vector<uint16_t> rank;   // read-position rank (qpos + 1)
+    std::vector<uint32_t> depth;  // claimed samples per position == the batchfile's Depth column
+    struct IndelToken {
+        uint32_t pos, sample;
+        std::string text;         // "+" + anchor base + inserted bases, or "-" + anchor base + deleted bases
+    };
+    std::vector<IndelToken> indels;  // sorted by (pos, sample) after pileup_tile()
+
+    size_t rows() const { return (size_t)(end - beg) + 1; }
+    size_t at(uint32_t pos, size_t sample) const { return (size_t)(pos - beg) * pitch + sample; }
+    void reset(const std::string &id, uint32_t b, uint32_t e, size_t n) {
+        ref_id = id; beg = b; end = e; n_samples = n; pitch = (n + 255) / 256 * 256;
+        const size_t cells = rows() * pitch;
+        cell.assign(cells, BV_CELL_N);
+        qual.assign(cells, 0);
+        mapq.assign(cells, 0);
+        rank.assign(cells, 0);
+        depth.assign(rows(), 0);
+        indels.clear();
+    }
 };
-inline std::vector<ReadAlignedPair> get_aligned_pairs(const BamAlignment &al, const std::string &fa) {
-    std::vector<ReadAlignedPair> pairs;
-    ReadAlignedPair p;
-    int64_t rpos = al.map_ref_start_pos();
+
+inline uint8_t pileup_base_code(char c) {  // read base letter -> cell code (bamio: A C G T N, ' ' for other nibbles)
+    switch (c) {
+        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+        case 'N': return BV_CELL_N;
+        default:  // the reference prints such a letter into the batchfile and then fails to parse it back (basetype.cpp:54-56)
+            throw std::runtime_error(std::string("[ERROR] Why dose the size of aligned base is not 1? Check: ") + c);
+    }
+}
+
+// One read of one sample: walk its CIGAR once and claim cells.  [gb, ge]: the reference's step (500 kb grid) that
+// bounds the walk; cells outside the tile's own window are not stored.
+inline void pileup_claim_read(const BamAlignment &al, const std::string &fa, uint32_t gb, uint32_t ge, size_t sample,
+                              PileupTile &t, std::vector<uint8_t> &seen, std::vector<PileupTile::IndelToken> &indels) {
+    const uint8_t strand = (al.flag & BAM_FREVERSE) ? BV_CELL_REV : 0;
+    const uint8_t mq = (uint8_t)al.mapq();
+    const uint8_t mean_q = (uint8_t)(int)al.mean_qqual();  // char(int(mean) + 33) in the reference, caller.cpp:963
+    int64_t rpos = al.pos;   // 0-based reference position of the next reference-consuming base
     uint32_t qpos = 0;
-    std::string read_qual(al.qual.size(), '!');
-    for (size_t i = 0; i < al.qual.size(); ++i) read_qual[i] = (char)(al.qual[i] + 33);
+    auto claim = [&](int64_t pos1, uint8_t code, uint8_t q, uint32_t rk) -> bool {
+        if (pos1 < (int64_t)t.beg || pos1 > (int64_t)t.end) return false;
+        uint8_t &s = seen[(size_t)(pos1 - t.beg)];
+        if (s) return false;  // first read wins
+        s = 1;
+        const size_t k = t.at((uint32_t)pos1, sample);
+        t.cell[k] = code; t.qual[k] = q; t.mapq[k] = mq; t.rank[k] = (uint16_t)rk;
+        __atomic_fetch_add(&t.depth[(size_t)(pos1 - t.beg)], 1u, __ATOMIC_RELAXED);
+        return true;
+    };
     for (uint32_t c : al.cigar) {
         const int op = c & 15;
         const int64_t len = c >> 4;
         if (op == BAM_CMATCH || op == BAM_CEQUAL || op == BAM_CDIFF) {
-            for (int64_t i = rpos; i < rpos + len; ++i) {
-                p.op = op; p.ref_pos = i; p.ref_base = fa.substr((size_t)i, 1); p.qpos = qpos;
-                p.read_base = al.seq.substr(qpos, 1); p.read_qual = read_qual.substr(qpos, 1);
-                pairs.push_back(p);
-                ++qpos;
+            for (int64_t i = 0; i < len; ++i) {
+                const int64_t pos1 = rpos + i + 1;
+                if ((int64_t)ge < pos1) return;      // beyond the step: the rest of the read too (caller.cpp:976)
+                if ((int64_t)gb > pos1) continue;    // before the step (caller.cpp:977)
+                const uint8_t b = pileup_base_code(al.seq[qpos + (uint32_t)i]);
+                claim(pos1, (uint8_t)(b | strand), al.qual[qpos + (uint32_t)i], qpos + (uint32_t)i + 1);
             }
-            rpos += len;
-        } else if (op == BAM_CINS || op == BAM_CSOFT_CLIP || op == BAM_CPAD) {
-            p.op = op; p.ref_pos = rpos; p.ref_base = ""; p.qpos = qpos;
-            p.read_base = al.seq.substr(qpos, (size_t)len); p.read_qual = read_qual.substr(qpos, (size_t)len);
-            pairs.push_back(p);
-            qpos += (uint32_t)len;
-        } else if (op == BAM_CDEL || op == BAM_CREF_SKIP) {
-            p.op = op; p.ref_pos = rpos; p.ref_base = fa.substr((size_t)rpos, (size_t)len); p.qpos = qpos;
-            p.read_base = ""; p.read_qual = "";
-            pairs.push_back(p);
-            rpos += len;
-        }  // BAM_CHARD_CLIP: nothing
-    }
-    return pairs;
-}
-
-// __seek_position, src/basetype_caller.cpp:941-1024
-inline void seek_position(const std::vector<BamAlignment> &reads, const std::string &fa_seq, const GenomeRegionTuple &region,
-                          PosMap &sample_posinfo_map) {
-    if (!sample_posinfo_map.empty())
-        throw std::runtime_error("[basetype.cpp::__seek_position] 'sample_posinfo_map' must be empty.");
-    const std::string &ref_id = std::get<0>(region);
-    const uint32_t reg_start = std::get<1>(region), reg_end = std::get<2>(region);
-    AlignBaseInfo abi;
-    abi.ref_id = ref_id;
-    for (const auto &al : reads) {
-        abi.map_strand = al.map_strand();
-        abi.mapq = al.mapq();
-        const std::vector<ReadAlignedPair> pairs = get_aligned_pairs(al, fa_seq);
-        const char mean_qqual_char = (char)(int(al.mean_qqual()) + 33);
-        for (const auto &ap : pairs) {
-            uint32_t map_ref_pos = (uint32_t)(ap.ref_pos + 1);
-            if (reg_end < map_ref_pos) break;
-            if (reg_start > map_ref_pos) continue;
-            if (ap.op == BAM_CMATCH || ap.op == BAM_CEQUAL || ap.op == BAM_CDIFF) {
-                abi.ref_base = ap.ref_base.substr(0, 1);
-                abi.read_base = ap.read_base.substr(0, 1);
-                abi.read_base_qual = ap.read_qual[0];
-            } else if (ap.op == BAM_CINS) {
-                if (!ap.ref_base.empty()) throw std::runtime_error("[ERROR] We got reference base in insertion region.");
-                --map_ref_pos;  // the base left of the insertion break point
-                abi.ref_base = std::string(1, fa_seq[(size_t)ap.ref_pos - 1]);
-                abi.read_base = fa_seq[(size_t)ap.ref_pos - 1] + ap.read_base;
-                abi.read_base_qual = mean_qqual_char;
-            } else if (ap.op == BAM_CDEL) {
-                if (!ap.read_base.empty()) throw std::runtime_error("[ERROR] We got read bases in deletion region.");
-                --map_ref_pos;
-                abi.ref_base = fa_seq[(size_t)ap.ref_pos - 1] + ap.ref_base;
-                abi.read_base = std::string(1, fa_seq[(size_t)ap.ref_pos - 1]);
-                abi.read_base_qual = mean_qqual_char;
-            } else {
-                continue;
-            }
-            abi.ref_pos = map_ref_pos;
-            abi.rpr = (int)ap.qpos + 1;
-            if (sample_posinfo_map.find(map_ref_pos) == sample_posinfo_map.end()) sample_posinfo_map.insert({map_ref_pos, abi});
-        }
-    }
-}
-
-// __fetch_base_in_region, src/basetype_caller.cpp:876-939.  Returns is_empty.  The samples are independent
-// (one BAM, one PosMap each), so `n_threads` > 1 deals them to worker threads; the result does not depend on it.
-inline void pileup_one_sample(const std::string &path, const std::string &fa_seq, int mapq_thd, const GenomeRegionTuple &region,
-                              bool use_index, PosMap &sample_posinfo_map) {
-    static const uint32_t REG_EXPEND_SIZE = 200;
-    const std::string &ref_id = std::get<0>(region);
-    const uint32_t reg_start = std::get<1>(region), reg_end = std::get<2>(region);
-    const uint32_t exp_reg_start = reg_start > REG_EXPEND_SIZE ? reg_start - REG_EXPEND_SIZE : 1;
-    const uint32_t exp_reg_end = reg_end + REG_EXPEND_SIZE;
-    BamFile bf(path, use_index);
-    // "chr:beg-end", 1-based inclusive == [beg - 1, end) 0-based
-    if (bf.fetch(bf.tid_of(ref_id), (int64_t)exp_reg_start - 1, (int64_t)exp_reg_end)) {
-        std::vector<BamAlignment> sample_target_reads;
-        BamAlignment al;
-        while (bf.next(al) >= 0) {
-            if (al.mapq() < mapq_thd || al.is_duplicate() || al.is_qc_fail()) continue;
-            const int64_t map_ref_start = al.map_ref_start_pos() + 1;  // 1-based
-            const int64_t map_ref_end = al.map_ref_end_pos();          // 1-based
-            if ((int64_t)reg_start > map_ref_end) continue;
-            if ((int64_t)reg_end < map_ref_start) break;
-            sample_target_reads.push_back(al);
-        }
-        if (!sample_target_reads.empty()) seek_position(sample_target_reads, fa_seq, region, sample_posinfo_map);
-    }
-}
-inline bool fetch_base_in_region(const std::vector<std::string> &batch_align_files, const std::string &fa_seq, int mapq_thd,
-                                 const GenomeRegionTuple &region, PosMapVector &out, bool use_index = true, int n_threads = 1) {
-    const size_t base = out.size(), n = batch_align_files.size();
-    out.resize(base + n);
-    if (n_threads <= 1 || n < 2) {
-        for (size_t i = 0; i < n; ++i) pileup_one_sample(batch_align_files[i], fa_seq, mapq_thd, region, use_index, out[base + i]);
-    } else {
-        std::atomic<size_t> next(0);
-        std::mutex mu;
-        std::string err;
-        auto work = [&]() {
-            for (size_t i; (i = next.fetch_add(1)) < n;) {
-                try {
-                    pileup_one_sample(batch_align_files[i], fa_seq, mapq_thd, region, use_index, out[base + i]);
-                } catch (const std::exception &ex) {
-                    std::lock_guard<std::mutex> g(mu);
-                    if (err.empty()) err = ex.what();
+            rpos += len; qpos += (uint32_t)len;
+        } else if (op == BAM_CINS || op == BAM_CDEL) {
+            const int64_t pos1 = rpos + 1;           // the UN-anchored position is what the step test sees
+            if ((int64_t)ge < pos1) return;
+            if ((int64_t)gb <= pos1 && rpos >= 1) {
+                // anchored on the base to the left of the break point (caller.cpp:982-1003)
+                if (claim(pos1 - 1, (uint8_t)((op == BAM_CINS ? BV_CELL_INS : BV_CELL_DEL) | strand), mean_q, qpos + 1)) {
+                    std::string text(1, op == BAM_CINS ? '+' : '-');
+                    text += fa[(size_t)rpos - 1];
+                    if (op == BAM_CINS) text += al.seq.substr(qpos, (size_t)len);
+                    else text += fa.substr((size_t)rpos, (size_t)len);
+                    indels.push_back({(uint32_t)(pos1 - 1), (uint32_t)sample, std::move(text)});
                 }
             }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(work);
-        for (auto &t : pool) t.join();
-        if (!err.empty()) throw std::runtime_error(err);
+            if (op == BAM_CINS) qpos += (uint32_t)len; else rpos += len;
+        } else if (op == BAM_CREF_SKIP) {
+            if ((int64_t)ge < rpos + 1) return;
+            rpos += len;
+        } else if (op == BAM_CSOFT_CLIP || op == BAM_CPAD) {
+            if ((int64_t)ge < rpos + 1) return;
+            qpos += (uint32_t)len;  // the reference advances the query on P as on S (bam_record.cpp:258-265)
+        }  // BAM_CHARD_CLIP: nothing
     }
-    bool is_empty = true;
-    for (size_t i = 0; i < n; ++i)
-        if (!out[base + i].empty()) is_empty = false;
-    return is_empty;
 }
 
-// __write_record_to_batchfile, src/basetype_caller.cpp:1027-1101: appends the rows of [start, end] to `out`
-inline void write_records(const PosMapVector &v, const std::string &fa_seq, const GenomeRegionTuple &region, std::string &out) {
-    const std::string &ref_id = std::get<0>(region);
-    const uint32_t reg_start = std::get<1>(region), reg_end = std::get<2>(region);
-    const size_t sn = v.size();
-    // the five per-sample columns are built as text directly (same characters as ngslib::join over the vectors
-    // of :1040-1045, without an ostringstream per item)
-    std::string mapq, bases, quals, ranks, strands;
-    for (uint32_t pos = reg_start; pos < reg_end + 1; ++pos) {
-        uint32_t depth = 0;
-        mapq.clear(); ranks.clear(); bases.clear(); quals.clear(); strands.clear();
-        for (size_t i = 0; i < sn; ++i) {
-            if (i) { mapq += ' '; bases += ' '; quals += ' '; ranks += ' '; strands += ' '; }
-            auto it = v[i].find(pos);
-            if (it != v[i].end()) {
-                ++depth;
-                const AlignBaseInfo &a = it->second;
-                if (a.ref_id != ref_id || a.ref_pos != pos) throw std::runtime_error("[ERROR] reference id or position not match.");
-                mapq += std::to_string(a.mapq);
-                if (a.ref_base.size() == a.read_base.size()) bases += a.read_base;
-                else if (a.ref_base.size() < a.read_base.size()) { bases += '+'; bases += a.read_base; }
-                else { bases += '-'; bases += a.ref_base; }
-                quals += a.read_base_qual;
-                ranks += std::to_string(a.rpr);
-                strands += a.map_strand;
-            } else {
-                mapq += '0';
-                bases += 'N';
-                quals += '!';
-                ranks += '0';
-                strands += '.';
+// All reads of one sample that touch the tile.  [gb, ge] as above.
+inline void pileup_one_sample(const std::string &path, const std::string &fa, int mapq_thd, uint32_t gb, uint32_t ge, bool use_index,
+                              size_t sample, PileupTile &t, std::vector<uint8_t> &seen, std::vector<PileupTile::IndelToken> &indels) {
+    std::fill(seen.begin(), seen.end(), (uint8_t)0);
+    // the reference fetches its step +- 200 bp and keeps the reads that overlap the step; for a window inside the
+    // step the reads that can claim one of its cells are those that overlap the window (+ 1 for a left anchor)
+    const uint32_t lo = t.beg > PILEUP_PAD ? t.beg - PILEUP_PAD : 1, hi = t.end + PILEUP_PAD;
+    BamFile bf(path, use_index);
+    if (!bf.fetch(bf.tid_of(t.ref_id), (int64_t)lo - 1, (int64_t)hi)) return;
+    BamAlignment al;
+    while (bf.next(al) >= 0) {
+        if (al.mapq() < mapq_thd || al.is_duplicate() || al.is_qc_fail()) continue;  // caller.cpp:906
+        const int64_t first = al.map_ref_start_pos() + 1, last = al.map_ref_end_pos();  // 1-based, inclusive
+        if ((int64_t)gb > last) continue;    // caller.cpp:909-910, against the step
+        if ((int64_t)ge < first) break;
+        if ((int64_t)t.end + 1 < first) break;        // nothing of this or any later read can reach the window
+        if ((int64_t)t.beg > last + 1) continue;      // (an insertion right after the read's last base anchors at `last`)
+        pileup_claim_read(al, fa, gb, ge, sample, t, seen, indels);
+    }
+}
+
+// The pileup of every sample over [beg, end] into `t`.  `region_beg`: where the caller's whole region starts -- the
+// reference's steps are laid out from there in units of 500 kb, and [beg, end] must lie inside one of them.
+inline void pileup_tile(const std::vector<std::string> &bams, const std::string &fa, const std::string &ref_id, uint32_t region_beg,
+                        uint32_t region_end, uint32_t beg, uint32_t end, int mapq_thd, bool use_index, int n_threads, PileupTile &t) {
+    const uint32_t gb = region_beg + (beg - region_beg) / PILEUP_STEP * PILEUP_STEP;
+    const uint32_t ge = std::min(region_end, gb + PILEUP_STEP - 1);
+    if (end > ge) throw std::runtime_error("[pileup_tile] a window must not cross the 500 kb step grid");
+    t.reset(ref_id, beg, end, bams.size());
+    const size_t n = bams.size();
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, n_threads), n));
+    std::vector<std::vector<PileupTile::IndelToken>> found((size_t)nt);
+    std::atomic<size_t> next(0);
+    std::mutex mu;
+    std::string err;
+    auto work = [&](int w) {
+        std::vector<uint8_t> seen(t.rows());
+        for (size_t i; (i = next.fetch_add(1)) < n;) {
+            try {
+                pileup_one_sample(bams[i], fa, mapq_thd, gb, ge, use_index, i, t, seen, found[(size_t)w]);
+            } catch (const std::exception &ex) {
+                std::lock_guard<std::mutex> g(mu);
+                if (err.empty()) err = ex.what();
             }
         }
-        out += ref_id; out += '\t'; out += std::to_string(pos); out += '\t'; out += fa_seq[pos - 1]; out += '\t';
-        out += std::to_string(depth); out += '\t'; out += mapq; out += '\t'; out += bases; out += '\t'; out += quals;
-        out += '\t'; out += ranks; out += '\t'; out += strands; out += '\n';
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int w = 0; w < nt; ++w) pool.emplace_back(work, w);
+        for (auto &th : pool) th.join();
     }
+    if (!err.empty()) throw std::runtime_error(err);
+    for (auto &f : found) t.indels.insert(t.indels.end(), std::make_move_iterator(f.begin()), std::make_move_iterator(f.end()));
+    std::sort(t.indels.begin(), t.indels.end(), [](const PileupTile::IndelToken &a, const PileupTile::IndelToken &b) {
+        return a.pos != b.pos ? a.pos < b.pos : a.sample < b.sample;
+    });
 }
 
-// The same cells as one row of write_records(), but as the BatchInfo that _basevar_caller would parse back from
-// that row (src/basetype_caller.cpp:688-736) -- for hosts that go from the pileup straight to the engine without
-// the batchfile text.  False when no sample covers the position (the reference skips such rows, :718).
-inline bool batchinfo_at(const PosMapVector &v, const std::string &fa_seq, const std::string &ref_id, uint32_t pos, BatchInfo &bi) {
-    const size_t sn = v.size();
-    bi = BatchInfo();
-    bi.n = sn;
-    bi.ref_id = ref_id;
-    bi.ref_pos = pos;
-    bi.ref_base = std::string(1, fa_seq[pos - 1]);
-    bi.align_bases.reserve(sn); bi.align_base_quals.reserve(sn); bi.mapqs.reserve(sn);
-    bi.map_strands.reserve(sn); bi.base_pos_ranks.reserve(sn);
-    for (size_t i = 0; i < sn; ++i) {
-        auto it = v[i].find(pos);
-        if (it != v[i].end()) {
-            const AlignBaseInfo &a = it->second;
-            ++bi.depth;
-            bi.mapqs.push_back(a.mapq);
-            if (a.ref_base.size() == a.read_base.size()) bi.align_bases.push_back(a.read_base);
-            else if (a.ref_base.size() < a.read_base.size()) bi.align_bases.push_back("+" + a.read_base);
-            else bi.align_bases.push_back("-" + a.ref_base);
-            bi.align_base_quals.push_back(a.read_base_qual);
-            bi.base_pos_ranks.push_back(a.rpr);
-            bi.map_strands.push_back(a.map_strand);
-        } else {
-            bi.mapqs.push_back(0);
-            bi.align_bases.push_back("N");
-            bi.align_base_quals.push_back('!');
-            bi.base_pos_ranks.push_back(0);
-            bi.map_strands.push_back('.');
+// Window length for n samples: the reference's whole step when it fits a cell budget, else what the budget allows.
+inline uint32_t pileup_window(size_t n_samples, size_t cell_budget = (size_t)1 << 27) {
+    const size_t pitch = (n_samples + 255) / 256 * 256;
+    return (uint32_t)std::max<size_t>(64, std::min<size_t>(PILEUP_STEP, cell_budget / std::max<size_t>(pitch, 1)));
+}
+
+// Calls fn(tile) for consecutive windows that cover [beg, end]; windows never cross the reference's step grid.
+template <typename Fn>
+inline void pileup_region(const std::vector<std::string> &bams, const std::string &fa, const std::string &ref_id, uint32_t beg,
+                          uint32_t end, int mapq_thd, bool use_index, int n_threads, Fn fn, uint32_t window = 0) {
+    if (window == 0) window = pileup_window(bams.size());
+    PileupTile t;
+    for (uint32_t sb = beg; sb <= end; sb += PILEUP_STEP) {
+        const uint32_t se = std::min(end, sb + PILEUP_STEP - 1);
+        for (uint32_t wb = sb; wb <= se; wb += window) {
+            const uint32_t we = std::min(se, wb + window - 1);
+            pileup_tile(bams, fa, ref_id, beg, end, wb, we, mapq_thd, use_index, n_threads, t);
+            fn(t);
+            if (we == UINT32_MAX) return;
         }
+        if (se == UINT32_MAX) return;
     }
-    return bi.depth > 0;
 }
 
-// __create_a_batchfile, src/basetype_caller.cpp:800-874: header + rows of the whole region, walked in
-// 500 kb sub-regions; `sink(text)` receives the text piecewise.  Returns has_data.
+// The text of the tile's rows in the reference's batchfile format, every position of the window, covered or not
+// (__write_record_to_batchfile, caller.cpp:1027-1101).
+inline void pileup_rows_text(const PileupTile &t, const std::string &fa, std::string &out) {
+    static const char LETTER[4] = {'A', 'C', 'G', 'T'};
+    std::string mapq, bases, quals, ranks, strands;
+    size_t next_indel = 0;
+    for (uint32_t pos = t.beg; pos <= t.end; ++pos) {
+        mapq.clear(); bases.clear(); quals.clear(); ranks.clear(); strands.clear();
+        for (size_t i = 0; i < t.n_samples; ++i) {
+            if (i) { mapq += ' '; bases += ' '; quals += ' '; ranks += ' '; strands += ' '; }
+            const size_t k = t.at(pos, i);
+            if (t.rank[k] == 0) {  // unclaimed: the reference's placeholders
+                mapq += '0'; bases += 'N'; quals += '!'; ranks += '0'; strands += '.';
+                continue;
+            }
+            const uint8_t c = t.cell[k];
+            mapq += std::to_string((int)t.mapq[k]);
+            if (!(c & BV_CELL_NOCALL)) bases += LETTER[c & 3];
+            else if ((c & 3) == 0) bases += 'N';
+            else {
+                while (next_indel < t.indels.size() && (t.indels[next_indel].pos < pos ||
+                       (t.indels[next_indel].pos == pos && t.indels[next_indel].sample < i))) ++next_indel;
+                bases += t.indels[next_indel].text;
+            }
+            quals += (char)(t.qual[k] + 33);
+            ranks += std::to_string((int)t.rank[k]);
+            strands += (c & BV_CELL_REV) ? '-' : '+';
+        }
+        out += t.ref_id; out += '\t'; out += std::to_string(pos); out += '\t'; out += fa[pos - 1]; out += '\t';
+        out += std::to_string(t.depth[pos - t.beg]); out += '\t'; out += mapq; out += '\t'; out += bases; out += '\t';
+        out += quals; out += '\t'; out += ranks; out += '\t'; out += strands; out += '\n';
+    }
+}
+
+// Batchfile creation (__create_a_batchfile, caller.cpp:800-874): header + the rows of the whole region; `sink(text)`
+// receives the text piecewise.  Returns has_data.
 template <typename Sink>
 inline bool create_a_batchfile(const std::vector<std::string> &batch_align_files, const std::vector<std::string> &batch_sample_ids,
                                const std::string &fa_seq, const GenomeRegionTuple &region, int mapq_thd, Sink sink,
-                               bool use_index = true, int n_threads = 1) {
-    static const uint32_t STEP_REGION_LEN = 500000;
-    const std::string &ref_id = std::get<0>(region);
-    const uint32_t reg_beg = std::get<1>(region), reg_end = std::get<2>(region);
+                               bool use_index = true, int n_threads = 1, uint32_t window = 0) {
     sink(batchfile_header(batch_sample_ids));
     bool has_data = false;
-    for (uint32_t i = reg_beg; i < reg_end + 1; i += STEP_REGION_LEN) {
-        const uint32_t sub_beg = i;
-        const uint32_t sub_end = sub_beg + STEP_REGION_LEN - 1 > reg_end ? reg_end : sub_beg + STEP_REGION_LEN - 1;
-        PosMapVector v;
-        v.reserve(batch_align_files.size());
-        const GenomeRegionTuple sub = std::make_tuple(ref_id, sub_beg, sub_end);
-        const auto t0 = std::chrono::steady_clock::now();
-        const bool is_empty = fetch_base_in_region(batch_align_files, fa_seq, mapq_thd, sub, v, use_index, n_threads);
-        if (!is_empty) has_data = true;
-        const auto t1 = std::chrono::steady_clock::now();
-        std::string rows;
-        write_records(v, fa_seq, sub, rows);
-        sink(rows);
-        if (std::getenv("BV_PILEUP_TIMING"))
-            std::fprintf(stderr, "[timing] %u-%u: pileup %.2f s, rows %.2f s\n", sub_beg, sub_end,
-                         std::chrono::duration<double>(t1 - t0).count(),
-                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
-    }
+    pileup_region(batch_align_files, fa_seq, std::get<0>(region), std::get<1>(region), std::get<2>(region), mapq_thd, use_index,
+                  n_threads, [&](const PileupTile &t) {
+                      for (uint32_t d : t.depth) has_data = has_data || d != 0;
+                      std::string rows;
+                      pileup_rows_text(t, fa_seq, rows);
+                      sink(rows);
+                  }, window);
     return has_data;
 }
 

@@ -2,9 +2,10 @@
 //
 // Text of one VCF record (_out_vcf_line, src/basetype_caller.cpp:1103-1209) and one CVG row
 // (_out_cvg_line, :1211-1260; __base_depth_and_indel, :1263-1289) from the engine's per-site
-// record plus the site's BatchInfo (needed for the per-sample GT:AB:SO:BP strings and the indel
-// tally, which are text operations on the tokens), and the two file headers
-// (src/basetype_utils.cpp:32-88).
+// record plus the site's slab row (the per-sample GT:AB:SO:BP strings need the call, strand and
+// phred of every sample -- exactly the two byte planes the engine was given) and its few indel
+// tokens (the CVG row's indel tally is a text operation on them), and the two file headers
+// (src/basetype_utils.cpp:32-88).  A host keeps, per pending site, a SiteText and nothing else.
 //
 // Number formatting is the reference's: std::to_string(double) ("%f", 6 decimals) for QUAL, QD,
 // FS, SOR, BP; ostringstream default (6 significant digits) through join() for CM_AF, CM_CAF and
@@ -31,11 +32,19 @@ static const char EMIT_BASES[4] = {'A', 'C', 'G', 'T'};  // src/basetype.h:19
 static const double EMIT_MLN10TO10 = -0.23025850929940458;  // src/basetype.h:20
 static const int EMIT_QUAL_THRESHOLD = 20;                  // src/basetype.h:22
 
+// What the text of one site needs besides the engine's record and the site's slab row: where it is, and the few
+// indel tokens ("+AT", "-CAG": one per sample that carries one) for the CVG row's indel tally.
+struct SiteText {
+    std::string ref_id, ref_base;
+    uint32_t ref_pos = 0;
+    std::vector<std::string> indel_tokens;
+};
+
 // __base_depth_and_indel, caller.cpp:1263-1289: "TOKEN|count" of the non-ACGT, non-N tokens,
 // ordered by std::map (lexicographic), "." if none.
-inline std::string indel_string(const std::vector<std::string> &align_bases) {
+inline std::string indel_string(const std::vector<std::string> &tokens) {
     std::map<std::string, int> indel_depth;
-    for (const auto &bs : align_bases) {
+    for (const auto &bs : tokens) {
         if (bs.empty() || bs[0] == 'N') continue;
         if (bs[0] == 'A' || bs[0] == 'C' || bs[0] == 'G' || bs[0] == 'T') continue;
         indel_depth[bs]++;
@@ -46,19 +55,20 @@ inline std::string indel_string(const std::vector<std::string> &align_bases) {
 }
 
 // _out_cvg_line, caller.cpp:1246-1257.  Empty string when the reference writes nothing.
-inline std::string format_cvg_line(const BatchInfo &bi, const bv_site_result &r) {
+inline std::string format_cvg_line(const SiteText &st, const bv_site_result &r) {
     if (r.total_depth == 0) return "";
     std::vector<int> dd = {(int)r.depth[0], (int)r.depth[1], (int)r.depth[2], (int)r.depth[3]};
-    return bi.ref_id + "\t" + std::to_string(bi.ref_pos) + "\t" + bi.ref_base + "\t" + std::to_string((int)r.total_depth) +
-           "\t" + join(dd, "\t") + "\t" + indel_string(bi.align_bases) + "\t" + std::to_string(r.cvg_fs) + "\t" +
+    return st.ref_id + "\t" + std::to_string(st.ref_pos) + "\t" + st.ref_base + "\t" + std::to_string((int)r.total_depth) +
+           "\t" + join(dd, "\t") + "\t" + indel_string(st.indel_tokens) + "\t" + std::to_string(r.cvg_fs) + "\t" +
            std::to_string(r.cvg_sor) + "\t" + std::to_string((int)r.cvg_sb[0]) + "," + std::to_string((int)r.cvg_sb[1]) +
            "," + std::to_string((int)r.cvg_sb[2]) + "," + std::to_string((int)r.cvg_sb[3]) + "\n";
 }
 
-// _out_vcf_line, caller.cpp:1103-1209.  `groups`/`group_names`: the site's bv_group_result records
+// _out_vcf_line, caller.cpp:1103-1209, from the site's slab row: `cell` / `phred` are the n per-sample bytes of the
+// base_strand and qual planes (include/basevar_amd.h).  `groups`/`group_names`: the site's bv_group_result records
 // and the group names in the reference's iteration order (std::map: sorted by name); may be empty.
-inline std::string format_vcf_line(const BatchInfo &bi, const bv_site_result &r, const bv_group_result *groups,
-                                   const std::vector<std::string> &group_names) {
+inline std::string format_vcf_line(const SiteText &st, const uint8_t *cell, const uint8_t *phred, size_t n, const bv_site_result &r,
+                                   const bv_group_result *groups, const std::vector<std::string> &group_names) {
     if (r.n_alt == 0) return "";  // caller.cpp:745
     std::map<char, std::string> alt_gt;
     std::vector<int> cm_ac;
@@ -74,15 +84,15 @@ inline std::string format_vcf_line(const BatchInfo &bi, const bv_site_result &r,
     }
     // per-sample GT:AB:SO:BP, caller.cpp:1125-1145
     std::vector<std::string> samples;
-    samples.reserve(bi.n);
-    const char upper_ref = (char)std::toupper((unsigned char)bi.ref_base[0]);
-    for (size_t i = 0; i < bi.n; ++i) {
-        const char fb = bi.align_bases[i][0];
-        if (fb != 'N' && fb != '+' && fb != '-') {
+    samples.reserve(n);
+    const char upper_ref = (char)std::toupper((unsigned char)st.ref_base[0]);
+    for (size_t i = 0; i < n; ++i) {
+        if (!(cell[i] & BV_CELL_NOCALL)) {
+            const char fb = EMIT_BASES[cell[i] & 3];
             if (alt_gt.find(fb) == alt_gt.end()) alt_gt[fb] = "./.";
             const std::string gt = (fb == upper_ref) ? "0/." : alt_gt[fb];
-            const double epsilon = std::exp((bi.align_base_quals[i] - 33) * EMIT_MLN10TO10);  // basetype.cpp:47-48
-            samples.push_back(gt + ":" + fb + ":" + bi.map_strands[i] + ":" + std::to_string(1.0 - epsilon));
+            const double epsilon = std::exp((int)phred[i] * EMIT_MLN10TO10);  // basetype.cpp:47-48 (quality char - 33)
+            samples.push_back(gt + ":" + fb + ":" + ((cell[i] & BV_CELL_REV) ? '-' : '+') + ":" + std::to_string(1.0 - epsilon));
         } else {
             samples.push_back("./.");
         }
@@ -110,8 +120,31 @@ inline std::string format_vcf_line(const BatchInfo &bi, const bv_site_result &r,
         }
     }
     const std::string qs = (r.qual > EMIT_QUAL_THRESHOLD) ? "." : "LowQual";
-    return bi.ref_id + "\t" + std::to_string(bi.ref_pos) + "\t.\t" + bi.ref_base + "\t" + join(alt_bases, ",") + "\t" +
+    return st.ref_id + "\t" + std::to_string(st.ref_pos) + "\t.\t" + st.ref_base + "\t" + join(alt_bases, ",") + "\t" +
            std::to_string(r.qual) + "\t" + qs + "\t" + join(info, ";") + "\tGT:AB:SO:BP\t" + join(samples, "\t") + "\n";
+}
+
+// The same from a BatchInfo (the reference's per-site input): its tokens are packed into a slab row first.
+inline SiteText site_text_of(const BatchInfo &bi) {
+    SiteText st;
+    st.ref_id = bi.ref_id; st.ref_base = bi.ref_base; st.ref_pos = bi.ref_pos;
+    for (const auto &tok : bi.align_bases)
+        if (!tok.empty() && (tok[0] == '+' || tok[0] == '-')) st.indel_tokens.push_back(tok);
+    return st;
+}
+inline std::string format_cvg_line(const BatchInfo &bi, const bv_site_result &r) { return format_cvg_line(site_text_of(bi), r); }
+inline std::string format_vcf_line(const BatchInfo &bi, const bv_site_result &r, const bv_group_result *groups,
+                                   const std::vector<std::string> &group_names) {
+    std::vector<uint8_t> cell(bi.n), phred(bi.n);
+    for (size_t i = 0; i < bi.n; ++i) {
+        const char fb = bi.align_bases[i].empty() ? 'N' : bi.align_bases[i][0];
+        uint8_t c = BV_CELL_N;
+        for (int k = 0; k < 4; ++k)
+            if (fb == EMIT_BASES[k]) c = (uint8_t)(k | (bi.map_strands[i] == '-' ? BV_CELL_REV : 0));
+        cell[i] = c;
+        phred[i] = (uint8_t)(bi.align_base_quals[i] - 33);
+    }
+    return format_vcf_line(site_text_of(bi), cell.data(), phred.data(), bi.n, r, groups, group_names);
 }
 
 // cvg_header_define, src/basetype_utils.cpp:72-88

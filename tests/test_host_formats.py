@@ -25,7 +25,7 @@ def cxx(src, exe, extra=()):
     import __graft_entry__ as g
     g.build()
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", LIB,
-                           "-lbasevar_amd", "-Wl,-rpath," + LIB, "-o", exe] + list(extra))
+                           "-lbasevar_amd", "-Wl,-rpath," + LIB, "-pthread", "-o", exe] + list(extra))
     return exe
 
 
@@ -315,3 +315,13 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
     lo = [l for l in crow if int(l.split("\t")[1]) <= 1050]
     hi = [l for l in crow if int(l.split("\t")[1]) > 1050]
     assert rows3 == hi + lo
+    # several engines (here two on the one GPU of the box), small batches finishing out of order: the same files
+    vcf4, cvg4 = str(tmp_path / "vz4.vcf"), str(tmp_path / "t4.cvg")
+    subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions", "CHROMOSOME_I:900-1200",
+                           "--mapq", "10", "--output-vcf", vcf4, "--output-cvg", cvg4, "--min-af", "0.05", "--batch-sites", "7",
+                           "--gpus", "2", "--devices", "0,0", "--thread", "2"])
+    assert open(vcf4).read() == open(vcf2).read() and open(cvg4).read() == open(cvg2).read()
+    vcf5, cvg5 = str(tmp_path / "vz5.vcf"), str(tmp_path / "t5.cvg")
+    subprocess.check_call([call, "--batchfiles", bf, "--output-vcf", vcf5, "--output-cvg", cvg5, "--min-af", "0.05", "--batch-sites", "5",
+                           "--devices", "0,0,0"])
+    assert open(vcf5).read() == open(vcf).read() and open(cvg5).read() == open(cvg).read()

@@ -44,6 +44,9 @@ def test_reference_bam_fixture_matches_python_derivation(tool, tmp_path, region,
     beg, end = map(int, span.split("-"))
     exp = bam_py.batchfile_text([bam, bam], fa, chrom, beg, end, mapq)
     assert got == exp
+    # the rows do not depend on how the region is cut into pileup windows, nor on the worker threads
+    for w in ("1", "7", "64"):
+        assert run_tool(tool, str(tmp_path / "w.bf"), fa, region, [bam, bam], mapq, extra=["--window", w, "--thread", "3"]) == got
     rows = [l.split("\t") for l in got.splitlines()[3:]]
     assert len(rows) == end - beg + 1 and all(len(r) == 9 for r in rows)
     if region == "CHROMOSOME_I:900-1200" and mapq == 10:
