@@ -345,16 +345,21 @@ def main():
         two_kernel = (shape == 0 and N <= 49152) or shape == 10
         kernel_name = "bv_p1s_stream_kernel" if two_kernel else ("bv_pass1_fused_kernel" if (shape == 9 or (shape == 0 and N <= 49152)) else "bv_pass1_kernel")
         achieved = algo_bytes / st_avg_s / 1e9
-        traffic = None
+        # HBM bytes per launch of that kernel from the PMC counters: NOT measured in this run (counter collection needs
+        # rocprofv3 around the process) but read from the committed record of the SAME kernel and configuration, if one
+        # exists (tools/collect_profiles.sh + tools/summarize_profiles.py); `traffic_source` says which
+        traffic = traffic_source = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                key = "pass1_%dx%d" % (B, N)
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_launch"]
+                for key in ("%s|%dx%d" % (kernel_name, B, N), "pass1_%dx%d" % (B, N)):
+                    if key in tj and (key.startswith(kernel_name) or kernel_name == "bv_pass1_kernel"):
+                        traffic = tj[key]["hbm_bytes_per_launch"]
+                        traffic_source = tj[key].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % key)
+                        break
             except Exception:
-                traffic = None
+                traffic = traffic_source = None
         line = {
             "metric": "genomic sites/sec through basetype caller at N samples",
             "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -376,7 +381,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": st_avg_s * 1e3, "pass1_avg_ms": p1_avg_s * 1e3,
                 "pass1_frac": algo_bytes / p1_avg_s / 1e9 / HBM_PEAK_GBS,  # all of pass 1 (streaming + solve kernels) over the same bytes

@@ -1,21 +1,45 @@
 #!/bin/bash
-# Runs on the MI355X box (through gpurun): everything the committed profiles/ summaries are made of.
-#   tools/collect_profiles.sh <tag>
-# then, back in the container:  python tools/summarize_profiles.py <tag> 131072 100000
-TAG=${1:-r1}
+# Runs on the MI355X box (through gpurun): rocprofv3 evidence for every shipped kernel.
+#   tools/collect_profiles.sh <tag>          e.g. r2
+# For each configuration below: one un-profiled bench run (the JSON line), one `--kernel-trace --stats` run and two PMC
+# runs (FETCH_SIZE, WRITE_SIZE -- separate passes, no tracing beside them), all of the same bench command.
+# Back in the container:  python tools/summarize_profiles.py <tag>
+TAG=${1:-r2}
 cd "$(dirname "$0")/.."; ROOT=$PWD
 export TMPDIR=/tmp
-O=$ROOT/gpurun_out
-rm -rf $O/prof_${TAG}_stats $O/prof_${TAG}_fetch $O/prof_${TAG}_write
-timeout 600 python3 bench.py > $O/bench_${TAG}.json 2> $O/bench_${TAG}.err
-timeout 300 python3 bench.py --streams 2 --no-cpu-baseline > $O/bench_${TAG}_2streams.json 2>> $O/bench_${TAG}.err
-timeout 300 python3 bench.py --samples 10000 --batch-sites 524288 --no-cpu-baseline > $O/bench_${TAG}_N10000.json 2>> $O/bench_${TAG}.err
-timeout 300 python3 bench.py --samples 1000000 --batch-sites 16384 --steps 8 --no-cpu-baseline > $O/bench_${TAG}_N1000000.json 2>> $O/bench_${TAG}.err
-timeout 300 python3 bench.py --tally-only --no-cpu-baseline > $O/bench_${TAG}_tallyonly.json 2>> $O/bench_${TAG}.err
-timeout 300 python3 bench.py --batch-sites 32768 --no-cpu-baseline > $O/bench_${TAG}_32k_batches.json 2>> $O/bench_${TAG}.err
-timeout 600 python3 bench.py --no-cpu-baseline --with-tile-mode --with-host-path --batch-sites 65536 --tile-sites 65536 --steps 3 --warmup 1 > $O/bench_${TAG}_tilemode_100k.json 2>> $O/bench_${TAG}.err
-timeout 900 python3 bench.py --no-cpu-baseline --with-tile-mode --samples 1000000 --batch-sites 8192 --tile-sites 8192 --steps 3 --warmup 1 > $O/bench_${TAG}_tilemode_1M.json 2>> $O/bench_${TAG}.err
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_stats -- python3 bench.py --no-cpu-baseline > $O/bench_${TAG}_profiled.json 2>> $O/bench_${TAG}.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/prof_${TAG}_fetch -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>> $O/bench_${TAG}.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/prof_${TAG}_write -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>> $O/bench_${TAG}.err
-tail -c 600 $O/bench_${TAG}.json
+O=$ROOT/gpurun_out/prof_$TAG
+rm -rf $O; mkdir -p $O
+run_cfg() {  # name, bench args
+  local name=$1; shift
+  echo "== $name: $*" >&2
+  echo "$*" > $O/$name.args
+  timeout 600 python3 bench.py --no-cpu-baseline "$@" > $O/$name.bench.json 2> $O/$name.err
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name.stats -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > /dev/null 2>> $O/$name.err
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/$name.fetch -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > /dev/null 2>> $O/$name.err
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/$name.write -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > /dev/null 2>> $O/$name.err
+  # keep only the CSVs that the summary reads (the merge back is capped at 64 MiB)
+  find $O/$name.stats $O/$name.fetch $O/$name.write -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
+}
+sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kernel, three passes
+  local name=$1; shift
+  local i=0
+  for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
+    timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/$name.sq$i -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > /dev/null 2>> $O/$name.err
+    find $O/$name.sq$i -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
+    i=$((i+1))
+  done
+}
+run_cfg n100k                                               # headline: bv_pass1_kernel<3,1>, bv_pass2_kernel<256,true,false>
+run_cfg n100k_groups2 --groups 2 --batch-sites 65536        # bv_pass2_kernel<256,true,true> on long rows
+run_cfg n1M --samples 1000000 --batch-sites 16384 --steps 8 # the same kernels at 1 M samples
+run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_solve_kernel, bv_pass2_short_kernel
+run_cfg n10k_524k --samples 10000 --batch-sites 524288
+run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_pass2_kernel<256,true,true>
+run_cfg n10k_groups1 --samples 10000 --batch-sites 100000 --groups 1   # bv_pass2_kernel<64,true,true>
+run_cfg n10k_noranks --samples 10000 --batch-sites 100000 --groups 2 --no-rank-planes   # bv_pass2_kernel<256,false,true>
+run_cfg tiles_joined_1M --samples 1000000 --batch-sites 8192 --tile-sites 8192 --with-tile-mode --steps 2 --warmup 1   # bv_tile_scatter_kernel
+run_cfg tiles_state_100k --samples 100000 --batch-sites 16384 --tile-sites 16384 --with-tile-mode --flags 8 --steps 2 --warmup 1   # bv_tile_tally_kernel, bv_tile_finish_kernel
+sq_cfg n10k --samples 10000 --batch-sites 100000
+sq_cfg n100k
+ls $O | head -80 >&2
+du -sh $O >&2

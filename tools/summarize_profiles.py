@@ -1,86 +1,146 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 output of one round (gpurun_out/prof_<tag>_{stats,fetch,write}) into the
-committed summaries under profiles/: per-kernel average durations (kernel-trace --stats) and
-HBM traffic per launch from the PMC passes, corrected as /opt/skills/guides/MI355X_MICROARCH.md
-(section HBM) prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request on wide coalesced
-streams -> x2; FETCH_SIZE / WRITE_SIZE are in KiB.
+"""Turns the rocprofv3 output of one round (gpurun_out/prof_<tag>/, written by tools/collect_profiles.sh on the GPU
+box) into the committed summaries under profiles/:
 
-    python tools/summarize_profiles.py <tag> <batch_sites> <samples>
+    profiles/<tag>_rocprof_summary.md / .json   per configuration and kernel: calls, average duration
+                                                (--kernel-trace --stats), HBM bytes per launch (PMC passes),
+                                                algorithmic bytes, the two ratios, SQ counters where collected
+    profiles/<tag>_bench_<config>.json          the un-profiled bench line of the same command
+    profiles/pmc_traffic.json                   kernel|batch x samples -> HBM bytes per launch (bench.py's `traffic`)
+
+HBM traffic is corrected as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950: FETCH_SIZE
+counts 64 B per 128-B request on wide coalesced streams -> x2; FETCH_SIZE / WRITE_SIZE are in KiB.
+
+    python tools/summarize_profiles.py <tag>
 """
 import collections
 import csv
 import glob
 import json
 import os
+import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK = 8000.0  # GB/s
 
 
-def find(tag, kind, pattern):
-    """newest matching file only: gpurun merges every call's output into the same local directory"""
-    hits = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_%s_%s" % (tag, kind), "**", pattern), recursive=True)
-    return sorted(hits, key=os.path.getmtime)[-1:]
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+def newest(pattern):
+    hits = glob.glob(pattern, recursive=True)
+    return sorted(hits, key=os.path.getmtime)[-1:] if hits else []
+
+
+def counters(dirpat):
+    acc, cnt = collections.defaultdict(float), collections.Counter()
+    for fn in glob.glob(dirpat, recursive=True):
+        for r in csv.DictReader(open(fn)):
+            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            acc[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return {k: acc[k] / cnt[k] for k in acc}
+
+
+def algorithmic_bytes(kernel, cfg, nvar):
+    B, N, G, ranks = cfg["batch_sites"], cfg["samples"], cfg.get("groups", 0), cfg.get("ranks", True)
+    if kernel.startswith(("bv_pass1_kernel", "bv_pass1_fused_kernel", "bv_p1s_stream_kernel")):
+        return 2.0 * B * N, "2 B/cell x %d sites x %d samples" % (B, N)
+    if kernel.startswith("bv_pass2"):
+        per = (4 if ranks else 1) + (1 if G else 0)
+        return float(per) * N * nvar, "%d B/cell x %d variant rows x %d samples" % (per, nvar, N)
+    return None, "-"
 
 
 def main():
-    tag, B, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    out = {"tag": tag, "batch_sites": B, "samples": N, "kernels": {}}
-    lines = ["# rocprofv3 summary, %s (batch %d sites x %d samples)" % (tag, B, N), "",
-             "Commands (on the MI355X box, from /tmp with TMPDIR=/tmp):", "",
-             "    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_%s_stats -- python3 bench.py --no-cpu-baseline" % tag,
-             "    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_%s_fetch -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1" % tag,
-             "    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_%s_write -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1" % tag,
-             ""]
-    for fn in find(tag, "stats", "*kernel_stats.csv"):
-        lines += ["## kernel-trace --stats (%s)" % os.path.relpath(fn, ROOT), "", "```"]
-        rows = list(csv.DictReader(open(fn)))
-        for r in rows:
-            name = r["Name"].split("(")[0].replace("void ", "")
-            lines.append("%-40s calls %4s  avg %12.1f ns  total %14s ns  %6s %%" % (
-                name[:40], r["Calls"], float(r["AverageNs"]), r["TotalDurationNs"], r["Percentage"]))
-            out["kernels"].setdefault(name, {})["avg_ns"] = float(r["AverageNs"])
-            out["kernels"][name]["calls"] = int(r["Calls"])
-        lines += ["```", ""]
-    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-        acc = collections.defaultdict(float)
-        cnt = collections.Counter()
-        for fn in find(tag, kind, "*counter_collection.csv"):
-            for r in csv.DictReader(open(fn)):
-                if r["Counter_Name"] != counter:
-                    continue
-                name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-                acc[name] += float(r["Counter_Value"])
-                cnt[name] += 1
-        for name in acc:
-            out["kernels"].setdefault(name, {})[counter + "_KiB_per_launch"] = acc[name] / cnt[name]
-    lines += ["## HBM traffic per launch (PMC, separate passes)", "",
-              "| kernel | FETCH_SIZE KiB (raw) | read bytes (x2 gfx950 correction) | WRITE_SIZE KiB | write bytes | algorithmic bytes | traffic / algorithmic |",
-              "|---|---|---|---|---|---|---|"]
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
+    names = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(src, "*.args")))
+    out = {"tag": tag, "configs": {}}
+    lines = ["# rocprofv3 summary, round tag %s" % tag, "",
+             "Every configuration is ONE bench command, run four times on the MI355X box (tools/collect_profiles.sh): un-profiled",
+             "(the JSON line, `profiles/%s_bench_<config>.json`), under `rocprofv3 --kernel-trace --stats`, and under" % tag,
+             "`rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes; nothing traced beside the counters).",
+             "HBM bytes = 2 x FETCH_SIZE KiB x 1024 (gfx950 counts 64 B per 128-B request on wide streams) + WRITE_SIZE KiB x 1024.",
+             "`frac` = algorithmic bytes / average duration / 8 TB/s.", ""]
     traffic = {}
-    for name, k in out["kernels"].items():
-        if "FETCH_SIZE_KiB_per_launch" not in k:
-            continue
-        rd = 2.0 * k["FETCH_SIZE_KiB_per_launch"] * 1024.0
-        wr = k.get("WRITE_SIZE_KiB_per_launch", 0.0) * 1024.0
-        algo = None
-        if name.startswith("bv_pass1"):
-            algo = 2.0 * B * N
-            traffic["pass1_%dx%d" % (B, N)] = {"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
-                                               "algorithmic_bytes": algo}
-        k["hbm_read_bytes"] = rd
-        k["hbm_write_bytes"] = wr
-        lines.append("| %s | %.0f | %.4g | %.0f | %.4g | %s | %s |" % (
-            name[:40], k["FETCH_SIZE_KiB_per_launch"], rd, k.get("WRITE_SIZE_KiB_per_launch", 0.0), wr,
-            ("%.4g" % algo) if algo else "-", ("%.3f" % ((rd + wr) / algo)) if algo else "-"))
+    for name in names:
+        args = open(os.path.join(src, name + ".args")).read().strip()
+        cfg = {"samples": 100000, "batch_sites": 131072, "groups": 0, "ranks": True}
+        toks = args.split()
+        for i, t in enumerate(toks):
+            if t == "--samples": cfg["samples"] = int(toks[i + 1])
+            if t == "--batch-sites": cfg["batch_sites"] = int(toks[i + 1])
+            if t == "--groups": cfg["groups"] = int(toks[i + 1])
+            if t == "--no-rank-planes": cfg["ranks"] = False
+        nvar = 0
+        bj = os.path.join(src, name + ".bench.json")
+        bench = None
+        if os.path.exists(bj) and os.path.getsize(bj):
+            try:
+                bench = json.loads([l for l in open(bj).read().splitlines() if l.startswith("{")][-1])
+                nvar = int(bench["config"]["variant_sites_last_batch"])
+                shutil.copy(bj, os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (tag, name)))
+            except Exception as ex:  # keep going: the profile is still worth having
+                print("[warn] %s: no bench line (%s)" % (name, ex), file=sys.stderr)
+        kern = collections.OrderedDict()
+        for fn in newest(os.path.join(src, name + ".stats", "**", "*kernel_stats.csv")):
+            for r in csv.DictReader(open(fn)):
+                k = short(r["Name"])
+                kern[k] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
+                           "pct": float(r["Percentage"])}
+        fetch = counters(os.path.join(src, name + ".fetch", "**", "*counter_collection.csv"))
+        write = counters(os.path.join(src, name + ".write", "**", "*counter_collection.csv"))
+        sq = {}
+        for d in glob.glob(os.path.join(src, name + ".sq*")):
+            sq.update(counters(os.path.join(d, "**", "*counter_collection.csv")))
+        lines += ["## %s" % name, "", "    python3 bench.py --no-cpu-baseline %s" % args, ""]
+        if bench:
+            r = bench["roofline"]
+            lines += ["un-profiled bench line: %.4g sites/s, %s avg %.4f ms = %.3f of peak (pass 1 as a whole %.4f ms, pass 2 %.4f ms), "
+                      "%d variant sites in the last batch" % (bench["value"], r["kernel"], r["avg_launch_ms"], r["frac"],
+                                                             r.get("pass1_avg_ms", r["avg_launch_ms"]), r["pass2_avg_launch_ms"], nvar), ""]
+        lines += ["| kernel | calls | avg duration | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch | algorithmic bytes | traffic / algorithmic | frac of 8 TB/s |",
+                  "|---|---|---|---|---|---|---|---|---|"]
+        for k, v in kern.items():
+            if not k.startswith("bv_"):
+                continue
+            f, w = fetch.get((k, "FETCH_SIZE")), write.get((k, "WRITE_SIZE"))
+            hbm = (2.0 * f * 1024.0 if f is not None else 0.0) + (w * 1024.0 if w is not None else 0.0)
+            algo, how = algorithmic_bytes(k, cfg, nvar)
+            v.update({"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": hbm if f is not None else None, "algorithmic_bytes": algo,
+                      "algorithmic_how": how})
+            frac = (algo / (v["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK) if algo else None
+            v["frac"] = frac
+            for (kk, cn), cv in sq.items():
+                if kk == k:
+                    v.setdefault("sq", {})[cn] = cv
+            lines.append("| %s | %d | %.1f us | %s | %s | %s | %s | %s | %s |" % (
+                k, v["calls"], v["avg_ns"] / 1e3, "%.0f" % f if f is not None else "-", "%.0f" % w if w is not None else "-",
+                "%.4g" % hbm if f is not None else "-", ("%.4g (%s)" % (algo, how)) if algo else "-",
+                "%.3f" % (hbm / algo) if (algo and f is not None) else "-", "%.3f" % frac if frac else "-"))
+            if algo and f is not None and k.startswith(("bv_pass1", "bv_p1s_stream")):
+                traffic["%s|%dx%d" % (k.split("<")[0], cfg["batch_sites"], cfg["samples"])] = {
+                    "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
+                    "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)}
+        lines.append("")
+        sqk = [k for k in kern if "sq" in kern[k]]
+        if sqk:
+            lines += ["SQ counters per launch (`rocprofv3 --pmc`, three passes):", "", "```"]
+            for k in sqk:
+                for cn in sorted(kern[k]["sq"]):
+                    lines.append("%-44s %-24s %.4g" % (k[:44], cn, kern[k]["sq"][cn]))
+            lines += ["```", ""]
+        out["configs"][name] = {"args": args, "config": cfg, "variant_sites": nvar, "kernels": kern}
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.md" % tag), "w").write("\n".join(lines) + "\n")
     json.dump(out, open(os.path.join(ROOT, "profiles", "%s_rocprof_summary.json" % tag), "w"), indent=1)
-    if traffic:
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        cur = json.load(open(tf)) if os.path.exists(tf) else {}
-        cur.update(traffic)
-        json.dump(cur, open(tf, "w"), indent=1)
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    cur = json.load(open(tf)) if os.path.exists(tf) else {}
+    cur.update(traffic)
+    json.dump(cur, open(tf, "w"), indent=1)
     print("\n".join(lines))
 
 
