@@ -60,7 +60,7 @@ struct __attribute__((aligned(16))) BvP1sStreamShared {
 // One slot of one row: tally its 64 x 16 cells into the wave's histogram.
 template <bool LAST>
 __device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint32_t chunk, uint32_t n_chunks, int tail,
-                                                  uint32_t *hist, uint32_t one) {
+                                                  uint32_t *hist, uint32_t one, int lane = 0) {
     if (LAST) {
         // the row's last slot: lanes past the row were not loaded (their LDS bytes are stale), and the last chunk may be partial
         if (chunk >= n_chunks) {
@@ -87,7 +87,11 @@ __device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint
     }
     // X = call << 8 | phred << 1 = twice the word index of the 8 x 128 histogram; call < 8 <=> X < 0x800
     vq.x <<= 1; vq.y <<= 1; vq.z <<= 1; vq.w <<= 1;
+#if defined(BV_ABL_P1S_NOTALLY)   /* attribution builds only: the stream without the tally (results are wrong) */
+    if ((vb.x ^ vq.y) == 0x12345678u && (vb.z ^ vq.w) == 0x9abcdef0u) hist[lane] = one;
+#else
     bv_tally_chunk<1>(vb, vq, hist, one);
+#endif
 }
 
 #ifndef BV_P1S_NW
@@ -162,8 +166,8 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             --inflight;
             issue();
             const uint32_t chunk = j * 64u + (uint32_t)lane;
-            if (j + 1u == n_slots) bv_p1s_tally_slot<true>(vb, vq, chunk, n_chunks, tail, hist, one);
-            else bv_p1s_tally_slot<false>(vb, vq, chunk, n_chunks, tail, hist, one);
+            if (j + 1u == n_slots) bv_p1s_tally_slot<true>(vb, vq, chunk, n_chunks, tail, hist, one, lane);
+            else bv_p1s_tally_slot<false>(vb, vq, chunk, n_chunks, tail, hist, one, lane);
         }
         bv_lrt_sync<0>();
 
