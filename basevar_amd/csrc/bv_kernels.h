@@ -12,8 +12,8 @@
 // site of an earlier batch of a pipelined sequence of submits is still reported.
 #define BV_CTR_VARIANTS (0u * BV_CTR_STRIDE)  /* number of BV_SITE_VARIANT sites = length of var_list */
 #define BV_CTR_TICKET (1u * BV_CTR_STRIDE)    /* pass-1 site ticket counter                           */
-#define BV_CTR_CANDS (2u * BV_CTR_STRIDE)     /* short rows: number of candidate sites = length of cand_list */
-#define BV_CTR_TICKET2 (3u * BV_CTR_STRIDE)   /* short rows: ticket counter of the candidate solver   */
+#define BV_CTR_CANDS (2u * BV_CTR_STRIDE)     /* short rows: candidates for the wave solver = length of cand_list */
+#define BV_CTR_EASY (3u * BV_CTR_STRIDE)      /* short rows: candidates for the 16-lane solver = length of easy_list */
 #define BV_CTR_PER_LAUNCH 4u                  /* lines zeroed per launch                              */
 #define BV_CTR_ZEROFREQ (4u * BV_CTR_STRIDE)  /* sticky: sites with BV_SITE_ZERO_FREQ                 */
 #define BV_CTR_TIMEOUT (5u * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag                */
@@ -66,7 +66,7 @@ struct __attribute__((aligned(16))) BvSiteSummary {  // 48 bytes per site
 };
 #define BV_SUM_Q0_MASK 0xFu /* bit b: base b has a phred-0 call           */
 #define BV_SUM_BADQ 0x10u   /* a covered cell had phred > 93               */
-#define BV_SUM_CAND 0x20u   /* solved by a whole wave from its bins        */
+#define BV_SUM_CAND 0x20u   /* a candidate: solved from its exported bins  */
 struct BvP1ShortArgs {
     const uint8_t *bs, *q, *ref_base;
     uint64_t pitch;
@@ -78,7 +78,8 @@ struct BvP1ShortArgs {
     uint32_t *counters;
     BvSiteSummary *summ;   // [n_sites]
     uint32_t *bins;        // [n_sites][BV_S_BIN_STRIDE]  (code << 16 | count), candidate sites only
-    uint32_t *cand_list;   // [n_sites]
+    uint32_t *cand_list;   // [n_sites]  candidates that take a whole wave (shallow, phred-0 calls, > 128 bins, min_af <= 0)
+    uint32_t *easy_list;   // [n_sites]  candidates solved four per wave (bv_solver16.h)
 };
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream);
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream);

@@ -26,6 +26,7 @@
 #include "bv_kernels.h"
 
 #include "bv_solver.h"
+#include "bv_solver16.h"
 #include "bv_tally.h"
 
 #define BV_S_HROWQ 128                       /* phred axis of the short-row histogram */
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
     for (int k = 0; k < K; ++k) issue();
 
     uint32_t ring_r = 0;
-    uint32_t cand = 0, n_cand = 0;  // lane k: the k-th candidate site of this wave since the last flush
+    uint32_t cand = 0, n_cand = 0;  // lane k: the k-th wave-solver candidate of this wave since the last flush
+    uint32_t easy = 0, n_easy = 0;  // the same for the candidates of the 16-lane solver
     uint32_t refv = 0;              // lane i: ref_base of site blk0 + i
     uint32_t blk0 = s0;
 #pragma unroll 1
@@ -249,8 +251,12 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
                     nb += (uint32_t)__popcll(m);
                 }
             }
-            cand = ((uint32_t)lane == n_cand) ? site : cand;
-            ++n_cand;
+            // four per wave (bv_solver16.h) unless the site needs what only the wave solver has: the ordered replay of a
+            // shallow site, the literal 0/0 arithmetic of phred-0 calls or of min_af <= 0, or more than 128 bins
+            const bool is_easy = q0_mask == 0u && total > (uint32_t)BV_ORD_MAX && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 &&
+                                 !(a.flags & BV_FLAG_WAVE_SOLVER);
+            if (is_easy) { easy = ((uint32_t)lane == n_easy) ? site : easy; ++n_easy; }
+            else { cand = ((uint32_t)lane == n_cand) ? site : cand; ++n_cand; }
         }
         {
             // 48-byte summary: 12 lanes, one dword each
@@ -281,6 +287,13 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if ((uint32_t)lane < n_cand) a.cand_list[base + (uint32_t)lane] = cand;
             n_cand = 0;
+        }
+        if (n_easy == 64u || (site + 1u == s1 && n_easy != 0u)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_EASY], n_easy);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((uint32_t)lane < n_easy) a.easy_list[base + (uint32_t)lane] = easy;
+            n_easy = 0;
         }
     }
 }
@@ -343,11 +356,11 @@ __device__ inline double bv_fisher_two_sided_lane(int n11, int n12, int n21, int
 
 // ------------------------------------------------------------------------------ solve kernel
 #define BV_P1S_SOLVE_NW 4
+#define BV_P1S_RAW_WORDS (2 * BV_SLOTS * BV_WAVE + 4 * 128)  /* 1280 words of per-wave scratch */
 struct __attribute__((aligned(16))) BvP1sSolveShared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    uint32_t bin_code[BV_P1S_SOLVE_NW][BV_SLOTS * BV_WAVE];
-    uint32_t bin_cnt[BV_P1S_SOLVE_NW][BV_SLOTS * BV_WAVE];
-    uint32_t hq[BV_P1S_SOLVE_NW][4 * 128];  // merged-strand (base, phred) counts of the wave's site
+    // per wave: bin codes [384], bin counts [384], merged (base, phred) counts [4][128]
+    uint32_t raw[BV_P1S_SOLVE_NW][BV_P1S_RAW_WORDS];
     BvSolverScratch sc[BV_P1S_SOLVE_NW];
 };
 
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
 
     // ---- (b) candidates, one wave per site
     const uint32_t n_cand = a.counters[BV_CTR_CANDS];
-    uint32_t *bin_code = sh.bin_code[wave], *bin_cnt = sh.bin_cnt[wave], *hq = sh.hq[wave];
+    uint32_t *bin_code = sh.raw[wave], *bin_cnt = sh.raw[wave] + BV_SLOTS * BV_WAVE, *hq = sh.raw[wave] + 2 * BV_SLOTS * BV_WAVE;
     BvSolverScratch *sv = &sh.sc[wave];
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
     uint32_t vlist = 0, n_vlist = 0;  // lane k: the k-th variant site of this wave since the last flush
@@ -479,6 +492,80 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
         bv_lrt_sync<0>();
     }
     if (n_vlist) flush_variants();
+
+}
+
+// ---- candidates, four per wave: one site per group of 16 lanes (bv_solver16.h).  A kernel of its own: its register
+// budget (and with it the waves per SIMD) is then not set by the other two phases.
+struct __attribute__((aligned(16))) BvP1sSolve16Shared {
+    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    uint32_t cls[BV_P1S_SOLVE_NW][4][2 * 128];          // per group: REF / ALT counts per phred
+    uint32_t vl[BV_P1S_SOLVE_NW][64];                   // the wave's variant sites since the last flush
+    bv_site_result res16[BV_P1S_SOLVE_NW][4];           // one staged record per group
+    double pm16[BV_P1S_SOLVE_NW][BV_G16_SLOTS * BV_WAVE];  // previous marginals, [slot][lane]
+};
+#ifndef BV_P1S_SOLVE16_OCC
+#define BV_P1S_SOLVE16_OCC 3
+#endif
+__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
+    __shared__ BvP1sSolve16Shared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE_NW) {
+        sh.tab_hit[i] = a.tables->hit[i];
+        sh.tab_miss[i] = a.tables->miss[i];
+    }
+    __syncthreads();
+    BvSolveArgs sa;
+    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
+    sa.min_af = a.min_af; sa.flags = a.flags;
+    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
+    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
+    const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;
+    const uint32_t n_easy = a.counters[BV_CTR_EASY];
+    const int grp = lane >> 4, gl = lane & 15;
+    uint32_t *cls = sh.cls[wave][grp], *vl = sh.vl[wave];
+    uint32_t n_vl = 0;  // variant sites in vl[]
+    auto flush_vl = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_VARIANTS], n_vl);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        bv_lrt_sync<0>();
+        if ((uint32_t)lane < n_vl) a.var_list[base + (uint32_t)lane] = vl[lane];
+        bv_lrt_sync<0>();
+        n_vl = 0;
+    };
+    for (uint32_t t = gw; (uint64_t)t * 4u < n_easy; t += n_waves) {
+        const uint32_t idx = t * 4u + (uint32_t)grp;
+        const bool active = idx < n_easy;
+        bool variant = false;
+        uint32_t site = 0;
+        if (active) {
+            site = a.easy_list[idx];
+            const BvSiteSummary sm = a.summ[site];
+            BvSiteSums S;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
+            S.q0_mask = 0; S.nb = sm.nb;
+            S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
+            BvG16Bins B;
+            B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sa.loghit; B.logmiss = sa.logmiss;
+            B.pm = sh.pm16[wave] + lane;
+            const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t i = (uint32_t)(s * 16 + gl);
+                B.w[s] = i < sm.nb ? src[i] : 0u;
+            }
+            variant = bv_site_solve_g16(sa, site, S, B, cls, &sh.res16[wave][grp], lane);
+        }
+        // the wave's variant sites of this round, in group order
+        const unsigned long long vm = __ballot(variant && gl == 0);
+        if (variant && gl == 0) vl[n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
+        n_vl += (uint32_t)__popcll(vm);
+        if (n_vl > 60u) flush_vl();
+    }
+    if (n_vl) flush_vl();
 }
 
 // ------------------------------------------------------------------------------ launchers
@@ -504,8 +591,12 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
 }
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;
-    uint32_t grid = cu * 3u;  // 3 waves per SIMD: the solver is VALU-bound, and at 4 (128 VGPRs) it spills
+    uint32_t grid = cu * 3u;  // 3 waves per SIMD (168 VGPRs)
     const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
     if (grid > need) grid = need > 0 ? need : 1;
     hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
+    uint32_t grid16 = cu * (uint32_t)BV_P1S_SOLVE16_OCC;
+    const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE_NW - 1) / (4 * BV_P1S_SOLVE_NW);  // four sites per wave
+    if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
+    hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
 }

@@ -1,0 +1,522 @@
+// bv_solver16.h -- the per-site solver on a GROUP of 16 lanes: four sites per wave, in lockstep.
+//
+// A short-row candidate (bv_pass1_short.hip) is a small problem: ~70 (base, phred) bins, Fisher families of a few
+// hundred tables, 128 phred values.  On a whole wave most of its solver is scalar work that 64 lanes repeat (the LRT's
+// control flow, QUAL's continued fraction, divisions, the tails of six-step reductions over mostly idle lanes) -- the
+// solve kernel is VALU-issue-bound, so instruction count is its time.  Here a row of 16 lanes (one DPP row) owns a site:
+// every instruction serves four sites, reductions are four DPP steps inside the row, and a site's bins live in the
+// registers of its 16 lanes (bin i in lane i % 16, slot i / 16: at most 8 x 16 = 128 bins -- deeper or shallower
+// candidates, or ones with a phred-0 call, keep the wave solver).
+//
+// Same reference functions, same arithmetic per term as the wave solver (bv_device.h / bv_solver.h); only the ORDER of
+// the floating-point sums over bins / tables / phred values differs (tree inside a row instead of a scan over the wave),
+// i.e. results agree with the wave solver to ~1e-15 relative, far inside the 1e-6 parity bar.
+//
+// Cross-lane rules: everything "uniform" here is uniform per GROUP and lives in VGPRs; control flow may diverge between
+// the four groups of a wave (the compiler masks), so only row-local operations are used: DPP quad_perm / row_mirror /
+// row_shr, and ballots cut to the group's 16 bits.
+#pragma once
+
+#include "bv_solver.h"
+
+#define BV_G16_SLOTS 8                      /* bins per lane: 8 x 16 = 128 bins per site */
+#define BV_G16_MAX_BINS (16 * BV_G16_SLOTS)
+
+// ------------------------------------------------------------------ row-local primitives
+#define BV_DPP_QUAD_XOR1 0xB1 /* quad_perm [1,0,3,2] */
+#define BV_DPP_QUAD_XOR2 0x4E /* quad_perm [2,3,0,1] */
+#define BV_DPP_ROW_MIRROR 0x140
+#define BV_DPP_ROW_HALF_MIRROR 0x141
+
+// All-reduce over the 16 lanes of a row.  Every step pairs lanes symmetrically (i <-> i^1, i^2, 7-i, 15-i) and IEEE
+// addition is commutative, so all 16 lanes end with the bit-identical sum -- no broadcast needed.
+__device__ __forceinline__ double bv_g16_sum(double v) {
+    v += bv_dpp_f64<BV_DPP_QUAD_XOR1, 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_QUAD_XOR2, 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_HALF_MIRROR, 0xf>(v);
+    v += bv_dpp_f64<BV_DPP_ROW_MIRROR, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ uint32_t bv_g16_sum_u32(uint32_t v) {
+    v += (uint32_t)bv_dpp_i32<BV_DPP_QUAD_XOR1, 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_QUAD_XOR2, 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_HALF_MIRROR, 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_MIRROR, 0xf>(0, (int)v);
+    return v;
+}
+__device__ __forceinline__ unsigned long long bv_g16_sum_u64(unsigned long long v) {
+    v += bv_dpp_u64<BV_DPP_QUAD_XOR1, 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_QUAD_XOR2, 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_ROW_HALF_MIRROR, 0xf>(v);
+    v += bv_dpp_u64<BV_DPP_ROW_MIRROR, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ int bv_g16_max_i32(int v) {
+    v = max(v, bv_dpp_i32<BV_DPP_QUAD_XOR1, 0xf>(v, v));
+    v = max(v, bv_dpp_i32<BV_DPP_QUAD_XOR2, 0xf>(v, v));
+    v = max(v, bv_dpp_i32<BV_DPP_ROW_HALF_MIRROR, 0xf>(v, v));
+    v = max(v, bv_dpp_i32<BV_DPP_ROW_MIRROR, 0xf>(v, v));
+    return v;
+}
+__device__ __forceinline__ int bv_g16_min_i32(int v) {
+    v = min(v, bv_dpp_i32<BV_DPP_QUAD_XOR1, 0xf>(v, v));
+    v = min(v, bv_dpp_i32<BV_DPP_QUAD_XOR2, 0xf>(v, v));
+    v = min(v, bv_dpp_i32<BV_DPP_ROW_HALF_MIRROR, 0xf>(v, v));
+    v = min(v, bv_dpp_i32<BV_DPP_ROW_MIRROR, 0xf>(v, v));
+    return v;
+}
+// inclusive prefix sum inside the row (lane 15 of the row ends with the total)
+__device__ __forceinline__ uint32_t bv_g16_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(1), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(2), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(4), 0xf>(0, (int)v);
+    v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(8), 0xf>(0, (int)v);
+    return v;
+}
+// the 16 ballot bits of this lane's group
+__device__ __forceinline__ uint32_t bv_g16_ballot(bool pred, int lane) {
+    return (uint32_t)(__ballot(pred) >> (lane & 48)) & 0xFFFFu;
+}
+// value held by lane `k` (0..15, uniform in the group) of this lane's group
+__device__ __forceinline__ double bv_g16_bcast_f64(double v, int k, int lane) {
+    const int src = ((lane & 48) | (k & 15)) << 2;
+    const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------ Fisher exact test, 16 tables per round
+// kt_fisher_exact (two-sided), htslib/kfunc.c:197-313; see bv_fisher_two_sided_wave for the formulation.  `T` as there.
+__device__ inline double bv_fisher_two_sided_g16(int n11, int n12, int n21, int n22, int lane, const BvLnTab &T) {
+    const int gl = lane & 15;
+    const int n1_ = n11 + n12, n_1 = n11 + n21, n = n11 + n12 + n21 + n22;
+    const int imax = (n_1 < n1_) ? n_1 : n1_;
+    int imin = n1_ + n_1 - n;
+    if (imin < 0) imin = 0;
+    if (imin == imax) return 1.;
+    {
+        // a row margin of at most 12 reads: product form, at most 13 tables -- one per lane of the group
+        const int n2_ = n21 + n22, n_2 = n - n_1;
+        const bool alt_row = n2_ <= n1_;
+        const int m = alt_row ? n2_ : n1_, jobs = alt_row ? n21 : n11;
+        if (m <= 12) {
+            const int jmin = max(0, m - n_2), jmax = min(m, n_1);
+            const int j = jmin + gl;
+            const bool have = j <= jmax;
+            double pn = 1.0, pd = 1.0;
+            for (int t = 0; t < m; ++t) {
+                const double num = (t < j) ? (double)(n_1 - t) * (double)(m - t) : (double)(n_2 - (t - j));
+                const double den = (t < j) ? (double)(n - t) * (double)(t + 1) : (double)(n - t);
+                pn *= num;
+                pd *= den;
+            }
+            const double p = have ? pn / pd : 0.;
+            const double q = bv_g16_bcast_f64(p, jobs - jmin, lane);
+            if (q == 0.0) return 0.0;
+            const double lo = 0.99999999 * q, hi = 1.00000001 * q;
+            const bool viol = have && !(p < lo);
+            const uint32_t vm = bv_g16_ballot(viol, lane);  // never empty: the observed table is in it
+            double two = bv_g16_sum(viol ? 0. : p);
+            const double pL = bv_g16_bcast_f64(p, __builtin_ctz(vm), lane), pR = bv_g16_bcast_f64(p, 31 - __builtin_clz(vm), lane);
+            if (pL < hi) two += pL;
+            if (pR < hi) two += pR;
+            return two > 1. ? 1. : two;
+        }
+    }
+    BvHyper h;
+    bv_hyper_init(h, T, n1_, n_1, n);
+    const int R = imax - imin + 1;
+    const double logq = bv_hyper_logp(h, n11);
+    const double q = exp(logq);
+    if (q == 0.0) return 0.0;  // kfunc.c:260-289
+    const double lo = 0.99999999 * q, hi = 1.00000001 * q;
+    const int INF = 0x7fffffff;
+    int wl = imin, wr = imax;
+    if (R > 4 * 16) {
+        // many tables: skip the far tails whose terms are below q * 2^-86 (16-point probes on either side)
+        const double cut = logq - 60.0;
+        {
+            const int span = n11 - imin, step = span / 15 + 1;
+            const int i = imin + gl * step;
+            const bool below = (i <= n11) && (bv_hyper_logp(h, min(i, n11)) < cut);
+            const int last = bv_g16_max_i32(below ? i : -1);
+            if (last >= 0) wl = last;
+        }
+        {
+            const int span = imax - n11, step = span / 15 + 1;
+            const int i = imax - gl * step;
+            const bool below = (i >= n11) && (bv_hyper_logp(h, max(i, n11)) < cut);
+            const int first = bv_g16_min_i32(below ? i : INF);
+            if (first != INF) wr = first;
+        }
+    }
+    // rounds of 16 tables, ascending over [wl, wr]
+    double tail = 0., pL = 0., pR = 0.;
+    bool seen = false;
+    for (int w = wl; w <= wr; w += 16) {
+        const int i = w + gl;
+        const bool have = i <= wr;
+        const double pe = bv_hyper_p(h, have ? i : wr);
+        const double p = have ? pe : 0.;
+        const bool viol = have && !(p < lo);
+        tail += viol ? 0. : p;
+        const uint32_t vm = bv_g16_ballot(viol, lane);
+        if (vm != 0u) {
+            if (!seen) pL = bv_g16_bcast_f64(p, __builtin_ctz(vm), lane);
+            seen = true;
+            pR = bv_g16_bcast_f64(p, 31 - __builtin_clz(vm), lane);
+        }
+    }
+    double two = bv_g16_sum(tail);
+    if (pL < hi) two += pL;
+    if (pR < hi) two += pR;
+    return two > 1. ? 1. : two;
+}
+
+// strand_bias tail, src/basetype.cpp:277-286 (see bv_strand_bias_wave for the SOR overflow note)
+__device__ inline void bv_strand_bias_g16(uint32_t ref_fwd, uint32_t ref_rev, uint32_t alt_fwd, uint32_t alt_rev, int lane,
+                                          const BvLnTab &T, double *fs_out, double *sor_out, uint32_t *flags) {
+    double fs = -10 * log10(bv_fisher_two_sided_g16((int)ref_fwd, (int)ref_rev, (int)alt_fwd, (int)alt_rev, lane, T));
+    if (isinf(fs)) fs = 10000;
+    else if (fs == 0) fs = 0.0;
+    int den = (int)(ref_rev * alt_fwd), num = (int)(ref_fwd * alt_rev);
+    if ((unsigned long long)ref_rev * alt_fwd > 0x7fffffffull || (unsigned long long)ref_fwd * alt_rev > 0x7fffffffull)
+        *flags |= BV_SITE_SOR_OVERFLOW;
+    *fs_out = fs;
+    *sor_out = (ref_rev != 0u && alt_fwd != 0u) ? (double)num / (double)den : 10000;
+}
+
+// ------------------------------------------------------------------ EM on the group's bins (in registers)
+// bin word = code << 16 | count (code = base << 7 | phred), 0 for an empty slot; bins with phred > 93 carry no likelihood
+// row of their own in the EM (as in the wave solver, which leaves them out of its bin list) and are masked here.
+struct BvG16Bins {
+    uint32_t w[BV_G16_SLOTS];
+    const double *hit, *miss;        // LDS tables
+    const double *loghit, *logmiss;  // device memory
+    double *pm;                      // LDS: this LANE's previous marginals, pm[s * 64] for slot s (kept out of the registers:
+                                     // the solver is occupancy-bound, 16 VGPRs buy a third wave per SIMD)
+};
+__device__ __forceinline__ bool bv_g16_bin(const BvG16Bins &B, int s, uint32_t &b, uint32_t &q, double &c) {
+    const uint32_t w = B.w[s];
+    q = (w >> 16) & 127u;
+    b = w >> 23;
+    c = (double)(w & 0xFFFFu);
+    return (w & 0xFFFFu) != 0u && q < BV_NQ_VALID;
+}
+
+// EM, algorithm.h:210-255, on the bins (no phred-0 call among them, start frequencies not all zero -- the wave solver
+// takes the other sites).  `in_set`: bit b = base b; bases outside keep frequency +0.0 (their terms are exact zeros).
+__device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsigned in_set, double n_cov, double *lr_out) {
+    const double epsilon = (double)0.001f;
+    const double inv_n = 1.0 / n_cov;
+    double *pm = B.pm;
+#pragma unroll
+    for (int s = 0; s < BV_G16_SLOTS; ++s) pm[s * BV_WAVE] = 1.0;
+    int iters = 0;
+    for (int k = 0; k <= 100; ++k) {
+        double pf0 = 0., pf1 = 0., pf2 = 0., pf3 = 0., delta = 0.;
+#pragma unroll
+        for (int s = 0; s < BV_G16_SLOTS; ++s) {
+            uint32_t b, q;
+            double c;
+            if (bv_g16_bin(B, s, b, q, c)) {
+                const double hit = B.hit[q], miss = B.miss[q];
+                const double L0 = (b == 0 ? hit : miss) * f[0], L1 = (b == 1 ? hit : miss) * f[1];
+                const double L2 = (b == 2 ? hit : miss) * f[2], L3 = (b == 3 ? hit : miss) * f[3];
+                double marg = L0;
+                marg += L1; marg += L2; marg += L3;
+                const double r = c / marg;
+                pf0 += L0 * r; pf1 += L1 * r; pf2 += L2 * r; pf3 += L3 * r;
+                const double old = pm[s * BV_WAVE];
+                if (k > 0 && !(marg < old * 2.7 && marg > old * 0.37)) delta += c * bv_int_abs_trunc(log(marg) - log(old));
+                pm[s * BV_WAVE] = marg;
+            }
+        }
+        pf0 = bv_g16_sum(pf0); pf1 = bv_g16_sum(pf1); pf2 = bv_g16_sum(pf2); pf3 = bv_g16_sum(pf3);
+        f[0] = (in_set & 1u) ? pf0 * inv_n : 0.;
+        f[1] = (in_set & 2u) ? pf1 * inv_n : 0.;
+        f[2] = (in_set & 4u) ? pf2 * inv_n : 0.;
+        f[3] = (in_set & 8u) ? pf3 * inv_n : 0.;
+        if (k == 0) continue;
+        ++iters;
+        if (bv_g16_sum(delta) < epsilon) break;  // zero unless some bin's log-marginal moved by >= 1
+    }
+    double lr = 0.;
+#pragma unroll
+    for (int s = 0; s < BV_G16_SLOTS; ++s) {
+        uint32_t b, q;
+        double c;
+        if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * BV_WAVE]);
+    }
+    *lr_out = bv_g16_sum(lr);
+    return iters;
+}
+
+// ------------------------------------------------------------------ LRT
+// BaseType::lrt + _f over ACGT (src/basetype.cpp:105-199), streaming form of bv_lrt: the subsets of a level are
+// visited in Combinations order and the first minimum is kept as they come.  Requires q0_mask == 0.
+__device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], uint32_t total, int ref_code, double min_af,
+                                  BvLrtOut &o) {
+    o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
+    o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false;
+    int act = 0, m = 0;
+    for (int b = 0; b < 4; ++b) {
+        if ((double)bv_sel4u(depth, b) / (int)total >= min_af) {  // basetype.cpp:137
+            act |= b << (2 * m);
+            ++m;
+        }
+    }
+    if (m == 0) return;
+    if (m == 1) {  // one active base, no phred-0 call: see bv_lrt
+        const int b = act & 3;
+        o.m = 1; o.first = b; o.em_iters = 1; o.n_em = 1;
+        if (b != ref_code) { o.n_alt = 1; o.alt_packed = b; o.af[0] = 1.0; }
+        return;
+    }
+    const double n_cov = (double)total;
+    const int m0 = m;
+    const double d0 = (double)depth[0] / n_cov, d1 = (double)depth[1] / n_cov, d2 = (double)depth[2] / n_cov,
+                 d3 = (double)depth[3] / n_cov;
+    double fr0 = 0., fr1 = 0., fr2 = 0., fr3 = 0.;  // active_bases_freq
+    double lr_alt = 0., chi = 0.;
+    for (int n = m0; n > 0; --n) {
+        const bool top = (n == m0);
+        const int ncomb = top ? 1 : m;
+        // closed-form log-likelihoods of the four single-base subsets (see bv_lrt): one sweep, at the level that needs them
+        double single0 = 0., single1 = 0., single2 = 0., single3 = 0.;
+        if (!top && m == 2) {
+            double a_ = 0., g0 = 0., g1 = 0., g2 = 0., g3 = 0.;
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                uint32_t b, q;
+                double c;
+                if (bv_g16_bin(B, s, b, q, c)) {
+                    const double lm = B.logmiss[q], dh = B.loghit[q] - lm;
+                    a_ += c * lm;
+                    g0 += (b == 0) ? c * dh : 0.;
+                    g1 += (b == 1) ? c * dh : 0.;
+                    g2 += (b == 2) ? c * dh : 0.;
+                    g3 += (b == 3) ? c * dh : 0.;
+                }
+            }
+            a_ = bv_g16_sum(a_);
+            single0 = a_ + bv_g16_sum(g0); single1 = a_ + bv_g16_sum(g1);
+            single2 = a_ + bv_g16_sum(g2); single3 = a_ + bv_g16_sum(g3);
+        }
+        double best_v = 0., best_lr = 0., bf0 = 0., bf1 = 0., bf2 = 0., bf3 = 0.;
+        int best_c = 0;
+        for (int c = 0; c < ncomb; ++c) {
+            const int drop = top ? -1 : m - 1 - c;
+            unsigned in_set = 0;
+            for (int k = 0; k < m; ++k)
+                if (k != drop) in_set |= 1u << ((act >> (2 * k)) & 3);
+            double f[4];
+            f[0] = (in_set & 1u) ? d0 : 0.; f[1] = (in_set & 2u) ? d1 : 0.;
+            f[2] = (in_set & 4u) ? d2 : 0.; f[3] = (in_set & 8u) ? d3 : 0.;
+            double s = 0.;
+            s += f[0]; s += f[1]; s += f[2]; s += f[3];
+            double lr;
+            int it;
+            if (s == 0.) {
+                // basetype.cpp:113-115: the reference throws; flagged, and the subset scored like the wave solver's generic
+                // path would is not reproducible here -- kernel A sends such sites (min_af == 0 only) to the wave solver
+                o.zero_freq = true;
+                lr = 0.; it = 0;
+            } else if ((in_set & (in_set - 1u)) == 0u) {
+                const int b1 = __builtin_ctz(in_set);
+                lr = bv_sel4(single0, single1, single2, single3, b1);
+                it = (bv_sel4(f[0], f[1], f[2], f[3], b1) < 0.36787944117144233) ? 2 : 1;
+                f[0] = (b1 == 0) ? 1.0 : 0.; f[1] = (b1 == 1) ? 1.0 : 0.;
+                f[2] = (b1 == 2) ? 1.0 : 0.; f[3] = (b1 == 3) ? 1.0 : 0.;
+            } else {
+                it = bv_em_g16(B, f, in_set, n_cov, &lr);
+            }
+            o.em_iters += it;
+            o.n_em += 1;
+            const double v = 2 * (lr_alt - lr);
+            if (top || c == 0 || v < best_v) {  // first minimum, algorithm.h:24-27
+                best_v = v; best_c = c; best_lr = lr;
+                bf0 = f[0]; bf1 = f[1]; bf2 = f[2]; bf3 = f[3];
+            }
+        }
+        lr_alt = best_lr;
+        bool accept = top;
+        if (!top) {
+            chi = best_v;
+            accept = chi < 24;  // LRT_THRESHOLD, basetype.h:21
+            if (accept) {
+                const int drop = m - 1 - best_c;
+                const int low = act & ((1 << (2 * drop)) - 1), high = act >> (2 * drop + 2);
+                act = low | (high << (2 * drop));
+                m = n;
+            }
+        }
+        if (!accept) break;
+        fr0 = bf0; fr1 = bf1; fr2 = bf2; fr3 = bf3;
+    }
+    o.chi2 = chi;
+    o.m = m;
+    o.first = act & 3;
+    double af0 = 0., af1 = 0., af2 = 0., af3 = 0.;
+    int na = 0, packed = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < m) {
+            const int b = (act >> (2 * k)) & 3;
+            if (b != ref_code) {  // basetype.cpp:172-177
+                const double v = bv_sel4(fr0, fr1, fr2, fr3, b);
+                if (na == 0) af0 = v; else if (na == 1) af1 = v; else if (na == 2) af2 = v; else af3 = v;
+                packed |= b << (2 * na);
+                ++na;
+            }
+        }
+    }
+    o.n_alt = na;
+    o.alt_packed = packed;
+    o.af[0] = af0; o.af[1] = af1; o.af[2] = af2; o.af[3] = af3;
+}
+
+// ------------------------------------------------------------------ Wilcoxon rank sum, 16 values per window
+__device__ inline unsigned long long bv_ranksum_window_g16(uint32_t ref_v, uint32_t alt_v, unsigned long long n,
+                                                           unsigned long long &below) {
+    const uint32_t t = ref_v + alt_v;
+    const uint32_t incl = bv_g16_incl_scan_u32(t);
+    const unsigned long long below_v = below + (incl - t);
+    const unsigned long long term = (unsigned long long)ref_v * (2ull * n - 2ull * below_v - t + 1ull);
+    const unsigned long long s = bv_g16_sum_u64(term);
+    below += (unsigned long long)bv_g16_sum_u32(t);
+    return s;
+}
+
+// ------------------------------------------------------------------ one site on one group
+// `S`: the site's totals; B: its bins; cls: LDS scratch of 2 x 128 words for this group (REF / ALT counts per phred);
+// `res`: LDS staging of the record for this group.  Returns whether the site is a variant site.
+__device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const BvG16Bins &B, uint32_t *cls,
+                                         bv_site_result *res, int lane) {
+    const int gl = lane & 15;
+    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+    uint32_t *res_words = reinterpret_cast<uint32_t *>(res);
+    for (int i = gl; i < REC_WORDS; i += 16) res_words[i] = 0u;
+    uint32_t depth[4], total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        depth[b] = S.fwd[b] + S.rev[b];
+        total += depth[b];
+    }
+    int ref = a.ref_base[site];
+    if (ref > 4) ref = 4;
+    const double qnan = __builtin_nan("");
+    uint32_t flags = BV_SITE_COVERED | (S.badq ? BV_SITE_BAD_QUAL : 0u);
+    uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;  // caller.cpp:1236-1245
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (b == ref) { c_rf += S.fwd[b]; c_rr += S.rev[b]; } else { c_af += S.fwd[b]; c_ar += S.rev[b]; }
+    }
+    BvLrtOut L;
+    L.n_alt = 0; L.alt_packed = 0; L.af[0] = L.af[1] = L.af[2] = L.af[3] = 0.;
+    L.m = 0; L.first = 0; L.chi2 = 0.; L.em_iters = 0; L.n_em = 0; L.zero_freq = false;
+    if (!(a.flags & BV_FLAG_SKIP_LRT)) bv_lrt_g16(B, depth, total, ref, a.min_af, L);
+    if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
+
+    double bq_ranksum = qnan, qual = 0., qd = 0.;
+    uint32_t v_rf = 0, v_rr = 0, v_af = 0, v_ar = 0;
+    const bool have_var = L.n_alt > 0;
+    double caf0 = 0., caf1 = 0., caf2 = 0., caf3 = 0.;
+    if (have_var) {
+        flags |= BV_SITE_VARIANT;
+        uint32_t alt_mask = 0, ad_sum_u = 0;
+#pragma unroll
+        for (int k = 0; k < BV_MAX_ALT; ++k) {
+            if (k < L.n_alt) {
+                alt_mask |= 1u << bv_alt_at(L, k);
+                ad_sum_u += bv_sel4u(depth, bv_alt_at(L, k));
+            }
+        }
+        // QUAL / QD / CAF (basetype.cpp:180-196, caller.cpp:1113-1122, 1160-1161)
+        {
+            const double r = (double)bv_sel4u(depth, L.first) / (double)total;
+            if (L.m == 1 && total > 10 && r > 0.5) qual = 5000.0;
+            else qual = bv_qual_from_chi2(L.chi2);
+            double ad_sum = 0;
+#pragma unroll
+            for (int k = 0; k < BV_MAX_ALT; ++k) {
+                if (k < L.n_alt) {
+                    const uint32_t d = bv_sel4u(depth, bv_alt_at(L, k));
+                    ad_sum = ad_sum + (double)d;
+                    const double cf = (double)d / (int)total;
+                    if (k == 0) caf0 = cf; else if (k == 1) caf1 = cf; else if (k == 2) caf2 = cf; else caf3 = cf;
+                }
+            }
+            qd = qual / ad_sum;
+            if (qd == 0) qd = 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {  // caller.cpp:1164
+            if (b == ref) { v_rf += S.fwd[b]; v_rr += S.rev[b]; }
+            else if ((alt_mask >> b) & 1u) { v_af += S.fwd[b]; v_ar += S.rev[b]; }
+        }
+        // base-quality rank sum (caller.cpp:1157): REF / ALT counts per phred value, scattered from the bins
+        {
+            for (int i = gl; i < 2 * 128; i += 16) cls[i] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t w = B.w[s];
+                if (w & 0xFFFFu) {
+                    const uint32_t q = (w >> 16) & 127u, b = w >> 23;
+                    // bins are unique per (base, phred); several ALT bases can share a phred: add, one lane at a time per word
+                    if ((int)b == ref) cls[q] = w & 0xFFFFu;
+                    else if ((alt_mask >> b) & 1u) atomicAdd(&cls[128 + q], w & 0xFFFFu);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
+            unsigned long long below = 0, twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) twoR += bv_ranksum_window_g16(cls[w * 16 + gl], cls[128 + w * 16 + gl], n1 + n2, below);
+            bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
+        }
+    }
+    double c_fs = 0, c_sor = 0, v_fs = 0, v_sor = 0;
+    if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
+        const bool same = have_var && v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar;
+        bv_strand_bias_g16(c_rf, c_rr, c_af, c_ar, lane, a.lnfact, &c_fs, &c_sor, &flags);
+        if (have_var && !same) bv_strand_bias_g16(v_rf, v_rr, v_af, v_ar, lane, a.lnfact, &v_fs, &v_sor, &flags);
+        if (same) { v_fs = c_fs; v_sor = c_sor; }
+    }
+    if (gl == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) res->depth[b] = depth[b];
+        res->total_depth = total;
+        res->status = flags;
+        if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
+            res->cvg_sb[0] = c_rf; res->cvg_sb[1] = c_rr; res->cvg_sb[2] = c_af; res->cvg_sb[3] = c_ar;
+            res->cvg_fs = c_fs; res->cvg_sor = c_sor;
+            if (have_var) {
+                res->var_sb[0] = v_rf; res->var_sb[1] = v_rr; res->var_sb[2] = v_af; res->var_sb[3] = v_ar;
+                res->var_fs = v_fs; res->var_sor = v_sor;
+            }
+        }
+        res->n_alt = (uint8_t)L.n_alt;
+#pragma unroll
+        for (int k = 0; k < BV_MAX_ALT; ++k) {
+            if (k < L.n_alt) {
+                res->alt[k] = (uint8_t)bv_alt_at(L, k);
+                res->af[k] = L.af[k];
+            }
+        }
+        if (L.n_alt > 0) { res->caf[0] = caf0; res->qual = qual; res->qd = qd; }
+        if (L.n_alt > 1) res->caf[1] = caf1;
+        if (L.n_alt > 2) res->caf[2] = caf2;
+        if (L.n_alt > 3) res->caf[3] = caf3;
+        res->chi2 = L.chi2;
+        res->em_iters = (uint16_t)L.em_iters;
+        res->n_em = (uint8_t)L.n_em;
+        res->mq_ranksum = qnan;
+        res->rpr_ranksum = qnan;
+        res->bq_ranksum = bq_ranksum;
+        if (L.zero_freq) atomicAdd(&a.counters[BV_CTR_ZEROFREQ], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = gl; i < REC_WORDS; i += 16) reinterpret_cast<uint32_t *>(&a.out[site])[i] = res_words[i];
+    return have_var;
+}
