@@ -65,6 +65,14 @@ __device__ __forceinline__ int bv_g16_min_i32(int v) {
     v = min(v, bv_dpp_i32<BV_DPP_ROW_MIRROR, 0xf>(v, v));
     return v;
 }
+// inclusive prefix PRODUCTS inside the row
+__device__ __forceinline__ double bv_g16_incl_scan_prod_f64(double v) {
+    v *= bv_dpp_f64_one<BV_DPP_ROW_SHR(1), 0xf>(v);
+    v *= bv_dpp_f64_one<BV_DPP_ROW_SHR(2), 0xf>(v);
+    v *= bv_dpp_f64_one<BV_DPP_ROW_SHR(4), 0xf>(v);
+    v *= bv_dpp_f64_one<BV_DPP_ROW_SHR(8), 0xf>(v);
+    return v;
+}
 // inclusive prefix sum inside the row (lane 15 of the row ends with the total)
 __device__ __forceinline__ uint32_t bv_g16_incl_scan_u32(uint32_t v) {
     v += (uint32_t)bv_dpp_i32<BV_DPP_ROW_SHR(1), 0xf>(0, (int)v);
@@ -149,13 +157,17 @@ __device__ inline double bv_fisher_two_sided_g16(int n11, int n12, int n21, int 
             if (first != INF) wr = first;
         }
     }
-    // rounds of 16 tables, ascending over [wl, wr]
+    // rounds of 16 tables, ascending over [wl, wr]; only the first table comes from log-factorials, the others by the
+    // multiplicative step as prefix products across the group's lanes (see bv_fisher_two_sided_wave)
     double tail = 0., pL = 0., pR = 0.;
     bool seen = false;
+    double pbase = bv_hyper_p(h, wl);
     for (int w = wl; w <= wr; w += 16) {
         const int i = w + gl;
         const bool have = i <= wr;
-        const double pe = bv_hyper_p(h, have ? i : wr);
+        const double step = (gl == 0 || !have) ? 1.0 : bv_hyper_ratio(h, i - 1);
+        const double pe = pbase * bv_g16_incl_scan_prod_f64(step);
+        pbase = bv_g16_bcast_f64(pe, 15, lane) * bv_hyper_ratio(h, w + 15);
         const double p = have ? pe : 0.;
         const bool viol = have && !(p < lo);
         tail += viol ? 0. : p;
