@@ -32,7 +32,7 @@
 #define BV_S_HROWQ 128                       /* phred axis of the short-row histogram */
 #define BV_S_HWORDS (BV_ROWS * BV_S_HROWQ)   /* 1024 words = 4 KiB */
 #define BV_S_OVF 8                           /* + per-row counts of covered cells with phred >= 128 (invalid input) */
-#define BV_S_SLOT_WORDS 512                  /* one slot: 1 KiB of calls, then 1 KiB of phreds */
+#define BV_S_SLOT_WORDS 512                  /* one slot of U = 1: 1 KiB of calls, then 1 KiB of phreds (U x that for U chunks per lane) */
 #define BV_S_SIMPLE_MAX_TABLES 32            /* a non-candidate site's strand table has at most this many Fisher tables */
 
 // ------------------------------------------------------------------------------ LDS-DMA
@@ -52,10 +52,10 @@ __device__ __forceinline__ const uint8_t *bv_uniform_ptr(const uint8_t *p) {
 }
 
 // ------------------------------------------------------------------------------ streaming kernel
-template <int NW, int K>
+template <int NW, int K, int U>
 struct __attribute__((aligned(16))) BvP1sStreamShared {
     uint32_t hist[NW][BV_S_HWORDS + BV_S_OVF + 8];     // per wave: [(rev<<2)|base][phred < 128], then the overflow rows
-    uint32_t ring[NW][K][BV_S_SLOT_WORDS];             // per wave: K slots
+    uint32_t ring[NW][K][U * BV_S_SLOT_WORDS];         // per wave: K slots of U x (1 KiB calls + 1 KiB phreds)
 };
 
 // One slot of one row: tally its 64 x 16 cells into the wave's histogram.
@@ -98,9 +98,9 @@ __device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint
 #ifndef BV_P1S_NW
 #define BV_P1S_NW 4
 #endif
-template <int NW, int K>
+template <int NW, int K, int U>
 __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArgs a) {
-    __shared__ BvP1sStreamShared<NW, K> sh;
+    __shared__ BvP1sStreamShared<NW, K, U> sh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *hist = sh.hist[wave];
@@ -116,10 +116,10 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
     const uint64_t n_waves = (uint64_t)gridDim.x * NW, gw = (uint64_t)blockIdx.x * NW + (uint64_t)wave;
     const uint32_t s0 = (uint32_t)((uint64_t)a.n_sites * gw / n_waves), s1 = (uint32_t)((uint64_t)a.n_sites * (gw + 1) / n_waves);
     if (s0 >= s1) return;
-    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 63u) >> 6;
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 64u * U - 1u) / (64u * U);
     const int tail = (int)(a.n_samples & 15u);
     const uint32_t voff = (uint32_t)lane * 16u;
-    const uint32_t last_valid = n_chunks - (n_slots - 1u) * 64u;  // lanes of a row's last slot that lie inside the row
+    const uint32_t last_valid = n_chunks - (n_slots - 1u) * 64u * U;  // chunks of a row's last slot that lie inside the row
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
 
@@ -127,12 +127,20 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
     uint32_t p_site = s0, p_j = 0, ring_w = 0, inflight = 0;
     auto issue = [&]() {
         if (p_site < s1) {
-            const size_t off = (size_t)p_site * a.pitch + (size_t)p_j * 1024u;
+            const size_t off = (size_t)p_site * a.pitch + (size_t)p_j * (1024u * U);
             const uint8_t *pb = bv_uniform_ptr(a.bs + off), *pq = bv_uniform_ptr(a.q + off);
-            const uint32_t dst = ring_lds + ring_w * (BV_S_SLOT_WORDS * 4u);
-            if (p_j + 1u < n_slots || (uint32_t)lane < last_valid) {  // lanes past the row's end load nothing
-                bv_glds16(dst, pb, voff);
-                bv_glds16(dst + 1024u, pq, voff);
+            const uint32_t dst = ring_lds + ring_w * (U * BV_S_SLOT_WORDS * 4u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {  // slot layout: U KiB of calls, then U KiB of phreds
+                // Every slot issues exactly 2 U loads (the counted waits rely on it): a KiB that lies wholly past the row's
+                // end is "loaded" by lane 0 alone from the row's first bytes (its cells are masked in the tally)
+                const bool any = p_j + 1u < n_slots || 64u * u < last_valid;
+                const uint8_t *sb = any ? pb + 1024u * u : bv_uniform_ptr(a.bs + (size_t)p_site * a.pitch);
+                const uint8_t *sq = any ? pq + 1024u * u : bv_uniform_ptr(a.q + (size_t)p_site * a.pitch);
+                if (any ? (p_j + 1u < n_slots || (uint32_t)lane + 64u * u < last_valid) : lane == 0) {  // chunks past the row's end load nothing
+                    bv_glds16(dst + 1024u * u, sb, voff);
+                    bv_glds16(dst + 1024u * (U + u), sq, voff);
+                }
             }
             ring_w = (ring_w + 1u == (uint32_t)K) ? 0u : ring_w + 1u;
             ++inflight;
@@ -159,17 +167,24 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
             // the oldest slot in flight has landed once at most 2 (K - 1) younger loads are outstanding
-            if (inflight == (uint32_t)K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (K - 1)) : "memory");
+            if (inflight == (uint32_t)K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * U * (K - 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(ring + ring_r * BV_S_SLOT_WORDS + lane * 4);
-            const bv_u32x4 vq = *reinterpret_cast<const bv_u32x4 *>(ring + ring_r * BV_S_SLOT_WORDS + 256 + lane * 4);
+            bv_u32x4 vb[U], vq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                vb[u] = *reinterpret_cast<const bv_u32x4 *>(ring + ring_r * (U * BV_S_SLOT_WORDS) + u * 256 + lane * 4);
+                vq[u] = *reinterpret_cast<const bv_u32x4 *>(ring + ring_r * (U * BV_S_SLOT_WORDS) + (U + u) * 256 + lane * 4);
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers: the slot may be refilled
             ring_r = (ring_r + 1u == (uint32_t)K) ? 0u : ring_r + 1u;
             --inflight;
             issue();
-            const uint32_t chunk = j * 64u + (uint32_t)lane;
-            if (j + 1u == n_slots) bv_p1s_tally_slot<true>(vb, vq, chunk, n_chunks, tail, hist, one, lane);
-            else bv_p1s_tally_slot<false>(vb, vq, chunk, n_chunks, tail, hist, one, lane);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t chunk = (j * U + u) * 64u + (uint32_t)lane;
+                if (j + 1u == n_slots) bv_p1s_tally_slot<true>(vb[u], vq[u], chunk, n_chunks, tail, hist, one, lane);
+                else bv_p1s_tally_slot<false>(vb[u], vq[u], chunk, n_chunks, tail, hist, one, lane);
+            }
         }
         bv_lrt_sync<0>();
 
@@ -569,25 +584,26 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
 }
 
 // ------------------------------------------------------------------------------ launchers
-template <int NW, int K>
+template <int NW, int K, int U = 1>
 static void bv_launch_p1s_stream_cfg(const BvP1ShortArgs &a, hipStream_t stream, uint32_t wg_per_cu) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;
     uint32_t grid = cu * wg_per_cu;
     const uint32_t need = (a.n_sites + NW - 1) / NW;  // at least one site per wave
     if (grid > need) grid = need > 0 ? need : 1;
-    hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
+    hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K, U>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
 }
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     // bits 12-15 of the flags select a ring depth / residency for tuning runs (0 = default)
     switch ((a.flags >> 12) & 0xFu) {
         case 1: return bv_launch_p1s_stream_cfg<4, 3>(a, stream, 4);   // 16 waves/CU, 2 slots in flight each
         case 2: return bv_launch_p1s_stream_cfg<4, 6>(a, stream, 2);   //  8 waves/CU, 5 slots in flight each
-        case 3: return bv_launch_p1s_stream_cfg<4, 8>(a, stream, 2);   //  8 waves/CU, 7 slots in flight each
-        case 4: return bv_launch_p1s_stream_cfg<2, 4>(a, stream, 6);   // 12 waves/CU in 2-wave workgroups
-        case 5: return bv_launch_p1s_stream_cfg<4, 4>(a, stream, 3);   // 12 waves/CU, 3 slots in flight each
+        case 6: return bv_launch_p1s_stream_cfg<4, 4, 1>(a, stream, 2);  // slots of 1 KiB per plane:  8 waves/CU, 6 KiB in flight each
+        case 8: return bv_launch_p1s_stream_cfg<4, 2, 2>(a, stream, 3);  //                          12 waves/CU, 4 KiB in flight each
         default: break;
     }
-    bv_launch_p1s_stream_cfg<4, 4>(a, stream, 2);                      // 8 waves/CU, 3 slots (6 KiB) in flight each: measured best with K = 6 (0.70-0.73 of peak at 10 k samples); leaves LDS for the solve kernel of the previous batch
+    // default: slots of 2 KiB per plane, 3 slots per wave (8 KiB in flight), 8 waves per CU: measured best (+4-5 % over 1 KiB
+    // slots; 4 slots of 2 KiB or 8 of 1 KiB need 82 KB of LDS per workgroup -- one workgroup per CU, 0.43 of peak)
+    bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);
 }
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;

@@ -101,6 +101,25 @@ def test_vs_real_reference_when_present(bv):
     check(got, exp, gexp, check_chi2=False)
 
 
+@pytest.mark.parametrize("flags", [0x10, 0x900, 0x1000, 0x8000], ids=["wave_solver_only", "one_kernel_form", "1KiB_slots_16_waves", "2KiB_slots_12_waves"])
+def test_short_row_kernel_variants_agree(bv, restatement, flags):
+    """The short-row pass 1 has several realisations behind diagnostic flags (all candidates on the one-site-per-wave solver;
+    round 1's one-kernel form; other ring shapes of the streaming kernel): every one must meet the oracle, and the integer
+    fields must equal those of the default path bit for bit."""
+    n = 12000
+    slab = make_slab(700, n, seed=77, coverage=0.1, n_groups=2, ref_n_frac=0.03, site_offset=3)
+    maf = bv.min_af(n)
+    ref_run = run_engine(bv, slab, maf)
+    eng = bv.BaseTypeEngine(max_sites=700, min_af_value=maf, device=0, flags=flags)
+    got = eng.lrt(slab)
+    eng.close()
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
+    for f in ("depth", "total_depth", "cvg_sb", "var_sb", "n_alt", "alt", "status"):
+        assert np.array_equal(ref_run.sites[f], got.sites[f]), f
+    assert np.allclose(ref_run.sites["qual"], got.sites["qual"], rtol=1e-9, atol=0, equal_nan=True)
+
+
 def test_no_rank_planes_and_no_groups(bv, restatement):
     slab = make_slab(64, 5000, seed=41, coverage=0.2)
     slab.pop("mapq"); slab.pop("rpr")
