@@ -435,7 +435,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
     a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
-    a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu;
+    a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
     bv_launch_pass2(a2, st);
     BV_HIP(e, hipGetLastError());
     BV_HIP(e, hipEventRecord(ev[2], st));

@@ -53,6 +53,7 @@ struct BvPass2Args {
     const uint32_t *var_list;
     const uint32_t *counters;
     uint32_t n_cu;
+    uint32_t flags;           // BV_FLAG_*
 };
 
 // short rows (bv_pass1_short.hip): pass 1 as a streaming kernel + a solve kernel that meet in HBM scratch

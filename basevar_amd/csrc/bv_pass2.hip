@@ -12,6 +12,7 @@
 // Traffic: 1 B (calls) + 1 B (mapq) + 2 B (rpr) per cell, + 1 B (phred) when groups exist;
 // the group-id vector is shared by all sites and stays in L2.
 #include "bv_kernels.h"
+#include "bv_tally.h"
 
 #ifndef BV_P2_U64
 #define BV_P2_U64 4
@@ -371,6 +372,276 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2S_WAVES, 4) void bv_pass2_short_kerne
     }
 }
 
+// ------------------------------------------------------------------------------ short rows, streamed through LDS
+// The same work as bv_pass2_short_kernel for rows of 2,049 .. 49,152 samples, built like the short-row pass 1
+// (bv_pass1_short.hip): every wave walks its share of the variant list as ONE sequence of slots -- 1 KiB of calls, 1 KiB of
+// mapq, 2 KiB of read-position ranks -- through a private ring in LDS filled by LDS-DMA (no VGPR staging, counted waits, the
+// next row already arriving while a row's rank sums are formed), and the per-cell work is cut to the tally's form:
+//   * one v_perm_b32 per FOUR cells turns the call bytes into class bytes: the call byte itself is the selector into a
+//     4-byte table (0x80 REF, 0x81 ALT, 0xFF neither; strand bit folded by giving both sources the same table); N / + / -
+//     (8..10) select a sign-replication of table bytes whose top bit is always set -> 0xFF, garbage -> 0x00 / 0xFF: neither;
+//   * after an XOR with 0x80808080, X = class << 8 | mapq and X' = rank_hi << 16 | class << 8 | rank_lo are glued by one
+//     v_perm each; "X < 0x200" is the whole predicate (REF/ALT class, and rank < 256) and X the histogram word: 3 VALU + one
+//     EXEC-predicated ds_add_u32 per cell and plane (bv_lds_add16), against ~20 VALU per cell in the branchy form.
+// A row that holds a rank >= 256 anywhere (long reads; one OR per slot finds it) is re-done by the window sweeps of
+// bv_pass2_short_kernel's code.  The per-site facts pass 1 left (depths, alt set, reference base) and the site indices are
+// fetched for 64 sites at a time, so the ring is drained once per 64 sites, not per site.
+#define BV_P2D_WAVES 4
+#define BV_P2D_K 3
+#define BV_P2D_SLOT_WORDS 1024  /* 1 KiB calls, 1 KiB mapq, 2 KiB ranks */
+struct __attribute__((aligned(16))) BvPass2DmaShared {
+    uint32_t h[BV_P2D_WAVES][4 * 256];                         // per wave: hm[2][256] then hr[2][256]
+    uint32_t ring[BV_P2D_WAVES][BV_P2D_K][BV_P2D_SLOT_WORDS];
+};
+__device__ __forceinline__ void bv_p2d_glds16(uint32_t lds_dst, const uint8_t *base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(base)
+                 : "memory");
+}
+__device__ __forceinline__ const uint8_t *bv_p2d_uniform_ptr(const uint8_t *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+template <int J>
+__device__ __forceinline__ uint32_t bv_p2d_xm(uint32_t cls4, uint32_t mq4) {  // class byte J << 8 | mapq byte J
+    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
+    return __builtin_amdgcn_perm(cls4, mq4, SEL);
+}
+template <int J, int H>
+__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // rank_hi << 16 | class byte J << 8 | rank_lo (rank H of r2)
+    constexpr uint32_t SEL = 0x0C000000u | ((uint32_t)(2 * H + 1) << 16) | ((4u + J) << 8) | (uint32_t)(2 * H);
+    return __builtin_amdgcn_perm(cls4, r2, SEL);
+}
+
+__global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvPass2Args a) {
+    __shared__ BvPass2DmaShared sh;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    uint32_t *h = sh.h[wave];
+    const uint32_t *ring = sh.ring[wave][0];
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(bv_lds_u32 *)sh.ring[wave][0]);
+    const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
+    const uint32_t n_waves = gridDim.x * BV_P2D_WAVES, gw = blockIdx.x * BV_P2D_WAVES + (uint32_t)wave;
+    if (gw >= n_var) return;
+    const uint32_t mine = (n_var - gw + n_waves - 1u) / n_waves;  // variant sites of this wave: gw, gw + n_waves, ...
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 63u) >> 6;
+    const int tail = (int)(a.n_samples & 15u);
+    const uint32_t last_valid = n_chunks - (n_slots - 1u) * 64u;
+    const uint32_t voff = (uint32_t)lane * 16u;
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+
+    // facts of 64 sites at a time (lane i: the wave's site number blk0 + i)
+    uint32_t siteA = 0, siteB = 0;  // site indices of the current and of the next block of 64
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0, altw0 = 0, altw1 = 0, refv = 4;
+    auto load_sites = [&](uint32_t blk) -> uint32_t {
+        const uint32_t k = blk * 64u + (uint32_t)lane;
+        return k < mine ? a.var_list[gw + k * n_waves] : 0u;
+    };
+    auto site_of = [&](uint32_t k, uint32_t blk0) -> uint32_t {  // k in [blk0, blk0 + 128)
+        const uint32_t i = k - blk0;
+        return (uint32_t)(i < 64u ? __builtin_amdgcn_readlane((int)siteA, (int)i) : __builtin_amdgcn_readlane((int)siteB, (int)(i - 64u)));
+    };
+    // prefetch cursor
+    uint32_t p_k = 0, p_j = 0, ring_w = 0, inflight = 0, blk0 = 0;
+    auto issue = [&]() {
+        if (p_k < mine) {
+            const uint32_t site = site_of(p_k, blk0);
+            const size_t row = (size_t)site * a.pitch + (size_t)p_j * 1024u;
+            const uint8_t *pb = bv_p2d_uniform_ptr(a.bs + row), *pm = bv_p2d_uniform_ptr(a.mapq + row);
+            const uint8_t *pr = bv_p2d_uniform_ptr(reinterpret_cast<const uint8_t *>(a.rpr) + 2u * row);
+            const uint32_t dst = ring_lds + ring_w * (BV_P2D_SLOT_WORDS * 4u);
+            if (p_j + 1u < n_slots || (uint32_t)lane < last_valid) {  // lanes past the row's end load nothing (lane 0 always loads)
+                bv_p2d_glds16(dst, pb, voff);
+                bv_p2d_glds16(dst + 1024u, pm, voff);
+                bv_p2d_glds16(dst + 2048u, pr, voff * 2u);         // 32 bytes of ranks per lane: two 16-byte halves
+                bv_p2d_glds16(dst + 3072u, pr + 16, voff * 2u);
+            }
+            ring_w = (ring_w + 1u == (uint32_t)BV_P2D_K) ? 0u : ring_w + 1u;
+            ++inflight;
+            if (++p_j == n_slots) { p_j = 0; ++p_k; }
+        }
+    };
+    siteA = load_sites(0);
+    siteB = load_sites(1);
+    asm volatile("" : "+v"(siteA), "+v"(siteB)::"memory");
+    uint32_t ring_r = 0;
+    unsigned long long tw_m = 0, tw_r = 0, fast_mask = 0;  // lane i: twice the REF rank sums of the block's i-th site; bit i: pending
+#pragma unroll 1
+    for (uint32_t k = 0; k < mine; ++k) {
+        if (k == blk0 + 64u) {  // next block of 64 sites (the prefetch cursor is at most one site ahead: n_slots >= K)
+            blk0 += 64u;
+            siteA = siteB;
+            siteB = load_sites(blk0 / 64u + 1u);
+            asm volatile("" : "+v"(siteA), "+v"(siteB)::"memory");
+        }
+        if (k == blk0) {
+            // what pass 1 decided for these 64 sites (one drain of the ring per 64 sites)
+            const uint32_t kk = k + (uint32_t)lane;
+            const uint32_t s_ = kk < mine ? siteA : 0xFFFFFFFFu;
+            if (s_ != 0xFFFFFFFFu) {
+                const uint4 dd = *reinterpret_cast<const uint4 *>(&a.out[s_].depth[0]);
+                const uint2 aw = *reinterpret_cast<const uint2 *>(&a.out[s_].n_alt);
+                d0 = dd.x; d1 = dd.y; d2 = dd.z; d3 = dd.w; altw0 = aw.x; altw1 = aw.y;
+                refv = a.ref_base[s_];
+            }
+            asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(altw0), "+v"(altw1), "+v"(refv)::"memory");
+            if (k == 0) {
+#pragma unroll 1
+                for (int t = 0; t < BV_P2D_K; ++t) issue();
+            }
+        }
+        const int li = (int)(k - blk0);
+        const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)siteA, li);
+        int ref = __builtin_amdgcn_readlane((int)refv, li);
+        if (ref > 4) ref = 4;
+        const uint32_t depth[4] = {(uint32_t)__builtin_amdgcn_readlane((int)d0, li), (uint32_t)__builtin_amdgcn_readlane((int)d1, li),
+                                   (uint32_t)__builtin_amdgcn_readlane((int)d2, li), (uint32_t)__builtin_amdgcn_readlane((int)d3, li)};
+        const uint32_t aw0 = (uint32_t)__builtin_amdgcn_readlane((int)altw0, li), aw1 = (uint32_t)__builtin_amdgcn_readlane((int)altw1, li);
+        const int n_alt = (int)(aw0 & 0xFFu);  // bytes at bv_site_result.n_alt: n_alt, alt[0..3]
+        // class table: byte b = class of base b (0x80 REF, 0x81 ALT, 0xFF neither) and the plain 2-bit lut of the sweep code
+        uint32_t L = 0xFFFFFFFFu, lut = 0xAAu;
+        unsigned long long n1 = 0, n2 = 0;
+        if (ref < 4) { L = (L & ~(0xFFu << (8 * ref))) | (0x80u << (8 * ref)); lut &= ~(3u << (2 * ref)); n1 = bv_sel4u(depth, ref); }
+#pragma unroll
+        for (int t = 0; t < BV_MAX_ALT; ++t) {
+            if (t < n_alt) {
+                const int b = (int)((t < 3 ? (aw0 >> (8 * (t + 1))) : aw1) & 3u);
+                L = (L & ~(0xFFu << (8 * b))) | (0x81u << (8 * b));
+                lut = (lut & ~(3u << (2 * b))) | (1u << (2 * b));
+                n2 += bv_sel4u(depth, b);
+            }
+        }
+        {
+            uint4 *z = reinterpret_cast<uint4 *>(h);
+#pragma unroll
+            for (int i = 0; i < 4 * 256 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+        }
+        uint32_t hi_acc = 0;
+#pragma unroll 1
+        for (uint32_t j = 0; j < n_slots; ++j) {
+            if (inflight == (uint32_t)BV_P2D_K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (BV_P2D_K - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t *sl = ring + ring_r * BV_P2D_SLOT_WORDS;
+            bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(sl + lane * 4);
+            const bv_u32x4 vm = *reinterpret_cast<const bv_u32x4 *>(sl + 256 + lane * 4);
+            bv_u32x4 r0 = *reinterpret_cast<const bv_u32x4 *>(sl + 512 + lane * 4);   // ranks 0-7
+            bv_u32x4 r1 = *reinterpret_cast<const bv_u32x4 *>(sl + 768 + lane * 4);   // ranks 8-15
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ring_r = (ring_r + 1u == (uint32_t)BV_P2D_K) ? 0u : ring_r + 1u;
+            --inflight;
+            issue();
+            if (j + 1u == n_slots) {
+                const uint32_t chunk = j * 64u + (uint32_t)lane;
+                if (chunk >= n_chunks) {  // not loaded: stale bytes
+                    vb = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+                    r0 = bv_u32x4{0u, 0u, 0u, 0u};
+                    r1 = r0;
+                } else if (tail && chunk == n_chunks - 1) {
+                    vb.x = bv_mask_tail_dword(vb.x, tail); vb.y = bv_mask_tail_dword(vb.y, tail - 4);
+                    vb.z = bv_mask_tail_dword(vb.z, tail - 8); vb.w = bv_mask_tail_dword(vb.w, tail - 12);
+                }
+            }
+            // class bytes of the 16 cells (REF 0x00, ALT 0x01, neither >= 0x7F)
+            const uint32_t c0 = __builtin_amdgcn_perm(L, L, vb.x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, vb.y) ^ 0x80808080u;
+            const uint32_t c2 = __builtin_amdgcn_perm(L, L, vb.z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, vb.w) ^ 0x80808080u;
+            // ranks of classified cells that do not fit the 256-rank window: remembered, the row is then re-done by sweeps
+            // (a rank dword counts only if one of its two cells is classified -- valid data has rank 0 in uncovered cells anyway)
+            hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & 0xFF00FF00u;
+            uint32_t x[16];
+            x[0] = bv_p2d_xm<0>(c0, vm.x); x[1] = bv_p2d_xm<1>(c0, vm.x); x[2] = bv_p2d_xm<2>(c0, vm.x); x[3] = bv_p2d_xm<3>(c0, vm.x);
+            x[4] = bv_p2d_xm<0>(c1, vm.y); x[5] = bv_p2d_xm<1>(c1, vm.y); x[6] = bv_p2d_xm<2>(c1, vm.y); x[7] = bv_p2d_xm<3>(c1, vm.y);
+            x[8] = bv_p2d_xm<0>(c2, vm.z); x[9] = bv_p2d_xm<1>(c2, vm.z); x[10] = bv_p2d_xm<2>(c2, vm.z); x[11] = bv_p2d_xm<3>(c2, vm.z);
+            x[12] = bv_p2d_xm<0>(c3, vm.w); x[13] = bv_p2d_xm<1>(c3, vm.w); x[14] = bv_p2d_xm<2>(c3, vm.w); x[15] = bv_p2d_xm<3>(c3, vm.w);
+            bv_lds_add16<2>(x, h, one, 0x200u);
+            x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
+            x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
+            x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
+            x[12] = bv_p2d_xr<0, 0>(c3, r1.z); x[13] = bv_p2d_xr<1, 1>(c3, r1.z); x[14] = bv_p2d_xr<2, 0>(c3, r1.w); x[15] = bv_p2d_xr<3, 1>(c3, r1.w);
+            bv_lds_add16<2>(x, h + 512, one, 0x200u);
+        }
+        bv_lrt_sync<0>();
+        uint32_t *hm = h, *hr = h + 512;
+        if (__ballot(hi_acc != 0u) != 0ull) {
+            // a rank >= 256 somewhere in the row: the exact window sweeps (plain loads; rare -- long reads)
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(h);
+#pragma unroll
+                for (int i = 0; i < 4 * 256 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+            }
+            bv_lrt_sync<0>();
+            BvP2Ctx cx;
+            cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
+            bv_p2_sweep<BV_WAVE, true, true, false, 256>(cx, a, site, lane);
+            const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
+            bv_lrt_sync<0>();
+            {
+                unsigned long long below = 0, twoR = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hm[w * 64 + lane], hm[256 + w * 64 + lane], n1 + n2, below, lane);
+                const double ph = bv_ranksum_phred(twoR, n1, n2);
+                if (lane == 0) a.out[site].mq_ranksum = ph;
+            }
+            unsigned long long below = 0, twoR = 0;
+            for (uint32_t win_lo = 0;; win_lo += 256u) {
+                const int nblk = (maxr < win_lo + 256u) ? (int)((maxr - win_lo) >> 6) + 1 : 4;
+                for (int w = 0; w < nblk; ++w) twoR += bv_ranksum_window(hr[w * 64 + lane], hr[256 + w * 64 + lane], n1 + n2, below, lane);
+                if (maxr < win_lo + 256u) break;
+                bv_lrt_sync<0>();
+                {
+                    uint4 *z = reinterpret_cast<uint4 *>(hr);
+#pragma unroll
+                    for (int i = 0; i < 2 * 256 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+                }
+                bv_lrt_sync<0>();
+                cx.win_lo = win_lo + 256u;
+                bv_p2_sweep<BV_WAVE, true, false, false, 256>(cx, a, site, lane);
+                bv_lrt_sync<0>();
+            }
+            const double ph = bv_ranksum_phred(twoR, n1, n2);
+            if (lane == 0) {
+                a.out[site].rpr_ranksum = ph;
+                atomicOr(&a.out[site].status, BV_SITE_RANKSUM);
+            }
+        } else {
+            // the two rank sums as exact integers; their phred values (erfc, log10: scalar work) are formed for 64 sites at a
+            // time, one site per lane, when the block of sites ends
+            unsigned long long below = 0, twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hm[w * 64 + lane], hm[256 + w * 64 + lane], n1 + n2, below, lane);
+            tw_m = (lane == li) ? twoR : tw_m;
+            below = 0; twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hr[w * 64 + lane], hr[256 + w * 64 + lane], n1 + n2, below, lane);
+            tw_r = (lane == li) ? twoR : tw_r;
+            fast_mask |= 1ull << li;
+        }
+        if (li == 63 || k + 1u == mine) {
+            if ((fast_mask >> lane) & 1ull) {
+                // this lane's site: n1 / n2 from its own facts (the same arithmetic as above, per lane)
+                int r_ = (int)refv;
+                if (r_ > 4) r_ = 4;
+                const uint32_t dl[4] = {d0, d1, d2, d3};
+                unsigned long long m1 = (r_ < 4) ? bv_sel4u(dl, r_) : 0ull, m2 = 0;
+                const int na = (int)(altw0 & 0xFFu);
+#pragma unroll
+                for (int t = 0; t < BV_MAX_ALT; ++t)
+                    if (t < na) m2 += bv_sel4u(dl, (int)((t < 3 ? (altw0 >> (8 * (t + 1))) : altw1) & 3u));
+                const double ph_m = bv_ranksum_phred(tw_m, m1, m2), ph_r = bv_ranksum_phred(tw_r, m1, m2);
+                a.out[siteA].mq_ranksum = ph_m;
+                a.out[siteA].rpr_ranksum = ph_r;
+                atomicOr(&a.out[siteA].status, BV_SITE_RANKSUM);
+            }
+            fast_mask = 0ull;
+        }
+        bv_lrt_sync<0>();
+    }
+}
+
 size_t bv_pass2_lds_bytes(uint32_t n_groups) { return (size_t)n_groups * 512u * sizeof(uint32_t); }
 
 template <int NT>
@@ -391,6 +662,13 @@ static void bv_launch_pass2_nt(const BvPass2Args &a, hipStream_t stream) {
 void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream) {
     const bool ranks = a.mapq != nullptr && a.rpr != nullptr;
     const bool groups = a.n_groups > 0 && a.group_id != nullptr && a.gout != nullptr;
+    if (a.n_samples > 2048u && a.n_samples <= BV_SHORT_ROW_MAX && ranks && !groups && !(a.flags & BV_FLAG_PASS2_SWEEP)) {
+        uint32_t grid = (a.n_cu ? a.n_cu : 256u) * 2u;  // 64 KiB of LDS per workgroup: 2 per CU, 8 waves
+        const uint32_t need = (a.n_sites + BV_P2D_WAVES - 1) / BV_P2D_WAVES;
+        if (grid > need) grid = need;
+        hipLaunchKernelGGL(bv_pass2_dma_kernel, dim3(grid), dim3(BV_WAVE * BV_P2D_WAVES), 0, stream, a);
+        return;
+    }
     if (a.n_samples <= 16384u && ranks && !groups) {
         uint32_t grid = (a.n_cu ? a.n_cu : 256u) * 4u;  // 16 KiB of LDS and <= 128 VGPRs: 4 workgroups per CU
         const uint32_t need = (a.n_sites + BV_P2S_WAVES - 1) / BV_P2S_WAVES;

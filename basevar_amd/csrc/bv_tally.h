@@ -14,33 +14,18 @@ __device__ __forceinline__ uint32_t bv_cell_index(uint32_t w, uint32_t qq) {
     constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
     return __builtin_amdgcn_perm(w, qq, SEL);
 }
-// One 16-byte chunk = 16 cells of this lane.  All 16 word addresses are formed first, unpredicated
-// (independent VALU work that pipelines), and only then come the 16 predicated ds_add_u32: a per-cell
-// perm -> cmp -> exec -> address -> ds_add chain cannot overlap with its neighbours because every
-// link goes through VCC / EXEC.
 typedef __attribute__((address_space(3))) uint32_t bv_lds_u32;
-// SH: log2 of the byte stride of index X (2: words indexed by X -- the 8 x 256 histogram; 1: X is twice the word index --
-// the 8 x 128 histogram of bv_pass1_short.hip, whose phred bytes arrive pre-shifted by one bit).
-template <int SH = 2>
-__device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x4 &vq, uint32_t *hist, uint32_t one) {
-    uint32_t x[16];
-    x[0] = bv_cell_index<0>(vb.x, vq.x); x[1] = bv_cell_index<1>(vb.x, vq.x);
-    x[2] = bv_cell_index<2>(vb.x, vq.x); x[3] = bv_cell_index<3>(vb.x, vq.x);
-    x[4] = bv_cell_index<0>(vb.y, vq.y); x[5] = bv_cell_index<1>(vb.y, vq.y);
-    x[6] = bv_cell_index<2>(vb.y, vq.y); x[7] = bv_cell_index<3>(vb.y, vq.y);
-    x[8] = bv_cell_index<0>(vb.z, vq.z); x[9] = bv_cell_index<1>(vb.z, vq.z);
-    x[10] = bv_cell_index<2>(vb.z, vq.z); x[11] = bv_cell_index<3>(vb.z, vq.z);
-    x[12] = bv_cell_index<0>(vb.w, vq.w); x[13] = bv_cell_index<1>(vb.w, vq.w);
-    x[14] = bv_cell_index<2>(vb.w, vq.w); x[15] = bv_cell_index<3>(vb.w, vq.w);
-    // 32-bit LDS byte addresses
+// 16 predicated LDS increments: word (x[j] << SH) / 4 of `hist` gets +1 for every lane with x[j] < lim.  All 16 word addresses
+// are formed first, unpredicated (independent VALU work that pipelines), the 16 compares go into 16 SGPR pairs, and only then
+// come the 16 x (s_and_b64 exec, ds_add_u32): pure SALU + LDS issue, no VALU in the chain, no branches.  Hand-scheduled because
+// the compiler either re-serialises the chains through VCC or branches around every add.  (LDS operations of one wave execute
+// in order, so reads that follow need no extra wait.)
+template <int SH>
+__device__ __forceinline__ void bv_lds_add16(const uint32_t x[16], uint32_t *hist, uint32_t one, uint32_t lim) {
     const uint32_t hbase = (uint32_t)(uintptr_t)(bv_lds_u32 *)hist;
     uint32_t ad[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) ad[j] = hbase + (x[j] << SH);
-    // 16 coverage masks into 16 SGPR pairs (independent VALU compares), then EXEC := mask, ds_add_u32 for
-    // each cell: pure SALU + LDS issue, no VALU in the chain, no branches.  Hand-scheduled because the
-    // compiler either re-serialises the chains through VCC or branches around every add.  (LDS
-    // operations of one wave execute in order, so the histogram reads that follow need no extra wait.)
     unsigned long long m[16], sv;
     asm volatile(
         "v_cmp_gt_u32_e64 %[m0], %[lim], %[x0]\n\t"
@@ -83,8 +68,27 @@ __device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x
         "s_mov_b64 exec, %[sv]"
 #endif
         : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [m2] "=&s"(m[2]), [m3] "=&s"(m[3]), [m4] "=&s"(m[4]), [m5] "=&s"(m[5]), [m6] "=&s"(m[6]), [m7] "=&s"(m[7]), [m8] "=&s"(m[8]), [m9] "=&s"(m[9]), [m10] "=&s"(m[10]), [m11] "=&s"(m[11]), [m12] "=&s"(m[12]), [m13] "=&s"(m[13]), [m14] "=&s"(m[14]), [m15] "=&s"(m[15]), [sv] "=&s"(sv)
-        : [x0] "v"(x[0]), [a0] "v"(ad[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]), [one] "v"(one), [lim] "s"(0x800u)
+        : [x0] "v"(x[0]), [a0] "v"(ad[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]), [one] "v"(one), [lim] "s"(lim)
         : "memory", "scc");
+}
+
+
+// One 16-byte chunk = 16 cells of this lane: a per-cell perm -> cmp -> exec -> address -> ds_add chain cannot overlap with
+// its neighbours because every link goes through VCC / EXEC, hence the batched form of bv_lds_add16.
+// SH: log2 of the byte stride of index X (2: words indexed by X -- the 8 x 256 histogram; 1: X is twice the word index --
+// the 8 x 128 histogram of bv_pass1_short.hip, whose phred bytes arrive pre-shifted by one bit).
+template <int SH = 2>
+__device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x4 &vq, uint32_t *hist, uint32_t one) {
+    uint32_t x[16];
+    x[0] = bv_cell_index<0>(vb.x, vq.x); x[1] = bv_cell_index<1>(vb.x, vq.x);
+    x[2] = bv_cell_index<2>(vb.x, vq.x); x[3] = bv_cell_index<3>(vb.x, vq.x);
+    x[4] = bv_cell_index<0>(vb.y, vq.y); x[5] = bv_cell_index<1>(vb.y, vq.y);
+    x[6] = bv_cell_index<2>(vb.y, vq.y); x[7] = bv_cell_index<3>(vb.y, vq.y);
+    x[8] = bv_cell_index<0>(vb.z, vq.z); x[9] = bv_cell_index<1>(vb.z, vq.z);
+    x[10] = bv_cell_index<2>(vb.z, vq.z); x[11] = bv_cell_index<3>(vb.z, vq.z);
+    x[12] = bv_cell_index<0>(vb.w, vq.w); x[13] = bv_cell_index<1>(vb.w, vq.w);
+    x[14] = bv_cell_index<2>(vb.w, vq.w); x[15] = bv_cell_index<3>(vb.w, vq.w);
+    bv_lds_add16<SH>(x, hist, one, 0x800u);
 }
 
 // cells at or beyond n_samples in the row's last chunk are forced to 'N'
