@@ -50,7 +50,8 @@ struct bv_engine {
     double acc1_ms = 0., acc2_ms = 0., acc_stream_ms = 0.;
     // short rows (bv_pass1_short.hip): HBM scratch between the streaming kernel and the solve kernel
     BvSiteSummary *d_summ = nullptr;
-    uint32_t *d_bins = nullptr, *d_cand_list = nullptr, *d_easy_list = nullptr;
+    uint32_t *d_bins = nullptr, *d_cand_list = nullptr, *d_easy_list = nullptr, *d_easy3_list = nullptr;
+    uint32_t short_sites = 0;          // sites the short-row scratch holds
     uint32_t acc_n = 0;
     bool submitted = false;
     // Host buffers (BV_MEM_HOST slabs, tiles, record buffers) go through a ring of device staging buffers filled by a
@@ -359,6 +360,7 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_bins) (void)hipFree(e->d_bins);
     if (e->d_cand_list) (void)hipFree(e->d_cand_list);
     if (e->d_easy_list) (void)hipFree(e->d_easy_list);
+    if (e->d_easy3_list) (void)hipFree(e->d_easy3_list);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &sl : e->sring) {
@@ -407,18 +409,26 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         return fail(e, BV_ERR_INVALID_ARG, "the two-kernel short-row pass 1 holds bin counts in 16 bits: n_samples <= 65535");
     BV_HIP(e, hipEventRecord(ev[0], st));
     if (two_kernel) {
-        if (!e->d_summ) {
-            // scratch between the two kernels, sized once for cfg.max_sites: 48 B + 2 KiB + 4 B per site
-            BV_HIP(e, hipMalloc(&e->d_summ, sizeof(BvSiteSummary) * (size_t)e->cfg.max_sites));
-            BV_HIP(e, hipMalloc(&e->d_bins, sizeof(uint32_t) * BV_S_BIN_STRIDE * (size_t)e->cfg.max_sites));
-            BV_HIP(e, hipMalloc(&e->d_cand_list, sizeof(uint32_t) * (size_t)e->cfg.max_sites));
-            BV_HIP(e, hipMalloc(&e->d_easy_list, sizeof(uint32_t) * (size_t)e->cfg.max_sites));
+        if (n_sites > e->short_sites) {
+            // scratch between the kernels, grown to the largest short-row submit seen: 48 B + 2 KiB + 8 B per site
+            if (e->d_summ) BV_HIP(e, hipFree(e->d_summ));
+            if (e->d_bins) BV_HIP(e, hipFree(e->d_bins));
+            if (e->d_cand_list) BV_HIP(e, hipFree(e->d_cand_list));
+            if (e->d_easy_list) BV_HIP(e, hipFree(e->d_easy_list));
+            if (e->d_easy3_list) BV_HIP(e, hipFree(e->d_easy3_list));
+            e->d_summ = nullptr; e->d_bins = nullptr; e->d_cand_list = nullptr; e->d_easy_list = nullptr; e->d_easy3_list = nullptr; e->short_sites = 0;
+            BV_HIP(e, hipMalloc(&e->d_summ, sizeof(BvSiteSummary) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_bins, sizeof(uint32_t) * BV_S_BIN_STRIDE * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_cand_list, sizeof(uint32_t) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_easy_list, sizeof(uint32_t) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_easy3_list, sizeof(uint32_t) * (size_t)n_sites));
+            e->short_sites = n_sites;
         }
         BvP1ShortArgs s1;
         s1.bs = bs; s1.q = q; s1.ref_base = refb; s1.pitch = P; s1.n_sites = n_sites; s1.n_samples = n_samples;
         s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout;
         s1.var_list = e->d_var_list; s1.counters = e->d_counters; s1.summ = e->d_summ; s1.bins = e->d_bins;
-        s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list;
+        s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list; s1.easy3_list = e->d_easy3_list;
         bv_launch_p1s_stream(s1, st);
         BV_HIP(e, hipGetLastError());
         BV_HIP(e, hipEventRecord(ev[3], st));

@@ -13,11 +13,12 @@
 #define BV_CTR_VARIANTS (0u * BV_CTR_STRIDE)  /* number of BV_SITE_VARIANT sites = length of var_list */
 #define BV_CTR_TICKET (1u * BV_CTR_STRIDE)    /* pass-1 site ticket counter                           */
 #define BV_CTR_CANDS (2u * BV_CTR_STRIDE)     /* short rows: candidates for the wave solver = length of cand_list */
-#define BV_CTR_EASY (3u * BV_CTR_STRIDE)      /* short rows: candidates for the 16-lane solver = length of easy_list */
-#define BV_CTR_PER_LAUNCH 4u                  /* lines zeroed per launch                              */
-#define BV_CTR_ZEROFREQ (4u * BV_CTR_STRIDE)  /* sticky: sites with BV_SITE_ZERO_FREQ                 */
-#define BV_CTR_TIMEOUT (5u * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag                */
-#define BV_CTR_WORDS (6u * BV_CTR_STRIDE)
+#define BV_CTR_EASY (3u * BV_CTR_STRIDE)      /* short rows: candidates for the 16-lane solver with <= 2 active bases = length of easy_list */
+#define BV_CTR_EASY3 (4u * BV_CTR_STRIDE)     /* short rows: the same with >= 3 active bases = length of easy3_list */
+#define BV_CTR_PER_LAUNCH 5u                  /* lines zeroed per launch                              */
+#define BV_CTR_ZEROFREQ (5u * BV_CTR_STRIDE)  /* sticky: sites with BV_SITE_ZERO_FREQ                 */
+#define BV_CTR_TIMEOUT (6u * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag                */
+#define BV_CTR_WORDS (7u * BV_CTR_STRIDE)
 
 struct BvPass1Args {
     const uint8_t *bs;        // [n_sites][pitch]
@@ -80,7 +81,9 @@ struct BvP1ShortArgs {
     BvSiteSummary *summ;   // [n_sites]
     uint32_t *bins;        // [n_sites][BV_S_BIN_STRIDE]  (code << 16 | count), candidate sites only
     uint32_t *cand_list;   // [n_sites]  candidates that take a whole wave (shallow, phred-0 calls, > 128 bins, min_af <= 0)
-    uint32_t *easy_list;   // [n_sites]  candidates solved four per wave (bv_solver16.h)
+    uint32_t *easy_list;   // [n_sites]  candidates solved four per wave (bv_solver16.h), at most two active bases
+    uint32_t *easy3_list;  // [n_sites]  the same with three or four active bases: several times the EM runs, so they are kept
+                           //            apart -- the four sites of a wave run in lockstep and pay for the slowest
 };
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream);
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream);

@@ -152,7 +152,8 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 
     uint32_t ring_r = 0;
     uint32_t cand = 0, n_cand = 0;  // lane k: the k-th wave-solver candidate of this wave since the last flush
-    uint32_t easy = 0, n_easy = 0;  // the same for the candidates of the 16-lane solver
+    uint32_t easy = 0, n_easy = 0;  // the same for the candidates of the 16-lane solver (<= 2 active bases)
+    uint32_t easy3 = 0, n_easy3 = 0;  //                                                  (>= 3 active bases)
     uint32_t refv = 0;              // lane i: ref_base of site blk0 + i
     uint32_t blk0 = s0;
 #pragma unroll 1
@@ -230,10 +231,12 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
         // ---- candidate or not.  Not a candidate: nothing covered, or exactly one active base (basetype.cpp:135-139), it is
         // the reference base, none of its calls has phred 0, and the all-sites strand table is shallow.
         bool is_cand = false;
+        uint32_t n_active = 0;
         if (total != 0u && !(a.flags & BV_FLAG_TALLY_ONLY)) {
             const int bsel = lane & 3;
             const bool act = (double)bv_sel4u(depth, bsel) / (int)total >= a.min_af;  // basetype.cpp:137, one base per lane
             const uint32_t act_mask = (uint32_t)(__ballot(act) & 0xFull);
+            n_active = (uint32_t)__popc(act_mask);
             int ref = __builtin_amdgcn_readlane((int)refv, (int)(site - blk0));
             if (ref > 4) ref = 4;
             const bool one_ref = act_mask != 0u && (act_mask & (act_mask - 1u)) == 0u && ref < 4 && act_mask == (1u << ref);
@@ -270,7 +273,8 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             // shallow site, the literal 0/0 arithmetic of phred-0 calls or of min_af <= 0, or more than 128 bins
             const bool is_easy = q0_mask == 0u && total > (uint32_t)BV_ORD_MAX && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 &&
                                  !(a.flags & BV_FLAG_WAVE_SOLVER);
-            if (is_easy) { easy = ((uint32_t)lane == n_easy) ? site : easy; ++n_easy; }
+            if (is_easy && n_active <= 2u) { easy = ((uint32_t)lane == n_easy) ? site : easy; ++n_easy; }
+            else if (is_easy) { easy3 = ((uint32_t)lane == n_easy3) ? site : easy3; ++n_easy3; }
             else { cand = ((uint32_t)lane == n_cand) ? site : cand; ++n_cand; }
         }
         {
@@ -309,6 +313,13 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if ((uint32_t)lane < n_easy) a.easy_list[base + (uint32_t)lane] = easy;
             n_easy = 0;
+        }
+        if (n_easy3 == 64u || (site + 1u == s1 && n_easy3 != 0u)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_EASY3], n_easy3);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if ((uint32_t)lane < n_easy3) a.easy3_list[base + (uint32_t)lane] = easy3;
+            n_easy3 = 0;
         }
     }
 }
@@ -537,7 +548,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
     const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;
-    const uint32_t n_easy = a.counters[BV_CTR_EASY];
     const int grp = lane >> 4, gl = lane & 15;
     uint32_t *cls = sh.cls[wave][grp], *vl = sh.vl[wave];
     uint32_t n_vl = 0;  // variant sites in vl[]
@@ -550,13 +560,17 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
         bv_lrt_sync<0>();
         n_vl = 0;
     };
-    for (uint32_t t = gw; (uint64_t)t * 4u < n_easy; t += n_waves) {
+    for (int pass = 0; pass < 2; ++pass) {  // first the sites with at most two active bases, then the others
+    const uint32_t n_easy = a.counters[pass ? BV_CTR_EASY3 : BV_CTR_EASY];
+    const uint32_t *list = pass ? a.easy3_list : a.easy_list;
+    // (the second list is dealt from the other end of the grid: the waves that got one round fewer of the first list go first)
+    for (uint32_t t = pass ? n_waves - 1u - gw : gw; (uint64_t)t * 4u < n_easy; t += n_waves) {
         const uint32_t idx = t * 4u + (uint32_t)grp;
         const bool active = idx < n_easy;
         bool variant = false;
         uint32_t site = 0;
         if (active) {
-            site = a.easy_list[idx];
+            site = list[idx];
             const BvSiteSummary sm = a.summ[site];
             BvSiteSums S;
 #pragma unroll
@@ -579,6 +593,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
         if (variant && gl == 0) vl[n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
         n_vl += (uint32_t)__popcll(vm);
         if (n_vl > 60u) flush_vl();
+    }
     }
     if (n_vl) flush_vl();
 }
