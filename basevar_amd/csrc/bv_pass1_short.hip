@@ -605,6 +605,8 @@ static void bv_launch_p1s_stream_cfg(const BvP1ShortArgs &a, hipStream_t stream,
     uint32_t grid = cu * wg_per_cu;
     const uint32_t need = (a.n_sites + NW - 1) / NW;  // at least one site per wave
     if (grid > need) grid = need > 0 ? need : 1;
+    const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
+    if (cap && grid > cap) grid = cap;
     hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K, U>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
 }
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
@@ -625,9 +627,12 @@ void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream) {
     uint32_t grid = cu * 3u;  // 3 waves per SIMD (168 VGPRs)
     const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
     if (grid > need) grid = need > 0 ? need : 1;
+    const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
+    if (cap && grid > cap) grid = cap;
     hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
     uint32_t grid16 = cu * (uint32_t)BV_P1S_SOLVE16_OCC;
     const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE_NW - 1) / (4 * BV_P1S_SOLVE_NW);  // four sites per wave
     if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
+    if (cap && grid16 > cap) grid16 = cap;
     hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
 }

@@ -666,6 +666,8 @@ void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream) {
         uint32_t grid = (a.n_cu ? a.n_cu : 256u) * 2u;  // 64 KiB of LDS per workgroup: 2 per CU, 8 waves
         const uint32_t need = (a.n_sites + BV_P2D_WAVES - 1) / BV_P2D_WAVES;
         if (grid > need) grid = need;
+        const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
+        if (cap && grid > cap) grid = cap;
         hipLaunchKernelGGL(bv_pass2_dma_kernel, dim3(grid), dim3(BV_WAVE * BV_P2D_WAVES), 0, stream, a);
         return;
     }

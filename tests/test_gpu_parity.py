@@ -120,6 +120,23 @@ def test_short_row_kernel_variants_agree(bv, restatement, flags):
     assert np.allclose(ref_run.sites["qual"], got.sites["qual"], rtol=1e-9, atol=0, equal_nan=True)
 
 
+def test_short_row_kernels_with_many_sites_per_wave(bv, restatement):
+    """BV_FLAG_GRID_LIMIT(1): one workgroup per short-row kernel, so that 3,000 sites walk the paths a large batch takes -- more
+    than 64 sites per wave in the streaming kernel (reference bases and candidate lists in blocks of 64), list flushes of the
+    solve kernels, more than 64 variant sites per wave in pass 2 (site facts in blocks of 64) -- with mostly variant sites."""
+    n = 3000
+    slab = make_slab(3000, n, seed=99, coverage=0.2, class_af=[(0.3, 0.0), (0.2, 0.2), (0.0, 0.0), (0.5, 0.0), (0.05, 0.0)],
+                     ref_n_frac=0.02)
+    slab["rpr"][17, np.nonzero(slab["base_strand"][17] < 8)[0][:3]] = 700   # one row takes the rank-window sweeps
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=3000, min_af_value=maf, device=0, flags=1 << 16)
+    got = eng.lrt(slab)
+    eng.close()
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
+    assert got.n_variant > 1500
+
+
 def test_no_rank_planes_and_no_groups(bv, restatement):
     slab = make_slab(64, 5000, seed=41, coverage=0.2)
     slab.pop("mapq"); slab.pop("rpr")
