@@ -62,6 +62,7 @@ class SynthParams(C.Structure):
 EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_wait",
            "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
+           "bv_host_log_probe", "bv_host_log_eval", "bv_engine_host_log_exact", "bv_engine_host_log_eval",
            "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
 
 _lib = None
@@ -117,6 +118,14 @@ def load():
     L.bv_engine_timing_get_ex.restype = C.c_int
     L.bv_engine_timing_get_ex.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                           C.POINTER(C.c_uint32)]
+    L.bv_host_log_probe.restype = C.c_int
+    L.bv_host_log_probe.argtypes = [C.POINTER(C.c_double)]
+    L.bv_host_log_eval.restype = C.c_double
+    L.bv_host_log_eval.argtypes = [C.POINTER(C.c_double), C.c_double]
+    L.bv_engine_host_log_exact.restype = C.c_int
+    L.bv_engine_host_log_exact.argtypes = [C.c_void_p]
+    L.bv_engine_host_log_eval.restype = C.c_int
+    L.bv_engine_host_log_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     L.bv_engine_last_variant_count.restype = C.c_int
     L.bv_engine_last_variant_count.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.bv_last_error.restype = C.c_char_p

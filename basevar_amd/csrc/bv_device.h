@@ -13,6 +13,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/basevar_amd.h"
@@ -30,6 +31,7 @@
 #ifndef BV_CELL_NOCALL
 #define BV_CELL_NOCALL 0x08u
 #endif
+#define BV_HOSTLOG_N 274  // ln2hi, ln2lo, A[5], B[11], 128 x {invc, logc}: glibc's __log_data
 
 // native 16-byte vector: one lane's share of a coalesced 1 KiB wave load
 typedef uint32_t bv_u32x4 __attribute__((ext_vector_type(4)));
@@ -44,7 +46,65 @@ struct BvTables {
     uint32_t pad_;
     double loghit[BV_QBINS];   // log(hit[q]), log(miss[q]) with the host's log(): the per-sample log-marginals of a
     double logmiss[BV_QBINS];  // single-base subset (algorithm.h:243 with f == 1), see bv_lrt
+    // The host libm's own log() data, found in the loaded libm at engine creation and accepted only after the
+    // restated algorithm (bv_log_host below) reproduced the host's log() bit for bit on a few hundred thousand
+    // arguments: ln2hi, ln2lo, A[5], B[11], then 128 x {invc, logc}.  hostlog[BV_HOSTLOG_N] != 0 <=> usable.
+    // Must follow logmiss directly: the ordered replay finds it as logmiss + BV_QBINS (bv_hostlog_of).
+    double hostlog[BV_HOSTLOG_N + 2];
 };
+static_assert(offsetof(BvTables, hostlog) == offsetof(BvTables, logmiss) + sizeof(double) * BV_QBINS, "hostlog follows logmiss");
+
+// `logmiss` (BvTables::logmiss in device memory, or NULL) -> the host-log table, or NULL when the engine could not
+// verify it (the ordered replay then uses the device library's log, ulps from the host's)
+__device__ __forceinline__ const double *bv_hostlog_of(const double *logmiss) {
+    if (!logmiss) return nullptr;
+    const double *t = logmiss + BV_QBINS;
+    return t[BV_HOSTLOG_N] != 0. ? t : nullptr;
+}
+
+// log(x) the way the host's glibc computes it on an FMA-capable x86-64 (sysdeps/ieee754/dbl-64/e_log.c, the variant
+// its ifunc picks there): a 128-entry table of (1/c, log c), a degree-5 polynomial in r = z/c - 1, the near-1 branch
+// with the split r = rhi + rlo, every fused multiply-add exactly where the compiled routine has one.  The reference's
+// EM compares and truncates sums of such logs (algorithm.h:238-255), so at tie-prone shallow sites the last bit matters.
+// T: BvTables::hostlog.  The same restatement runs on the host against log() before the table is accepted.
+__device__ __forceinline__ double bv_log_host(double x, const double *__restrict__ T) {
+    const double *A = T + 2, *Bc = T + 7, *tab = T + 18;
+    uint64_t ix = (uint64_t)__double_as_longlong(x);
+    const uint64_t LO = 0x3fee000000000000ull, HI = 0x3ff1090000000000ull;  // 1 - 2^-4, 1 + 0x1.09p-4
+    if (ix - LO < HI - LO) {
+        if (ix == 0x3ff0000000000000ull) return 0.;
+        const double r = __dadd_rn(x, -1.0), r2 = __dmul_rn(r, r), r3 = __dmul_rn(r, r2);
+        const double pA = __fma_rn(r2, Bc[3], __fma_rn(r, Bc[2], Bc[1]));
+        const double pB = __fma_rn(r2, Bc[6], __fma_rn(r, Bc[5], Bc[4]));
+        const double pC = __fma_rn(r3, Bc[10], __fma_rn(r2, Bc[9], __fma_rn(r, Bc[8], Bc[7])));
+        const double p = __fma_rn(__fma_rn(pC, r3, pB), r3, pA);
+        const double t = __fma_rn(r, 0x1p27, r), rhi = __fma_rn(-0x1p27, r, t), rlo = __dadd_rn(r, -rhi);
+        const double s = __dmul_rn(rhi, rhi);
+        const double hi = __fma_rn(s, Bc[0], r);
+        const double lo = __fma_rn(s, Bc[0], __dadd_rn(r, -hi));
+        const double lo2 = __fma_rn(__dmul_rn(Bc[0], rlo), __dadd_rn(rhi, r), lo);
+        return __dadd_rn(__fma_rn(p, r3, lo2), hi);
+    }
+    const uint32_t top = (uint32_t)(ix >> 48);
+    if (top - 0x0010u >= 0x7ff0u - 0x0010u) {
+        if ((ix << 1) == 0ull) return -__longlong_as_double(0x7ff0000000000000ll);
+        if (ix == 0x7ff0000000000000ull) return x;
+        if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) return __longlong_as_double(0x7ff8000000000000ll);
+        ix = (uint64_t)__double_as_longlong(__dmul_rn(x, 0x1p52));  // subnormal: scale up, take it off the exponent
+        ix -= 52ull << 52;
+    }
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+    const int k = (int)((int64_t)tmp >> 52);
+    const double z = __longlong_as_double((long long)(ix - (tmp & (0xfffull << 52))));
+    const double invc = tab[2u * i], logc = tab[2u * i + 1u], kd = (double)k;
+    const double r = __fma_rn(z, invc, -1.0);
+    const double w = __fma_rn(kd, T[0], logc), hi = __dadd_rn(r, w);
+    const double lo = __fma_rn(kd, T[1], __dadd_rn(__dadd_rn(w, -hi), r));
+    const double r2 = __dmul_rn(r, r), r3 = __dmul_rn(r, r2);
+    const double p = __fma_rn(__fma_rn(r, A[4], A[3]), r2, __fma_rn(r, A[2], A[1]));
+    return __dadd_rn(__fma_rn(r3, p, __fma_rn(r2, A[0], lo)), hi);
+}
 
 // ------------------------------------------------------------------ wave reductions
 // All cross-lane sums use DPP (data-parallel primitives: a VALU operand read from another
@@ -784,8 +844,8 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], unsigned
 // sites with at most BV_ORD_MAX covered samples replay the reference literally: the covered cells are gathered in
 // sample order, one sample per lane, e_step / m_step as algorithm.h:148-198 (per-sample products, the marginal summed
 // over A, C, G, T in that order, four IEEE divisions, the m_step's sums taken over the samples in order, no fused
-// multiply-add), the convergence term and the final sum in sample order.  Only log() itself (ocml instead of glibc,
-// ulps) is not the reference's.
+// multiply-add), the convergence term and the final sum in sample order, and log() as the host's libm computes it
+// (bv_log_host; the device library's log only when the engine could not verify the host's table).
 #define BV_ORD_MAX 64
 
 // covered cells of one row in sample order -> ord[] (at most BV_ORD_MAX); returns how many the row holds.  With `gid`:
@@ -829,7 +889,7 @@ __device__ __noinline__ uint32_t bv_gather_ordered(const uint8_t *bs_row, const 
 
 // EM, algorithm.h:210-255, literally, on n <= BV_ORD_MAX samples (lane i = sample i).  f: initial freqs in, final out.
 __device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const double *hit, const double *miss, double f[4],
-                                          double *lr_out, int lane) {
+                                          double *lr_out, int lane, const double *hostlog) {
     const double epsilon = (double)0.001f;
     const bool have = lane < n;
     const uint32_t w = have ? ord[lane] : 0u;
@@ -852,14 +912,15 @@ __device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const doub
         f[0] = __ddiv_rn(seq_sum(p0), dn); f[1] = __ddiv_rn(seq_sum(p1), dn);
         f[2] = __ddiv_rn(seq_sum(p2), dn); f[3] = __ddiv_rn(seq_sum(p3), dn);
     };
+    auto ln = [&](double v) { return hostlog ? bv_log_host(v, hostlog) : log(v); };  // algorithm.h:243
     e_step();
-    double llh = log(marg);
+    double llh = ln(marg);
     m_step();
     int iters = 0;
     for (int it = 0; it < 100; ++it) {
         e_step();
         m_step();
-        const double now = log(marg);
+        const double now = ln(marg);
         const double d = have ? bv_int_abs_trunc(now - llh) : 0.;
         llh = now;
         ++iters;
@@ -978,7 +1039,7 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             double lr;
             int it;
             if (B.ord != nullptr && s != 0.) {
-                it = bv_em_ordered(B.ord, B.n_ord, B.hit, B.miss, f, &lr, lane);
+                it = bv_em_ordered(B.ord, B.n_ord, B.hit, B.miss, f, &lr, lane, bv_hostlog_of(B.logmiss));
             } else if (NW == 0 && B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
                 // A single-base subset {b} with every likelihood positive: the reference's EM needs no arithmetic.  Its
                 // first e_step gives every sample the posterior L/L == 1.0 for b, the m_step f_b == n/n == 1.0, and from

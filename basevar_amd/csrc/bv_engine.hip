@@ -5,6 +5,7 @@
 // runs on.  No oracle, no CPU arithmetic path: if no HIP device or no gfx950 code object is
 // usable, creation fails loudly with BV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <link.h>
 
 #include <cmath>
 #include <cstdio>
@@ -26,6 +27,123 @@ void set_global_error(const std::string &m) {
     std::lock_guard<std::mutex> lk(g_err_mu);
     g_err = m;
 }
+
+// ---- the host libm's log() table (BvTables::hostlog, bv_log_host in bv_device.h) ----------------------------------
+// The reference's EM takes log() of per-sample marginals with the host's libm (algorithm.h:243) and compares /
+// truncates sums of them; at tie-prone shallow sites the last bit of log() decides the call.  The device replays those
+// sites with the host's own algorithm: its data table is looked up in the libm this process has loaded, and it is used
+// only if the restated algorithm agrees with log() bit for bit on every probe below.  Anything else (another libm,
+// another ifunc variant) leaves the table off and the device library's log in place -- correct, ulps from the host's.
+struct HostLogFind {
+    const double *tab;
+};
+
+int host_log_phdr_cb(struct dl_phdr_info *info, size_t, void *user) {
+    if (!info->dlpi_name || !std::strstr(info->dlpi_name, "libm")) return 0;
+    const double ln2hi = 0x1.62e42fefa3800p-1, ln2lo = 0x1.ef35793c76730p-45;  // the table opens with ln 2, split
+    const size_t need = sizeof(double) * BV_HOSTLOG_N;
+    for (int i = 0; i < info->dlpi_phnum; ++i) {
+        const ElfW(Phdr) &ph = info->dlpi_phdr[i];
+        if (ph.p_type != PT_LOAD || !(ph.p_flags & PF_R) || ph.p_memsz < need) continue;
+        const char *base = reinterpret_cast<const char *>(info->dlpi_addr + ph.p_vaddr);
+        for (size_t o = 0; o + need <= ph.p_memsz; o += 8) {
+            double d[4];
+            std::memcpy(d, base + o, sizeof d);
+            if (d[0] == ln2hi && d[1] == ln2lo && d[2] < -0.49 && d[2] > -0.51 && d[3] > 0.33 && d[3] < 0.34) {
+                static_cast<HostLogFind *>(user)->tab = reinterpret_cast<const double *>(base + o);
+                return 1;
+            }
+        }
+    }
+    return 0;
+}
+
+inline uint64_t f64_bits(double x) {
+    uint64_t u;
+    std::memcpy(&u, &x, 8);
+    return u;
+}
+inline double bits_f64(uint64_t u) {
+    double x;
+    std::memcpy(&x, &u, 8);
+    return x;
+}
+
+// bv_log_host, on the host (same operations in the same order; std::fma is a true fused multiply-add)
+double host_log_restated(double x, const double *T) {
+    const double *A = T + 2, *B = T + 7, *tab = T + 18;
+    uint64_t ix = f64_bits(x);
+    const uint64_t LO = 0x3fee000000000000ull, HI = 0x3ff1090000000000ull;
+    if (ix - LO < HI - LO) {
+        if (ix == 0x3ff0000000000000ull) return 0.;
+        const double r = x - 1.0, r2 = r * r, r3 = r * r2;
+        const double pA = std::fma(r2, B[3], std::fma(r, B[2], B[1]));
+        const double pB = std::fma(r2, B[6], std::fma(r, B[5], B[4]));
+        const double pC = std::fma(r3, B[10], std::fma(r2, B[9], std::fma(r, B[8], B[7])));
+        const double p = std::fma(std::fma(pC, r3, pB), r3, pA);
+        const double t = std::fma(r, 0x1p27, r), rhi = std::fma(-0x1p27, r, t), rlo = r - rhi;
+        const double s = rhi * rhi;
+        const double hi = std::fma(s, B[0], r);
+        const double lo = std::fma(s, B[0], r - hi);
+        const double lo2 = std::fma(B[0] * rlo, rhi + r, lo);
+        return std::fma(p, r3, lo2) + hi;
+    }
+    const uint32_t top = (uint32_t)(ix >> 48);
+    if (top - 0x0010u >= 0x7ff0u - 0x0010u) {
+        if ((ix << 1) == 0) return -HUGE_VAL;
+        if (ix == 0x7ff0000000000000ull) return x;
+        if ((top & 0x8000u) || (top & 0x7ff0u) == 0x7ff0u) return std::nan("");
+        ix = f64_bits(x * 0x1p52);
+        ix -= 52ull << 52;
+    }
+    const uint64_t tmp = ix - 0x3fe6000000000000ull;
+    const uint32_t i = (uint32_t)(tmp >> 45) & 127u;
+    const int k = (int)((int64_t)tmp >> 52);
+    const double z = bits_f64(ix - (tmp & (0xfffull << 52)));
+    const double invc = tab[2 * i], logc = tab[2 * i + 1], kd = (double)k;
+    const double r = std::fma(z, invc, -1.0);
+    const double w = std::fma(kd, T[0], logc), hi = r + w;
+    const double lo = std::fma(kd, T[1], (w - hi) + r);
+    const double r2 = r * r, r3 = r * r2;
+    const double p = std::fma(std::fma(r, A[4], A[3]), r2, std::fma(r, A[2], A[1]));
+    return std::fma(r3, p, std::fma(r2, A[0], lo)) + hi;
+}
+
+// fills dst[0..BV_HOSTLOG_N) + the "usable" flag behind it; true when the host's log() is reproduced exactly
+bool load_host_log_table(double *dst) {
+    std::memset(dst, 0, sizeof(double) * (BV_HOSTLOG_N + 2));
+    HostLogFind find{nullptr};
+    dl_iterate_phdr(host_log_phdr_cb, &find);
+    if (!find.tab) return false;
+    std::memcpy(dst, find.tab, sizeof(double) * BV_HOSTLOG_N);
+    // probes: the marginals the EM sees are mixtures of (1 - eps_q) and eps_q / 3 -- those values, fractions of them,
+    // a dense sweep of the near-1 branch, every table cell's two edges, and a spread of exponents down to subnormals
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    auto next = [&]() {
+        rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+        return rng;
+    };
+    auto same = [&](double x) {
+        volatile double vx = x;  // keep the compiler from folding log() of a constant
+        const double a = host_log_restated(x, dst), b = std::log(vx);
+        return f64_bits(a) == f64_bits(b) || (a != a && b != b);
+    };
+    bool ok = true;
+    for (int qv = 0; qv < BV_QBINS && ok; ++qv) {
+        const double eps = std::exp((double)qv * -0.23025850929940458);
+        ok = ok && same(1.0 - eps) && same(eps / 3);
+        for (int k = 1; k < 64 && ok; ++k) ok = same((1.0 - eps) * k / 64.0) && same(eps / 3 * k / 64.0) && same((1.0 - eps) * k / 64.0 + eps / 3 * (64 - k) / 64.0);
+    }
+    for (int n = 0; n < 200000 && ok; ++n) {
+        const double u = (double)(next() >> 11) * 0x1p-53;                    // (0, 1)
+        ok = same(u) && same(0.93 + 0.14 * u) && same(std::ldexp(0.5 + 0.5 * u, -(int)(next() % 1070)));
+    }
+    for (uint64_t i = 0; i < 128 && ok; ++i)
+        for (int d = -2; d <= 2 && ok; ++d) ok = same(bits_f64(0x3fe6000000000000ull + (i << 45) + (uint64_t)(int64_t)d));
+    ok = ok && same(5e-324) && same(2.0) && same(1e300) && same(0.0) && same(-1.0) && same(HUGE_VAL);
+    dst[BV_HOSTLOG_N] = ok ? 1.0 : 0.0;
+    return ok;
+}
 }  // namespace
 
 struct bv_engine {
@@ -36,6 +154,7 @@ struct bv_engine {
     hipEvent_t ev_done = nullptr;      // end of the last submit: a submit on ANOTHER stream waits for it (shared scratch)
     bool ev_done_set = false;
     uint32_t n_cu = 256;               // hipDeviceProp_t::multiProcessorCount
+    int host_log_exact = 0;            // 1: the device replays shallow sites with the host libm's log(), verified bit-exact
     uint8_t *d_gid = nullptr;          // engine-owned copy of group_id, padded to 16 bytes with BV_NO_GROUP
     size_t d_gid_bytes = 0;
     BvTables *d_tables = nullptr;
@@ -320,6 +439,7 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         t.loghit[qv] = log(t.hit[qv]);
         t.logmiss[qv] = log(t.miss[qv]);
     }
+    e->host_log_exact = load_host_log_table(t.hostlog) ? 1 : 0;
     // log-factorials for the Fisher test with the host libm -- kfunc.c:197-201 calls lgamma(n + 1) --
     // for every depth a site of this engine can reach (deeper tables fall back to a series on the device)
     {
@@ -829,6 +949,41 @@ int bv_engine_timing_get_ex(bv_engine *e, double *stream_total_ms, double *pass1
     if (pass1_total_ms) *pass1_total_ms = e->acc1_ms;
     if (pass2_total_ms) *pass2_total_ms = e->acc2_ms;
     if (n_submits) *n_submits = e->acc_n;
+    return BV_OK;
+}
+
+int bv_host_log_probe(double *table) {
+    double t[BV_HOSTLOG_N + 2];
+    const bool ok = load_host_log_table(t);
+    if (ok && table) std::memcpy(table, t, sizeof(double) * BV_HOSTLOG_N);
+    return ok ? 1 : 0;
+}
+
+double bv_host_log_eval(const double *table, double x) { return host_log_restated(x, table); }
+
+int bv_engine_host_log_exact(const bv_engine *e) { return e ? e->host_log_exact : 0; }
+
+__global__ void bv_host_log_eval_kernel(const BvTables *tables, const double *x, double *y, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = bv_log_host(x[i], tables->hostlog);
+}
+
+int bv_engine_host_log_eval(bv_engine *e, const double *x, double *y, uint32_t n) {
+    if (!e || !x || !y) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_host_log_eval: null argument");
+    if (!e->host_log_exact) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_host_log_eval: the host log table was not verified on this host");
+    if (n == 0) return BV_OK;
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    double *d = nullptr;
+    BV_HIP(e, hipMalloc(&d, sizeof(double) * 2 * (size_t)n));
+    hipError_t st = hipMemcpy(d, x, sizeof(double) * n, hipMemcpyHostToDevice);
+    if (st == hipSuccess) {
+        bv_host_log_eval_kernel<<<(n + 255u) / 256u, 256, 0, e->stream>>>(e->d_tables, d, d + n, n);
+        st = hipGetLastError();
+    }
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    if (st == hipSuccess) st = hipMemcpy(y, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (st != hipSuccess) return fail(e, BV_ERR_HIP, std::string("bv_engine_host_log_eval: ") + hipGetErrorString(st));
     return BV_OK;
 }
 

@@ -149,6 +149,20 @@ class BaseTypeEngine:
             raise RuntimeError("bv_engine_timing_get_ex: " + self._err())
         return s.value, a.value, b.value, n.value
 
+    @property
+    def host_log_exact(self):
+        """True when shallow sites are replayed with the host libm's own log() (verified bit-exact at creation)."""
+        return bool(self._lib.bv_engine_host_log_exact(self._h))
+
+    def host_log_eval(self, x):
+        """The device restatement of the host's log() at the float64 array x (diagnostic)."""
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        if self._lib.bv_engine_host_log_eval(self._h, x.ctypes.data, y.ctypes.data, x.size) != 0:
+            raise RuntimeError("bv_engine_host_log_eval: " + self._err())
+        return y
+
     def last_variant_count(self):
         n = C.c_uint32()
         self._lib.bv_engine_last_variant_count(self._h, C.byref(n))

@@ -252,6 +252,21 @@ int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_tot
 int bv_engine_timing_get_ex(bv_engine *e, double *stream_total_ms, double *pass1_total_ms, double *pass2_total_ms,
                             uint32_t *n_submits);
 
+/* ---- the host's log() on the device ---------------------------------------------
+ * The reference's EM takes log() of per-sample marginals with the host libm (src/algorithm.h:243) and compares sums of
+ * them; at tie-prone shallow sites (<= 64 covered samples) the engine replays that arithmetic in the reference's
+ * order, with the host libm's own log algorithm restated on the device.  The libm data table is located in the
+ * running process and accepted only after the restated algorithm matched log() bit for bit on ~10^6 probes.
+ *   bv_host_log_probe  1 when that check passes (needs no GPU); copies the 274 doubles of the table when table != NULL
+ *   bv_host_log_eval   the restated algorithm on the host (table from bv_host_log_probe)
+ *   bv_engine_host_log_exact   1 when engine e uses it; 0: the device library's log() (ulps from the host's)
+ *   bv_engine_host_log_eval    y[i] = the DEVICE restatement at x[i] (host pointers; diagnostic used by the tests) */
+#define BV_HOST_LOG_TABLE_DOUBLES 274
+int bv_host_log_probe(double *table);
+double bv_host_log_eval(const double *table, double x);
+int bv_engine_host_log_exact(const bv_engine *e);
+int bv_engine_host_log_eval(bv_engine *e, const double *x, double *y, uint32_t n);
+
 /* Number of BV_SITE_VARIANT sites found by the last submit (valid after wait). */
 int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant);
 

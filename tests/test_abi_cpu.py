@@ -65,6 +65,23 @@ def test_record_layout_matches_header(tmp_path):
         assert vals[("g", f)] == _capi.GROUP_DTYPE.fields[f][1], f
 
 
+def test_host_log_table_is_found_and_reproduces_libm(lib):
+    """The shallow-site replay uses the host libm's own log(): the table must be found in the loaded libm and the restated
+    algorithm must equal log() bit for bit (math.log calls the same libm routine)."""
+    import math
+    table = (C.c_double * 274)()
+    assert lib.bv_host_log_probe(table) == 1
+    assert table[0] + table[1] == math.log(2.0)
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.random(60000), 0.93 + 0.14 * rng.random(60000), np.exp(rng.uniform(-700, 5, 60000)),
+                         [1.0, 0.5, 2.0, 5e-324, 1e-310, 1e300]])
+    for x in xs.tolist():
+        assert lib.bv_host_log_eval(table, x) == math.log(x), x
+    assert lib.bv_host_log_eval(table, 0.0) == -math.inf
+    assert math.isnan(lib.bv_host_log_eval(table, -1.0)) and math.isnan(lib.bv_host_log_eval(table, math.nan))
+    assert lib.bv_host_log_eval(table, math.inf) == math.inf
+
+
 def test_min_af_matches_reference_rounding(lib):
     import basevar_amd
     assert basevar_amd.min_af(100000) == 0.0010000000474974513
