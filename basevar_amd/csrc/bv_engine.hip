@@ -171,6 +171,10 @@ struct bv_engine {
     BvSiteSummary *d_summ = nullptr;
     uint32_t *d_bins = nullptr, *d_cand_list = nullptr, *d_easy_list = nullptr, *d_easy3_list = nullptr;
     uint32_t short_sites = 0;          // sites the short-row scratch holds
+    uint32_t *d_gitems = nullptr;      // pop-group calls handed from the pass-2 tally kernels to bv_p2g_solve16_kernel
+    uint32_t gitem_cap = 0;            // items (of BV_P2G_ITEM_WORDS words) d_gitems holds
+    uint8_t *d_gidp = nullptr;         // group ids prepared for bv_p2g_stream_kernel (bv_launch_gid_prepare)
+    size_t d_gidp_bytes = 0;
     uint32_t acc_n = 0;
     bool submitted = false;
     // Host buffers (BV_MEM_HOST slabs, tiles, record buffers) go through a ring of device staging buffers filled by a
@@ -481,6 +485,8 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_cand_list) (void)hipFree(e->d_cand_list);
     if (e->d_easy_list) (void)hipFree(e->d_easy_list);
     if (e->d_easy3_list) (void)hipFree(e->d_easy3_list);
+    if (e->d_gitems) (void)hipFree(e->d_gitems);
+    if (e->d_gidp) (void)hipFree(e->d_gidp);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &sl : e->sring) {
@@ -566,7 +572,36 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
+    a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
+    if (G && gid && dgout) {
+        // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
+        // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel
+        const uint64_t want64 = (uint64_t)S * G, most = (8192ull << 20) / (sizeof(uint32_t) * BV_P2G_ITEM_WORDS);
+        const uint32_t want = (uint32_t)(want64 < most ? want64 : most);
+        if (want > e->gitem_cap) {
+            if (e->d_gitems) BV_HIP(e, hipFree(e->d_gitems));
+            e->d_gitems = nullptr; e->gitem_cap = 0;
+            BV_HIP(e, hipMalloc(&e->d_gitems, sizeof(uint32_t) * BV_P2G_ITEM_WORDS * (size_t)want));
+            e->gitem_cap = want;
+        }
+        a2.gitems = e->d_gitems; a2.gitem_cap = e->gitem_cap;
+        // short rows: the group plane as the streaming group tally wants it
+        const size_t n16 = ((size_t)n_samples + 15) & ~(size_t)15;
+        if (n16 > e->d_gidp_bytes) {
+            if (e->d_gidp) BV_HIP(e, hipFree(e->d_gidp));
+            e->d_gidp = nullptr; e->d_gidp_bytes = 0;
+            BV_HIP(e, hipMalloc(&e->d_gidp, n16 + 256));
+            e->d_gidp_bytes = n16;
+        }
+        a2.gidp = e->d_gidp;
+        if (bv_p2g_streams(a2)) {
+            bv_launch_gid_prepare(gid, e->d_gidp, (uint32_t)n16, n_groups, st);
+            BV_HIP(e, hipGetLastError());
+        }
+    }
     bv_launch_pass2(a2, st);
+    BV_HIP(e, hipGetLastError());
+    bv_launch_p2g_solve16(a2, st);
     BV_HIP(e, hipGetLastError());
     BV_HIP(e, hipEventRecord(ev[2], st));
 

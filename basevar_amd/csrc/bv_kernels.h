@@ -55,7 +55,17 @@ struct BvPass2Args {
     const uint32_t *counters;
     uint32_t n_cu;
     uint32_t flags;           // BV_FLAG_*
+    uint32_t *gitems;         // pop-group calls handed from the tally kernels to the group solve kernels: item v * n_groups + g
+    uint32_t gitem_cap;       // (v = position in var_list) = BV_P2G_ITEM_WORDS words; items >= gitem_cap, or gitems == NULL:
+                              // the tally kernel solves the group itself (one wave per group)
+    const uint8_t *gidp;      // group_id prepared for bv_p2g_stream_kernel: g << 2, or 0x80 for "no group" (bv_launch_gid_prepare)
 };
+// item: [0] = number of bins | state, [1..4] = the group's ACGT depths, [5] = bases with a phred-0 call, [8..] = its bins
+// (code << 16 | count, valid phreds only, (base, phred) order)
+#define BV_P2G_ITEM_WORDS (8u + BV_SLOTS * BV_WAVE)
+#define BV_P2G_PENDING 0x80000000u  /* for bv_p2g_solve16_kernel: four items per wave */
+#define BV_P2G_HARD 0x40000000u     /* for bv_p2g_hard_kernel: one wave per item (shallow group, phred-0 calls, > 128 bins, min_af <= 0) */
+#define BV_P2G_SHALLOW 0x20000000u  /* ... and its EMs replay the reference's per-sample order */
 
 // short rows (bv_pass1_short.hip): pass 1 as a streaming kernel + a solve kernel that meet in HBM scratch
 #define BV_SHORT_ROW_MAX 49152u /* measured crossover with the long-row kernel (one row shared by several tally waves) */
@@ -140,4 +150,7 @@ void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream);
 // host-callable launchers (defined next to the kernels)
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);
 void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream);
+void bv_launch_p2g_solve16(const BvPass2Args &a, hipStream_t stream);
+bool bv_p2g_streams(const BvPass2Args &a);  // whether bv_launch_pass2 takes the LDS-DMA group tally (needs a.gidp)
+void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, uint32_t n_groups, hipStream_t stream);
 size_t bv_pass2_lds_bytes(uint32_t n_groups);

@@ -266,15 +266,28 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
 // ------------------------------------------------------------------ LRT
 // BaseType::lrt + _f over ACGT (src/basetype.cpp:105-199), streaming form of bv_lrt: the subsets of a level are
 // visited in Combinations order and the first minimum is kept as they come.  Requires q0_mask == 0.
+// SPEC: the candidate bases are `nspec` entries of `specific_packed` (3 bits each, reference order, 4 = not ACGT) as in
+// bv_lrt -- the pop-group calls of pass 2, lrt([REF] + alts); otherwise A, C, G, T.
+template <bool SPEC = false>
 __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], uint32_t total, int ref_code, double min_af,
-                                  BvLrtOut &o) {
+                                  BvLrtOut &o, int specific_packed = 0, int nspec = 0) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
     o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false;
     int act = 0, m = 0;
-    for (int b = 0; b < 4; ++b) {
-        if ((double)bv_sel4u(depth, b) / (int)total >= min_af) {  // basetype.cpp:137
-            act |= b << (2 * m);
-            ++m;
+    if (SPEC) {
+        for (int k = 0; k < nspec; ++k) {
+            const int b = (specific_packed >> (3 * k)) & 7;
+            if (b < 4 && (double)bv_sel4u(depth, b) / (int)total >= min_af) {  // basetype.cpp:137
+                act |= b << (2 * m);
+                ++m;
+            }
+        }
+    } else {
+        for (int b = 0; b < 4; ++b) {
+            if ((double)bv_sel4u(depth, b) / (int)total >= min_af) {  // basetype.cpp:137
+                act |= b << (2 * m);
+                ++m;
+            }
         }
     }
     if (m == 0) return;

@@ -137,6 +137,55 @@ def test_short_row_kernels_with_many_sites_per_wave(bv, restatement):
     assert got.n_variant > 1500
 
 
+def test_short_row_group_kernels_with_many_sites_per_wave(bv, restatement):
+    """Pop-groups on short rows (bv_p2g_stream_kernel -> bv_p2g_solve16_kernel / bv_p2g_hard_kernel) under
+    BV_FLAG_GRID_LIMIT(1): more than 64 variant sites per wave, groups of very different size -- deep ones (four items per
+    wave), a 12-sample one (shallow: ordered replay in the one-wave kernel), samples in no group, phred-0 calls."""
+    n, S, G = 3000, 1500, 5
+    slab = make_slab(S, n, seed=123, coverage=0.25, class_af=[(0.3, 0.0), (0.2, 0.2), (0.0, 0.0), (0.5, 0.0)], ref_n_frac=0.02)
+    rng = np.random.default_rng(5)
+    gid = rng.choice([0, 1, 2, 3, 0xFF], size=n, p=[0.5, 0.3, 0.1, 0.05, 0.05]).astype(np.uint8)
+    gid[rng.choice(n, 12, replace=False)] = 4
+    slab["group_id"] = gid
+    slab["n_groups"] = G
+    for r in range(0, S, 37):  # phred-0 calls: 1 - eps == 0, the reference's literal 0/0 arithmetic
+        cov = np.nonzero(slab["base_strand"][r] < 8)[0]
+        slab["qual"][r, cov[:2]] = 0
+    maf = bv.min_af(n)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    for flags in (1 << 16, 0):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=flags)
+        got = eng.lrt(slab)
+        eng.close()
+        check(got, exp, gexp, margins)
+        assert got.n_variant > 700
+
+
+def test_short_row_group_tally_with_invalid_bytes(bv):
+    """Call bytes above 15 and phred bytes above 127 leave the packed index of the streaming group tally: such slots are
+    tallied cell by cell, with the result of the plain-load kernels (flag 0x20 | 0x10: every group solved by one wave)."""
+    n, S = 4000, 96
+    slab = make_slab(S, n, seed=77, coverage=0.3, class_af=[(0.4, 0.0), (0.2, 0.2)], n_groups=3)
+    rng = np.random.default_rng(8)
+    for r in range(0, S, 5):
+        cols = rng.choice(n, 6, replace=False)
+        slab["base_strand"][r, cols[:3]] = [0x23, 0x10, 0xF1]
+        slab["qual"][r, cols[3:]] = [128, 200, 255]
+    maf = bv.min_af(n)
+    res = []
+    for flags in (0, 0x30):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=flags)
+        res.append(eng.lrt(slab))
+        eng.close()
+    a, b = res
+    assert a.n_variant == b.n_variant and a.n_variant > 40
+    for f in ("n_alt", "total_depth", "alt"):
+        assert np.array_equal(a.groups[f], b.groups[f]), f
+    assert np.allclose(a.groups["af"], b.groups["af"], rtol=1e-9, atol=0, equal_nan=True)
+    for f in ("depth", "total_depth", "n_alt", "alt", "status"):
+        assert np.array_equal(a.sites[f], b.sites[f]), f
+
+
 def test_no_rank_planes_and_no_groups(bv, restatement):
     slab = make_slab(64, 5000, seed=41, coverage=0.2)
     slab.pop("mapq"); slab.pop("rpr")
