@@ -888,6 +888,9 @@ __device__ __noinline__ uint32_t bv_gather_ordered(const uint8_t *bs_row, const 
 }
 
 // EM, algorithm.h:210-255, literally, on n <= BV_ORD_MAX samples (lane i = sample i).  f: initial freqs in, final out.
+// hipcc contracts a * b + c into fused multiply-adds (-ffp-contract=fast: across statements, pragmas ignored) and
+// __dmul_rn / __dadd_rn are plain * and + in its headers; the reference's marginal (algorithm.h:164-165) is a sum of
+// ROUNDED products, so every product passes through an empty asm statement before it is added.
 __device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const double *hit, const double *miss, double f[4],
                                           double *lr_out, int lane, const double *hostlog) {
     const double epsilon = (double)0.001f;
@@ -898,7 +901,8 @@ __device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const doub
     const double lh0 = b == 0 ? hv : mv, lh1 = b == 1 ? hv : mv, lh2 = b == 2 ? hv : mv, lh3 = b == 3 ? hv : mv;
     double p0 = 0., p1 = 0., p2 = 0., p3 = 0., marg = 1.;
     auto e_step = [&]() {  // algorithm.h:161-171
-        const double L0 = __dmul_rn(lh0, f[0]), L1 = __dmul_rn(lh1, f[1]), L2 = __dmul_rn(lh2, f[2]), L3 = __dmul_rn(lh3, f[3]);
+        double L0 = __dmul_rn(lh0, f[0]), L1 = __dmul_rn(lh1, f[1]), L2 = __dmul_rn(lh2, f[2]), L3 = __dmul_rn(lh3, f[3]);
+        asm volatile("" : "+v"(L0), "+v"(L1), "+v"(L2), "+v"(L3));  // rounded products: not to be fused into the sum
         marg = __dadd_rn(__dadd_rn(__dadd_rn(L0, L1), L2), L3);
         p0 = __ddiv_rn(L0, marg); p1 = __ddiv_rn(L1, marg); p2 = __ddiv_rn(L2, marg); p3 = __ddiv_rn(L3, marg);
     };

@@ -439,7 +439,30 @@ def test_very_many_short_sites(bv, restatement):
     exp, gexp, margins = restatement.run_with_margins(slab, maf, n_threads=8)
     n_excused = check(got, exp, gexp, margins)  # 300,000 tie-prone sites (depth ~32), replayed in the reference's order
     assert n_excused == 0                       # with the host's own log(): no call may differ, tie or not
+    # ... and the replay is literal: the last LRT statistic and the allele frequencies agree to the bit
+    assert np.array_equal(got.sites["chi2"].view(np.uint64), exp["chi2"].view(np.uint64))
+    assert np.array_equal(got.sites["af"].view(np.uint64), exp["af"].view(np.uint64))
     assert got.n_variant > 50000
+
+
+def test_exact_tie_site_follows_the_reference_rounding(bv, restatement):
+    """Three samples, three different bases, one phred: every allele subset of a size has mathematically the same
+    likelihood, and the reference's pick hangs on the last bit of sums of ROUNDED products (algorithm.h:164-165) -- a fused
+    multiply-add in the marginal flips it (found by the shallow campaign, seed 310).  The reference keeps C (= REF: no ALT)."""
+    n = 37
+    bs = np.full((4, 48), 8, np.uint8); q = np.zeros((4, 48), np.uint8)
+    for r, cells in enumerate([[(4, 2), (10, 1), (34, 0)], [(0, 2), (1, 1), (2, 0)], [(4, 0), (10, 1), (34, 2)], [(4, 6), (10, 1), (34, 4)]]):
+        for col, b in cells:
+            bs[r, col] = b; q[r, col] = 15
+    bs[:, 37:] = 0; q[:, 37:] = 40  # padding that looks covered
+    slab = {"n_sites": 4, "n_samples": n, "pitch": 48, "base_strand": bs, "qual": q, "ref_base": np.full(4, 1, np.uint8), "n_groups": 0}
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    assert (margins <= 1e-9).all()  # ties, all of them
+    assert np.array_equal(got.sites["n_alt"], exp["n_alt"]) and np.array_equal(got.sites["alt"], exp["alt"])
+    assert np.array_equal(got.sites["chi2"].view(np.uint64), exp["chi2"].view(np.uint64))
+    assert got.sites["n_alt"][0] == 0
 
 
 def test_two_engines_on_two_host_threads(bv, restatement):
