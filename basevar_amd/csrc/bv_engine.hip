@@ -174,6 +174,8 @@ struct bv_engine {
     uint32_t *d_gitems = nullptr;      // pop-group calls handed from the pass-2 tally kernels to bv_p2g_solve16_kernel
     uint32_t gitem_cap = 0;            // items (of BV_P2G_ITEM_WORDS words) d_gitems holds
     uint8_t *d_gidp = nullptr;         // group ids prepared for bv_p2g_stream_kernel (bv_launch_gid_prepare)
+    BvChain *d_chain = nullptr;        // segment tables of chained launches (bv_engine_submit_many)
+    unsigned chain_next = 0;
     size_t d_gidp_bytes = 0;
     uint32_t acc_n = 0;
     bool submitted = false;
@@ -487,6 +489,7 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_easy3_list) (void)hipFree(e->d_easy3_list);
     if (e->d_gitems) (void)hipFree(e->d_gitems);
     if (e->d_gidp) (void)hipFree(e->d_gidp);
+    if (e->d_chain) (void)hipFree(e->d_chain);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &sl : e->sring) {
@@ -509,7 +512,7 @@ int bv_engine_destroy(bv_engine *e) {
 // The two passes over device-resident planes + the copies back (records to a host caller, counters).
 static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
-                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st) {
+                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr) {
     const size_t S = n_sites, G = n_groups;
     BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));  // not the sticky error counters
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
@@ -518,6 +521,14 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
     a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
     a1.var_list = e->d_var_list; a1.counters = e->d_counters; a1.n_cu = e->n_cu;
+    a1.ch = nullptr;
+    if (chain) {
+        // the segment table lives in device memory (a ring of 16: a table is rewritten only 16 chained launches later)
+        if (!e->d_chain) BV_HIP(e, hipMalloc(&e->d_chain, sizeof(BvChain) * 16));
+        BvChain *slot_ch = e->d_chain + (e->chain_next++ & 15u);
+        BV_HIP(e, hipMemcpyAsync(slot_ch, chain, sizeof(BvChain), hipMemcpyHostToDevice, st));
+        a1.ch = slot_ch;
+    }
     if (e->ring_count == bv_engine::kRing) {
         int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
         if (rc != BV_OK) return rc;
@@ -573,6 +584,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
+    a2.ch = a1.ch;
     if (G && gid && dgout) {
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
         // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel
@@ -682,6 +694,67 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     int rc = launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st);
     if (rc == BV_OK && slot) rc = stage_release(e, slot, st);  // planes read, records copied back: the slot may be refilled
     return rc;
+}
+
+// Several device-resident slabs of one row length, ONE launch per pass (BvChain): what a host with a few small batches
+// ready should call -- the tail of every batch but the last hides under the next batch's stream.  Falls back to one
+// submit per slab whenever the chained kernels do not apply (short rows, pop-groups, host memory, a forced kernel shape).
+int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, bv_site_result *const *outs, void *stream_) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null engine");
+    if (!slabs || !outs || n_slabs == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null / empty argument");
+    bool chainable = n_slabs > 1 && ((e->cfg.flags >> 8) & 0xFu) == 0u;
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < n_slabs; ++k) {
+        const bv_slab &s = slabs[k];
+        if (!outs[k]) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null record buffer");
+        chainable = chainable && s.mem_kind != BV_MEM_HOST && s.n_groups == 0 && s.n_samples > BV_SHORT_ROW_MAX &&
+                    s.n_samples == slabs[0].n_samples && s.pitch == slabs[0].pitch && (s.mapq == nullptr) == (slabs[0].mapq == nullptr);
+        total += s.n_sites;
+    }
+    if (!chainable) {
+        for (uint32_t k = 0; k < n_slabs; ++k) {
+            int rc = bv_engine_submit(e, &slabs[k], outs[k], nullptr, stream_);
+            if (rc != BV_OK) return rc;
+        }
+        return BV_OK;
+    }
+    if (total > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_submit_many: the slabs together exceed cfg.max_sites");
+    auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    {
+        int rc = use_stream(e, st);
+        if (rc != BV_OK) return rc;
+    }
+    e->host_out = nullptr; e->host_gout = nullptr;
+    const size_t P = slabs[0].pitch;
+    const bool ranks = slabs[0].mapq != nullptr;
+    // at most BV_MAX_CHAIN slabs per launch
+    for (uint32_t k0 = 0; k0 < n_slabs; k0 += BV_MAX_CHAIN) {
+        const uint32_t nk = n_slabs - k0 < (uint32_t)BV_MAX_CHAIN ? n_slabs - k0 : (uint32_t)BV_MAX_CHAIN;
+        BvChain ch{};
+        ch.n = nk;
+        uint32_t first = 0;
+        for (uint32_t i = 0; i < nk; ++i) {
+            const bv_slab &s = slabs[k0 + i];
+            if (s.n_sites == 0 || s.pitch < s.n_samples || (s.pitch & 15ull) || !s.base_strand || !s.qual || !s.ref_base ||
+                (s.mapq == nullptr) != (s.rpr == nullptr) || misaligned(s.base_strand) || misaligned(s.qual) || misaligned(s.mapq) ||
+                misaligned(s.rpr) || misaligned(outs[k0 + i]))
+                return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab fails the checks of bv_engine_submit");
+            const size_t bias = (size_t)first * P;
+            ch.first[i] = first;
+            ch.bs[i] = s.base_strand - bias; ch.q[i] = s.qual - bias;
+            ch.mapq[i] = ranks ? s.mapq - bias : nullptr; ch.rpr[i] = ranks ? s.rpr - bias : nullptr;
+            ch.ref_base[i] = s.ref_base - first;
+            ch.out[i] = outs[k0 + i] - first;
+            first += s.n_sites;
+        }
+        const bv_slab &s0 = slabs[k0];
+        int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, nullptr, P, first, s0.n_samples, 0, outs[k0], nullptr,
+                               st, nk > 1 ? &ch : nullptr);
+        if (rc != BV_OK) return rc;
+    }
+    return BV_OK;
 }
 
 // ---------------------------------------------------------------- sample-axis tile mode

@@ -20,6 +20,27 @@
 #define BV_CTR_TIMEOUT (6u * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag                */
 #define BV_CTR_WORDS (7u * BV_CTR_STRIDE)
 
+// A queue of slabs (same row length, no pop-groups) solved by ONE launch of each pass -- bv_engine_submit_many: the
+// persistent grid of pass 1 draws its site tickets across the whole queue, so the solve of the last deep sites of one
+// slab runs under the stream of the next.  Global site t of segment k is first[k] + its local index; every pointer is
+// biased by -first[k] rows / records on the host, so the kernels index it with t directly.
+#define BV_MAX_CHAIN 16
+struct BvChain {
+    uint32_t n;
+    uint32_t first[BV_MAX_CHAIN];
+    const uint8_t *bs[BV_MAX_CHAIN], *q[BV_MAX_CHAIN], *mapq[BV_MAX_CHAIN], *ref_base[BV_MAX_CHAIN];
+    const uint16_t *rpr[BV_MAX_CHAIN];
+    bv_site_result *out[BV_MAX_CHAIN];
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t bv_chain_seg(const BvChain &c, uint32_t site) {  // site: wave-uniform
+    uint32_t k = 0;
+#pragma unroll
+    for (int i = 1; i < BV_MAX_CHAIN; ++i) k += (i < (int)c.n && site >= c.first[i]) ? 1u : 0u;
+    return k;
+}
+#endif
+
 struct BvPass1Args {
     const uint8_t *bs;        // [n_sites][pitch]
     const uint8_t *q;         // [n_sites][pitch]
@@ -34,6 +55,7 @@ struct BvPass1Args {
     uint32_t *var_list;       // [n_sites]  indices of BV_SITE_VARIANT sites (unordered)
     uint32_t *counters;       // BV_CTR_* words; VARIANTS and TICKET zeroed before the launch
     uint32_t n_cu;            // compute units of the device (hipDeviceProp_t::multiProcessorCount): sizes persistent grids
+    const BvChain *ch;        // device memory, or NULL: not chained.  Long rows only (bv_pass1_kernel)
 };
 
 struct BvPass2Args {
@@ -59,6 +81,7 @@ struct BvPass2Args {
     uint32_t gitem_cap;       // (v = position in var_list) = BV_P2G_ITEM_WORDS words; items >= gitem_cap, or gitems == NULL:
                               // the tally kernel solves the group itself (one wave per group)
     const uint8_t *gidp;      // group_id prepared for bv_p2g_stream_kernel: g << 2, or 0x80 for "no group" (bv_launch_gid_prepare)
+    const BvChain *ch;        // device memory, or NULL.  Long rows without pop-groups only (bv_pass2_kernel<256, true, false>)
 };
 // item: [0] = number of bins | state, [1..4] = the group's ACGT depths, [5] = bases with a phred-0 call, [8..] = its bins
 // (code << 16 | count, valid phreds only, (base, phred) order)

@@ -163,7 +163,7 @@ __device__ __forceinline__ void bv_add_flag(uint32_t *flag, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NTALLY, int NSOLVE>
+template <int NTALLY, int NSOLVE, bool CHAIN = false>
 __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel(BvPass1Args a) {
     constexpr int NT = BV_WAVE * (NTALLY + NSOLVE);
     constexpr int NBUF = NSOLVE + BV_RING_EXTRA;  // the tally may run BV_RING_EXTRA sites ahead of a slow (variant-site) solve
@@ -231,7 +231,12 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                 }
                 break;
             }
-            bv_tally_row_wave<NTALLY>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples,
+            const uint8_t *pb = a.bs, *pq = a.q;
+            if (CHAIN && a.ch != nullptr) {  // a chained launch: the segment's (biased) planes
+                const uint32_t sg = bv_chain_seg(*a.ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                pb = a.ch->bs[sg]; pq = a.ch->q[sg];
+            }
+            bv_tally_row_wave<NTALLY>(pb + (size_t)site * a.pitch, pq + (size_t)site * a.pitch, a.n_samples,
                                       sh.hist[buf], wave, lane);
             bv_add_flag(&sh.filled[buf], lane);  // release: this wave's ds_add of the row are done
         }
@@ -249,6 +254,10 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
             bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[BV_CTR_TIMEOUT]);
             const uint32_t site = sh.site_of[buf];
             if (site == 0xFFFFFFFFu) break;
+            if (CHAIN && a.ch != nullptr) {
+                const uint32_t sg = bv_chain_seg(*a.ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                sa.ref_base = a.ch->ref_base[sg]; sa.out = a.ch->out[sg]; sa.bs = a.ch->bs[sg]; sa.q = a.ch->q[sg];
+            }
             bv_solve_site_wave<false>(sa, site, (BV_LDS uint32_t *)sh.hist[buf], (BV_LDS uint32_t *)sh.sv[s].bin_code,
                                       (BV_LDS uint32_t *)sh.sv[s].bin_cnt, (BV_LDS BvSolverScratch *)&sh.sv[s].sc,
                                       (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
@@ -369,7 +378,9 @@ static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + BV_RING_EXTRA, NSOLVE>));
     uint32_t grid = (a.n_cu ? a.n_cu : 256u) * (by_vgpr < by_lds ? by_vgpr : by_lds);
     if (grid > a.n_sites) grid = a.n_sites;
-    hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
+    // (the chained form is an instantiation of its own: the headline kernel keeps its register allocation)
+    if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, true>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
+    else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, false>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
 }
 
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {

@@ -151,6 +151,10 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     if (v >= n_var) return;
     {
         const uint32_t site = a.var_list[v];
+        if (!GROUPS && a.ch != nullptr) {  // a chained launch: the segment's (biased) planes and records
+            const uint32_t sg = bv_chain_seg(*a.ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+            a.bs = a.ch->bs[sg]; a.mapq = a.ch->mapq[sg]; a.rpr = a.ch->rpr[sg]; a.ref_base = a.ch->ref_base[sg]; a.out = a.ch->out[sg];
+        }
         // ---- what pass 1 decided for this site
         const bv_site_result *res = &a.out[site];
         int ref = a.ref_base[site];

@@ -112,6 +112,20 @@ class BaseTypeEngine:
         if rc != 0:
             raise RuntimeError("bv_engine_submit failed (%d): %s" % (rc, self._err()))
 
+    def submit_many_ptrs(self, n_samples, pitch, slabs, stream=0):
+        """Several device-resident slabs as ONE launch per pass (bv_engine_submit_many).  `slabs`: a sequence of
+        (n_sites, base_strand, qual, ref_base, out, mapq, rpr) with device pointers as ints (mapq = rpr = 0: no rank sums)."""
+        n = len(slabs)
+        arr = (_capi.Slab * n)()
+        outs = (C.c_void_p * n)()
+        for k, (n_sites, bs, q, ref, out, mq, rp) in enumerate(slabs):
+            arr[k] = _capi.Slab(int(n_sites), int(n_samples), int(pitch), bs or None, q or None, mq or None, rp or None, ref or None,
+                                None, 0, _capi.BV_MEM_DEVICE)
+            outs[k] = out
+        rc = self._lib.bv_engine_submit_many(self._h, n, arr, outs, stream or None)
+        if rc != 0:
+            raise RuntimeError("bv_engine_submit_many failed (%d): %s" % (rc, self._err()))
+
     def stream_handle(self):
         """hipStream_t of the engine's own stream as an int (e.g. for torch.cuda.ExternalStream)."""
         return int(self._lib.bv_engine_stream(self._h) or 0)

@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--seed", type=int, default=0xBA5E7A7)
     ap.add_argument("--tally-only", action="store_true", help="diagnostic: time pass 1 without its solver")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
+    ap.add_argument("--chain", type=int, default=1,
+                    help="batches handed to the engine per step as ONE chained launch (bv_engine_submit_many): the tail of a small "
+                         "batch runs under the stream of the next; 1 = one submit per batch")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines/HIP streams used round-robin for consecutive batches (tails of one batch overlap the next)")
     ap.add_argument("--groups", type=int, default=0,
@@ -224,7 +227,11 @@ def main():
         B = args.batch_sites // world  # this rank's contiguous share of the job's batch
     pitch = (N + 255) // 256 * 256
     maf = basevar_amd.min_af(N)
+    K = max(1, args.chain)          # batches per launch
+    Bl = B * K                      # sites per launch (= per step)
     nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    if K > 1:
+        nb = max(nb, min(K, 8))
     ranks = not args.no_rank_planes
 
     # ---- synthetic batches, resident in HBM.  Global site index = ((batch * world) + rank) * B + row,
@@ -243,7 +250,7 @@ def main():
     torch.cuda.synchronize()
 
     ns = max(1, args.streams)
-    engs = [basevar_amd.BaseTypeEngine(max_sites=B, min_af_value=maf, device=local_rank,
+    engs = [basevar_amd.BaseTypeEngine(max_sites=Bl, min_af_value=maf, device=local_rank,
                                        flags=(1 if args.tally_only else 0) | args.flags) for _ in range(ns)]
     eng = engs[0]
     rec = basevar_amd.SITE_DTYPE.itemsize
@@ -251,15 +258,15 @@ def main():
     # batch i (RCCL, asynchronous) overlaps the kernels of batches i+1 and i+2
     depth = 3 if dist_on else ns
     gloo_host = dist_on and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
-    outs = [torch.zeros(B * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
-    houts = [torch.zeros(B * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None
+    outs = [torch.zeros(Bl * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
+    houts = [torch.zeros(Bl * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None
     # Everything of engine k -- its kernels and the gather of its records -- is issued on that engine's OWN
     # HIP stream, wrapped for torch.  (Not torch's default stream: its handle is 0, which the C ABI reads as
     # "engine's own stream", so a gather issued from torch would not be ordered behind the kernels.  Not
     # torch's pooled streams either: two of them may share one hardware queue, and --streams 2 then
     # overlaps nothing.)
     streams = [torch.cuda.ExternalStream(e.stream_handle(), device=dev) for e in engs]
-    gatherer = RecordGatherer(B * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if dist_on else None
+    gatherer = RecordGatherer(Bl * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if dist_on else None
     last_slot = [0]
 
     G = max(0, min(args.groups, 32))
@@ -280,10 +287,19 @@ def main():
                 # the gather that last read this buffer must have completed; Work.wait() orders the
                 # CURRENT stream behind the collective, so it has to be called on the stream that writes
                 gatherer.before_reuse(slot)
-            engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
-                                mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
-                                group_id=gid.data_ptr() if G else 0, n_groups=G, gout=gouts[slot].data_ptr() if G else 0,
-                                stream=streams[k].cuda_stream)
+            if K > 1:
+                # K batches, one launch per pass: segment j writes records [j * B, (j + 1) * B) of the step's buffer
+                segs = []
+                for j in range(K):
+                    sb, sq, smq, srp, sref = batches[(i * K + j) % nb]
+                    segs.append((B, sb.data_ptr(), sq.data_ptr(), sref.data_ptr(), out.data_ptr() + j * B * rec,
+                                 smq.data_ptr() if ranks else 0, srp.data_ptr() if ranks else 0))
+                engs[k].submit_many_ptrs(N, pitch, segs, stream=streams[k].cuda_stream)
+            else:
+                engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
+                                    mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
+                                    group_id=gid.data_ptr() if G else 0, n_groups=G, gout=gouts[slot].data_ptr() if G else 0,
+                                    stream=streams[k].cuda_stream)
             if gatherer is not None:
                 if gloo_host:
                     houts[slot].copy_(out)
@@ -318,8 +334,8 @@ def main():
         # the gathered buffer holds world x B records in rank order: every record must be a covered site
         recs = torch.cat([p.cpu() for p in gatherer.parts(last_slot[0])]).numpy().view(basevar_amd.SITE_DTYPE)
         mine = outs[last_slot[0]].cpu().numpy().view(basevar_amd.SITE_DTYPE)
-        gathered_ok = bool(len(recs) == world * B and (recs["total_depth"] > 0).all() and
-                           recs[:B].tobytes() == mine.tobytes())
+        gathered_ok = bool(len(recs) == world * Bl and (recs["total_depth"] > 0).all() and
+                           recs[:Bl].tobytes() == mine.tobytes())
     p1_ms = p2_ms = st_ms = 0.0
     nsub = 0
     for e in engs:
@@ -334,11 +350,13 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
-        sites_per_s = world * B * args.steps / elapsed
+        sites_per_s = world * Bl * args.steps / elapsed
         p1_avg_s = p1_ms / max(nsub, 1) / 1e3
         p2_avg_s = p2_ms / max(nsub, 1) / 1e3
         st_avg_s = st_ms / max(nsub, 1) / 1e3
-        algo_bytes = 2.0 * B * N  # pass 1: u8 call + u8 phred per cell
+        # pass 1: u8 call + u8 phred per cell of every batch of a launch (a chain longer than the engine's queue is
+        # split into several launches: bytes of the timed region / its launches)
+        algo_bytes = 2.0 * Bl * N * args.steps / max(nsub, 1)
         # the dominant (HBM-bound) kernel: on short rows pass 1 is a streaming kernel + a solve kernel that reads no
         # planes; on long rows it is one kernel (st_avg_s == p1_avg_s)
         shape = (args.flags >> 8) & 0xF
@@ -353,13 +371,15 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                for key in ("%s|%dx%d" % (kernel_name, B, N), "pass1_%dx%d" % (B, N)):
+                for key in ("%s|%dx%d" % (kernel_name, Bl, N), "pass1_%dx%d" % (Bl, N)):
                     if key in tj and (key.startswith(kernel_name) or kernel_name == "bv_pass1_kernel"):
                         traffic = tj[key]["hbm_bytes_per_launch"]
                         traffic_source = tj[key].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % key)
                         break
             except Exception:
                 traffic = traffic_source = None
+        # variant fraction of the last launch (a chained launch counts its whole queue)
+        fvar = nvar / max(1.0, Bl * args.steps / max(nsub, 1))
         line = {
             "metric": "genomic sites/sec through basetype caller at N samples",
             "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -367,14 +387,14 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
-                            "HBM-resident batches of %d sites per GPU per step (%s; 1M-site job = %d such steps)" % (
-                                N, args.coverage, B,
+                            "HBM-resident batches of %d sites per GPU%s (%s; 1M-site job = %d such batches)" % (
+                                N, args.coverage, B, " per step" if K == 1 else ", %d batches per step chained into one launch per pass" % K,
                                 "strong scaling: the job's %d-site batch split over the ranks" % (world * B)
                                 if args.scaling == "strong" else "weak scaling: per-GPU batch fixed",
                                 (1000000 + world * B - 1) // (world * B) if args.scaling == "strong" else (1000000 + B - 1) // B),
-                "samples": N, "batch_sites": B, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
+                "samples": N, "batch_sites": B, "chain": K, "sites_per_launch": Bl, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
                 "parallelism": "site-sharded x%d, gather of %d-byte records to rank 0" % (world, rec),
-                "job_batch_sites": world * B, "backend": (backend if dist_on else None),
+                "job_batch_sites": world * Bl, "backend": (backend if dist_on else None),
                 "rccl_ranks": (dist.get_world_size() if dist_on and backend == "nccl" else 0),
                 "dist_world_size": (dist.get_world_size() if dist_on else 1),
                 "variant_sites_last_batch": nvar, "gathered_records_ok": gathered_ok,
@@ -388,8 +408,8 @@ def main():
                 "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
                 # BASELINE.md section 3's whole-path figure: S*N*(2 + 3 f_var) bytes over both kernels' time
                 # (pass 2 also re-reads the call byte of variant rows: its own traffic is 4 B/cell)
-                "whole_path_GBps": (2.0 + 3.0 * nvar / B) * B * N / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9,
-                "whole_path_frac": (2.0 + 3.0 * nvar / B) * B * N / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "whole_path_GBps": (1.0 + 1.5 * fvar) * algo_bytes / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9,
+                "whole_path_frac": (1.0 + 1.5 * fvar) * algo_bytes / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
             },
         }
         if world == 1:

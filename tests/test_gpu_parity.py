@@ -710,3 +710,41 @@ def test_tile_job_interleaved_with_row_submits_and_abandoned_jobs(bv, restatemen
     check(rows_b, exp_b, gexp_b, m_b)
     assert lib.bv_engine_tiles_begin(eng._h, 40, 1200, 0, 1) == 0          # left open
     eng.close()
+
+
+def test_chained_submit_equals_separate_submits(bv):
+    """bv_engine_submit_many: several device slabs, one launch per pass (the site tickets span the queue) -- every record
+    must be the one a submit of its own slab writes (byte for byte: which workgroup solves a site has no influence)."""
+    import torch
+    n = 60000
+    sizes = [96, 17, 200, 64, 1, 130, 48, 77, 33, 120, 5, 5, 60, 41, 9, 88, 150, 3, 70]  # 19 slabs: two chained launches (16 + 3)
+    slabs = [make_slab(s, n, seed=300 + k, coverage=0.05 + 0.02 * (k % 3), class_af=[(0.0, 0.0), (0.3, 0.0), (0.2, 0.1)])
+             for k, s in enumerate(sizes)]
+    maf = bv.min_af(n)
+    dev = torch.device("cuda", 0)
+    eng = bv.BaseTypeEngine(max_sites=sum(sizes), min_af_value=maf, device=0)
+    rec = bv.SITE_DTYPE.itemsize
+    keep, segs, outs = [], [], []
+    for sl in slabs:
+        t = [torch.from_numpy(np.ascontiguousarray(sl[k])).to(dev) for k in ("base_strand", "qual", "ref_base", "mapq")]
+        t.append(torch.from_numpy(np.ascontiguousarray(sl["rpr"]).view(np.int16)).to(dev))
+        out = torch.zeros(sl["n_sites"] * rec, dtype=torch.uint8, device=dev)
+        keep.append(t); outs.append(out)
+        segs.append((sl["n_sites"], t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr(), t[3].data_ptr(), t[4].data_ptr()))
+    torch.cuda.synchronize()
+    eng.submit_many_ptrs(n, slabs[0]["pitch"], segs)
+    eng.wait()
+    chained = [o.cpu().numpy().view(bv.SITE_DTYPE).copy() for o in outs]
+    n_var_chain = eng.last_variant_count()
+    total_var = 0
+    for k, sl in enumerate(slabs):
+        outs[k].zero_()
+        eng.submit_ptrs(sl["n_sites"], n, sl["pitch"], segs[k][1], segs[k][2], segs[k][3], segs[k][4], segs[k][5], segs[k][6])
+        eng.wait()
+        single = outs[k].cpu().numpy().view(bv.SITE_DTYPE)
+        assert single.tobytes() == chained[k].tobytes(), "slab %d" % k
+        total_var += int(((single["status"] & 2) != 0).sum())
+    assert total_var > 100
+    # the last chained launch held slabs 16, 17 and 18
+    assert n_var_chain == sum(int(((c["status"] & 2) != 0).sum()) for c in chained[16:])
+    eng.close()
