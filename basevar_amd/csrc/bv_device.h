@@ -847,6 +847,11 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], unsigned
 // multiply-add), the convergence term and the final sum in sample order, and log() as the host's libm computes it
 // (bv_log_host; the device library's log only when the engine could not verify the host's table).
 #define BV_ORD_MAX 64
+// An ordered-cell buffer in LDS: BV_ORD_MAX cells (uint16_t) followed by the scratch of bv_em_ordered's in-order sums
+// (BV_SEQ_N quantities x BV_SEQ_STRIDE doubles); declare it `alignas(8) uint16_t ord[BV_ORD_ALLOC]`.
+#define BV_SEQ_N 5
+#define BV_SEQ_STRIDE 65 /* 64 + 1: the BV_SEQ_N lanes that walk the rows read different banks */
+#define BV_ORD_ALLOC (BV_ORD_MAX + 4 * BV_SEQ_N * BV_SEQ_STRIDE)
 
 // covered cells of one row in sample order -> ord[] (at most BV_ORD_MAX); returns how many the row holds.  With `gid`:
 // only the samples of pop-group `g` (gid: one byte per sample, readable in 16-byte chunks up to the row's last chunk).
@@ -906,31 +911,57 @@ __device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const doub
         marg = __dadd_rn(__dadd_rn(__dadd_rn(L0, L1), L2), L3);
         p0 = __ddiv_rn(L0, marg); p1 = __ddiv_rn(L1, marg); p2 = __ddiv_rn(L2, marg); p3 = __ddiv_rn(L3, marg);
     };
-    auto seq_sum = [&](double v) {  // sum over the samples in sample order, from 0.0 (algorithm.h:190-193, :29-33)
-        double s = 0.;
-        for (int i = 0; i < n; ++i) s = __dadd_rn(s, bv_readlane_f64(v, i));
-        return s;
+    // Sums over the samples IN SAMPLE ORDER, from 0.0 (algorithm.h:190-193, :29-33), of up to BV_SEQ_N quantities at once:
+    // every lane parks its values in LDS, then lane k alone adds quantity k of samples 0 .. n-1 one after the other (the
+    // loads do not depend on the running sum, so they pipeline; the k chains run side by side).  A loop of v_readlane +
+    // add per quantity took five times the instructions, all of them on the critical path.
+    typedef __attribute__((address_space(3))) double bv_lds_f64;
+    bv_lds_f64 *seq = (bv_lds_f64 *)reinterpret_cast<double *>(const_cast<uint16_t *>(ord) + BV_ORD_MAX);  // `ord` is LDS
+    double sums[BV_SEQ_N];
+    auto wave_fence = [&]() {  // LDS operations of one wave execute in order: only the compiler has to be held back
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     };
-    auto m_step = [&]() {  // algorithm.h:184-198
-        const double dn = (double)n;
-        f[0] = __ddiv_rn(seq_sum(p0), dn); f[1] = __ddiv_rn(seq_sum(p1), dn);
-        f[2] = __ddiv_rn(seq_sum(p2), dn); f[3] = __ddiv_rn(seq_sum(p3), dn);
+    auto seq_sums = [&](const double (&v)[BV_SEQ_N], int nq) {
+#pragma unroll
+        for (int k = 0; k < BV_SEQ_N; ++k)
+            if (k < nq) seq[k * BV_SEQ_STRIDE + lane] = v[k];
+        wave_fence();
+        double acc = 0.;
+        if (lane < nq) {
+            const bv_lds_f64 *row = seq + lane * BV_SEQ_STRIDE;
+            for (int i = 0; i < n; ++i) acc = __dadd_rn(acc, row[i]);
+        }
+#pragma unroll
+        for (int k = 0; k < BV_SEQ_N; ++k) sums[k] = (k < nq) ? bv_readlane_f64(acc, k) : 0.;
+        wave_fence();
     };
+    const double dn = (double)n;
     auto ln = [&](double v) { return hostlog ? bv_log_host(v, hostlog) : log(v); };  // algorithm.h:243
     e_step();
     double llh = ln(marg);
-    m_step();
+    {
+        const double v[BV_SEQ_N] = {p0, p1, p2, p3, 0.};
+        seq_sums(v, 4);  // m_step, algorithm.h:184-198
+        f[0] = __ddiv_rn(sums[0], dn); f[1] = __ddiv_rn(sums[1], dn); f[2] = __ddiv_rn(sums[2], dn); f[3] = __ddiv_rn(sums[3], dn);
+    }
     int iters = 0;
     for (int it = 0; it < 100; ++it) {
         e_step();
-        m_step();
         const double now = ln(marg);
         const double d = have ? bv_int_abs_trunc(now - llh) : 0.;
         llh = now;
+        const double v[BV_SEQ_N] = {p0, p1, p2, p3, d};
+        seq_sums(v, 5);  // the m_step's four sums and the convergence term, one walk
+        f[0] = __ddiv_rn(sums[0], dn); f[1] = __ddiv_rn(sums[1], dn); f[2] = __ddiv_rn(sums[2], dn); f[3] = __ddiv_rn(sums[3], dn);
         ++iters;
-        if (seq_sum(d) < epsilon) break;
+        if (sums[4] < epsilon) break;
     }
-    *lr_out = seq_sum(have ? llh : 0.);
+    {
+        const double v[BV_SEQ_N] = {have ? llh : 0., 0., 0., 0., 0.};
+        seq_sums(v, 1);
+    }
+    *lr_out = sums[0];
     return iters;
 }
 

@@ -84,7 +84,7 @@ struct BvPass2Args {
     const BvChain *ch;        // device memory, or NULL.  Long rows without pop-groups only (bv_pass2_kernel<256, true, false>)
 };
 // item: [0] = number of bins | state, [1..4] = the group's ACGT depths, [5] = bases with a phred-0 call, [8..] = its bins
-// (code << 16 | count, valid phreds only, (base, phred) order)
+// (valid phreds only, (base, phred) order): code << 16 | count for BV_P2G_PENDING items, code << 23 | count for BV_P2G_HARD ones
 #define BV_P2G_ITEM_WORDS (8u + BV_SLOTS * BV_WAVE)
 #define BV_P2G_PENDING 0x80000000u  /* for bv_p2g_solve16_kernel: four items per wave */
 #define BV_P2G_HARD 0x40000000u     /* for bv_p2g_hard_kernel: one wave per item (shallow group, phred-0 calls, > 128 bins, min_af <= 0) */
@@ -174,6 +174,7 @@ void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream);
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);
 void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream);
 void bv_launch_p2g_solve16(const BvPass2Args &a, hipStream_t stream);
+bool bv_p2g_all_items(const BvPass2Args &a);
 bool bv_p2g_streams(const BvPass2Args &a);  // whether bv_launch_pass2 takes the LDS-DMA group tally (needs a.gidp)
 void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, uint32_t n_groups, hipStream_t stream);
 size_t bv_pass2_lds_bytes(uint32_t n_groups);

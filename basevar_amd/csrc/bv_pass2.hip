@@ -23,16 +23,18 @@
 #endif
 #define BV_RPR_WIN 1024  /* read-position ranks per LDS window; longer reads take extra sweeps */
 
-template <int NW>
+// INLINE: the kernel solves pop-groups itself (one wave per group) and needs the solver's LDS; otherwise every group leaves
+// as an item for the group solve kernels and that LDS (and the solver's registers) are not taken.
+template <int NW, bool INLINE = true>
 struct __attribute__((aligned(16))) BvPass2Shared {
     uint32_t hm[2 * 256];         // [class][mapq]        class 0 = REF reads, 1 = ALT reads
     uint32_t hr[2 * BV_RPR_WIN];  // [class][rank - win_lo]
     uint32_t maxr[NW];
-    uint32_t bin_code[NW][BV_SLOTS * BV_WAVE];
-    uint32_t bin_cnt[NW][BV_SLOTS * BV_WAVE];
-    BvLrtShared lrt[NW];
-    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    uint16_t ord[NW][BV_ORD_MAX];  // shallow pop-groups: the group's covered cells in sample order (bv_gather_ordered)
+    uint32_t bin_code[INLINE ? NW : 1][INLINE ? BV_SLOTS * BV_WAVE : 4];
+    uint32_t bin_cnt[INLINE ? NW : 1][INLINE ? BV_SLOTS * BV_WAVE : 4];
+    BvLrtShared lrt[INLINE ? NW : 1];
+    double tab_hit[INLINE ? BV_QBINS : 2], tab_miss[INLINE ? BV_QBINS : 2];
+    alignas(8) uint16_t ord[INLINE ? NW : 1][BV_ORD_ALLOC];  // shallow pop-groups: the group's covered cells in sample order (bv_gather_ordered)
 };
 
 extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_groups][4][128]
@@ -130,14 +132,14 @@ __device__ __forceinline__ void bv_p2_sweep(BvP2Ctx &cx, const BvPass2Args &a, u
     }
 }
 
-template <int NT, bool RANKS, bool GROUPS>
+template <int NT, bool RANKS, bool GROUPS, bool INLINE = true>
 __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     constexpr int NW = NT / BV_WAVE;
-    __shared__ BvPass2Shared<NW> sh;
+    __shared__ BvPass2Shared<NW, INLINE> sh;
     uint32_t *hg = bv_dyn_lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
-    if (GROUPS) {
+    if (GROUPS && INLINE) {
         for (int i = tid; i < BV_QBINS; i += NT) {
             sh.tab_hit[i] = a.tables->hit[i];
             sh.tab_miss[i] = a.tables->miss[i];
@@ -239,6 +241,52 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         if (GROUPS) {
             for (uint32_t g = wave; g < a.n_groups; g += NW) {
                 const uint32_t *h = hg + g * 512u;
+                if (!INLINE) {
+                    // every group leaves as an item (bv_p2g_solve16_kernel / bv_p2g_hard_kernel): bins straight from the histogram
+                    uint32_t c[8], dpart[4], q0 = 0, cm = 0, nbv = 0;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        c[r] = h[((r >> 1) << 7) | ((r & 1) << 6) | lane];
+                        cm = max(cm, c[r]);
+                        if (!(r & 1) && __builtin_amdgcn_readfirstlane((int)c[r]) != 0) q0 |= 1u << (r >> 1);
+                        const bool valid = c[r] != 0u && (((r & 1) << 6) | lane) < BV_NQ_VALID;
+                        nbv += (uint32_t)__popcll(__ballot(valid));
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) dpart[b] = c[2 * b] + c[2 * b + 1];
+                    uint32_t gd[4];
+                    {
+                        const uint32_t v8[8] = {dpart[0], dpart[1], dpart[2], dpart[3], 0u, 0u, 0u, 0u};
+                        uint32_t t8[8];
+                        bv_wave_sum8_u32(v8, t8, lane);
+                        gd[0] = t8[0]; gd[1] = t8[1]; gd[2] = t8[2]; gd[3] = t8[3];
+                    }
+                    const uint32_t gt = gd[0] + gd[1] + gd[2] + gd[3];
+                    const int seen = (gd[0] != 0) + (gd[1] != 0) + (gd[2] != 0) + (gd[3] != 0);
+                    const bool shal = gt <= (uint32_t)BV_ORD_MAX && seen >= 2;
+                    const bool big = __ballot(cm > 0xFFFFu) != 0ull;
+                    const bool four = !shal && q0 == 0u && nbv <= (uint32_t)BV_G16_MAX_BINS && !big && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
+                    uint32_t *dst = a.gitems + ((size_t)v * a.n_groups + g) * BV_P2G_ITEM_WORDS;
+                    if (gt != 0u) {
+                        uint32_t pos0 = 0;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const uint32_t code = ((uint32_t)(r >> 1) << 7) | (uint32_t)(((r & 1) << 6) | lane);
+                            const bool valid = c[r] != 0u && (code & 127u) < (uint32_t)BV_NQ_VALID;
+                            const unsigned long long m = __ballot(valid);
+                            const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (valid) dst[8u + pos] = four ? ((code << 16) | c[r]) : ((code << 23) | c[r]);
+                            pos0 += (uint32_t)__popcll(m);
+                        }
+                    }
+                    const uint32_t hdr = gt == 0u ? 0u : (nbv | (four ? BV_P2G_PENDING : BV_P2G_HARD | (shal ? BV_P2G_SHALLOW : 0u)));
+                    uint32_t w = hdr;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) w = (lane == 1 + b) ? gd[b] : w;
+                    w = (lane == 5) ? q0 : w;
+                    if (lane < 6) dst[lane] = w;
+                    continue;
+                }
                 uint32_t nb = 0, gdepth[4], gtotal = 0, q0_mask = 0;
                 uint32_t cmax = 0;
 #pragma unroll
@@ -827,7 +875,16 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GS_WAVES) void bv_p2g_stream_kernel(B
             const size_t item = ((size_t)gw + (size_t)k * n_waves) * G + g;
             uint32_t *dst = a.gitems + item * BV_P2G_ITEM_WORDS;
             uint32_t nb = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                for (int qr = 0; qr < 2; ++qr) nb += (uint32_t)__popcll(__ballot(c[b][qr] != 0u && ((qr << 6) | lane) < BV_NQ_VALID));
+            }
+            const int n_seen = (gdepth[0] != 0) + (gdepth[1] != 0) + (gdepth[2] != 0) + (gdepth[3] != 0);
+            const bool shallow = gtotal <= (uint32_t)BV_ORD_MAX && n_seen >= 2;
+            const bool four = !shallow && q0_mask == 0u && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
             if (gtotal != 0u) {
+                uint32_t pos0 = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
 #pragma unroll
@@ -835,15 +892,13 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GS_WAVES) void bv_p2g_stream_kernel(B
                         const int q = (qr << 6) | lane;
                         const bool valid = c[b][qr] != 0u && q < BV_NQ_VALID;
                         const unsigned long long m = __ballot(valid);
-                        const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        if (valid) dst[8u + pos] = ((((uint32_t)b << 7) | (uint32_t)q) << 16) | c[b][qr];
-                        nb += (uint32_t)__popcll(m);
+                        const uint32_t pos = pos0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        const uint32_t code = ((uint32_t)b << 7) | (uint32_t)q;
+                        if (valid) dst[8u + pos] = four ? ((code << 16) | c[b][qr]) : ((code << 23) | c[b][qr]);
+                        pos0 += (uint32_t)__popcll(m);
                     }
                 }
             }
-            const int n_seen = (gdepth[0] != 0) + (gdepth[1] != 0) + (gdepth[2] != 0) + (gdepth[3] != 0);
-            const bool shallow = gtotal <= (uint32_t)BV_ORD_MAX && n_seen >= 2;
-            const bool four = !shallow && q0_mask == 0u && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
             const uint32_t hdr = gtotal == 0u ? 0u : (nb | (four ? BV_P2G_PENDING : BV_P2G_HARD | (shallow ? BV_P2G_SHALLOW : 0u)));
             uint32_t w = hdr;
 #pragma unroll
@@ -862,7 +917,7 @@ struct __attribute__((aligned(16))) BvP2ghShared {
     uint32_t bin_cnt[BV_P2GH_WAVES][BV_SLOTS * BV_WAVE];
     BvLrtShared lrt[BV_P2GH_WAVES];
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    uint16_t ord[BV_P2GH_WAVES][BV_ORD_MAX];
+    alignas(8) uint16_t ord[BV_P2GH_WAVES][BV_ORD_ALLOC];
 };
 __global__ __launch_bounds__(BV_WAVE *BV_P2GH_WAVES) void bv_p2g_hard_kernel(BvPass2Args a) {
     __shared__ BvP2ghShared sh;
@@ -876,15 +931,16 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GH_WAVES) void bv_p2g_hard_kernel(BvP
     const uint64_t all = (uint64_t)n_var * a.n_groups;
     const uint32_t n_items = all < (uint64_t)a.gitem_cap ? (uint32_t)all : a.gitem_cap;
     const uint32_t n_waves = gridDim.x * BV_P2GH_WAVES, gw = blockIdx.x * BV_P2GH_WAVES + (uint32_t)wave;
-    // headers 64 at a time: block t of the item list belongs to wave t mod n_waves
-    for (uint32_t t = gw; (uint64_t)t * 64u < n_items; t += n_waves) {
-        const uint32_t mine = t * 64u + (uint32_t)lane;
+    // this wave's items: gw, gw + n_waves, ... (interleaved, so that runs of hard items spread over the grid); their headers
+    // are read 64 at a time
+    for (uint32_t t = 0; (uint64_t)gw + (uint64_t)t * 64u * n_waves < (uint64_t)n_items; ++t) {
+        const uint32_t mine = gw + (t * 64u + (uint32_t)lane) * n_waves;  // (items number at most a few million: no overflow)
         const uint32_t hdr_l = mine < n_items ? a.gitems[(size_t)mine * BV_P2G_ITEM_WORDS] : 0u;
         unsigned long long todo = __ballot((hdr_l & BV_P2G_HARD) != 0u);
         while (todo) {
             const int li = __builtin_ctzll(todo);
             todo &= todo - 1ull;
-            const uint32_t idx = t * 64u + (uint32_t)li;
+            const uint32_t idx = gw + (t * 64u + (uint32_t)li) * n_waves;
             const uint32_t hdr = (uint32_t)__builtin_amdgcn_readlane((int)hdr_l, li);
             const uint32_t *it = a.gitems + (size_t)idx * BV_P2G_ITEM_WORDS;
             const uint32_t nb = hdr & 0xFFFFu;
@@ -905,9 +961,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GH_WAVES) void bv_p2g_hard_kernel(BvP
             uint32_t gdepth[4] = {it[1], it[2], it[3], it[4]};
             const uint32_t gtotal = gdepth[0] + gdepth[1] + gdepth[2] + gdepth[3], q0_mask = it[5];
             for (uint32_t i = (uint32_t)lane; i < nb; i += BV_WAVE) {
-                const uint32_t w = it[8u + i];
-                sh.bin_code[wave][i] = w >> 16;
-                sh.bin_cnt[wave][i] = w & 0xFFFFu;
+                const uint32_t w = it[8u + i];  // code << 23 | count
+                sh.bin_code[wave][i] = w >> 23;
+                sh.bin_cnt[wave][i] = w & 0x7FFFFFu;
             }
             bv_lrt_sync<0>();
             BvBins B;
@@ -1034,13 +1090,19 @@ void bv_launch_p2g_solve16(const BvPass2Args &a, hipStream_t stream) {
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
     if (cap && grid > cap) grid = cap;
     hipLaunchKernelGGL(bv_p2g_solve16_kernel, dim3(grid), dim3(BV_WAVE * BV_P2G_NW), 0, stream, a);
-    if (bv_p2g_streams(a)) {  // the workgroup-per-row kernels solve what the 16-lane solver cannot take themselves
-        uint32_t gridh = (a.n_cu ? a.n_cu : 256u) * 2u;
-        const uint64_t needh = (items + 64u * BV_P2GH_WAVES - 1u) / (64u * BV_P2GH_WAVES);
+    if (bv_p2g_all_items(a)) {  // (when some items do not fit the scratch, the workgroup-per-row kernel solves the rest of them itself)
+        uint32_t gridh = (a.n_cu ? a.n_cu : 256u) * 4u;  // 127 VGPRs: four waves per SIMD
+        const uint64_t needh = (items + BV_P2GH_WAVES - 1u) / BV_P2GH_WAVES;
         if ((uint64_t)gridh > needh) gridh = needh > 0 ? (uint32_t)needh : 1u;
         if (cap && gridh > cap) gridh = cap;
         hipLaunchKernelGGL(bv_p2g_hard_kernel, dim3(gridh), dim3(BV_WAVE * BV_P2GH_WAVES), 0, stream, a);
     }
+}
+
+// every (variant site, group) has an item: no tally kernel needs the solver
+bool bv_p2g_all_items(const BvPass2Args &a) {
+    const bool groups = a.n_groups > 0 && a.group_id != nullptr && a.gout != nullptr;
+    return groups && a.gitems != nullptr && (uint64_t)a.n_sites * a.n_groups <= (uint64_t)a.gitem_cap;
 }
 
 bool bv_p2g_streams(const BvPass2Args &a) {
@@ -1079,12 +1141,17 @@ static void bv_launch_pass2_nt(const BvPass2Args &a, hipStream_t stream) {
     if (!ranks && !groups) return;
     uint32_t grid = a.n_sites;
     size_t dyn = groups ? bv_pass2_lds_bytes(a.n_groups) : 0;
-    if (ranks && groups)
-        hipLaunchKernelGGL((bv_pass2_kernel<NT, true, true>), dim3(grid), dim3(NT), dyn, stream, a);
+    const bool items = bv_p2g_all_items(a);
+    if (ranks && groups && items)
+        hipLaunchKernelGGL((bv_pass2_kernel<NT, true, true, false>), dim3(grid), dim3(NT), dyn, stream, a);
+    else if (ranks && groups)
+        hipLaunchKernelGGL((bv_pass2_kernel<NT, true, true, true>), dim3(grid), dim3(NT), dyn, stream, a);
     else if (ranks)
         hipLaunchKernelGGL((bv_pass2_kernel<NT, true, false>), dim3(grid), dim3(NT), dyn, stream, a);
+    else if (items)
+        hipLaunchKernelGGL((bv_pass2_kernel<NT, false, true, false>), dim3(grid), dim3(NT), dyn, stream, a);
     else
-        hipLaunchKernelGGL((bv_pass2_kernel<NT, false, true>), dim3(grid), dim3(NT), dyn, stream, a);
+        hipLaunchKernelGGL((bv_pass2_kernel<NT, false, true, true>), dim3(grid), dim3(NT), dyn, stream, a);
 }
 
 void bv_launch_pass2(const BvPass2Args &a_in, hipStream_t stream) {

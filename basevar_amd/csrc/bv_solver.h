@@ -11,7 +11,7 @@
 struct BvSolverScratch {
     BvLrtShared lrt;
     bv_site_result res;  // staged record, stored with one coalesced write
-    uint16_t ord[BV_ORD_MAX];  // shallow sites: the covered cells in sample order (bv_gather_ordered)
+    alignas(8) uint16_t ord[BV_ORD_ALLOC];  // shallow sites: the covered cells in sample order (bv_gather_ordered) + bv_em_ordered's scratch
 };
 struct BvSolverShared {
     uint32_t bin_code[BV_SLOTS * BV_WAVE];  // compacted non-empty (base<<7 | phred) bins
