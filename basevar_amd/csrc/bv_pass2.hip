@@ -319,7 +319,8 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                 if (a.gitems != nullptr && item < (size_t)a.gitem_cap) {
                     uint32_t *dst = a.gitems + item * BV_P2G_ITEM_WORDS;
                     const bool big = __ballot(cmax > 0xFFFFu) != 0ull;
-                    const bool hand_over = gtotal > 0 && !shallow && q0_mask == 0u && nb <= (uint32_t)BV_G16_MAX_BINS && !big && a.min_af > 0.0;
+                    const bool hand_over = gtotal > 0 && !shallow && q0_mask == 0u && nb <= (uint32_t)BV_G16_MAX_BINS && !big && a.min_af > 0.0 &&
+                                           !(a.flags & BV_FLAG_WAVE_SOLVER);
                     if (lane == 0) {
                         dst[0] = hand_over ? (nb | BV_P2G_PENDING) : 0u;
                         dst[1] = gdepth[0]; dst[2] = gdepth[1]; dst[3] = gdepth[2]; dst[4] = gdepth[3]; dst[5] = q0_mask;

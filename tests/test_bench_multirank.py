@@ -63,7 +63,8 @@ def test_bench_self_launch_fails_in_the_children_without_a_gpu():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert p.returncode != 0
-    assert p.stderr.count("bench.py needs a GPU") == 2, p.stderr[-2000:]   # both ranks got to the GPU check
+    # the ranks got to the GPU check (torchrun ends the other rank as soon as one has failed: one or both messages)
+    assert p.stderr.count("bench.py needs a GPU") >= 1, p.stderr[-2000:]
     assert "2-rank launch failed" in p.stderr and "must be launched with" not in p.stderr
 
 

@@ -748,3 +748,30 @@ def test_chained_submit_equals_separate_submits(bv):
     # the last chained launch held slabs 16, 17 and 18
     assert n_var_chain == sum(int(((c["status"] & 2) != 0).sum()) for c in chained[16:])
     eng.close()
+
+
+def test_submit_many_falls_back_on_short_rows(bv):
+    """Slabs the chained kernels do not take (rows of <= 49,152 samples here) are submitted one by one: same records."""
+    import torch
+    n = 3000
+    slabs = [make_slab(s, n, seed=400 + k, coverage=0.2, class_af=[(0.0, 0.0), (0.3, 0.0)]) for k, s in enumerate([50, 80, 33])]
+    maf = bv.min_af(n)
+    dev = torch.device("cuda", 0)
+    eng = bv.BaseTypeEngine(max_sites=256, min_af_value=maf, device=0)
+    rec = bv.SITE_DTYPE.itemsize
+    keep, segs, outs = [], [], []
+    for sl in slabs:
+        t = [torch.from_numpy(np.ascontiguousarray(sl[k])).to(dev) for k in ("base_strand", "qual", "ref_base", "mapq")]
+        t.append(torch.from_numpy(np.ascontiguousarray(sl["rpr"]).view(np.int16)).to(dev))
+        out = torch.zeros(sl["n_sites"] * rec, dtype=torch.uint8, device=dev)
+        keep.append(t); outs.append(out)
+        segs.append((sl["n_sites"], t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr(), t[3].data_ptr(), t[4].data_ptr()))
+    torch.cuda.synchronize()
+    eng.submit_many_ptrs(n, slabs[0]["pitch"], segs)
+    eng.wait()
+    many = [o.cpu().numpy().view(bv.SITE_DTYPE).copy() for o in outs]
+    eng.close()
+    for sl, m in zip(slabs, many):
+        one = run_engine(bv, sl, maf).sites
+        assert one.tobytes() == m.tobytes()
+        assert ((m["status"] & 2) != 0).sum() > 5

@@ -45,11 +45,20 @@ def counters(dirpat):
 
 
 def algorithmic_bytes(kernel, cfg, nvar):
-    B, N, G, ranks = cfg["batch_sites"], cfg["samples"], cfg.get("groups", 0), cfg.get("ranks", True)
+    B, N = cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"]
     if kernel.startswith(("bv_pass1_kernel", "bv_pass1_fused_kernel", "bv_p1s_stream_kernel")):
         return 2.0 * B * N, "2 B/cell x %d sites x %d samples" % (B, N)
-    if kernel.startswith("bv_pass2"):
-        per = (4 if ranks else 1) + (1 if G else 0)
+    per = None
+    if kernel.startswith(("bv_pass2_dma_kernel", "bv_pass2_short_kernel")):
+        per = 4                      # call + mapq + 2 B rank
+    elif kernel.startswith("bv_p2g_stream_kernel"):
+        per = 2                      # call + phred (the group plane is the same 10-50 KB for every row: L2)
+    elif kernel.startswith("bv_pass2_kernel"):
+        targs = [t.strip() for t in kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")] if "<" in kernel else []
+        rk = len(targs) > 1 and targs[1] == "true"
+        gr = len(targs) > 2 and targs[2] == "true"
+        per = 1 + (3 if rk else 0) + (1 if gr else 0)
+    if per is not None:
         return float(per) * N * nvar, "%d B/cell x %d variant rows x %d samples" % (per, nvar, N)
     return None, "-"
 
@@ -74,6 +83,7 @@ def main():
             if t == "--samples": cfg["samples"] = int(toks[i + 1])
             if t == "--batch-sites": cfg["batch_sites"] = int(toks[i + 1])
             if t == "--groups": cfg["groups"] = int(toks[i + 1])
+            if t == "--chain": cfg["chain"] = int(toks[i + 1])
             if t == "--no-rank-planes": cfg["ranks"] = False
         nvar = 0
         bj = os.path.join(src, name + ".bench.json")
@@ -122,7 +132,7 @@ def main():
                 "%.4g" % hbm if f is not None else "-", ("%.4g (%s)" % (algo, how)) if algo else "-",
                 "%.3f" % (hbm / algo) if (algo and f is not None) else "-", "%.3f" % frac if frac else "-"))
             if algo and f is not None and k.startswith(("bv_pass1", "bv_p1s_stream")):
-                traffic["%s|%dx%d" % (k.split("<")[0], cfg["batch_sites"], cfg["samples"])] = {
+                traffic["%s|%dx%d" % (k.split("<")[0], cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"])] = {
                     "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
                     "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)}
         lines.append("")
