@@ -21,6 +21,9 @@
 #ifndef BV_P2_WIDE_GROUPS
 #define BV_P2_WIDE_GROUPS 2 /* from this many pop-groups on, short rows also take the four-wave kernel: one wave per group */
 #endif
+#ifndef BV_P2_BIG_GROUPS
+#define BV_P2_BIG_GROUPS 12 /* from this many pop-groups on, long rows take workgroups of eight waves */
+#endif
 #define BV_RPR_WIN 1024  /* read-position ranks per LDS window; longer reads take extra sweeps */
 
 // INLINE: the kernel solves pop-groups itself (one wave per group) and needs the solver's LDS; otherwise every group leaves
@@ -1184,5 +1187,8 @@ void bv_launch_pass2(const BvPass2Args &a_in, hipStream_t stream) {
         return;
     }
     if (a.n_samples <= 16384u && !(groups && a.n_groups >= BV_P2_WIDE_GROUPS)) bv_launch_pass2_nt<64>(a, stream);
+    // many pop-groups: 2 KiB of histogram per group leave room for two workgroups per CU only -- eight waves each then
+    // (sixteen waves were measured too: 10 % slower than eight at 24-32 groups)
+    else if (groups && a.n_groups >= BV_P2_BIG_GROUPS && bv_p2g_all_items(a) && a.n_samples > 16384u) bv_launch_pass2_nt<512>(a, stream);
     else bv_launch_pass2_nt<256>(a, stream);
 }
