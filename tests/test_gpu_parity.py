@@ -775,3 +775,31 @@ def test_submit_many_falls_back_on_short_rows(bv):
         one = run_engine(bv, sl, maf).sites
         assert one.tobytes() == m.tobytes()
         assert ((m["status"] & 2) != 0).sum() > 5
+
+
+@pytest.mark.parametrize("n,groups", [(2049, 3), (49152, 7), (4099, 6), (70000, 2)], ids=["n2049_g3", "n49152_g7", "n4099_g6", "n70000_g2"])
+def test_group_kernels_at_their_row_length_limits(bv, restatement, n, groups):
+    """The streaming group tally at the first and the last row length it takes (ragged tails, two- and three-slot rings), and
+    the workgroup-per-row kernel behind it -- all groups through the item kernels."""
+    slab = make_slab(40, n, seed=500 + n % 97, coverage=0.15, class_af=[(0.3, 0.0), (0.2, 0.2), (0.0, 0.0)], n_groups=groups)
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
+    assert got.n_variant > 10
+
+
+def test_group_bin_counts_past_16_bits(bv, restatement):
+    """One pop-group holding 150,000 fully covered samples of ONE phred: bin counts > 65,535 do not fit the 16-lane solver's
+    items and take the one-wave kernel (23-bit counts)."""
+    n = 150000
+    slab = make_slab(6, n, seed=611, coverage=1.0, indel_frac=0.0, class_af=[(0.3, 0.0), (0.1, 0.1)], qual_mean=35, qual_sd=0.1,
+                     qual_min=35, qual_max=35, n_groups=0)
+    slab["group_id"] = np.zeros(n, np.uint8)
+    slab["group_id"][::7] = 1
+    slab["n_groups"] = 2
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
+    assert (got.groups["total_depth"][:, 0] > 100000).all() and got.n_variant == 6
