@@ -585,7 +585,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
     a2.ch = a1.ch;
-    if (G && gid && dgout) {
+    if (G && gid && dgout && !(e->cfg.flags & BV_FLAG_GROUP_INLINE)) {
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
         // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel
         const uint64_t want64 = (uint64_t)S * G, most = (8192ull << 20) / (sizeof(uint32_t) * BV_P2G_ITEM_WORDS);

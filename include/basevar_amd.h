@@ -150,6 +150,8 @@ typedef struct bv_group_result {
 #define BV_FLAG_SKIP_LRT 0x4u    /* diagnostic: no EM / LRT (no site is called variant) */
 #define BV_FLAG_GRID_LIMIT(n) (((uint32_t)(n) & 0xFFu) << 16) /* diagnostic / tests: at most n workgroups per persistent short-row kernel,
                                      so that a small input walks the many-sites-per-wave paths (list flushes, 64-site blocks) */
+#define BV_FLAG_GROUP_INLINE 0x40u /* diagnostic / tests: pop-group calls are solved inside the pass-2 tally kernel, one wave per group
+                                     (the path taken when the item scratch cannot hold every (variant site, group)) */
 #define BV_FLAG_PASS2_SWEEP 0x20u /* diagnostic: short rows take the plain-load pass-2 kernels (not the LDS-DMA one) */
 #define BV_FLAG_WAVE_SOLVER 0x10u /* diagnostic: short-row candidates and pop-group calls all take the one-per-wave solver (none the 16-lane one) */
 #define BV_FLAG_TILE_STATE 0x8u  /* tile mode: always accumulate per-site tallies (the fallback for jobs whose

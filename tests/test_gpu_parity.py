@@ -803,3 +803,17 @@ def test_group_bin_counts_past_16_bits(bv, restatement):
     exp, gexp, margins = oracle_run(restatement, slab, maf)
     check(got, exp, gexp, margins)
     assert (got.groups["total_depth"][:, 0] > 100000).all() and got.n_variant == 6
+
+
+@pytest.mark.parametrize("n", [3000, 60000], ids=["short_rows", "long_rows"])
+def test_group_calls_inside_the_tally_kernel(bv, restatement, n):
+    """BV_FLAG_GROUP_INLINE (0x40): no item scratch -- the workgroup-per-row kernel solves every pop-group itself, the path
+    a job takes whose (variant site x group) items do not fit the scratch."""
+    slab = make_slab(48, n, seed=700 + n % 13, coverage=0.2, class_af=[(0.3, 0.0), (0.2, 0.2), (0.0, 0.0)], n_groups=5)
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=48, min_af_value=maf, device=0, flags=0x40)
+    got = eng.lrt(slab)
+    eng.close()
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
+    assert got.n_variant > 10
