@@ -371,7 +371,7 @@ def main():
         if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile))
-                for key in ("%s|%dx%d" % (kernel_name, Bl, N), "pass1_%dx%d" % (Bl, N)):
+                for key in ("%s|%dx%d" % (kernel_name, Bl, N) + ("|chain%d" % K if K > 1 else ""),) + (("pass1_%dx%d" % (Bl, N),) if K == 1 else ()):
                     if key in tj and (key.startswith(kernel_name) or kernel_name == "bv_pass1_kernel"):
                         traffic = tj[key]["hbm_bytes_per_launch"]
                         traffic_source = tj[key].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % key)

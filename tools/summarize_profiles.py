@@ -63,6 +63,12 @@ def algorithmic_bytes(kernel, cfg, nvar):
     return None, "-"
 
 
+def tkey(kernel, cfg):
+    """pmc_traffic.json key: kernel | sites per launch x samples (| chainK for chained launches); bench.py forms the same"""
+    key = "%s|%dx%d" % (kernel.split("<")[0], cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"])
+    return key + ("|chain%d" % cfg["chain"] if cfg.get("chain", 1) > 1 else "")
+
+
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
     src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
@@ -132,9 +138,10 @@ def main():
                 "%.4g" % hbm if f is not None else "-", ("%.4g (%s)" % (algo, how)) if algo else "-",
                 "%.3f" % (hbm / algo) if (algo and f is not None) else "-", "%.3f" % frac if frac else "-"))
             if algo and f is not None and k.startswith(("bv_pass1", "bv_p1s_stream")):
-                traffic["%s|%dx%d" % (k.split("<")[0], cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"])] = {
+                # (several configurations run the same kernel on the same shape: the first one, in name order, is quoted)
+                traffic.setdefault(tkey(k, cfg), {}).update({} if traffic[tkey(k, cfg)] else {
                     "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
-                    "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)}
+                    "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)})
         lines.append("")
         sqk = [k for k in kern if "sq" in kern[k]]
         if sqk:
