@@ -175,6 +175,8 @@ struct bv_engine {
     uint32_t gitem_cap = 0;            // items (of BV_P2G_ITEM_WORDS words) d_gitems holds
     uint8_t *d_gidp = nullptr;         // group ids prepared for bv_p2g_stream_kernel (bv_launch_gid_prepare)
     BvChain *d_chain = nullptr;        // segment tables of chained launches (bv_engine_submit_many)
+    uint8_t *d_ref_cat = nullptr;      // chained short-row launches: reference bases / records of all segments, contiguous
+    bv_site_result *d_out_cat = nullptr;
     unsigned chain_next = 0;
     size_t d_gidp_bytes = 0;
     uint32_t acc_n = 0;
@@ -490,6 +492,8 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_gitems) (void)hipFree(e->d_gitems);
     if (e->d_gidp) (void)hipFree(e->d_gidp);
     if (e->d_chain) (void)hipFree(e->d_chain);
+    if (e->d_ref_cat) (void)hipFree(e->d_ref_cat);
+    if (e->d_out_cat) (void)hipFree(e->d_out_cat);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &sl : e->sring) {
@@ -512,7 +516,7 @@ int bv_engine_destroy(bv_engine *e) {
 // The two passes over device-resident planes + the copies back (records to a host caller, counters).
 static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
-                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr) {
+                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */) {
     const size_t S = n_sites, G = n_groups;
     BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));  // not the sticky error counters
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
@@ -521,14 +525,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
     a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
     a1.var_list = e->d_var_list; a1.counters = e->d_counters; a1.n_cu = e->n_cu;
-    a1.ch = nullptr;
-    if (chain) {
-        // the segment table lives in device memory (a ring of 16: a table is rewritten only 16 chained launches later)
-        if (!e->d_chain) BV_HIP(e, hipMalloc(&e->d_chain, sizeof(BvChain) * 16));
-        BvChain *slot_ch = e->d_chain + (e->chain_next++ & 15u);
-        BV_HIP(e, hipMemcpyAsync(slot_ch, chain, sizeof(BvChain), hipMemcpyHostToDevice, st));
-        a1.ch = slot_ch;
-    }
+    a1.ch = chain;
     if (e->ring_count == bv_engine::kRing) {
         int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
         if (rc != BV_OK) return rc;
@@ -566,6 +563,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout;
         s1.var_list = e->d_var_list; s1.counters = e->d_counters; s1.summ = e->d_summ; s1.bins = e->d_bins;
         s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list; s1.easy3_list = e->d_easy3_list;
+        s1.ch = chain;
         bv_launch_p1s_stream(s1, st);
         BV_HIP(e, hipGetLastError());
         BV_HIP(e, hipEventRecord(ev[3], st));
@@ -707,7 +705,8 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
     for (uint32_t k = 0; k < n_slabs; ++k) {
         const bv_slab &s = slabs[k];
         if (!outs[k]) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null record buffer");
-        chainable = chainable && s.mem_kind != BV_MEM_HOST && s.n_groups == 0 && s.n_samples > BV_SHORT_ROW_MAX &&
+        // (rows of up to 2048 samples and the diagnostic kernel choices take kernels that know no chain)
+        chainable = chainable && s.mem_kind != BV_MEM_HOST && s.n_groups == 0 && s.n_samples > 2048u && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP) &&
                     s.n_samples == slabs[0].n_samples && s.pitch == slabs[0].pitch && (s.mapq == nullptr) == (slabs[0].mapq == nullptr);
         total += s.n_sites;
     }
@@ -750,9 +749,35 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
             first += s.n_sites;
         }
         const bv_slab &s0 = slabs[k0];
-        int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, nullptr, P, first, s0.n_samples, 0, outs[k0], nullptr,
-                               st, nk > 1 ? &ch : nullptr);
-        if (rc != BV_OK) return rc;
+        if (nk == 1) {
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, nullptr, P, first, s0.n_samples, 0, outs[k0], nullptr, st);
+            if (rc != BV_OK) return rc;
+            continue;
+        }
+        // the segment table lives in device memory (a ring of 16: a table is rewritten only 16 chained launches later)
+        if (!e->d_chain) BV_HIP(e, hipMalloc(&e->d_chain, sizeof(BvChain) * 16));
+        BvChain *d_ch = e->d_chain + (e->chain_next++ & 15u);
+        BV_HIP(e, hipMemcpyAsync(d_ch, &ch, sizeof(BvChain), hipMemcpyHostToDevice, st));
+        if (s0.n_samples > BV_SHORT_ROW_MAX) {
+            // long rows: every kernel looks its segment up per site (planes, reference bases, records)
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, nullptr, P, first, s0.n_samples, 0, outs[k0], nullptr, st, d_ch);
+            if (rc != BV_OK) return rc;
+        } else {
+            // short rows: the planes are looked up per row (wave-uniform places only); the per-site reference bases and records,
+            // which the lane-per-site and four-per-wave kernels touch with one site per lane, go through contiguous copies
+            if (!e->d_ref_cat) {
+                BV_HIP(e, hipMalloc(&e->d_ref_cat, (size_t)e->cfg.max_sites + 256));
+                BV_HIP(e, hipMalloc(&e->d_out_cat, sizeof(bv_site_result) * (size_t)e->cfg.max_sites));
+            }
+            bv_launch_chain_gather_ref(d_ch, first, e->d_ref_cat, st);
+            BV_HIP(e, hipGetLastError());
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, e->d_ref_cat, nullptr, P, first, s0.n_samples, 0, e->d_out_cat, nullptr, st, d_ch);
+            if (rc != BV_OK) return rc;
+            bv_launch_chain_scatter_out(d_ch, first, e->d_out_cat, st);
+            BV_HIP(e, hipGetLastError());
+            rc = mark_done(e, st);  // the scatter is the end of this submit
+            if (rc != BV_OK) return rc;
+        }
     }
     return BV_OK;
 }

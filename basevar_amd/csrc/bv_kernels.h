@@ -33,10 +33,16 @@ struct BvChain {
     bv_site_result *out[BV_MAX_CHAIN];
 };
 #if defined(__HIPCC__)
-__device__ __forceinline__ uint32_t bv_chain_seg(const BvChain &c, uint32_t site) {  // site: wave-uniform
+// The table is written by the host before the launch and never by a kernel: read it through the constant address space, so
+// that wave-uniform look-ups are SCALAR loads (lgkmcnt) -- a vector load would sit in the vmcnt queue of the streaming
+// kernels and drain their LDS-DMA rings at every row.
+typedef const __attribute__((address_space(4))) BvChain *BvChainC;
+__device__ __forceinline__ BvChainC bv_chain_const(const BvChain *p) { return (BvChainC)(uintptr_t)p; }
+__device__ __forceinline__ uint32_t bv_chain_seg(BvChainC c, uint32_t site) {
     uint32_t k = 0;
+    const uint32_t n = c->n;
 #pragma unroll
-    for (int i = 1; i < BV_MAX_CHAIN; ++i) k += (i < (int)c.n && site >= c.first[i]) ? 1u : 0u;
+    for (int i = 1; i < BV_MAX_CHAIN; ++i) k += ((uint32_t)i < n && site >= c->first[i]) ? 1u : 0u;
     return k;
 }
 #endif
@@ -117,7 +123,12 @@ struct BvP1ShortArgs {
     uint32_t *easy_list;   // [n_sites]  candidates solved four per wave (bv_solver16.h), at most two active bases
     uint32_t *easy3_list;  // [n_sites]  the same with three or four active bases: several times the EM runs, so they are kept
                            //            apart -- the four sites of a wave run in lockstep and pay for the slowest
+    const BvChain *ch;     // device memory, or NULL: a chained launch -- the call / phred planes come per segment (biased), while
+                           // ref_base / out are the engine's contiguous copies indexed with the global site number
 };
+// chained short-row launches: reference bases of all segments -> one array; records of all segments <- one array
+void bv_launch_chain_gather_ref(const BvChain *ch, uint32_t n_sites, uint8_t *ref_cat, hipStream_t stream);
+void bv_launch_chain_scatter_out(const BvChain *ch, uint32_t n_sites, const bv_site_result *out_cat, hipStream_t stream);
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream);
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream);
 

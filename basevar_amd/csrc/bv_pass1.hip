@@ -233,8 +233,9 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
             }
             const uint8_t *pb = a.bs, *pq = a.q;
             if (CHAIN && a.ch != nullptr) {  // a chained launch: the segment's (biased) planes
-                const uint32_t sg = bv_chain_seg(*a.ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
-                pb = a.ch->bs[sg]; pq = a.ch->q[sg];
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                pb = ch->bs[sg]; pq = ch->q[sg];
             }
             bv_tally_row_wave<NTALLY>(pb + (size_t)site * a.pitch, pq + (size_t)site * a.pitch, a.n_samples,
                                       sh.hist[buf], wave, lane);
@@ -255,8 +256,9 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
             const uint32_t site = sh.site_of[buf];
             if (site == 0xFFFFFFFFu) break;
             if (CHAIN && a.ch != nullptr) {
-                const uint32_t sg = bv_chain_seg(*a.ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
-                sa.ref_base = a.ch->ref_base[sg]; sa.out = a.ch->out[sg]; sa.bs = a.ch->bs[sg]; sa.q = a.ch->q[sg];
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                sa.ref_base = ch->ref_base[sg]; sa.out = ch->out[sg]; sa.bs = ch->bs[sg]; sa.q = ch->q[sg];
             }
             bv_solve_site_wave<false>(sa, site, (BV_LDS uint32_t *)sh.hist[buf], (BV_LDS uint32_t *)sh.sv[s].bin_code,
                                       (BV_LDS uint32_t *)sh.sv[s].bin_cnt, (BV_LDS BvSolverScratch *)&sh.sv[s].sc,

@@ -98,7 +98,7 @@ __device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint
 #ifndef BV_P1S_NW
 #define BV_P1S_NW 4
 #endif
-template <int NW, int K, int U>
+template <int NW, int K, int U, bool CHAIN = false>
 __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sStreamShared<NW, K, U> sh;
     const int lane = threadIdx.x & 63;
@@ -125,18 +125,24 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 
     // prefetch cursor: the next slot to request
     uint32_t p_site = s0, p_j = 0, ring_w = 0, inflight = 0;
+    const uint8_t *seg_bs = a.bs, *seg_q = a.q;  // CHAIN: the (biased) planes of the segment that holds p_site
     auto issue = [&]() {
         if (p_site < s1) {
+            if (CHAIN && p_j == 0u) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)p_site));
+                seg_bs = ch->bs[sg]; seg_q = ch->q[sg];
+            }
             const size_t off = (size_t)p_site * a.pitch + (size_t)p_j * (1024u * U);
-            const uint8_t *pb = bv_uniform_ptr(a.bs + off), *pq = bv_uniform_ptr(a.q + off);
+            const uint8_t *pb = bv_uniform_ptr(seg_bs + off), *pq = bv_uniform_ptr(seg_q + off);
             const uint32_t dst = ring_lds + ring_w * (U * BV_S_SLOT_WORDS * 4u);
 #pragma unroll
             for (int u = 0; u < U; ++u) {  // slot layout: U KiB of calls, then U KiB of phreds
                 // Every slot issues exactly 2 U loads (the counted waits rely on it): a KiB that lies wholly past the row's
                 // end is "loaded" by lane 0 alone from the row's first bytes (its cells are masked in the tally)
                 const bool any = p_j + 1u < n_slots || 64u * u < last_valid;
-                const uint8_t *sb = any ? pb + 1024u * u : bv_uniform_ptr(a.bs + (size_t)p_site * a.pitch);
-                const uint8_t *sq = any ? pq + 1024u * u : bv_uniform_ptr(a.q + (size_t)p_site * a.pitch);
+                const uint8_t *sb = any ? pb + 1024u * u : bv_uniform_ptr(seg_bs + (size_t)p_site * a.pitch);
+                const uint8_t *sq = any ? pq + 1024u * u : bv_uniform_ptr(seg_q + (size_t)p_site * a.pitch);
                 if (any ? (p_j + 1u < n_slots || (uint32_t)lane + 64u * u < last_valid) : lane == 0) {  // chunks past the row's end load nothing
                     bv_glds16(dst + 1024u * u, sb, voff);
                     bv_glds16(dst + 1024u * (U + u), sq, voff);
@@ -511,6 +517,11 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
         S.nb = nb;
         bv_lrt_sync<0>();
         BvHqMerged H{hq};
+        if (a.ch != nullptr) {  // chained launch: the ordered gather of a shallow site reads the segment's (biased) planes
+            const BvChainC ch = bv_chain_const(a.ch);
+            const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+            sa.bs = ch->bs[sg]; sa.q = ch->q[sg];
+        }
         if (bv_site_solve<false, BvHqMerged, true>(sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
             vlist = ((uint32_t)lane == n_vlist) ? site : vlist;
             if (++n_vlist == 64u) flush_variants();
@@ -598,6 +609,29 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
     if (n_vl) flush_vl();
 }
 
+// ------------------------------------------------------------------------------ chained launches (bv_engine_submit_many)
+__global__ void bv_chain_gather_ref_kernel(const BvChain *ch, uint32_t n_sites, uint8_t *ref_cat) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const BvChainC c = bv_chain_const(ch);
+    if (t < n_sites) ref_cat[t] = c->ref_base[bv_chain_seg(c, t)][t];
+}
+// one 16-byte piece of a record per thread (13 per record)
+__global__ void bv_chain_scatter_out_kernel(const BvChain *ch, uint32_t n_sites, const bv_site_result *out_cat) {
+    constexpr uint32_t PIECES = (uint32_t)(sizeof(bv_site_result) / 16);
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = (uint32_t)(i / PIECES), piece = (uint32_t)(i % PIECES);
+    const BvChainC c = bv_chain_const(ch);
+    if (t < n_sites)
+        reinterpret_cast<uint4 *>(&c->out[bv_chain_seg(c, t)][t])[piece] = reinterpret_cast<const uint4 *>(&out_cat[t])[piece];
+}
+void bv_launch_chain_gather_ref(const BvChain *ch, uint32_t n_sites, uint8_t *ref_cat, hipStream_t stream) {
+    hipLaunchKernelGGL(bv_chain_gather_ref_kernel, dim3((n_sites + 255u) / 256u), dim3(256), 0, stream, ch, n_sites, ref_cat);
+}
+void bv_launch_chain_scatter_out(const BvChain *ch, uint32_t n_sites, const bv_site_result *out_cat, hipStream_t stream) {
+    const uint64_t n = (uint64_t)n_sites * (sizeof(bv_site_result) / 16);
+    hipLaunchKernelGGL(bv_chain_scatter_out_kernel, dim3((uint32_t)((n + 255u) / 256u)), dim3(256), 0, stream, ch, n_sites, out_cat);
+}
+
 // ------------------------------------------------------------------------------ launchers
 template <int NW, int K, int U = 1>
 static void bv_launch_p1s_stream_cfg(const BvP1ShortArgs &a, hipStream_t stream, uint32_t wg_per_cu) {
@@ -607,7 +641,8 @@ static void bv_launch_p1s_stream_cfg(const BvP1ShortArgs &a, hipStream_t stream,
     if (grid > need) grid = need > 0 ? need : 1;
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
     if (cap && grid > cap) grid = cap;
-    hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K, U>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
+    if (a.ch != nullptr) hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K, U, true>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
+    else hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K, U, false>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
 }
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     // bits 12-15 of the flags select a ring depth / residency for tuning runs (0 = default)

@@ -157,8 +157,9 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     {
         const uint32_t site = a.var_list[v];
         if (!GROUPS && a.ch != nullptr) {  // a chained launch: the segment's (biased) planes and records
-            const uint32_t sg = bv_chain_seg(*a.ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
-            a.bs = a.ch->bs[sg]; a.mapq = a.ch->mapq[sg]; a.rpr = a.ch->rpr[sg]; a.ref_base = a.ch->ref_base[sg]; a.out = a.ch->out[sg];
+            const BvChainC ch = bv_chain_const(a.ch);
+            const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+            a.bs = ch->bs[sg]; a.mapq = ch->mapq[sg]; a.rpr = ch->rpr[sg]; a.ref_base = ch->ref_base[sg]; a.out = ch->out[sg];
         }
         // ---- what pass 1 decided for this site
         const bv_site_result *res = &a.out[site];
@@ -526,12 +527,20 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
     };
     // prefetch cursor
     uint32_t p_k = 0, p_j = 0, ring_w = 0, inflight = 0, blk0 = 0;
+    // a chained launch (a.ch): the planes of the segment that holds the prefetch cursor's site (biased: indexed with the
+    // global site number); ref_base / out are contiguous either way
+    const uint8_t *seg_bs = a.bs, *seg_mq = a.mapq, *seg_rp = reinterpret_cast<const uint8_t *>(a.rpr);
     auto issue = [&]() {
         if (p_k < mine) {
             const uint32_t site = site_of(p_k, blk0);
+            if (a.ch != nullptr && p_j == 0u) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, site);
+                seg_bs = ch->bs[sg]; seg_mq = ch->mapq[sg]; seg_rp = reinterpret_cast<const uint8_t *>(ch->rpr[sg]);
+            }
             const size_t row = (size_t)site * a.pitch + (size_t)p_j * 1024u;
-            const uint8_t *pb = bv_p2d_uniform_ptr(a.bs + row), *pm = bv_p2d_uniform_ptr(a.mapq + row);
-            const uint8_t *pr = bv_p2d_uniform_ptr(reinterpret_cast<const uint8_t *>(a.rpr) + 2u * row);
+            const uint8_t *pb = bv_p2d_uniform_ptr(seg_bs + row), *pm = bv_p2d_uniform_ptr(seg_mq + row);
+            const uint8_t *pr = bv_p2d_uniform_ptr(seg_rp + 2u * row);
             const uint32_t dst = ring_lds + ring_w * (BV_P2D_SLOT_WORDS * 4u);
             if (p_j + 1u < n_slots || (uint32_t)lane < last_valid) {  // lanes past the row's end load nothing (lane 0 always loads)
                 bv_p2d_glds16(dst, pb, voff);
@@ -654,7 +663,13 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
             bv_lrt_sync<0>();
             BvP2Ctx cx;
             cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
-            bv_p2_sweep<BV_WAVE, true, true, false, 256>(cx, a, site, lane);
+            BvPass2Args as = a;  // the sweeps index the planes with the site number themselves
+            if (a.ch != nullptr) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, site);
+                as.bs = ch->bs[sg]; as.mapq = ch->mapq[sg]; as.rpr = ch->rpr[sg];
+            }
+            bv_p2_sweep<BV_WAVE, true, true, false, 256>(cx, as, site, lane);
             const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
             bv_lrt_sync<0>();
             {
@@ -677,7 +692,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
                 }
                 bv_lrt_sync<0>();
                 cx.win_lo = win_lo + 256u;
-                bv_p2_sweep<BV_WAVE, true, false, false, 256>(cx, a, site, lane);
+                bv_p2_sweep<BV_WAVE, true, false, false, 256>(cx, as, site, lane);
                 bv_lrt_sync<0>();
             }
             const double ph = bv_ranksum_phred(twoR, n1, n2);
