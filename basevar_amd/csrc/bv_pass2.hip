@@ -818,7 +818,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GS_WAVES) void bv_p2g_stream_kernel(B
 #pragma unroll 1
             for (int t = 0; t < K; ++t) issue();
         }
-        const uint32_t site = (uint32_t)__builtin_amdgcn_readlane((int)siteA, (int)(k - blk0));
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
             if (inflight == (uint32_t)K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * (K - 1)) : "memory");

@@ -40,6 +40,8 @@ run_cfg n10k_noranks --samples 10000 --batch-sites 100000 --groups 2 --no-rank-p
 run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more than 7 groups: bv_pass2_kernel<256,true,true,false> + the group solve kernels
 run_cfg n100k_chain16 --batch-sites 8192 --chain 16                    # small batches chained: bv_pass1_kernel<3,1,true>
 run_cfg n100k_8192 --batch-sites 8192 --steps 20                       # ... and one launch per small batch
+run_cfg n10k_chain16 --samples 10000 --batch-sites 8192 --chain 16     # short rows chained: bv_p1s_stream_kernel<4,3,2,true>, bv_chain_* kernels
+run_cfg n10k_8192 --samples 10000 --batch-sites 8192 --steps 30
 run_cfg tiles_joined_1M --samples 1000000 --batch-sites 8192 --tile-sites 8192 --with-tile-mode --steps 2 --warmup 1   # bv_tile_scatter_kernel
 run_cfg tiles_state_100k --samples 100000 --batch-sites 16384 --tile-sites 16384 --with-tile-mode --flags 8 --steps 2 --warmup 1   # bv_tile_tally_kernel, bv_tile_finish_kernel
 sq_cfg n10k --samples 10000 --batch-sites 100000
