@@ -231,7 +231,10 @@ def main():
     Bl = B * K                      # sites per launch (= per step)
     nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
     if K > 1:
-        nb = max(nb, min(K, 8))
+        # every batch of a chained launch is a different one (no re-reads that the 256 MB infinity cache could serve), as far
+        # as 96 GB of HBM go
+        fit = max(1, int(96e9 // (5.0 * B * pitch)))
+        nb = max(nb, min(K, fit))
     ranks = not args.no_rank_planes
 
     # ---- synthetic batches, resident in HBM.  Global site index = ((batch * world) + rank) * B + row,
