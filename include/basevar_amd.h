@@ -200,7 +200,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
  * gout is not taken), but the persistent kernels draw their sites across the whole queue, so the fixed tail of a launch --
  * the solve of its last deep sites, ~0.1 ms during which the chip has nothing left to stream -- is paid once per queue, not
  * once per slab.  Meant for hosts that hold several small batches (a few thousand sites each): 8,192-site batches run at
- * the rate of one large batch (100 k samples: 14.9 -> 20 M sites/s; 10 k samples: 52 -> 144 M).  Chained, 16 slabs per
+ * the rate of one large batch (100 k samples: 14.9 -> 20 M sites/s; 10 k samples: 52 -> 143 M).  Chained, 16 slabs per
  * launch, when the slabs are BV_MEM_DEVICE, share n_samples (> 2048) and pitch, have no groups and at most cfg.max_sites
  * sites together; anything else is submitted slab by slab.  bv_engine_last_variant_count then counts the last launch.
  * Replaces nothing in the reference (its workers take one position at a time, basetype_caller.cpp:738-762). */
