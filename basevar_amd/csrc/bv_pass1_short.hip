@@ -195,6 +195,7 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
         }
         bv_lrt_sync<0>();
 
+#ifndef BV_ABL_P1S_NOROWEND  /* attribution builds only: the stream and the tally without the per-row epilogue (results are wrong) */
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
         bool bad = false;
@@ -296,6 +297,9 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             w = (lane == 9) ? fl : w;
             if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
         }
+#else
+        if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = hist[lane * 37];
+#endif
         // ---- hand the histogram back, zeroed
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
