@@ -712,12 +712,14 @@ def test_tile_job_interleaved_with_row_submits_and_abandoned_jobs(bv, restatemen
     eng.close()
 
 
-@pytest.mark.parametrize("n", [60000, 6000, 70], ids=["long_rows", "short_rows", "shallow_rows"])
-def test_chained_submit_equals_separate_submits(bv, n):
+@pytest.mark.parametrize("n,flags", [(60000, 0), (6000, 0), (6000, 1 << 16), (70, 0)],
+                         ids=["long_rows", "short_rows", "short_rows_one_workgroup", "shallow_rows"])
+def test_chained_submit_equals_separate_submits(bv, n, flags):
     """bv_engine_submit_many: several device slabs, one launch per pass (the site tickets / site ranges span the queue) --
     every record must be the one a submit of its own slab writes (byte for byte: which workgroup solves a site has no
     influence).  Long rows: every kernel looks its segment up per site; short rows: planes per row, reference bases and
-    records through the engine's contiguous copies; 70-sample rows take the plain submits (no chained kernels there)."""
+    records through the engine's contiguous copies (with BV_FLAG_GRID_LIMIT(1) every wave walks sites of many segments);
+    70-sample rows take the plain submits (no chained kernels there)."""
     import torch
     sizes = [96, 17, 200, 64, 1, 130, 48, 77, 33, 120, 5, 5, 60, 41, 9, 88, 150, 3, 70]  # 19 slabs: two chained launches (16 + 3)
     slabs = [make_slab(s, n, seed=300 + k, coverage=(0.05 + 0.02 * (k % 3)) if n > 1000 else 0.4,
@@ -730,7 +732,7 @@ def test_chained_submit_equals_separate_submits(bv, n):
         sl["rpr"][3, np.nonzero(sl["base_strand"][3] < 8)[0][:3]] = 700
     maf = bv.min_af(n)
     dev = torch.device("cuda", 0)
-    eng = bv.BaseTypeEngine(max_sites=sum(sizes), min_af_value=maf, device=0)
+    eng = bv.BaseTypeEngine(max_sites=sum(sizes), min_af_value=maf, device=0, flags=flags)
     rec = bv.SITE_DTYPE.itemsize
     keep, segs, outs = [], [], []
     for sl in slabs:
@@ -744,6 +746,8 @@ def test_chained_submit_equals_separate_submits(bv, n):
     eng.wait()
     chained = [o.cpu().numpy().view(bv.SITE_DTYPE).copy() for o in outs]
     n_var_chain = eng.last_variant_count()
+    eng.close()
+    eng = bv.BaseTypeEngine(max_sites=sum(sizes), min_af_value=maf, device=0)  # the single submits: default launch shapes
     total_var = 0
     for k, sl in enumerate(slabs):
         outs[k].zero_()
