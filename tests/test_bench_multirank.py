@@ -84,3 +84,19 @@ def test_bench_rccl_backend_single_rank():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["gathered_records_ok"] is True and d["value"] > 0
     assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("samples", [60000, 6000], ids=["long_rows", "short_rows"])
+def test_bench_chained_batches(samples):
+    """`--chain K`: K batches per step as one chained launch (bv_engine_submit_many); the line keeps the contract and says so."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--samples", str(samples),
+           "--batch-sites", "1024", "--chain", "4", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["config"]["chain"] == 4 and d["config"]["batch_sites"] == 1024 and d["config"]["sites_per_launch"] == 4096
+    assert d["roofline"]["launches"] == 3 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.0 * 4096 * samples
