@@ -18,6 +18,35 @@ from basevar_amd.synth import make_slab  # noqa: E402
 from parity import ambiguous_sites, compare_groups, compare_sites, describe  # noqa: E402
 
 
+class _Got:
+    pass
+
+
+def lrt_chained(eng, slab, rng):
+    """The slab cut into 2-5 row ranges, uploaded, and submitted as ONE chained launch (CAMPAIGN_CHAIN=1; no pop-groups)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    S, n, pitch = slab["n_sites"], slab["n_samples"], slab["pitch"]
+    t = {k: torch.from_numpy(np.ascontiguousarray(slab[k])).to(dev) for k in ("base_strand", "qual", "ref_base", "mapq")}
+    t["rpr"] = torch.from_numpy(np.ascontiguousarray(slab["rpr"]).view(np.int16)).to(dev)
+    rec = basevar_amd.SITE_DTYPE.itemsize
+    out = torch.zeros(S * rec, dtype=torch.uint8, device=dev)
+    k = int(rng.integers(2, 6))
+    cuts = sorted(set([0, S] + [int(c) for c in rng.integers(1, max(2, S), size=k - 1)]))
+    segs = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        segs.append((hi - lo, t["base_strand"][lo].data_ptr(), t["qual"][lo].data_ptr(), t["ref_base"][lo:].data_ptr(),
+                     out.data_ptr() + lo * rec, t["mapq"][lo].data_ptr(), t["rpr"][lo].data_ptr()))
+    torch.cuda.synchronize()
+    eng.submit_many_ptrs(n, pitch, segs)
+    eng.wait()
+    g = _Got()
+    g.sites = out.cpu().numpy().view(basevar_amd.SITE_DTYPE)
+    g.groups = None
+    g.n_variant = int(((g.sites["status"] & 2) != 0).sum())
+    return g
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     use_ref = oracle.ref_available() and os.environ.get("CAMPAIGN_ORACLE", "ref") == "ref"
@@ -45,7 +74,10 @@ def main():
                          qual_min=1, qual_max=60, n_groups=ng, class_af=classes, ref_n_frac=0.03)
         maf = res.min_af(n, float(rng.choice([0.01, 0.001])))
         eng = basevar_amd.BaseTypeEngine(sites, maf)
-        got = eng.lrt(slab)
+        if os.environ.get("CAMPAIGN_CHAIN") == "1" and ng == 0:
+            got = lrt_chained(eng, slab, rng)  # the same rows as 2-5 slabs through bv_engine_submit_many
+        else:
+            got = eng.lrt(slab)
         eng.close()
         exp, gexp = chk.run(slab, maf, n_threads=threads)
         # decision margins always come from the restatement (bit-identical to the reference)
