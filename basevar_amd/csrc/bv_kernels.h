@@ -92,6 +92,9 @@ struct BvPass2Args {
 // item: [0] = number of bins | state, [1..4] = the group's ACGT depths, [5] = bases with a phred-0 call, [8..] = its bins
 // (valid phreds only, (base, phred) order): code << 16 | count for BV_P2G_PENDING items, code << 23 | count for BV_P2G_HARD ones
 #define BV_P2G_ITEM_WORDS (8u + BV_SLOTS * BV_WAVE)
+// the 16-lane solver (bv_solver16.h) keeps a site's or a group's bins in the registers of its 16 lanes
+#define BV_G16_SLOTS 8                      /* bins per lane: 8 x 16 = 128 bins per site */
+#define BV_G16_MAX_BINS (16 * BV_G16_SLOTS)
 #define BV_P2G_PENDING 0x80000000u  /* for bv_p2g_solve16_kernel: four items per wave */
 #define BV_P2G_HARD 0x40000000u     /* for bv_p2g_hard_kernel: one wave per item (shallow group, phred-0 calls, > 128 bins, min_af <= 0) */
 #define BV_P2G_SHALLOW 0x20000000u  /* ... and its EMs replay the reference's per-sample order */
@@ -185,6 +188,7 @@ void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream);
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);
 void bv_launch_pass2(const BvPass2Args &a, hipStream_t stream);
 void bv_launch_p2g_solve16(const BvPass2Args &a, hipStream_t stream);
+void bv_launch_p2g_stream(const BvPass2Args &a, hipStream_t stream);
 bool bv_p2g_all_items(const BvPass2Args &a);
 bool bv_p2g_streams(const BvPass2Args &a);  // whether bv_launch_pass2 takes the LDS-DMA group tally (needs a.gidp)
 void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, uint32_t n_groups, hipStream_t stream);

@@ -35,21 +35,6 @@
 #define BV_S_SLOT_WORDS 512                  /* one slot of U = 1: 1 KiB of calls, then 1 KiB of phreds (U x that for U chunks per lane) */
 #define BV_S_SIMPLE_MAX_TABLES 32            /* a non-candidate site's strand table has at most this many Fisher tables */
 
-// ------------------------------------------------------------------------------ LDS-DMA
-// 64 lanes x 16 bytes from base + voff into LDS at lds_dst + lane * 16; counted on vmcnt like any load.
-__device__ __forceinline__ void bv_glds16(uint32_t lds_dst, const uint8_t *base, uint32_t voff) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(lds_dst), "s"(base)
-                 : "memory");
-}
-__device__ __forceinline__ const uint8_t *bv_uniform_ptr(const uint8_t *p) {
-    const uint64_t v = (uint64_t)(uintptr_t)p;
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
-    return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
-}
 
 // ------------------------------------------------------------------------------ streaming kernel
 template <int NW, int K, int U>

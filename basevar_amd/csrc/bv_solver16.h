@@ -19,8 +19,6 @@
 
 #include "bv_solver.h"
 
-#define BV_G16_SLOTS 8                      /* bins per lane: 8 x 16 = 128 bins per site */
-#define BV_G16_MAX_BINS (16 * BV_G16_SLOTS)
 
 // ------------------------------------------------------------------ row-local primitives
 #define BV_DPP_QUAD_XOR1 0xB1 /* quad_perm [1,0,3,2] */

@@ -99,3 +99,20 @@ __device__ __forceinline__ uint32_t bv_mask_tail_dword(uint32_t w, int keep) {
     return (w & low) | (0x08080808u & ~low);
 }
 
+// ------------------------------------------------------------------------------ LDS-DMA
+// 64 lanes x 16 bytes from base + voff into LDS at lds_dst + lane * 16 (M0 saved / restored); counted on vmcnt like any load,
+// invisible to the compiler's own wait insertion: the callers count their waits by hand.
+__device__ __forceinline__ void bv_glds16(uint32_t lds_dst, const uint8_t *base, uint32_t voff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(base)
+                 : "memory");
+}
+// a pointer the compiler knows to be wave-uniform (the "s" operand above)
+__device__ __forceinline__ const uint8_t *bv_uniform_ptr(const uint8_t *p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
