@@ -134,6 +134,77 @@ __device__ __forceinline__ void bv_p2_sweep(BvP2Ctx &cx, const BvPass2Args &a, u
     }
 }
 
+// ---- the perm form of the rank-sum tally (see bv_pass2_dma_kernel for the derivation): class byte J << 8 | mapq byte J, and
+// rank_hi << 16 | class byte J << 8 | rank_lo (rank H of the dword r2); "< 0x200" is the whole predicate, the value the word
+// of a [class][256] histogram
+template <int J>
+__device__ __forceinline__ uint32_t bv_p2d_xm(uint32_t cls4, uint32_t mq4) {  // class byte J << 8 | mapq byte J
+    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
+    return __builtin_amdgcn_perm(cls4, mq4, SEL);
+}
+template <int J, int H>
+__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // rank_hi << 16 | class byte J << 8 | rank_lo (rank H of r2)
+    constexpr uint32_t SEL = 0x0C000000u | ((uint32_t)(2 * H + 1) << 16) | ((4u + J) << 8) | (uint32_t)(2 * H);
+    return __builtin_amdgcn_perm(cls4, r2, SEL);
+}
+
+// One sweep over the row in that form, by the whole workgroup into its shared mapq / rank histograms ([2][256] each; `hr` uses the
+// first 512 words of the 1024-rank window).  Returns this thread's OR of the high rank bytes: non-zero somewhere in the
+// workgroup = a rank >= 256 in the row, the caller re-does the row with the window sweeps (bv_p2_sweep).  L: class table
+// (byte b = 0x80 REF / 0x81 ALT / 0xFF neither).  ~6 VALU + 2 predicated ds_add per cell; the branchy sweep takes ~18 VALU.
+template <int NT>
+__device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr) {
+    const size_t row = (size_t)site * a.pitch;
+    const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
+    const bv_u32x4 *m4 = reinterpret_cast<const bv_u32x4 *>(a.mapq + row);
+    const bv_u32x4 *r4 = reinterpret_cast<const bv_u32x4 *>(a.rpr + row);
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4;
+    const int tail = (int)(a.n_samples & 15u);
+    const bv_u32x4 zero = bv_u32x4{0u, 0u, 0u, 0u}, none = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+    uint32_t hi_acc = 0;
+    constexpr int U = 2;
+    for (uint32_t base = 0; base < n_chunks; base += NT * U) {
+        bv_u32x4 vb[U], vm[U], vr0[U], vr1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t idx = base + u * NT + tid;
+            vb[u] = none; vm[u] = vr0[u] = vr1[u] = zero;
+            if (idx < n_chunks) {
+                vb[u] = __builtin_nontemporal_load(b4 + idx);
+                vm[u] = __builtin_nontemporal_load(m4 + idx);
+                vr0[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx);
+                vr1[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx + 1);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t idx = base + u * NT + tid;
+            if (tail && idx == n_chunks - 1) {
+                vb[u].x = bv_p2_mask_tail(vb[u].x, tail); vb[u].y = bv_p2_mask_tail(vb[u].y, tail - 4);
+                vb[u].z = bv_p2_mask_tail(vb[u].z, tail - 8); vb[u].w = bv_p2_mask_tail(vb[u].w, tail - 12);
+            }
+            const bv_u32x4 r0 = vr0[u], r1 = vr1[u], vmq = vm[u];
+            const uint32_t c0 = __builtin_amdgcn_perm(L, L, vb[u].x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, vb[u].y) ^ 0x80808080u;
+            const uint32_t c2 = __builtin_amdgcn_perm(L, L, vb[u].z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, vb[u].w) ^ 0x80808080u;
+            hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & 0xFF00FF00u;
+            uint32_t x[16];
+            x[0] = bv_p2d_xm<0>(c0, vmq.x); x[1] = bv_p2d_xm<1>(c0, vmq.x); x[2] = bv_p2d_xm<2>(c0, vmq.x); x[3] = bv_p2d_xm<3>(c0, vmq.x);
+            x[4] = bv_p2d_xm<0>(c1, vmq.y); x[5] = bv_p2d_xm<1>(c1, vmq.y); x[6] = bv_p2d_xm<2>(c1, vmq.y); x[7] = bv_p2d_xm<3>(c1, vmq.y);
+            x[8] = bv_p2d_xm<0>(c2, vmq.z); x[9] = bv_p2d_xm<1>(c2, vmq.z); x[10] = bv_p2d_xm<2>(c2, vmq.z); x[11] = bv_p2d_xm<3>(c2, vmq.z);
+            x[12] = bv_p2d_xm<0>(c3, vmq.w); x[13] = bv_p2d_xm<1>(c3, vmq.w); x[14] = bv_p2d_xm<2>(c3, vmq.w); x[15] = bv_p2d_xm<3>(c3, vmq.w);
+            bv_lds_add16<2>(x, hm, one, 0x200u);
+            x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
+            x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
+            x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
+            x[12] = bv_p2d_xr<0, 0>(c3, r1.z); x[13] = bv_p2d_xr<1, 1>(c3, r1.z); x[14] = bv_p2d_xr<2, 0>(c3, r1.w); x[15] = bv_p2d_xr<3, 1>(c3, r1.w);
+            bv_lds_add16<2>(x, hr, one, 0x200u);
+        }
+    }
+    return hi_acc;
+}
+
 template <int NT, bool RANKS, bool GROUPS, bool INLINE = true>
 __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     constexpr int NW = NT / BV_WAVE;
@@ -167,14 +238,16 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         const int n_alt = res->n_alt;
         uint32_t depth[4] = {res->depth[0], res->depth[1], res->depth[2], res->depth[3]};
         uint32_t lut = 0xAAu;  // every base "neither"
+        uint32_t Ltab = 0xFFFFFFFFu;  // the same as a byte table for the perm form: 0x80 REF, 0x81 ALT, 0xFF neither
         unsigned long long n1 = 0, n2 = 0;
-        if (ref < 4) { lut &= ~(3u << (2 * ref)); n1 = bv_sel4u(depth, ref); }
+        if (ref < 4) { lut &= ~(3u << (2 * ref)); Ltab = (Ltab & ~(0xFFu << (8 * ref))) | (0x80u << (8 * ref)); n1 = bv_sel4u(depth, ref); }
         int comb = ref, nc = 1;  // caller.cpp:750-753: [toupper(REF)] + alts, 3 bits per entry
 #pragma unroll
         for (int k = 0; k < BV_MAX_ALT; ++k) {
             if (k < n_alt) {
                 const int b = res->alt[k] & 3;
                 lut = (lut & ~(3u << (2 * b))) | (1u << (2 * b));
+                Ltab = (Ltab & ~(0xFFu << (8 * b))) | (0x81u << (8 * b));
                 n2 += bv_sel4u(depth, b);
                 comb |= b << (3 * nc);
                 ++nc;
@@ -194,16 +267,41 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         BvP2Ctx cx;
         cx.hm = sh.hm; cx.hr = sh.hr; cx.hg = hg;
         cx.lut = lut; cx.win_lo = 0; cx.n_groups = a.n_groups; cx.maxr = 0;
-        bv_p2_sweep<NT, RANKS, RANKS, GROUPS>(cx, a, site, tid);
-        if (RANKS) {
-            uint32_t mx = (uint32_t)bv_wave_max_i32((int)cx.maxr);
-            if (lane == 0) sh.maxr[wave] = mx;
+        // Rank sums without pop-groups: the perm form first (a third of the instructions; 256-rank window).  A row that holds a
+        // rank >= 256 (long reads) is re-done by the window sweeps below.
+        constexpr bool FAST = RANKS && !GROUPS;
+        bool fast_ok = false;
+        if (FAST) {
+            const uint32_t hi = bv_p2_fast_sweep<NT>(a, site, tid, Ltab, sh.hm, sh.hr);
+            const bool any_hi = __ballot(hi != 0u) != 0ull;
+            if (lane == 0) sh.maxr[wave] = any_hi ? 1u : 0u;
+            __syncthreads();
+            uint32_t slow = 0;
+            for (int w = 0; w < NW; ++w) slow |= sh.maxr[w];
+            fast_ok = slow == 0u;
+            __syncthreads();
+            if (!fast_ok) {
+                uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
+                for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
+                __syncthreads();
+            }
         }
-        __syncthreads();
+        if (!fast_ok) {
+            bv_p2_sweep<NT, RANKS, RANKS, GROUPS>(cx, a, site, tid);
+            if (RANKS) {
+                uint32_t mx = (uint32_t)bv_wave_max_i32((int)cx.maxr);
+                if (lane == 0) sh.maxr[wave] = mx;
+            }
+            __syncthreads();
+        }
 
         if (RANKS) {
-            uint32_t maxr = 0;
-            for (int w = 0; w < NW; ++w) maxr = max(maxr, sh.maxr[w]);
+            uint32_t maxr = 255u;  // the perm form: one window of 256 ranks, ALT counts at word 256
+            const uint32_t alt_off = fast_ok ? 256u : (uint32_t)BV_RPR_WIN;
+            if (!fast_ok) {
+                maxr = 0;
+                for (int w = 0; w < NW; ++w) maxr = max(maxr, sh.maxr[w]);
+            }
             // MQRankSum on wave 0
             if (wave == 0) {
                 unsigned long long below = 0, twoR = 0;
@@ -220,7 +318,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     // ranks beyond the row's largest classified rank hold nothing: stop at its 64-wide block
                     const int nblk = (maxr < win_lo + BV_RPR_WIN) ? (int)((maxr - win_lo) >> 6) + 1 : BV_RPR_WIN / 64;
                     for (int w = 0; w < nblk; ++w)
-                        twoR += bv_ranksum_window(sh.hr[w * 64 + lane], sh.hr[BV_RPR_WIN + w * 64 + lane], n1 + n2,
+                        twoR += bv_ranksum_window(sh.hr[w * 64 + lane], sh.hr[alt_off + w * 64 + lane], n1 + n2,
                                                   below, lane);
                 }
                 if (maxr < win_lo + BV_RPR_WIN) break;
@@ -471,16 +569,6 @@ struct __attribute__((aligned(16))) BvPass2DmaShared {
     uint32_t h[BV_P2D_WAVES][4 * 256];                         // per wave: hm[2][256] then hr[2][256]
     uint32_t ring[BV_P2D_WAVES][BV_P2D_K][BV_P2D_SLOT_WORDS];
 };
-template <int J>
-__device__ __forceinline__ uint32_t bv_p2d_xm(uint32_t cls4, uint32_t mq4) {  // class byte J << 8 | mapq byte J
-    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
-    return __builtin_amdgcn_perm(cls4, mq4, SEL);
-}
-template <int J, int H>
-__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // rank_hi << 16 | class byte J << 8 | rank_lo (rank H of r2)
-    constexpr uint32_t SEL = 0x0C000000u | ((uint32_t)(2 * H + 1) << 16) | ((4u + J) << 8) | (uint32_t)(2 * H);
-    return __builtin_amdgcn_perm(cls4, r2, SEL);
-}
 
 __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvPass2Args a) {
     __shared__ BvPass2DmaShared sh;
