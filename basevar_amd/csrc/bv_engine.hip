@@ -604,10 +604,9 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             e->d_gidp_bytes = n16;
         }
         a2.gidp = e->d_gidp;
-        if (bv_p2g_streams(a2)) {
-            bv_launch_gid_prepare(gid, e->d_gidp, (uint32_t)n16, n_groups, st);
-            BV_HIP(e, hipGetLastError());
-        }
+        // the group plane as the perm-form tallies read it (short rows: bv_p2g_stream_kernel; long rows: bv_p2_fast_sweep)
+        bv_launch_gid_prepare(gid, e->d_gidp, (uint32_t)n16, n_groups, st);
+        BV_HIP(e, hipGetLastError());
     }
     bv_launch_pass2(a2, st);
     BV_HIP(e, hipGetLastError());

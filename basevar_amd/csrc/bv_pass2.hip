@@ -149,15 +149,19 @@ __device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // 
 }
 
 // One sweep over the row in that form, by the whole workgroup into its shared mapq / rank histograms ([2][256] each; `hr` uses the
-// first 512 words of the 1024-rank window).  Returns this thread's OR of the high rank bytes: non-zero somewhere in the
-// workgroup = a rank >= 256 in the row, the caller re-does the row with the window sweeps (bv_p2_sweep).  L: class table
-// (byte b = 0x80 REF / 0x81 ALT / 0xFF neither).  ~6 VALU + 2 predicated ds_add per cell; the branchy sweep takes ~18 VALU.
-template <int NT>
-__device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr) {
+// first 512 words of the 1024-rank window) and, with GROUPS, into the per-group (base, phred) histograms `hg`.  Returns this
+// thread's OR of what does not fit the form: non-zero somewhere in the workgroup = a rank >= 256 (or a call byte > 15 / a
+// phred byte > 127) in the row, the caller re-does the row with the branchy window sweeps (bv_p2_sweep).  L: class table
+// (byte b = 0x80 REF / 0x81 ALT / 0xFF neither).  ~6 VALU + 2 predicated ds_add per cell for the rank sums, ~4 + 1 for the
+// groups; the branchy sweep takes ~18 VALU for the rank sums alone.
+template <int NT, bool RANKS, bool GROUPS>
+__device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr, uint32_t *hg) {
     const size_t row = (size_t)site * a.pitch;
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
-    const bv_u32x4 *m4 = reinterpret_cast<const bv_u32x4 *>(a.mapq + row);
-    const bv_u32x4 *r4 = reinterpret_cast<const bv_u32x4 *>(a.rpr + row);
+    const bv_u32x4 *m4 = RANKS ? reinterpret_cast<const bv_u32x4 *>(a.mapq + row) : nullptr;
+    const bv_u32x4 *r4 = RANKS ? reinterpret_cast<const bv_u32x4 *>(a.rpr + row) : nullptr;
+    const bv_u32x4 *q4 = GROUPS ? reinterpret_cast<const bv_u32x4 *>(a.q + row) : nullptr;
+    const bv_u32x4 *g4 = GROUPS ? reinterpret_cast<const bv_u32x4 *>(a.gidp) : nullptr;  // g << 2, or 0x80: no group
     const uint32_t n_chunks = (a.n_samples + 15u) >> 4;
     const int tail = (int)(a.n_samples & 15u);
     const bv_u32x4 zero = bv_u32x4{0u, 0u, 0u, 0u}, none = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
@@ -166,16 +170,22 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
     uint32_t hi_acc = 0;
     constexpr int U = 2;
     for (uint32_t base = 0; base < n_chunks; base += NT * U) {
-        bv_u32x4 vb[U], vm[U], vr0[U], vr1[U];
+        bv_u32x4 vb[U], vm[U], vr0[U], vr1[U], vq[U], vg[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t idx = base + u * NT + tid;
-            vb[u] = none; vm[u] = vr0[u] = vr1[u] = zero;
+            vb[u] = none; vm[u] = vr0[u] = vr1[u] = vq[u] = vg[u] = zero;
             if (idx < n_chunks) {
                 vb[u] = __builtin_nontemporal_load(b4 + idx);
-                vm[u] = __builtin_nontemporal_load(m4 + idx);
-                vr0[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx);
-                vr1[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx + 1);
+                if (RANKS) {
+                    vm[u] = __builtin_nontemporal_load(m4 + idx);
+                    vr0[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx);
+                    vr1[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx + 1);
+                }
+                if (GROUPS) {
+                    vq[u] = __builtin_nontemporal_load(q4 + idx);
+                    vg[u] = g4[idx];  // shared by every row: cacheable
+                }
             }
         }
 #pragma unroll
@@ -185,21 +195,38 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
                 vb[u].x = bv_p2_mask_tail(vb[u].x, tail); vb[u].y = bv_p2_mask_tail(vb[u].y, tail - 4);
                 vb[u].z = bv_p2_mask_tail(vb[u].z, tail - 8); vb[u].w = bv_p2_mask_tail(vb[u].w, tail - 12);
             }
-            const bv_u32x4 r0 = vr0[u], r1 = vr1[u], vmq = vm[u];
-            const uint32_t c0 = __builtin_amdgcn_perm(L, L, vb[u].x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, vb[u].y) ^ 0x80808080u;
-            const uint32_t c2 = __builtin_amdgcn_perm(L, L, vb[u].z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, vb[u].w) ^ 0x80808080u;
-            hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & 0xFF00FF00u;
             uint32_t x[16];
-            x[0] = bv_p2d_xm<0>(c0, vmq.x); x[1] = bv_p2d_xm<1>(c0, vmq.x); x[2] = bv_p2d_xm<2>(c0, vmq.x); x[3] = bv_p2d_xm<3>(c0, vmq.x);
-            x[4] = bv_p2d_xm<0>(c1, vmq.y); x[5] = bv_p2d_xm<1>(c1, vmq.y); x[6] = bv_p2d_xm<2>(c1, vmq.y); x[7] = bv_p2d_xm<3>(c1, vmq.y);
-            x[8] = bv_p2d_xm<0>(c2, vmq.z); x[9] = bv_p2d_xm<1>(c2, vmq.z); x[10] = bv_p2d_xm<2>(c2, vmq.z); x[11] = bv_p2d_xm<3>(c2, vmq.z);
-            x[12] = bv_p2d_xm<0>(c3, vmq.w); x[13] = bv_p2d_xm<1>(c3, vmq.w); x[14] = bv_p2d_xm<2>(c3, vmq.w); x[15] = bv_p2d_xm<3>(c3, vmq.w);
-            bv_lds_add16<2>(x, hm, one, 0x200u);
-            x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
-            x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
-            x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
-            x[12] = bv_p2d_xr<0, 0>(c3, r1.z); x[13] = bv_p2d_xr<1, 1>(c3, r1.z); x[14] = bv_p2d_xr<2, 0>(c3, r1.w); x[15] = bv_p2d_xr<3, 1>(c3, r1.w);
-            bv_lds_add16<2>(x, hr, one, 0x200u);
+            if (RANKS) {
+                const bv_u32x4 r0 = vr0[u], r1 = vr1[u], vmq = vm[u];
+                const uint32_t c0 = __builtin_amdgcn_perm(L, L, vb[u].x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, vb[u].y) ^ 0x80808080u;
+                const uint32_t c2 = __builtin_amdgcn_perm(L, L, vb[u].z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, vb[u].w) ^ 0x80808080u;
+                hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & 0xFF00FF00u;
+                x[0] = bv_p2d_xm<0>(c0, vmq.x); x[1] = bv_p2d_xm<1>(c0, vmq.x); x[2] = bv_p2d_xm<2>(c0, vmq.x); x[3] = bv_p2d_xm<3>(c0, vmq.x);
+                x[4] = bv_p2d_xm<0>(c1, vmq.y); x[5] = bv_p2d_xm<1>(c1, vmq.y); x[6] = bv_p2d_xm<2>(c1, vmq.y); x[7] = bv_p2d_xm<3>(c1, vmq.y);
+                x[8] = bv_p2d_xm<0>(c2, vmq.z); x[9] = bv_p2d_xm<1>(c2, vmq.z); x[10] = bv_p2d_xm<2>(c2, vmq.z); x[11] = bv_p2d_xm<3>(c2, vmq.z);
+                x[12] = bv_p2d_xm<0>(c3, vmq.w); x[13] = bv_p2d_xm<1>(c3, vmq.w); x[14] = bv_p2d_xm<2>(c3, vmq.w); x[15] = bv_p2d_xm<3>(c3, vmq.w);
+                bv_lds_add16<2>(x, hm, one, 0x200u);
+                x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
+                x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
+                x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
+                x[12] = bv_p2d_xr<0, 0>(c3, r1.z); x[13] = bv_p2d_xr<1, 1>(c3, r1.z); x[14] = bv_p2d_xr<2, 0>(c3, r1.w); x[15] = bv_p2d_xr<3, 1>(c3, r1.w);
+                bv_lds_add16<2>(x, hr, one, 0x200u);
+            }
+            if (GROUPS) {
+                // the group tally of bv_p2g_stream_kernel: byte = group << 2 | base, bit 7 for "no call" / "no group"; X = byte << 8 |
+                // phred << 1 is twice the word index of hg[group][base][128].  Call bytes above 15 and phred bytes above 127 do not
+                // fit the packed index: reported like a long read, the row is then re-done by the branchy sweep
+                bv_u32x4 q2 = vq[u];
+                hi_acc |= ((vb[u].x | vb[u].y | vb[u].z | vb[u].w) & 0xF0F0F0F0u) | ((q2.x | q2.y | q2.z | q2.w) & 0x80808080u);
+                const uint32_t y0 = (((vb[u].x & 0x08080808u) << 4) | (vb[u].x & 0x03030303u)) | vg[u].x, y1 = (((vb[u].y & 0x08080808u) << 4) | (vb[u].y & 0x03030303u)) | vg[u].y;
+                const uint32_t y2 = (((vb[u].z & 0x08080808u) << 4) | (vb[u].z & 0x03030303u)) | vg[u].z, y3 = (((vb[u].w & 0x08080808u) << 4) | (vb[u].w & 0x03030303u)) | vg[u].w;
+                q2.x = (q2.x & 0x7F7F7F7Fu) << 1; q2.y = (q2.y & 0x7F7F7F7Fu) << 1; q2.z = (q2.z & 0x7F7F7F7Fu) << 1; q2.w = (q2.w & 0x7F7F7F7Fu) << 1;
+                x[0] = bv_cell_index<0>(y0, q2.x); x[1] = bv_cell_index<1>(y0, q2.x); x[2] = bv_cell_index<2>(y0, q2.x); x[3] = bv_cell_index<3>(y0, q2.x);
+                x[4] = bv_cell_index<0>(y1, q2.y); x[5] = bv_cell_index<1>(y1, q2.y); x[6] = bv_cell_index<2>(y1, q2.y); x[7] = bv_cell_index<3>(y1, q2.y);
+                x[8] = bv_cell_index<0>(y2, q2.z); x[9] = bv_cell_index<1>(y2, q2.z); x[10] = bv_cell_index<2>(y2, q2.z); x[11] = bv_cell_index<3>(y2, q2.z);
+                x[12] = bv_cell_index<0>(y3, q2.w); x[13] = bv_cell_index<1>(y3, q2.w); x[14] = bv_cell_index<2>(y3, q2.w); x[15] = bv_cell_index<3>(y3, q2.w);
+                bv_lds_add16<1>(x, hg, one, 0x8000u);
+            }
         }
     }
     return hi_acc;
@@ -269,10 +296,10 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         cx.lut = lut; cx.win_lo = 0; cx.n_groups = a.n_groups; cx.maxr = 0;
         // Rank sums without pop-groups: the perm form first (a third of the instructions; 256-rank window).  A row that holds a
         // rank >= 256 (long reads) is re-done by the window sweeps below.
-        constexpr bool FAST = RANKS && !GROUPS;
+        const bool FAST = !GROUPS || a.gidp != nullptr;
         bool fast_ok = false;
         if (FAST) {
-            const uint32_t hi = bv_p2_fast_sweep<NT>(a, site, tid, Ltab, sh.hm, sh.hr);
+            const uint32_t hi = bv_p2_fast_sweep<NT, RANKS, GROUPS>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
             const bool any_hi = __ballot(hi != 0u) != 0ull;
             if (lane == 0) sh.maxr[wave] = any_hi ? 1u : 0u;
             __syncthreads();
@@ -283,6 +310,8 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
             if (!fast_ok) {
                 uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
                 for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
+                if (GROUPS)
+                    for (uint32_t i = tid; i < a.n_groups * 512u; i += NT) hg[i] = 0u;
                 __syncthreads();
             }
         }
