@@ -807,3 +807,36 @@ def test_group_calls_inside_the_tally_kernel(bv, restatement, n):
     exp, gexp, margins = oracle_run(restatement, slab, maf)
     check(got, exp, gexp, margins)
     assert got.n_variant > 10
+
+
+@pytest.mark.parametrize("n", [60000, 5000], ids=["long_rows", "short_rows"])
+def test_chained_submit_without_rank_planes_and_error_paths(bv, n):
+    """bv_engine_submit_many with no mapq / rpr planes (no pass 2 at all), the size check, and slabs of different row length
+    (submitted one by one)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    maf = bv.min_af(n)
+    rec = bv.SITE_DTYPE.itemsize
+    slabs = [make_slab(s, n, seed=900 + k, coverage=0.1, class_af=[(0.0, 0.0), (0.3, 0.0)]) for k, s in enumerate([40, 25, 60])]
+    eng = bv.BaseTypeEngine(max_sites=125, min_af_value=maf, device=0)
+    keep, segs, outs = [], [], []
+    for sl in slabs:
+        t = [torch.from_numpy(np.ascontiguousarray(sl[k])).to(dev) for k in ("base_strand", "qual", "ref_base")]
+        out = torch.zeros(sl["n_sites"] * rec, dtype=torch.uint8, device=dev)
+        keep.append(t); outs.append(out)
+        segs.append((sl["n_sites"], t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr(), 0, 0))
+    torch.cuda.synchronize()
+    eng.submit_many_ptrs(n, slabs[0]["pitch"], segs)
+    eng.wait()
+    for sl, o in zip(slabs, outs):
+        s2 = dict(sl); s2.pop("mapq"); s2.pop("rpr")
+        one = run_engine(bv, s2, maf).sites
+        got = o.cpu().numpy().view(bv.SITE_DTYPE)
+        assert one.tobytes() == got.tobytes()
+        assert np.isnan(got["mq_ranksum"]).all()
+    eng.close()
+    # together more sites than the engine was created for
+    small = bv.BaseTypeEngine(max_sites=100, min_af_value=maf, device=0)
+    with pytest.raises(RuntimeError, match="exceed cfg.max_sites"):
+        small.submit_many_ptrs(n, slabs[0]["pitch"], segs)
+    small.close()
