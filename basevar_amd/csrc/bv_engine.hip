@@ -39,7 +39,11 @@ struct HostLogFind {
 };
 
 int host_log_phdr_cb(struct dl_phdr_info *info, size_t, void *user) {
-    if (!info->dlpi_name || !std::strstr(info->dlpi_name, "libm")) return 0;
+    // the C math library only: file name "libm.so*" or "libm-<version>.so" (not libmagma, libmpi, ...)
+    if (!info->dlpi_name) return 0;
+    const char *slash = std::strrchr(info->dlpi_name, '/');
+    const char *fname = slash ? slash + 1 : info->dlpi_name;
+    if (std::strncmp(fname, "libm.so", 7) != 0 && std::strncmp(fname, "libm-", 5) != 0) return 0;
     const double ln2hi = 0x1.62e42fefa3800p-1, ln2lo = 0x1.ef35793c76730p-45;  // the table opens with ln 2, split
     const size_t need = sizeof(double) * BV_HOSTLOG_N;
     for (int i = 0; i < info->dlpi_phnum; ++i) {
@@ -110,7 +114,17 @@ double host_log_restated(double x, const double *T) {
 }
 
 // fills dst[0..BV_HOSTLOG_N) + the "usable" flag behind it; true when the host's log() is reproduced exactly
+bool load_host_log_table_once(double *dst);
+// (searched and verified once per process: every engine gets a copy of the result)
 bool load_host_log_table(double *dst) {
+    static std::once_flag once;
+    static double cached[BV_HOSTLOG_N + 2];
+    static bool ok = false;
+    std::call_once(once, [] { ok = load_host_log_table_once(cached); });
+    std::memcpy(dst, cached, sizeof(cached));
+    return ok;
+}
+bool load_host_log_table_once(double *dst) {
     std::memset(dst, 0, sizeof(double) * (BV_HOSTLOG_N + 2));
     HostLogFind find{nullptr};
     dl_iterate_phdr(host_log_phdr_cb, &find);
