@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -174,8 +175,17 @@ struct bv_engine {
     BvTables *d_tables = nullptr;
     double *d_lnfact = nullptr;
     uint32_t *d_var_list = nullptr;
-    uint32_t *d_counters = nullptr;    // BV_CTR_* words (bv_kernels.h)
+    // Counter blocks (BV_CTR_* words each, bv_kernels.h): a launch that is cut into chunks (short rows, launch_passes)
+    // gives every chunk a block of its own; everything else uses block 0.
+    static constexpr uint32_t kCtrBlocks = 8;
+    uint32_t *d_counters = nullptr;    // [kCtrBlocks][BV_CTR_WORDS]
     uint32_t *h_counters = nullptr;    // pinned host mirror
+    uint32_t last_blocks = 1;          // blocks the last launch used (their VARIANTS words add up to its variant count)
+    // Short rows: the solve kernels of pass 1 read no planes (issue-bound) while the streaming kernels leave the VALU idle, so
+    // a large batch runs as a software pipeline of chunks over two streams -- the caller's (streaming kernels, pass 2) and
+    // this one (solve kernels): solve(c) runs under stream(c + 1), pass2(c) under solve(c + 1).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_s[kCtrBlocks] = {}, ev_v[kCtrBlocks] = {};  // per chunk: streaming kernel done / solve kernels done
     static constexpr int kRing = 256;
     hipEvent_t ring[kRing][4] = {};    // per-submit events: start, end of pass 1, end of pass 2, [3] end of the streaming kernel of pass 1
     int ring_head = 0, ring_count = 0; // pending (not yet accumulated) triplets
@@ -444,10 +454,20 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         for (auto &ev : tri) BV_TRY(hipEventCreate(&ev));
     BV_TRY(hipMalloc(&e->d_tables, sizeof(BvTables)));
     BV_TRY(hipMalloc(&e->d_var_list, sizeof(uint32_t) * (size_t)cfg->max_sites));
-    BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS));
-    BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * BV_CTR_WORDS));
-    std::memset(e->h_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS);
-    BV_TRY(hipMemset(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS));
+    BV_TRY(hipMalloc(&e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks));
+    BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks));
+    std::memset(e->h_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks);
+    BV_TRY(hipMemset(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks));
+    {
+        // the second stream carries short kernels that must get in beside long streaming kernels: highest queue priority
+        int least = 0, greatest = 0;
+        BV_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char *pr = std::getenv("BASEVAR_AMD_AUX_PRIO");  // tuning: 0 = default priority
+        if (pr && pr[0] == '0') BV_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+        else BV_TRY(hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, greatest));
+    }
+    for (auto &ev : e->ev_s) BV_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (auto &ev : e->ev_v) BV_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     // eps table with the host libm, exactly the reference's expression (basetype.cpp:47-48, :63)
     BvTables t;
@@ -490,6 +510,10 @@ int bv_engine_destroy(bv_engine *e) {
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipStream_t st : e->used_streams) (void)hipStreamSynchronize(st);
+    if (e->aux) (void)hipStreamSynchronize(e->aux);
+    for (auto &ev : e->ev_s) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->ev_v) if (ev) (void)hipEventDestroy(ev);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     for (auto &tri : e->ring)
         for (auto &ev : tri)
             if (ev) (void)hipEventDestroy(ev);
@@ -528,18 +552,22 @@ int bv_engine_destroy(bv_engine *e) {
 }
 
 // The two passes over device-resident planes + the copies back (records to a host caller, counters).
+//
+// Short rows (bv_pass1_short.hip) run as a software pipeline.  Their pass 1 is a streaming kernel (HBM-bound, VALU half
+// idle) followed by solve kernels that read no planes (issue-bound, HBM idle), and pass 2 streams again: back to back on one
+// stream each of them leaves half the chip unused.  A batch is therefore cut into H chunks of consecutive sites, each with
+// its own slice of the scratch, of the variant list and its own counter block, and the chunks go through two streams:
+//     st :  stream(0) stream(1) ... stream(H-1)  pass2(0)      pass2(1) ...       pass2(H-1)
+//     aux:            solve(0)  ...              solve(H-2)    solve(H-1)
+// with events stream(c) -> solve(c) -> pass2(c).  Which chunk a site falls into has no influence on its record (every site is
+// solved from its own row), so the records are those of the unsplit launch byte for byte.  Reference analogue: none -- its
+// workers take one position at a time (basetype_caller.cpp:738-762).
 static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
                          bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */) {
     const size_t S = n_sites, G = n_groups;
-    BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));  // not the sticky error counters
     if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
 
-    BvPass1Args a1;
-    a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
-    a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
-    a1.var_list = e->d_var_list; a1.counters = e->d_counters; a1.n_cu = e->n_cu;
-    a1.ch = chain;
     if (e->ring_count == bv_engine::kRing) {
         int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
         if (rc != BV_OK) return rc;
@@ -555,59 +583,36 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     const bool two_kernel = (shape == 0 && n_samples <= BV_SHORT_ROW_MAX) || shape == 10;
     if (two_kernel && n_samples > 65535u)
         return fail(e, BV_ERR_INVALID_ARG, "the two-kernel short-row pass 1 holds bin counts in 16 bits: n_samples <= 65535");
-    BV_HIP(e, hipEventRecord(ev[0], st));
-    if (two_kernel) {
-        if (n_sites > e->short_sites) {
-            // scratch between the kernels, grown to the largest short-row submit seen: 48 B + 2 KiB + 8 B per site
-            if (e->d_summ) BV_HIP(e, hipFree(e->d_summ));
-            if (e->d_bins) BV_HIP(e, hipFree(e->d_bins));
-            if (e->d_cand_list) BV_HIP(e, hipFree(e->d_cand_list));
-            if (e->d_easy_list) BV_HIP(e, hipFree(e->d_easy_list));
-            if (e->d_easy3_list) BV_HIP(e, hipFree(e->d_easy3_list));
-            e->d_summ = nullptr; e->d_bins = nullptr; e->d_cand_list = nullptr; e->d_easy_list = nullptr; e->d_easy3_list = nullptr; e->short_sites = 0;
-            BV_HIP(e, hipMalloc(&e->d_summ, sizeof(BvSiteSummary) * (size_t)n_sites));
-            BV_HIP(e, hipMalloc(&e->d_bins, sizeof(uint32_t) * BV_S_BIN_STRIDE * (size_t)n_sites));
-            BV_HIP(e, hipMalloc(&e->d_cand_list, sizeof(uint32_t) * (size_t)n_sites));
-            BV_HIP(e, hipMalloc(&e->d_easy_list, sizeof(uint32_t) * (size_t)n_sites));
-            BV_HIP(e, hipMalloc(&e->d_easy3_list, sizeof(uint32_t) * (size_t)n_sites));
-            e->short_sites = n_sites;
-        }
-        BvP1ShortArgs s1;
-        s1.bs = bs; s1.q = q; s1.ref_base = refb; s1.pitch = P; s1.n_sites = n_sites; s1.n_samples = n_samples;
-        s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout;
-        s1.var_list = e->d_var_list; s1.counters = e->d_counters; s1.summ = e->d_summ; s1.bins = e->d_bins;
-        s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list; s1.easy3_list = e->d_easy3_list;
-        s1.ch = chain;
-        bv_launch_p1s_stream(s1, st);
-        BV_HIP(e, hipGetLastError());
-        BV_HIP(e, hipEventRecord(ev[3], st));
-        bv_launch_p1s_solve(s1, st);
-        BV_HIP(e, hipGetLastError());
-    } else {
-        bv_launch_pass1(a1, st);
-        BV_HIP(e, hipGetLastError());
-        BV_HIP(e, hipEventRecord(ev[3], st));
-    }
-    BV_HIP(e, hipEventRecord(ev[1], st));
 
+    // ---- pass-2 arguments common to every chunk; scratch of the pop-group calls
     BvPass2Args a2;
     a2.bs = bs; a2.q = q; a2.mapq = mq; a2.rpr = rp; a2.ref_base = refb; a2.group_id = gid; a2.pitch = P;
     a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
-    a2.ch = a1.ch;
+    a2.ch = chain;
+    bool gitems_all = true;  // the item scratch holds every (site, group) of this launch
     if (G && gid && dgout && !(e->cfg.flags & BV_FLAG_GROUP_INLINE)) {
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
-        // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel
+        // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel.  An allocation that
+        // fails is retried at half the size (the inline path takes what the scratch cannot).
         const uint64_t want64 = (uint64_t)S * G, most = (8192ull << 20) / (sizeof(uint32_t) * BV_P2G_ITEM_WORDS);
-        const uint32_t want = (uint32_t)(want64 < most ? want64 : most);
+        uint32_t want = (uint32_t)(want64 < most ? want64 : most);
         if (want > e->gitem_cap) {
             if (e->d_gitems) BV_HIP(e, hipFree(e->d_gitems));
             e->d_gitems = nullptr; e->gitem_cap = 0;
-            BV_HIP(e, hipMalloc(&e->d_gitems, sizeof(uint32_t) * BV_P2G_ITEM_WORDS * (size_t)want));
-            e->gitem_cap = want;
+            while (want >= 1024u) {
+                if (hipMalloc(&e->d_gitems, sizeof(uint32_t) * BV_P2G_ITEM_WORDS * (size_t)want) == hipSuccess) {
+                    e->gitem_cap = want;
+                    break;
+                }
+                (void)hipGetLastError();
+                e->d_gitems = nullptr;
+                want /= 2u;
+            }
         }
+        gitems_all = (uint64_t)e->gitem_cap >= want64;
         a2.gitems = e->d_gitems; a2.gitem_cap = e->gitem_cap;
         // short rows: the group plane as the streaming group tally wants it
         const size_t n16 = ((size_t)n_samples + 15) & ~(size_t)15;
@@ -622,13 +627,102 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         bv_launch_gid_prepare(gid, e->d_gidp, (uint32_t)n16, n_groups, st);
         BV_HIP(e, hipGetLastError());
     }
-    bv_launch_pass2(a2, st);
-    BV_HIP(e, hipGetLastError());
-    bv_launch_p2g_solve16(a2, st);
-    BV_HIP(e, hipGetLastError());
+
+    // ---- chunks of the pipeline (1: the plain sequence on `st`)
+    uint32_t H = 1;
+    if (two_kernel && chain == nullptr && gitems_all) {
+        const uint32_t forced = (e->cfg.flags >> 24) & 0xFu;  // BV_FLAG_SPLIT(n)
+        // default: no pipeline.  Measured (round 3, 10 k samples): beside a streaming kernel the solve kernels get one
+        // workgroup per CU (LDS) and run 3 x longer, while the streaming kernel itself slows by 50-70 % -- both are bound by
+        // what a CU can issue, not by HBM, so the overlap loses (100 k sites: 0.66 ms unsplit, 0.76 with 2 chunks, 0.79 with 4)
+        H = forced ? forced : 1u;
+        if (H > bv_engine::kCtrBlocks) H = bv_engine::kCtrBlocks;
+        while (H > 1u && n_sites / H < 256u) --H;
+    }
+    e->last_blocks = H;
+    for (uint32_t c = 0; c < H; ++c)  // the per-launch lines of every block used (not the sticky error counters)
+        BV_HIP(e, hipMemsetAsync(e->d_counters + (size_t)c * BV_CTR_WORDS, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));
+    auto chunk_lo = [&](uint32_t c) -> uint32_t {  // multiples of 64 sites
+        return c >= H ? n_sites : (uint32_t)(((uint64_t)n_sites * c / H) & ~(uint64_t)63);
+    };
+
+    BV_HIP(e, hipEventRecord(ev[0], st));
+    if (two_kernel) {
+        if (n_sites > e->short_sites) {
+            // scratch between the kernels, grown to the largest short-row submit seen: 48 B + 2 KiB + 12 B per site
+            if (e->d_summ) BV_HIP(e, hipFree(e->d_summ));
+            if (e->d_bins) BV_HIP(e, hipFree(e->d_bins));
+            if (e->d_cand_list) BV_HIP(e, hipFree(e->d_cand_list));
+            if (e->d_easy_list) BV_HIP(e, hipFree(e->d_easy_list));
+            if (e->d_easy3_list) BV_HIP(e, hipFree(e->d_easy3_list));
+            e->d_summ = nullptr; e->d_bins = nullptr; e->d_cand_list = nullptr; e->d_easy_list = nullptr; e->d_easy3_list = nullptr; e->short_sites = 0;
+            BV_HIP(e, hipMalloc(&e->d_summ, sizeof(BvSiteSummary) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_bins, sizeof(uint32_t) * BV_S_BIN_STRIDE * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_cand_list, sizeof(uint32_t) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_easy_list, sizeof(uint32_t) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_easy3_list, sizeof(uint32_t) * (size_t)n_sites));
+            e->short_sites = n_sites;
+        }
+        for (uint32_t c = 0; c < H; ++c) {
+            const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
+            BvP1ShortArgs s1;
+            s1.bs = bs + (size_t)c0 * P; s1.q = q + (size_t)c0 * P; s1.ref_base = refb + c0; s1.pitch = P; s1.n_sites = nc; s1.n_samples = n_samples;
+            s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout + c0;
+            s1.var_list = e->d_var_list + c0; s1.counters = e->d_counters + (size_t)c * BV_CTR_WORDS;
+            s1.summ = e->d_summ + c0; s1.bins = e->d_bins + (size_t)c0 * BV_S_BIN_STRIDE;
+            s1.cand_list = e->d_cand_list + c0; s1.easy_list = e->d_easy_list + c0; s1.easy3_list = e->d_easy3_list + c0;
+            s1.ch = chain;
+            bv_launch_p1s_stream(s1, st);
+            BV_HIP(e, hipGetLastError());
+            if (H > 1u) {
+                BV_HIP(e, hipEventRecord(e->ev_s[c], st));
+                BV_HIP(e, hipStreamWaitEvent(e->aux, e->ev_s[c], 0));
+                bv_launch_p1s_solve(s1, e->aux, true);
+                BV_HIP(e, hipGetLastError());
+                BV_HIP(e, hipEventRecord(e->ev_v[c], e->aux));
+            } else {
+                BV_HIP(e, hipEventRecord(ev[3], st));
+                bv_launch_p1s_solve(s1, st);
+                BV_HIP(e, hipGetLastError());
+            }
+        }
+        if (H > 1u) {
+            BV_HIP(e, hipEventRecord(ev[3], st));      // the last streaming kernel
+            BV_HIP(e, hipEventRecord(ev[1], e->aux));  // the last solve kernel: end of pass 1
+        } else {
+            BV_HIP(e, hipEventRecord(ev[1], st));
+        }
+    } else {
+        BvPass1Args a1;
+        a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
+        a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
+        a1.var_list = e->d_var_list; a1.counters = e->d_counters; a1.n_cu = e->n_cu;
+        a1.ch = chain;
+        bv_launch_pass1(a1, st);
+        BV_HIP(e, hipGetLastError());
+        BV_HIP(e, hipEventRecord(ev[3], st));
+        BV_HIP(e, hipEventRecord(ev[1], st));
+    }
+
+    for (uint32_t c = 0; c < H; ++c) {
+        const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
+        BvPass2Args ac = a2;
+        if (H > 1u) {
+            BV_HIP(e, hipStreamWaitEvent(st, e->ev_v[c], 0));
+            ac.bs = bs + (size_t)c0 * P; ac.q = q + (size_t)c0 * P;
+            ac.mapq = mq ? mq + (size_t)c0 * P : nullptr; ac.rpr = rp ? rp + (size_t)c0 * P : nullptr;
+            ac.ref_base = refb + c0; ac.n_sites = nc; ac.out = dout + c0; ac.gout = dgout ? dgout + (size_t)c0 * G : nullptr;
+            ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)c * BV_CTR_WORDS;
+            if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * G * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * G); }
+        }
+        bv_launch_pass2(ac, st);
+        BV_HIP(e, hipGetLastError());
+        bv_launch_p2g_solve16(ac, st);
+        BV_HIP(e, hipGetLastError());
+    }
     BV_HIP(e, hipEventRecord(ev[2], st));
 
-    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS, hipMemcpyDeviceToHost, st));
+    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks, hipMemcpyDeviceToHost, st));
     if (e->host_out) {
         BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
         if (e->host_gout && e->host_gout_bytes)
@@ -1004,7 +1098,8 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     f.out = dout; f.gout = dgout; f.var_list = e->d_var_list; f.counters = e->d_counters;
     bv_launch_tile_finish(f, st);
     BV_HIP(e, hipGetLastError());
-    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS, hipMemcpyDeviceToHost, st));
+    e->last_blocks = 1;
+    BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks, hipMemcpyDeviceToHost, st));
     if (e->host_out) {
         BV_HIP(e, hipMemcpyAsync(e->host_out, e->stage_out, e->host_out_bytes, hipMemcpyDeviceToHost, st));
         if (e->host_gout && e->host_gout_bytes)
@@ -1031,13 +1126,19 @@ int bv_engine_wait(bv_engine *e) {
     for (hipStream_t st : e->used_streams) BV_HIP(e, hipStreamSynchronize(st));
     e->used_streams.clear();
     e->used_streams.push_back(e->last_stream);
-    const uint32_t timed_out = e->h_counters[BV_CTR_TIMEOUT], zero_freq = e->h_counters[BV_CTR_ZEROFREQ];
+    uint32_t timed_out = 0, zero_freq = 0;
+    for (uint32_t b = 0; b < bv_engine::kCtrBlocks; ++b) {
+        timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
+        zero_freq += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ];
+    }
     if (timed_out != 0 || zero_freq != 0) {
         // the error counters are sticky on the device (they accumulate over submits): reported once, then cleared
-        BV_HIP(e, hipMemsetAsync(e->d_counters + BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, 0,
-                                 sizeof(uint32_t) * (BV_CTR_WORDS - BV_CTR_PER_LAUNCH * BV_CTR_STRIDE), e->last_stream));
+        for (uint32_t b = 0; b < bv_engine::kCtrBlocks; ++b) {
+            BV_HIP(e, hipMemsetAsync(e->d_counters + (size_t)b * BV_CTR_WORDS + BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, 0,
+                                     sizeof(uint32_t) * (BV_CTR_WORDS - BV_CTR_PER_LAUNCH * BV_CTR_STRIDE), e->last_stream));
+            e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT] = e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ] = 0;
+        }
         BV_HIP(e, hipStreamSynchronize(e->last_stream));
-        e->h_counters[BV_CTR_TIMEOUT] = e->h_counters[BV_CTR_ZEROFREQ] = 0;
     }
     if (timed_out != 0)
         return fail(e, BV_ERR_HIP, "pass 1: an intra-workgroup hand-off timed out (internal error; results invalid)");
@@ -1135,7 +1236,9 @@ int bv_engine_host_log_eval(bv_engine *e, const double *x, double *y, uint32_t n
 
 int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant) {
     if (!e || !n_variant) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_last_variant_count: null argument");
-    *n_variant = e->h_counters[BV_CTR_VARIANTS];
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < e->last_blocks; ++b) n += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_VARIANTS];
+    *n_variant = n;
     return BV_OK;
 }
 

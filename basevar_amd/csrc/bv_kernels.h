@@ -95,6 +95,9 @@ struct BvPass2Args {
 // the 16-lane solver (bv_solver16.h) keeps a site's or a group's bins in the registers of its 16 lanes
 #define BV_G16_SLOTS 8                      /* bins per lane: 8 x 16 = 128 bins per site */
 #define BV_G16_MAX_BINS (16 * BV_G16_SLOTS)
+// LDS scratch of one group: the EM's previous marginals [BV_G16_SLOTS][16] doubles (256 words; later the rank sum's counts and
+// the staged record), padded so that the four groups of a wave fall on different halves of the LDS banks
+#define BV_G16_GRP_WORDS 288
 #define BV_P2G_PENDING 0x80000000u  /* for bv_p2g_solve16_kernel: four items per wave */
 #define BV_P2G_HARD 0x40000000u     /* for bv_p2g_hard_kernel: one wave per item (shallow group, phred-0 calls, > 128 bins, min_af <= 0) */
 #define BV_P2G_SHALLOW 0x20000000u  /* ... and its EMs replay the reference's per-sample order */
@@ -133,7 +136,7 @@ struct BvP1ShortArgs {
 void bv_launch_chain_gather_ref(const BvChain *ch, uint32_t n_sites, uint8_t *ref_cat, hipStream_t stream);
 void bv_launch_chain_scatter_out(const BvChain *ch, uint32_t n_sites, const bv_site_result *out_cat, hipStream_t stream);
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream);
-void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream);
+void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside_stream = false);
 
 // sample-axis tile mode (bv_tiles.hip)
 struct BvTileArgs {

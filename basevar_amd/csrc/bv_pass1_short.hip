@@ -86,6 +86,9 @@ __device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint
 template <int NW, int K, int U, bool CHAIN = false>
 __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sStreamShared<NW, K, U> sh;
+#ifdef BV_STREAM_PRIO
+    __builtin_amdgcn_s_setprio(BV_STREAM_PRIO);  // beside the solve kernels of the previous chunk: the stream goes first
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *hist = sh.hist[wave];
@@ -375,8 +378,64 @@ __device__ inline double bv_fisher_two_sided_lane(int n11, int n12, int n21, int
     return two;
 }
 
-// ------------------------------------------------------------------------------ solve kernel
-#define BV_P1S_SOLVE_NW 4
+// ------------------------------------------------------------------------------ solve kernels
+// A non-candidate site (hom-ref or uncovered), finished by ONE LANE: depths, flags, one small Fisher test.
+__device__ __forceinline__ void bv_p1s_simple_site(const BvP1ShortArgs &a, const BvLnTab &lnfact, uint32_t site) {
+    const double qnan = __builtin_nan("");
+    const uint4 *sp = reinterpret_cast<const uint4 *>(&a.summ[site]);
+    const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
+    if (s2.y & BV_SUM_CAND) return;
+    const uint32_t fwd[4] = {s0.x, s0.y, s0.z, s0.w}, rev[4] = {s1.x, s1.y, s1.z, s1.w};
+    bv_site_result r;
+    {
+        uint32_t *w = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(r) / 4); ++i) w[i] = 0u;
+    }
+    uint32_t total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { r.depth[b] = fwd[b] + rev[b]; total += r.depth[b]; }
+    r.total_depth = total;
+    if (a.flags & BV_FLAG_TALLY_ONLY) {
+        // diagnostic: depths only
+    } else if (total == 0) {
+        r.mq_ranksum = r.rpr_ranksum = r.bq_ranksum = qnan;  // caller.cpp:718 / basetype.cpp:132
+    } else {
+        int ref = a.ref_base[site];
+        if (ref > 4) ref = 4;
+        uint32_t flags = BV_SITE_COVERED | ((s2.y & BV_SUM_BADQ) ? BV_SITE_BAD_QUAL : 0u);
+        uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;  // caller.cpp:1236-1245
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b == ref) { c_rf += fwd[b]; c_rr += rev[b]; } else { c_af += fwd[b]; c_ar += rev[b]; }
+        }
+        if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
+            // strand_bias tail, src/basetype.cpp:277-286 (see bv_strand_bias_wave for the SOR overflow note)
+            double fs = -10 * log10(bv_fisher_two_sided_lane((int)c_rf, (int)c_rr, (int)c_af, (int)c_ar, lnfact));
+            if (isinf(fs)) fs = 10000;
+            else if (fs == 0) fs = 0.0;
+            const int den = (int)(c_rr * c_af), num = (int)(c_rf * c_ar);
+            if ((unsigned long long)c_rr * c_af > 0x7fffffffull || (unsigned long long)c_rf * c_ar > 0x7fffffffull)
+                flags |= BV_SITE_SOR_OVERFLOW;
+            r.cvg_fs = fs;
+            r.cvg_sor = (c_rr != 0u && c_af != 0u) ? (double)num / (double)den : 10000;
+            r.cvg_sb[0] = c_rf; r.cvg_sb[1] = c_rr; r.cvg_sb[2] = c_af; r.cvg_sb[3] = c_ar;
+        }
+        r.status = flags;
+        // lrt() with one active base, the reference base: no ALT, chi2 0, one EM run of one iteration (bv_lrt)
+        const bool lrt_ran = !(a.flags & BV_FLAG_SKIP_LRT);
+        r.em_iters = lrt_ran ? 1 : 0;
+        r.n_em = lrt_ran ? 1 : 0;
+        r.mq_ranksum = r.rpr_ranksum = r.bq_ranksum = qnan;
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(&a.out[site]);
+    const uint4 *src = reinterpret_cast<const uint4 *>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(r) / 16); ++i) dst[i] = src[i];
+}
+
+// Candidates that need the wave solver (shallow sites, phred-0 calls, > 128 bins, min_af <= 0): one wave per site.
+#define BV_P1S_SOLVE_NW 2
 #define BV_P1S_RAW_WORDS (2 * BV_SLOTS * BV_WAVE + 4 * 128)  /* 1280 words of per-wave scratch */
 struct __attribute__((aligned(16))) BvP1sSolveShared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
@@ -388,6 +447,9 @@ struct __attribute__((aligned(16))) BvP1sSolveShared {
 __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolveShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // most batches have few such candidates, or none: a workgroup that gets none leaves at once (the kernel runs on the
+    // engine's second stream, beside a streaming kernel that keeps the memory system busy)
+    if (blockIdx.x * BV_P1S_SOLVE_NW >= a.counters[BV_CTR_CANDS]) return;
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
@@ -399,66 +461,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
-
-    // ---- (a) non-candidate sites, one lane per site
     const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;
-    const double qnan = __builtin_nan("");
-    for (uint32_t blk = gw; (uint64_t)blk * 64u < a.n_sites; blk += n_waves) {
-        const uint32_t site = blk * 64u + (uint32_t)lane;
-        if (site >= a.n_sites) continue;
-        const uint4 *sp = reinterpret_cast<const uint4 *>(&a.summ[site]);
-        const uint4 s0 = sp[0], s1 = sp[1], s2 = sp[2];
-        if (s2.y & BV_SUM_CAND) continue;
-        const uint32_t fwd[4] = {s0.x, s0.y, s0.z, s0.w}, rev[4] = {s1.x, s1.y, s1.z, s1.w};
-        bv_site_result r;
-        {
-            uint32_t *w = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(r) / 4); ++i) w[i] = 0u;
-        }
-        uint32_t total = 0;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { r.depth[b] = fwd[b] + rev[b]; total += r.depth[b]; }
-        r.total_depth = total;
-        if (a.flags & BV_FLAG_TALLY_ONLY) {
-            // diagnostic: depths only
-        } else if (total == 0) {
-            r.mq_ranksum = r.rpr_ranksum = r.bq_ranksum = qnan;  // caller.cpp:718 / basetype.cpp:132
-        } else {
-            int ref = a.ref_base[site];
-            if (ref > 4) ref = 4;
-            uint32_t flags = BV_SITE_COVERED | ((s2.y & BV_SUM_BADQ) ? BV_SITE_BAD_QUAL : 0u);
-            uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;  // caller.cpp:1236-1245
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                if (b == ref) { c_rf += fwd[b]; c_rr += rev[b]; } else { c_af += fwd[b]; c_ar += rev[b]; }
-            }
-            if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
-                // strand_bias tail, src/basetype.cpp:277-286 (see bv_strand_bias_wave for the SOR overflow note)
-                double fs = -10 * log10(bv_fisher_two_sided_lane((int)c_rf, (int)c_rr, (int)c_af, (int)c_ar, sa.lnfact));
-                if (isinf(fs)) fs = 10000;
-                else if (fs == 0) fs = 0.0;
-                const int den = (int)(c_rr * c_af), num = (int)(c_rf * c_ar);
-                if ((unsigned long long)c_rr * c_af > 0x7fffffffull || (unsigned long long)c_rf * c_ar > 0x7fffffffull)
-                    flags |= BV_SITE_SOR_OVERFLOW;
-                r.cvg_fs = fs;
-                r.cvg_sor = (c_rr != 0u && c_af != 0u) ? (double)num / (double)den : 10000;
-                r.cvg_sb[0] = c_rf; r.cvg_sb[1] = c_rr; r.cvg_sb[2] = c_af; r.cvg_sb[3] = c_ar;
-            }
-            r.status = flags;
-            // lrt() with one active base, the reference base: no ALT, chi2 0, one EM run of one iteration (bv_lrt)
-            const bool lrt_ran = !(a.flags & BV_FLAG_SKIP_LRT);
-            r.em_iters = lrt_ran ? 1 : 0;
-            r.n_em = lrt_ran ? 1 : 0;
-            r.mq_ranksum = r.rpr_ranksum = r.bq_ranksum = qnan;
-        }
-        uint4 *dst = reinterpret_cast<uint4 *>(&a.out[site]);
-        const uint4 *src = reinterpret_cast<const uint4 *>(&r);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(r) / 16); ++i) dst[i] = src[i];
-    }
 
-    // ---- (b) candidates, one wave per site
     const uint32_t n_cand = a.counters[BV_CTR_CANDS];
     uint32_t *bin_code = sh.raw[wave], *bin_cnt = sh.raw[wave] + BV_SLOTS * BV_WAVE, *hq = sh.raw[wave] + 2 * BV_SLOTS * BV_WAVE;
     BvSolverScratch *sv = &sh.sc[wave];
@@ -521,22 +525,24 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
 
 }
 
-// ---- candidates, four per wave: one site per group of 16 lanes (bv_solver16.h).  A kernel of its own: its register
-// budget (and with it the waves per SIMD) is then not set by the other two phases.
-struct __attribute__((aligned(16))) BvP1sSolve16Shared {
+// ---- non-candidates one per lane, then the ordinary candidates four per wave: one site per group of 16 lanes
+// (bv_solver16.h).  21 KB of LDS per workgroup: one of them fits a CU beside two workgroups of the streaming kernel, which is
+// where this kernel runs when a batch is pipelined in chunks (bv_engine.hip, launch_passes).
+#ifndef BV_P1S_SOLVE16_NW
+#define BV_P1S_SOLVE16_NW 4
+#endif
+struct __attribute__((aligned(16))) BvP1sSolve16Shared {   // 21 KB: one workgroup fits beside two of the streaming kernel's
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    uint32_t cls[BV_P1S_SOLVE_NW][4][2 * 128];          // per group: REF / ALT counts per phred
-    uint32_t vl[BV_P1S_SOLVE_NW][64];                   // the wave's variant sites since the last flush
-    bv_site_result res16[BV_P1S_SOLVE_NW][4];           // one staged record per group
-    double pm16[BV_P1S_SOLVE_NW][BV_G16_SLOTS * BV_WAVE];  // previous marginals, [slot][lane]
+    uint32_t grp[BV_P1S_SOLVE16_NW][4][BV_G16_GRP_WORDS];  // per group: the solver's scratch (bv_site_solve_g16)
+    uint32_t vl[BV_P1S_SOLVE16_NW][64];                    // the wave's variant sites since the last flush
 };
 #ifndef BV_P1S_SOLVE16_OCC
 #define BV_P1S_SOLVE16_OCC 3
 #endif
-__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
+__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolve16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE_NW) {
+    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE16_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
     }
@@ -547,9 +553,15 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
-    const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;
+    const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE16_NW, gw = blockIdx.x * BV_P1S_SOLVE16_NW + (uint32_t)wave;
+    // ---- every non-candidate site first, one lane per site (blocks of 64 sites dealt round-robin to the waves)
+    for (uint32_t blk = gw; (uint64_t)blk * 64u < a.n_sites; blk += n_waves) {
+        const uint32_t site = blk * 64u + (uint32_t)lane;
+        if (site < a.n_sites) bv_p1s_simple_site(a, sa.lnfact, site);
+    }
+    // ---- the candidates of the 16-lane solver, four per wave
     const int grp = lane >> 4, gl = lane & 15;
-    uint32_t *cls = sh.cls[wave][grp], *vl = sh.vl[wave];
+    uint32_t *scratch = sh.grp[wave][grp], *vl = sh.vl[wave];
     uint32_t n_vl = 0;  // variant sites in vl[]
     auto flush_vl = [&]() {
         uint32_t base = 0;
@@ -579,14 +591,14 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, BV_P1S_SOLVE16_OCC) void 
             S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
             BvG16Bins B;
             B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sa.loghit; B.logmiss = sa.logmiss;
-            B.pm = sh.pm16[wave] + lane;
+            B.pm = reinterpret_cast<double *>(scratch) + gl;
             const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
 #pragma unroll
             for (int s = 0; s < BV_G16_SLOTS; ++s) {
                 const uint32_t i = (uint32_t)(s * 16 + gl);
                 B.w[s] = i < sm.nb ? src[i] : 0u;
             }
-            variant = bv_site_solve_g16(sa, site, S, B, cls, &sh.res16[wave][grp], lane);
+            variant = bv_site_solve_g16(sa, site, S, B, scratch, lane);
         }
         // the wave's variant sites of this round, in group order
         const unsigned long long vm = __ballot(variant && gl == 0);
@@ -646,17 +658,20 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     // slots; 4 slots of 2 KiB or 8 of 1 KiB need 82 KB of LDS per workgroup -- one workgroup per CU, 0.43 of peak)
     bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);
 }
-void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream) {
+// `beside_stream`: the kernels will run beside a streaming kernel (the next chunk's pass 1 or an earlier chunk's pass 2) whose
+// two workgroups per CU leave 28-32 KB of LDS: grids of ONE workgroup per CU then -- with more, whatever starts in the
+// gap between two streaming kernels takes the LDS of a streaming workgroup for its whole (persistent) life.
+void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside_stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;
-    uint32_t grid = cu * 3u;  // 3 waves per SIMD (168 VGPRs)
+    const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
+    uint32_t grid = beside_stream ? cu : cu * 3u * (4u / BV_P1S_SOLVE_NW);  // 3 waves per SIMD (168 VGPRs)
     const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
     if (grid > need) grid = need > 0 ? need : 1;
-    const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
     if (cap && grid > cap) grid = cap;
     hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
-    uint32_t grid16 = cu * (uint32_t)BV_P1S_SOLVE16_OCC;
-    const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE_NW - 1) / (4 * BV_P1S_SOLVE_NW);  // four sites per wave
+    uint32_t grid16 = beside_stream ? cu : cu * (uint32_t)BV_P1S_SOLVE16_OCC * (4u / BV_P1S_SOLVE16_NW);
+    const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE16_NW - 1) / (4 * BV_P1S_SOLVE16_NW);  // four sites per wave
     if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
     if (cap && grid16 > cap) grid16 = cap;
-    hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
+    hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
 }

@@ -601,6 +601,9 @@ struct __attribute__((aligned(16))) BvPass2DmaShared {
 
 __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvPass2Args a) {
     __shared__ BvPass2DmaShared sh;
+#ifdef BV_STREAM_PRIO
+    __builtin_amdgcn_s_setprio(BV_STREAM_PRIO);
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *h = sh.h[wave];

@@ -311,7 +311,7 @@ void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, 
 #endif
 struct __attribute__((aligned(16))) BvP2gShared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    double pm16[BV_P2G_NW][BV_G16_SLOTS * BV_WAVE];  // previous marginals, [slot][lane]
+    uint32_t grp[BV_P2G_NW][4][BV_G16_GRP_WORDS];  // per group of 16 lanes: previous marginals, [slot][lane of the group]
 };
 __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16_kernel(BvPass2Args a) {
     __shared__ BvP2gShared sh;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         const uint32_t gtotal = gdepth[0] + gdepth[1] + gdepth[2] + gdepth[3];
         BvG16Bins B;
         B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss;
-        B.pm = sh.pm16[wave] + lane;
+        B.pm = reinterpret_cast<double *>(sh.grp[wave][grp]) + gl;
 #pragma unroll
         for (int s = 0; s < BV_G16_SLOTS; ++s) {
             const uint32_t i = (uint32_t)(s * 16 + gl);

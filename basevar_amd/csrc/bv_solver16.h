@@ -137,7 +137,7 @@ __device__ inline double bv_fisher_two_sided_g16(int n11, int n12, int n21, int 
     const double lo = 0.99999999 * q, hi = 1.00000001 * q;
     const int INF = 0x7fffffff;
     int wl = imin, wr = imax;
-    if (R > 4 * 16) {
+    if (R > 8 * 16) {
         // many tables: skip the far tails whose terms are below q * 2^-86 (16-point probes on either side)
         const double cut = logq - 60.0;
         {
@@ -155,30 +155,35 @@ __device__ inline double bv_fisher_two_sided_g16(int n11, int n12, int n21, int 
             if (first != INF) wr = first;
         }
     }
-    // rounds of 16 tables, ascending over [wl, wr]; only the first table comes from log-factorials, the others by the
-    // multiplicative step as prefix products across the group's lanes (see bv_fisher_two_sided_wave)
-    double tail = 0., pL = 0., pR = 0.;
+    // The tables of [wl, wr] in 16 consecutive blocks, one per lane: the lane seeds its first table from log-factorials and
+    // walks its block with the multiplicative step of the reference's own walk (hypergeo_acc, kfunc.c:226-231) -- at most
+    // ~25 steps from an exact seed (the reference re-seeds every 11).  Per table: one division and a few multiplies on ONE
+    // lane, against a 16-lane prefix product, two broadcasts and a ballot per 16 tables in the round form this replaces
+    // (the Fisher tests were 45 % of the solver's instructions).
+    const int Lb = (wr - wl + 16) >> 4;  // tables per lane
+    const int i0 = wl + gl * Lb;
+    const int i1 = min(i0 + Lb - 1, wr);
+    const bool mine = i0 <= wr;
+    double p = mine ? bv_hyper_p(h, i0) : 0.;
+    double tail = 0., pfirst = 0., plast = 0.;
     bool seen = false;
-    double pbase = bv_hyper_p(h, wl);
-    for (int w = wl; w <= wr; w += 16) {
-        const int i = w + gl;
-        const bool have = i <= wr;
-        const double step = (gl == 0 || !have) ? 1.0 : bv_hyper_ratio(h, i - 1);
-        const double pe = pbase * bv_g16_incl_scan_prod_f64(step);
-        pbase = bv_g16_bcast_f64(pe, 15, lane) * bv_hyper_ratio(h, w + 15);
-        const double p = have ? pe : 0.;
-        const bool viol = have && !(p < lo);
-        tail += viol ? 0. : p;
-        const uint32_t vm = bv_g16_ballot(viol, lane);
-        if (vm != 0u) {
-            if (!seen) pL = bv_g16_bcast_f64(p, __builtin_ctz(vm), lane);
-            seen = true;
-            pR = bv_g16_bcast_f64(p, 31 - __builtin_clz(vm), lane);
-        }
+    for (int t = 0; t < Lb; ++t) {
+        const int i = i0 + t;
+        const bool in = mine && i <= i1;
+        const bool viol = in && !(p < lo);
+        tail += (in && !viol) ? p : 0.;
+        if (viol && !seen) pfirst = p;
+        if (viol) { plast = p; seen = true; }
+        p *= bv_hyper_ratio(h, i);
     }
+    const uint32_t vm = bv_g16_ballot(seen, lane);  // never empty: the observed table lies inside [wl, wr]
     double two = bv_g16_sum(tail);
-    if (pL < hi) two += pL;
-    if (pR < hi) two += pR;
+    const double pL = bv_g16_bcast_f64(pfirst, __builtin_ctz(vm | 0x10000u), lane);
+    const double pR = bv_g16_bcast_f64(plast, 31 - __builtin_clz(vm | 1u), lane);
+    if (vm != 0u) {
+        if (pL < hi) two += pL;
+        if (pR < hi) two += pR;
+    }
     return two > 1. ? 1. : two;
 }
 
@@ -202,8 +207,8 @@ struct BvG16Bins {
     uint32_t w[BV_G16_SLOTS];
     const double *hit, *miss;        // LDS tables
     const double *loghit, *logmiss;  // device memory
-    double *pm;                      // LDS: this LANE's previous marginals, pm[s * 64] for slot s (kept out of the registers:
-                                     // the solver is occupancy-bound, 16 VGPRs buy a third wave per SIMD)
+    double *pm;                      // LDS: this LANE's previous marginals, pm[s * 16] for slot s, inside its GROUP's scratch
+                                     // (BV_G16_GRP_WORDS; kept out of the registers: the solver is occupancy-bound)
 };
 __device__ __forceinline__ bool bv_g16_bin(const BvG16Bins &B, int s, uint32_t &b, uint32_t &q, double &c) {
     const uint32_t w = B.w[s];
@@ -220,7 +225,7 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
     const double inv_n = 1.0 / n_cov;
     double *pm = B.pm;
 #pragma unroll
-    for (int s = 0; s < BV_G16_SLOTS; ++s) pm[s * BV_WAVE] = 1.0;
+    for (int s = 0; s < BV_G16_SLOTS; ++s) pm[s * 16] = 1.0;
     int iters = 0;
     for (int k = 0; k <= 100; ++k) {
         double pf0 = 0., pf1 = 0., pf2 = 0., pf3 = 0., delta = 0.;
@@ -236,9 +241,9 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
                 marg += L1; marg += L2; marg += L3;
                 const double r = c / marg;
                 pf0 += L0 * r; pf1 += L1 * r; pf2 += L2 * r; pf3 += L3 * r;
-                const double old = pm[s * BV_WAVE];
+                const double old = pm[s * 16];
                 if (k > 0 && !(marg < old * 2.7 && marg > old * 0.37)) delta += c * bv_int_abs_trunc(log(marg) - log(old));
-                pm[s * BV_WAVE] = marg;
+                pm[s * 16] = marg;
             }
         }
         pf0 = bv_g16_sum(pf0); pf1 = bv_g16_sum(pf1); pf2 = bv_g16_sum(pf2); pf3 = bv_g16_sum(pf3);
@@ -255,7 +260,7 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
     for (int s = 0; s < BV_G16_SLOTS; ++s) {
         uint32_t b, q;
         double c;
-        if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * BV_WAVE]);
+        if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * 16]);
     }
     *lr_out = bv_g16_sum(lr);
     return iters;
@@ -411,14 +416,17 @@ __device__ inline unsigned long long bv_ranksum_window_g16(uint32_t ref_v, uint3
 }
 
 // ------------------------------------------------------------------ one site on one group
-// `S`: the site's totals; B: its bins; cls: LDS scratch of 2 x 128 words for this group (REF / ALT counts per phred);
-// `res`: LDS staging of the record for this group.  Returns whether the site is a variant site.
-__device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const BvG16Bins &B, uint32_t *cls,
-                                         bv_site_result *res, int lane) {
+// `S`: the site's totals; B: its bins; `scratch`: the group's BV_G16_GRP_WORDS words of LDS, used one after the other as
+// the EM's previous marginals (B.pm points into it), as 2 x 128 REF / ALT counts per phred for the rank sum, and as the
+// staging of the record (the three never live at the same time; a wavefront fence separates them).  Returns whether the
+// site is a variant site.
+__device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const BvG16Bins &B, uint32_t *scratch,
+                                         int lane) {
     const int gl = lane & 15;
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
-    uint32_t *res_words = reinterpret_cast<uint32_t *>(res);
-    for (int i = gl; i < REC_WORDS; i += 16) res_words[i] = 0u;
+    uint32_t *cls = scratch;
+    bv_site_result *res = reinterpret_cast<bv_site_result *>(scratch);
+    uint32_t *res_words = scratch;
     uint32_t depth[4], total = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -479,6 +487,7 @@ __device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, co
         }
         // base-quality rank sum (caller.cpp:1157): REF / ALT counts per phred value, scattered from the bins
         {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the EM is done with the scratch
             for (int i = gl; i < 2 * 128; i += 16) cls[i] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
@@ -495,7 +504,11 @@ __device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, co
             const unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
             unsigned long long below = 0, twoR = 0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) twoR += bv_ranksum_window_g16(cls[w * 16 + gl], cls[128 + w * 16 + gl], n1 + n2, below);
+            for (int w = 0; w < 8; ++w) {
+                // (a window without a count adds nothing to the sum nor to `below`: skipped per group)
+                const uint32_t rv = cls[w * 16 + gl], av = cls[128 + w * 16 + gl];
+                if (bv_g16_ballot((rv | av) != 0u, lane) != 0u) twoR += bv_ranksum_window_g16(rv, av, n1 + n2, below);
+            }
             bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
         }
     }
@@ -506,6 +519,9 @@ __device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, co
         if (have_var && !same) bv_strand_bias_g16(v_rf, v_rr, v_af, v_ar, lane, a.lnfact, &v_fs, &v_sor, &flags);
         if (same) { v_fs = c_fs; v_sor = c_sor; }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rank sum is done with the scratch
+    for (int i = gl; i < REC_WORDS; i += 16) res_words[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (gl == 0) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) res->depth[b] = depth[b];

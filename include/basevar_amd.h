@@ -154,6 +154,10 @@ typedef struct bv_group_result {
                                      (the path taken when the item scratch cannot hold every (variant site, group)) */
 #define BV_FLAG_PASS2_SWEEP 0x20u /* diagnostic: short rows take the plain-load pass-2 kernels (not the LDS-DMA one) */
 #define BV_FLAG_WAVE_SOLVER 0x10u /* diagnostic: short-row candidates and pop-group calls all take the one-per-wave solver (none the 16-lane one) */
+#define BV_FLAG_SPLIT(n) (((uint32_t)(n) & 0xFu) << 24) /* tuning / tests: short-row batches (<= 49,152 samples) run as a software
+                                     pipeline of n chunks of consecutive sites over two streams (solve kernels of chunk c under the
+                                     streaming kernel of chunk c + 1); 0 = the engine's default (by batch size), 1 = no pipeline.
+                                     Records do not depend on n. */
 #define BV_FLAG_TILE_STATE 0x8u  /* tile mode: always accumulate per-site tallies (the fallback for jobs whose
                                     joined planes do not fit the HBM) instead of joining the tiles into rows */
 
