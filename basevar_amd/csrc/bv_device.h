@@ -421,8 +421,14 @@ __device__ __forceinline__ double bv_lnfact_series(int n) {
     return (x - 0.5) * log(x) - x + 0.91893853320467274178 + s;
 }
 __device__ __forceinline__ double bv_lnfact(const BvLnTab &T, int n) {
+#ifdef BV_LNFACT_TABLE_ONLY
+    // short-row kernels: a depth is at most 65,535 there and the engine's table never has fewer than 65,536 entries
+    // (bv_engine_create), so the series -- a log() and a select chain inlined at every one of ~60 call sites -- stays out
+    return T.t[n < T.n ? n : T.n - 1];
+#else
     if (n < T.n) return T.t[n];
     return bv_lnfact_series(n);
+#endif
 }
 
 // One 2x2 table family: margins fixed, n11 = i varies over [imin, imax].

@@ -15,10 +15,16 @@
 #define BV_CTR_CANDS (2u * BV_CTR_STRIDE)     /* short rows: candidates for the wave solver = length of cand_list */
 #define BV_CTR_EASY (3u * BV_CTR_STRIDE)      /* short rows: candidates for the 16-lane solver with <= 2 active bases = length of easy_list */
 #define BV_CTR_EASY3 (4u * BV_CTR_STRIDE)     /* short rows: the same with >= 3 active bases = length of easy3_list */
-#define BV_CTR_PER_LAUNCH 5u                  /* lines zeroed per launch                              */
-#define BV_CTR_ZEROFREQ (5u * BV_CTR_STRIDE)  /* sticky: sites with BV_SITE_ZERO_FREQ                 */
-#define BV_CTR_TIMEOUT (6u * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag                */
-#define BV_CTR_WORDS (7u * BV_CTR_STRIDE)
+// short rows: job tickets of the two kernels of the 16-lane solver, BV_TICKET_SLICES lines each -- workgroup w draws from
+// slice w % BV_TICKET_SLICES, which owns every BV_TICKET_SLICES-th job (one address serves ~88 M atomics/s; the slices are
+// on lines of their own)
+#define BV_TICKET_SLICES 8u
+#define BV_CTR_TICKET_A (5u * BV_CTR_STRIDE)
+#define BV_CTR_TICKET_B ((5u + BV_TICKET_SLICES) * BV_CTR_STRIDE)
+#define BV_CTR_PER_LAUNCH (5u + 2u * BV_TICKET_SLICES) /* lines zeroed per launch                     */
+#define BV_CTR_ZEROFREQ (BV_CTR_PER_LAUNCH * BV_CTR_STRIDE)         /* sticky: sites with BV_SITE_ZERO_FREQ       */
+#define BV_CTR_TIMEOUT ((BV_CTR_PER_LAUNCH + 1u) * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag      */
+#define BV_CTR_WORDS ((BV_CTR_PER_LAUNCH + 2u) * BV_CTR_STRIDE)
 
 // A queue of slabs (same row length, no pop-groups) solved by ONE launch of each pass -- bv_engine_submit_many: the
 // persistent grid of pass 1 draws its site tickets across the whole queue, so the solve of the last deep sites of one

@@ -23,6 +23,7 @@
 // kt_fisher_exact does (kfunc.c:291-307, incremental hypergeo_acc with its re-seeding every 11 tables).
 //
 // HBM-bound by design (2 B per cell, each byte read once); no MFMA (categorical tallies).
+#define BV_LNFACT_TABLE_ONLY 1  /* rows of at most 65,535 samples: see bv_lnfact */
 #include "bv_kernels.h"
 
 #include "bv_solver.h"
@@ -525,23 +526,72 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
 
 }
 
-// ---- non-candidates one per lane, then the ordinary candidates four per wave: one site per group of 16 lanes
-// (bv_solver16.h).  21 KB of LDS per workgroup: one of them fits a CU beside two workgroups of the streaming kernel, which is
-// where this kernel runs when a batch is pipelined in chunks (bv_engine.hip, launch_passes).
+// ---- every non-candidate site (hom-ref or uncovered), one lane per site.  A kernel of its own (as are the two phases of the
+// 16-lane solver below): each then runs out of a few KB of code -- as one kernel the three were 207 KB against an instruction
+// cache of 64 KB per pair of CUs.
+__global__ __launch_bounds__(256) void bv_p1s_simple_kernel(BvP1ShortArgs a) {
+    const uint32_t site = blockIdx.x * 256u + threadIdx.x;
+    if (site >= a.n_sites) return;
+    BvLnTab lnfact;
+    lnfact.t = a.tables->lnfact; lnfact.n = (int)a.tables->lnfact_n;
+    bv_p1s_simple_site(a, lnfact, site);
+}
+
+// ---- the ordinary candidates, four per wave: one site per group of 16 lanes (bv_solver16.h), in two kernels -- the LRT,
+// then everything that follows it.  Jobs (four sites of one list) are numbered with the sites of three or four active bases
+// first (several times the EM runs: longest jobs first).  Jobs and workgroups are dealt to BV_TICKET_SLICES slices (job j and
+// workgroup w belong to slice j, w mod BV_TICKET_SLICES); a wave's first job is its rank in the slice, every further one is
+// drawn from the slice's ticket counter when the wave gets there -- no draw at the start of the kernel, where all waves
+// would queue on one address (~88 M atomics/s: 35 us for 3072 waves), and eight addresses instead of one after that.
 #ifndef BV_P1S_SOLVE16_NW
 #define BV_P1S_SOLVE16_NW 4
 #endif
-struct __attribute__((aligned(16))) BvP1sSolve16Shared {   // 21 KB: one workgroup fits beside two of the streaming kernel's
+struct __attribute__((aligned(16))) BvP1sSolve16Shared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    uint32_t grp[BV_P1S_SOLVE16_NW][4][BV_G16_GRP_WORDS];  // per group: the solver's scratch (bv_site_solve_g16)
+    uint32_t grp[BV_P1S_SOLVE16_NW][4][BV_G16_GRP_WORDS];  // per group: the solver's scratch (bv_site_lrt_g16 / bv_site_tail_g16)
     uint32_t vl[BV_P1S_SOLVE16_NW][64];                    // the wave's variant sites since the last flush
 };
 #ifndef BV_P1S_SOLVE16_OCC
 #define BV_P1S_SOLVE16_OCC 3
 #endif
-__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
+struct BvP1sJob {
+    const uint32_t *list;
+    uint32_t idx;
+    bool active;
+};
+// the k-th job of this wave's slice; its next k
+struct BvP1sTickets {
+    uint32_t slice, n_slices, slice_waves, k;
+    uint32_t *ctr;
+    __device__ __forceinline__ void init(uint32_t *counters_base, uint32_t wave) {
+        n_slices = gridDim.x < BV_TICKET_SLICES ? gridDim.x : BV_TICKET_SLICES;  // (every slice needs a workgroup)
+        slice = blockIdx.x % n_slices;
+        const uint32_t slice_wgs = (gridDim.x - slice + n_slices - 1u) / n_slices;
+        slice_waves = slice_wgs * BV_P1S_SOLVE16_NW;
+        k = (blockIdx.x / n_slices) * BV_P1S_SOLVE16_NW + wave;
+        ctr = counters_base + slice * BV_CTR_STRIDE;
+    }
+    __device__ __forceinline__ uint32_t job() const { return slice + n_slices * k; }
+    __device__ __forceinline__ void next(int lane) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(ctr, 1u);
+        k = slice_waves + (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    }
+};
+__device__ __forceinline__ BvP1sJob bv_p1s_job(const BvP1ShortArgs &a, uint32_t job, uint32_t n_easy, uint32_t n_easy3, int grp) {
+    const uint32_t j3 = (n_easy3 + 3u) >> 2;
+    BvP1sJob j;
+    if (job < j3) { j.list = a.easy3_list; j.idx = job * 4u + (uint32_t)grp; j.active = j.idx < n_easy3; }
+    else { j.list = a.easy_list; j.idx = (job - j3) * 4u + (uint32_t)grp; j.active = j.idx < n_easy; }
+    return j;
+}
+
+__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_lrt16_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolve16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t n_easy = a.counters[BV_CTR_EASY], n_easy3 = a.counters[BV_CTR_EASY3];
+    const uint32_t n_jobs = ((n_easy + 3u) >> 2) + ((n_easy3 + 3u) >> 2);
+    if (blockIdx.x >= n_jobs) return;  // not even its first wave has a job
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE16_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
@@ -553,13 +603,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
-    const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE16_NW, gw = blockIdx.x * BV_P1S_SOLVE16_NW + (uint32_t)wave;
-    // ---- every non-candidate site first, one lane per site (blocks of 64 sites dealt round-robin to the waves)
-    for (uint32_t blk = gw; (uint64_t)blk * 64u < a.n_sites; blk += n_waves) {
-        const uint32_t site = blk * 64u + (uint32_t)lane;
-        if (site < a.n_sites) bv_p1s_simple_site(a, sa.lnfact, site);
-    }
-    // ---- the candidates of the 16-lane solver, four per wave
     const int grp = lane >> 4, gl = lane & 15;
     uint32_t *scratch = sh.grp[wave][grp], *vl = sh.vl[wave];
     uint32_t n_vl = 0;  // variant sites in vl[]
@@ -572,23 +615,18 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         bv_lrt_sync<0>();
         n_vl = 0;
     };
-    for (int pass = 0; pass < 2; ++pass) {  // first the sites with at most two active bases, then the others
-    const uint32_t n_easy = a.counters[pass ? BV_CTR_EASY3 : BV_CTR_EASY];
-    const uint32_t *list = pass ? a.easy3_list : a.easy_list;
-    // (the second list is dealt from the other end of the grid: the waves that got one round fewer of the first list go first)
-    for (uint32_t t = pass ? n_waves - 1u - gw : gw; (uint64_t)t * 4u < n_easy; t += n_waves) {
-        const uint32_t idx = t * 4u + (uint32_t)grp;
-        const bool active = idx < n_easy;
+    BvP1sTickets tk;
+    tk.init(a.counters + BV_CTR_TICKET_A, (uint32_t)wave);
+    for (; tk.job() < n_jobs; tk.next(lane)) {
+        const BvP1sJob jb = bv_p1s_job(a, tk.job(), n_easy, n_easy3, grp);
         bool variant = false;
         uint32_t site = 0;
-        if (active) {
-            site = list[idx];
+        if (jb.active) {
+            site = jb.list[jb.idx];
             const BvSiteSummary sm = a.summ[site];
-            BvSiteSums S;
+            uint32_t depth[4], total = 0;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
-            S.q0_mask = 0; S.nb = sm.nb;
-            S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
+            for (int b = 0; b < 4; ++b) { depth[b] = sm.fwd[b] + sm.rev[b]; total += depth[b]; }
             BvG16Bins B;
             B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sa.loghit; B.logmiss = sa.logmiss;
             B.pm = reinterpret_cast<double *>(scratch) + gl;
@@ -598,7 +636,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
                 const uint32_t i = (uint32_t)(s * 16 + gl);
                 B.w[s] = i < sm.nb ? src[i] : 0u;
             }
-            variant = bv_site_solve_g16(sa, site, S, B, scratch, lane);
+            variant = bv_site_lrt_g16(sa, site, depth, total, (sm.flags & BV_SUM_BADQ) ? 1u : 0u, B, scratch, lane);
         }
         // the wave's variant sites of this round, in group order
         const unsigned long long vm = __ballot(variant && gl == 0);
@@ -606,8 +644,47 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         n_vl += (uint32_t)__popcll(vm);
         if (n_vl > 60u) flush_vl();
     }
-    }
     if (n_vl) flush_vl();
+}
+
+#ifndef BV_P1S_TAIL16_OCC
+#define BV_P1S_TAIL16_OCC 4
+#endif
+__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_TAIL16_OCC) void bv_p1s_tail16_kernel(BvP1ShortArgs a) {
+    __shared__ BvP1sSolve16Shared sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t n_easy = a.counters[BV_CTR_EASY], n_easy3 = a.counters[BV_CTR_EASY3];
+    const uint32_t n_jobs = ((n_easy + 3u) >> 2) + ((n_easy3 + 3u) >> 2);
+    BvSolveArgs sa;
+    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
+    sa.min_af = a.min_af; sa.flags = a.flags;
+    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
+    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
+    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
+    const int grp = lane >> 4, gl = lane & 15;
+    uint32_t *scratch = sh.grp[wave][grp];
+    BvP1sTickets tk;
+    tk.init(a.counters + BV_CTR_TICKET_B, (uint32_t)wave);
+    for (; tk.job() < n_jobs; tk.next(lane)) {
+        const BvP1sJob jb = bv_p1s_job(a, tk.job(), n_easy, n_easy3, grp);
+        if (jb.active) {
+            const uint32_t site = jb.list[jb.idx];
+            const BvSiteSummary sm = a.summ[site];
+            BvSiteSums S;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
+            S.q0_mask = 0; S.nb = sm.nb;
+            S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
+            uint32_t w[BV_G16_SLOTS];
+            const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t i = (uint32_t)(s * 16 + gl);
+                w[s] = i < sm.nb ? src[i] : 0u;
+            }
+            bv_site_tail_g16(sa, site, S, w, scratch, lane);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------ chained launches (bv_engine_submit_many)
@@ -664,6 +741,7 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside_stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
+    hipLaunchKernelGGL(bv_p1s_simple_kernel, dim3((a.n_sites + 255u) / 256u), dim3(256), 0, stream, a);
     uint32_t grid = beside_stream ? cu : cu * 3u * (4u / BV_P1S_SOLVE_NW);  // 3 waves per SIMD (168 VGPRs)
     const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
     if (grid > need) grid = need > 0 ? need : 1;
@@ -673,5 +751,9 @@ void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside
     const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE16_NW - 1) / (4 * BV_P1S_SOLVE16_NW);  // four sites per wave
     if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
     if (cap && grid16 > cap) grid16 = cap;
-    hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
+    hipLaunchKernelGGL(bv_p1s_lrt16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
+    uint32_t gridt = beside_stream ? cu : cu * (uint32_t)BV_P1S_TAIL16_OCC * (4u / BV_P1S_SOLVE16_NW);
+    if (gridt > need16) gridt = need16 > 0 ? need16 : 1;
+    if (cap && gridt > cap) gridt = cap;
+    hipLaunchKernelGGL(bv_p1s_tail16_kernel, dim3(gridt), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
 }

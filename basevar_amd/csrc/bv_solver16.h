@@ -415,18 +415,70 @@ __device__ inline unsigned long long bv_ranksum_window_g16(uint32_t ref_v, uint3
     return s;
 }
 
-// ------------------------------------------------------------------ one site on one group
-// `S`: the site's totals; B: its bins; `scratch`: the group's BV_G16_GRP_WORDS words of LDS, used one after the other as
-// the EM's previous marginals (B.pm points into it), as 2 x 128 REF / ALT counts per phred for the rank sum, and as the
-// staging of the record (the three never live at the same time; a wavefront fence separates them).  Returns whether the
-// site is a variant site.
-__device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const BvG16Bins &B, uint32_t *scratch,
-                                         int lane) {
+// ------------------------------------------------------------------ one site on one group, in two phases
+// The solve of a candidate is split over two kernels so that each kernel's code fits the instruction cache (64 KB per pair
+// of CUs; as one kernel the solve was 207 KB and 1.2 % of its instruction fetches missed):
+//   phase 1 (bv_site_lrt_g16)   BaseType::lrt -- active set, EMs, LRT, alt set and AF -- and the record's LRT fields;
+//   phase 2 (bv_site_tail_g16)  QUAL / QD / CAF, the base-quality rank sum and the two strand-bias tests, patched into the record.
+// Between them the record itself carries the state; two facts of the LRT that are no record fields ride in spare status bits.
+#define BV_G16_STASH_M_SHIFT 16      /* bits 16-18: final active-set size (BvLrtOut::m)      */
+#define BV_G16_STASH_FIRST_SHIFT 20  /* bits 20-21: active_bases[0]        (BvLrtOut::first)  */
+#define BV_G16_STASH_MASK 0x00370000u
+
+// Phase 1.  `scratch`: the group's BV_G16_GRP_WORDS words of LDS -- the EM's previous marginals (B.pm points into it), then
+// the staging of the record.  Returns whether the site is a variant site.
+__device__ inline bool bv_site_lrt_g16(const BvSolveArgs &a, uint32_t site, const uint32_t depth[4], uint32_t total, uint32_t badq,
+                                       const BvG16Bins &B, uint32_t *scratch, int lane) {
     const int gl = lane & 15;
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
-    uint32_t *cls = scratch;
     bv_site_result *res = reinterpret_cast<bv_site_result *>(scratch);
-    uint32_t *res_words = scratch;
+    int ref = a.ref_base[site];
+    if (ref > 4) ref = 4;
+    const double qnan = __builtin_nan("");
+    uint32_t flags = BV_SITE_COVERED | (badq ? BV_SITE_BAD_QUAL : 0u);
+    BvLrtOut L;
+    L.n_alt = 0; L.alt_packed = 0; L.af[0] = L.af[1] = L.af[2] = L.af[3] = 0.;
+    L.m = 0; L.first = 0; L.chi2 = 0.; L.em_iters = 0; L.n_em = 0; L.zero_freq = false;
+    if (!(a.flags & BV_FLAG_SKIP_LRT)) bv_lrt_g16(B, depth, total, ref, a.min_af, L);
+    if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
+    if (L.n_alt > 0) flags |= BV_SITE_VARIANT;
+    flags |= ((uint32_t)L.m << BV_G16_STASH_M_SHIFT) | ((uint32_t)L.first << BV_G16_STASH_FIRST_SHIFT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the EM is done with the scratch
+    for (int i = gl; i < REC_WORDS; i += 16) scratch[i] = 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (gl == 0) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) res->depth[b] = depth[b];
+        res->total_depth = total;
+        res->status = flags;
+        res->n_alt = (uint8_t)L.n_alt;
+#pragma unroll
+        for (int k = 0; k < BV_MAX_ALT; ++k) {
+            if (k < L.n_alt) {
+                res->alt[k] = (uint8_t)bv_alt_at(L, k);
+                res->af[k] = L.af[k];
+            }
+        }
+        res->chi2 = L.chi2;
+        res->em_iters = (uint16_t)L.em_iters;
+        res->n_em = (uint8_t)L.n_em;
+        res->mq_ranksum = qnan;
+        res->rpr_ranksum = qnan;
+        res->bq_ranksum = qnan;
+        if (L.zero_freq) atomicAdd(&a.counters[BV_CTR_ZEROFREQ], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int i = gl; i < REC_WORDS; i += 16) reinterpret_cast<uint32_t *>(&a.out[site])[i] = scratch[i];
+    return L.n_alt > 0;
+}
+
+// Phase 2.  `S`: the site's strand totals; `w`: its bins (bv_g16_bin layout; read only for variant sites); `cls`: the group's
+// scratch, here 2 x 128 REF / ALT counts per phred for the rank sum.  Everything it computes is patched into the record
+// phase 1 wrote, by the group's first lane.
+__device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const uint32_t w[BV_G16_SLOTS],
+                                        uint32_t *cls, int lane) {
+    const int gl = lane & 15;
+    bv_site_result *rec = &a.out[site];
     uint32_t depth[4], total = 0;
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -435,43 +487,46 @@ __device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, co
     }
     int ref = a.ref_base[site];
     if (ref > 4) ref = 4;
+    // what phase 1 left: status (with the stash), n_alt + alt[4] (8 bytes), chi2
+    const uint32_t st = rec->status;
+    const uint2 aw = *reinterpret_cast<const uint2 *>(&rec->n_alt);
+    const int n_alt = (int)(aw.x & 0xFFu);
+    const int m = (int)((st >> BV_G16_STASH_M_SHIFT) & 7u), first = (int)((st >> BV_G16_STASH_FIRST_SHIFT) & 3u);
+    uint32_t flags = st & ~BV_G16_STASH_MASK;
     const double qnan = __builtin_nan("");
-    uint32_t flags = BV_SITE_COVERED | (S.badq ? BV_SITE_BAD_QUAL : 0u);
     uint32_t c_rf = 0, c_rr = 0, c_af = 0, c_ar = 0;  // caller.cpp:1236-1245
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
         if (b == ref) { c_rf += S.fwd[b]; c_rr += S.rev[b]; } else { c_af += S.fwd[b]; c_ar += S.rev[b]; }
     }
-    BvLrtOut L;
-    L.n_alt = 0; L.alt_packed = 0; L.af[0] = L.af[1] = L.af[2] = L.af[3] = 0.;
-    L.m = 0; L.first = 0; L.chi2 = 0.; L.em_iters = 0; L.n_em = 0; L.zero_freq = false;
-    if (!(a.flags & BV_FLAG_SKIP_LRT)) bv_lrt_g16(B, depth, total, ref, a.min_af, L);
-    if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
-
     double bq_ranksum = qnan, qual = 0., qd = 0.;
     uint32_t v_rf = 0, v_rr = 0, v_af = 0, v_ar = 0;
-    const bool have_var = L.n_alt > 0;
+    const bool have_var = n_alt > 0;
     double caf0 = 0., caf1 = 0., caf2 = 0., caf3 = 0.;
     if (have_var) {
-        flags |= BV_SITE_VARIANT;
         uint32_t alt_mask = 0, ad_sum_u = 0;
 #pragma unroll
         for (int k = 0; k < BV_MAX_ALT; ++k) {
-            if (k < L.n_alt) {
-                alt_mask |= 1u << bv_alt_at(L, k);
-                ad_sum_u += bv_sel4u(depth, bv_alt_at(L, k));
+            if (k < n_alt) {
+                const int b = (int)((k < 3 ? (aw.x >> (8 * (k + 1))) : aw.y) & 3u);
+                alt_mask |= 1u << b;
+                ad_sum_u += bv_sel4u(depth, b);
             }
         }
         // QUAL / QD / CAF (basetype.cpp:180-196, caller.cpp:1113-1122, 1160-1161)
         {
-            const double r = (double)bv_sel4u(depth, L.first) / (double)total;
-            if (L.m == 1 && total > 10 && r > 0.5) qual = 5000.0;
-            else qual = bv_qual_from_chi2(L.chi2);
+            const double r = (double)bv_sel4u(depth, first) / (double)total;
+            if (m == 1 && total > 10 && r > 0.5) qual = 5000.0;
+#ifdef BV_ABL16_NO_QUAL  /* attribution builds only */
+            else qual = rec->chi2;
+#else
+            else qual = bv_qual_from_chi2(rec->chi2);
+#endif
             double ad_sum = 0;
 #pragma unroll
             for (int k = 0; k < BV_MAX_ALT; ++k) {
-                if (k < L.n_alt) {
-                    const uint32_t d = bv_sel4u(depth, bv_alt_at(L, k));
+                if (k < n_alt) {
+                    const uint32_t d = bv_sel4u(depth, (int)((k < 3 ? (aw.x >> (8 * (k + 1))) : aw.y) & 3u));
                     ad_sum = ad_sum + (double)d;
                     const double cf = (double)d / (int)total;
                     if (k == 0) caf0 = cf; else if (k == 1) caf1 = cf; else if (k == 2) caf2 = cf; else caf3 = cf;
@@ -486,76 +541,67 @@ __device__ inline bool bv_site_solve_g16(const BvSolveArgs &a, uint32_t site, co
             else if ((alt_mask >> b) & 1u) { v_af += S.fwd[b]; v_ar += S.rev[b]; }
         }
         // base-quality rank sum (caller.cpp:1157): REF / ALT counts per phred value, scattered from the bins
+#ifndef BV_ABL16_NO_BQ
         {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the EM is done with the scratch
             for (int i = gl; i < 2 * 128; i += 16) cls[i] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int s = 0; s < BV_G16_SLOTS; ++s) {
-                const uint32_t w = B.w[s];
-                if (w & 0xFFFFu) {
-                    const uint32_t q = (w >> 16) & 127u, b = w >> 23;
+                const uint32_t ws = w[s];
+                if (ws & 0xFFFFu) {
+                    const uint32_t q = (ws >> 16) & 127u, b = ws >> 23;
                     // bins are unique per (base, phred); several ALT bases can share a phred: add, one lane at a time per word
-                    if ((int)b == ref) cls[q] = w & 0xFFFFu;
-                    else if ((alt_mask >> b) & 1u) atomicAdd(&cls[128 + q], w & 0xFFFFu);
+                    if ((int)b == ref) cls[q] = ws & 0xFFFFu;
+                    else if ((alt_mask >> b) & 1u) atomicAdd(&cls[128 + q], ws & 0xFFFFu);
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
             unsigned long long below = 0, twoR = 0;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
+            for (int wi = 0; wi < 8; ++wi) {
                 // (a window without a count adds nothing to the sum nor to `below`: skipped per group)
-                const uint32_t rv = cls[w * 16 + gl], av = cls[128 + w * 16 + gl];
+                const uint32_t rv = cls[wi * 16 + gl], av = cls[128 + wi * 16 + gl];
                 if (bv_g16_ballot((rv | av) != 0u, lane) != 0u) twoR += bv_ranksum_window_g16(rv, av, n1 + n2, below);
             }
             bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // before the next site's zeroing
         }
+#endif
     }
+    // strand bias: FS / SOR of the CVG table, then of the VCF table unless it is the same 2 x 2 table.  ONE call site for the
+    // test (its code is the bulk of this kernel)
     double c_fs = 0, c_sor = 0, v_fs = 0, v_sor = 0;
     if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
         const bool same = have_var && v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar;
-        bv_strand_bias_g16(c_rf, c_rr, c_af, c_ar, lane, a.lnfact, &c_fs, &c_sor, &flags);
-        if (have_var && !same) bv_strand_bias_g16(v_rf, v_rr, v_af, v_ar, lane, a.lnfact, &v_fs, &v_sor, &flags);
+#ifdef BV_ABL16_NO_VARFS
+        const int ntab = 1;
+#else
+        const int ntab = (have_var && !same) ? 2 : 1;
+#endif
+#pragma unroll 1
+        for (int t = 0; t < ntab; ++t) {
+            double fs, sor;
+            bv_strand_bias_g16(t ? v_rf : c_rf, t ? v_rr : c_rr, t ? v_af : c_af, t ? v_ar : c_ar, lane, a.lnfact, &fs, &sor, &flags);
+            if (t) { v_fs = fs; v_sor = sor; } else { c_fs = fs; c_sor = sor; }
+        }
         if (same) { v_fs = c_fs; v_sor = c_sor; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the rank sum is done with the scratch
-    for (int i = gl; i < REC_WORDS; i += 16) res_words[i] = 0u;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (gl == 0) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) res->depth[b] = depth[b];
-        res->total_depth = total;
-        res->status = flags;
+        rec->status = flags;
         if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
-            res->cvg_sb[0] = c_rf; res->cvg_sb[1] = c_rr; res->cvg_sb[2] = c_af; res->cvg_sb[3] = c_ar;
-            res->cvg_fs = c_fs; res->cvg_sor = c_sor;
+            *reinterpret_cast<uint2 *>(&rec->cvg_sb[0]) = make_uint2(c_rf, c_rr);
+            *reinterpret_cast<uint2 *>(&rec->cvg_sb[2]) = make_uint2(c_af, c_ar);
+            rec->cvg_fs = c_fs; rec->cvg_sor = c_sor;
             if (have_var) {
-                res->var_sb[0] = v_rf; res->var_sb[1] = v_rr; res->var_sb[2] = v_af; res->var_sb[3] = v_ar;
-                res->var_fs = v_fs; res->var_sor = v_sor;
+                *reinterpret_cast<uint2 *>(&rec->var_sb[0]) = make_uint2(v_rf, v_rr);
+                *reinterpret_cast<uint2 *>(&rec->var_sb[2]) = make_uint2(v_af, v_ar);
+                rec->var_fs = v_fs; rec->var_sor = v_sor;
             }
         }
-        res->n_alt = (uint8_t)L.n_alt;
-#pragma unroll
-        for (int k = 0; k < BV_MAX_ALT; ++k) {
-            if (k < L.n_alt) {
-                res->alt[k] = (uint8_t)bv_alt_at(L, k);
-                res->af[k] = L.af[k];
-            }
-        }
-        if (L.n_alt > 0) { res->caf[0] = caf0; res->qual = qual; res->qd = qd; }
-        if (L.n_alt > 1) res->caf[1] = caf1;
-        if (L.n_alt > 2) res->caf[2] = caf2;
-        if (L.n_alt > 3) res->caf[3] = caf3;
-        res->chi2 = L.chi2;
-        res->em_iters = (uint16_t)L.em_iters;
-        res->n_em = (uint8_t)L.n_em;
-        res->mq_ranksum = qnan;
-        res->rpr_ranksum = qnan;
-        res->bq_ranksum = bq_ranksum;
-        if (L.zero_freq) atomicAdd(&a.counters[BV_CTR_ZEROFREQ], 1u);
+        if (n_alt > 0) { rec->caf[0] = caf0; rec->qual = qual; rec->qd = qd; rec->bq_ranksum = bq_ranksum; }
+        if (n_alt > 1) rec->caf[1] = caf1;
+        if (n_alt > 2) rec->caf[2] = caf2;
+        if (n_alt > 3) rec->caf[3] = caf3;
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    for (int i = gl; i < REC_WORDS; i += 16) reinterpret_cast<uint32_t *>(&a.out[site])[i] = res_words[i];
-    return have_var;
 }
