@@ -166,6 +166,7 @@ struct bv_engine {
     hipStream_t stream = nullptr;      // engine-owned stream
     hipStream_t last_stream = nullptr; // stream of the last submit
     std::vector<hipStream_t> used_streams;  // every stream that carried work since the last bv_engine_wait
+    hipEvent_t ev_host = nullptr;      // BV_FLAG_HOST_ORDERED: what the copy stream waits for before it reads host planes
     hipEvent_t ev_done = nullptr;      // end of the last submit: a submit on ANOTHER stream waits for it (shared scratch)
     bool ev_done_set = false;
     uint32_t n_cu = 256;               // hipDeviceProp_t::multiProcessorCount
@@ -337,6 +338,16 @@ int stage_acquire(bv_engine *e, size_t bytes, bv_engine::StageSlot **out) {
     *out = &sl;
     return BV_OK;
 }
+// BV_FLAG_HOST_ORDERED: the copies of host planes wait for everything queued on the caller's stream so far (a caller that
+// fills its pinned planes with asynchronous work on that stream).  Default: host planes are complete when the call is made
+// (include/basevar_amd.h) and the copy runs ahead, under the kernels of earlier submits.
+int stage_order(bv_engine *e, bv_engine::StageSlot *sl, hipStream_t st) {
+    if (!(e->cfg.flags & BV_FLAG_HOST_ORDERED)) return BV_OK;
+    if (!e->ev_host) BV_HIP(e, hipEventCreateWithFlags(&e->ev_host, hipEventDisableTiming));
+    BV_HIP(e, hipEventRecord(e->ev_host, st));
+    BV_HIP(e, hipStreamWaitEvent(sl->cs, e->ev_host, 0));
+    return BV_OK;
+}
 int stage_publish(bv_engine *e, bv_engine::StageSlot *sl, hipStream_t st) {  // the copies are queued: `st` may read after them
     BV_HIP(e, hipEventRecord(sl->copied, sl->cs));
     BV_HIP(e, hipStreamWaitEvent(st, sl->copied, 0));
@@ -365,22 +376,32 @@ struct HostPlane {
     const uint8_t *dev;  // out: where the plane lives in the staging buffer
 };
 // Queue the host->device copies of `n` planes into a fresh staging slot (+ `extra` bytes of device scratch behind them).
-int stage_host_planes(bv_engine *e, HostPlane *pl, int n, size_t extra, bv_engine::StageSlot **slot_out, uint8_t **extra_dev) {
+int stage_host_planes(bv_engine *e, HostPlane *pl, int n, size_t extra, bv_engine::StageSlot **slot_out, uint8_t **extra_dev, hipStream_t st) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     HostSpan sp;
     size_t sum = 0;
-    bool aligned = true;
     for (int i = 0; i < n; ++i) {
         if (!pl[i].src || !pl[i].bytes) continue;
         sp.add(pl[i].src, pl[i].bytes);
         sum += up(pl[i].bytes);
     }
-    for (int i = 0; i < n; ++i)
-        if (pl[i].src && pl[i].bytes && ((static_cast<const uint8_t *>(pl[i].src) - sp.lo) & 15)) aligned = false;
-    const bool one_copy = sp.lo && aligned && sp.bytes() <= sum + 4096;  // the planes tile one allocation (small gaps allowed)
+    // ONE copy only for the exact layout of bv_tile_packed_layout: the planes in order, each at the 256-aligned end of the one
+    // before it, in one allocation -- then every byte of [lo, hi) is the caller's.  (Planes that merely lie close together
+    // are copied one by one: the bytes between them are not ours to read.)
+    bool one_copy = sp.lo != nullptr && (reinterpret_cast<uintptr_t>(sp.lo) & 15u) == 0;
+    {
+        size_t at = 0;
+        for (int i = 0; i < n && one_copy; ++i) {
+            if (!pl[i].src || !pl[i].bytes) continue;
+            one_copy = static_cast<const uint8_t *>(pl[i].src) == sp.lo + at;
+            at += up(pl[i].bytes);
+        }
+    }
     const size_t planes_bytes = one_copy ? up(sp.bytes()) : sum;
     bv_engine::StageSlot *sl = nullptr;
     int rc = stage_acquire(e, planes_bytes + up(extra), &sl);
+    if (rc != BV_OK) return rc;
+    rc = stage_order(e, sl, st);
     if (rc != BV_OK) return rc;
     uint8_t *base = static_cast<uint8_t *>(sl->buf);
     if (one_copy) {
@@ -482,6 +503,17 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
         t.logmiss[qv] = log(t.miss[qv]);
     }
     e->host_log_exact = load_host_log_table(t.hostlog) ? 1 : 0;
+    if (!e->host_log_exact) {
+        // not silent: said once per process on stderr, kept as the global message (bv_last_error(NULL)) of this successful
+        // create, and flagged per record (BV_SITE_LOG_APPROX) on the sites it concerns
+        static const char *note =
+            "basevar_amd: note: the host libm's log() could not be reproduced on the device (no glibc __log_data table found, or it "
+            "failed verification); sites of <= 64 covered samples use the device library's log(): values within 1e-6, exact ties "
+            "between allele subsets undecided (records carry BV_SITE_LOG_APPROX)";
+        static std::once_flag said;
+        std::call_once(said, [] { if (!std::getenv("BASEVAR_AMD_QUIET")) std::fprintf(stderr, "%s\n", note); });
+        set_global_error(note);
+    }
     // log-factorials for the Fisher test with the host libm -- kfunc.c:197-201 calls lgamma(n + 1) --
     // for every depth a site of this engine can reach (deeper tables fall back to a series on the device)
     {
@@ -533,6 +565,7 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_ref_cat) (void)hipFree(e->d_ref_cat);
     if (e->d_out_cat) (void)hipFree(e->d_out_cat);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+    if (e->ev_host) (void)hipEventDestroy(e->ev_host);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &sl : e->sring) {
         if (sl.buf) (void)hipFree(sl.buf);
@@ -775,7 +808,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
                            {rp, rp ? S * P * 2 : 0, nullptr}, {refb, S, nullptr}};
         const size_t out_b = up(S * sizeof(bv_site_result)), gout_b = up(S * G * sizeof(bv_group_result));
         uint8_t *extra = nullptr;
-        int rc = stage_host_planes(e, pl, 5, out_b + gout_b, &slot, &extra);
+        int rc = stage_host_planes(e, pl, 5, out_b + gout_b, &slot, &extra, st);
         if (rc != BV_OK) return rc;
         rc = stage_publish(e, slot, st);
         if (rc != BV_OK) return rc;
@@ -809,9 +842,16 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
     if (!slabs || !outs || n_slabs == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null / empty argument");
     bool chainable = n_slabs > 1 && ((e->cfg.flags >> 8) & 0xFu) == 0u;
     uint64_t total = 0;
+    auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
+    // every slab is checked before anything is launched (the checks of bv_engine_submit)
     for (uint32_t k = 0; k < n_slabs; ++k) {
         const bv_slab &s = slabs[k];
         if (!outs[k]) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null record buffer");
+        if (s.n_sites == 0 || s.n_samples == 0 || s.pitch < s.n_samples || (s.pitch & 15ull) || !s.base_strand || !s.qual || !s.ref_base ||
+            (s.mapq == nullptr) != (s.rpr == nullptr) || misaligned(s.base_strand) || misaligned(s.qual) || misaligned(s.mapq) ||
+            misaligned(s.rpr) || (s.mem_kind != BV_MEM_HOST && misaligned(outs[k])))
+            return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab fails the checks of bv_engine_submit");
+        if (s.n_sites > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_submit_many: a slab exceeds cfg.max_sites");
         // (rows of up to 2048 samples and the diagnostic kernel choices take kernels that know no chain)
         chainable = chainable && s.mem_kind != BV_MEM_HOST && s.n_groups == 0 && s.n_samples > 2048u && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP) &&
                     s.n_samples == slabs[0].n_samples && s.pitch == slabs[0].pitch && (s.mapq == nullptr) == (slabs[0].mapq == nullptr);
@@ -819,13 +859,13 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
     }
     if (!chainable) {
         for (uint32_t k = 0; k < n_slabs; ++k) {
+            if (slabs[k].n_groups != 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many takes no pop-groups (no gout): use bv_engine_submit");
             int rc = bv_engine_submit(e, &slabs[k], outs[k], nullptr, stream_);
             if (rc != BV_OK) return rc;
         }
         return BV_OK;
     }
     if (total > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_submit_many: the slabs together exceed cfg.max_sites");
-    auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
     {
@@ -843,10 +883,6 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
         uint32_t first = 0;
         for (uint32_t i = 0; i < nk; ++i) {
             const bv_slab &s = slabs[k0 + i];
-            if (s.n_sites == 0 || s.pitch < s.n_samples || (s.pitch & 15ull) || !s.base_strand || !s.qual || !s.ref_base ||
-                (s.mapq == nullptr) != (s.rpr == nullptr) || misaligned(s.base_strand) || misaligned(s.qual) || misaligned(s.mapq) ||
-                misaligned(s.rpr) || misaligned(outs[k0 + i]))
-                return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab fails the checks of bv_engine_submit");
             const size_t bias = (size_t)first * P;
             ch.first[i] = first;
             ch.bs[i] = s.base_strand - bias; ch.q[i] = s.qual - bias;
@@ -872,7 +908,10 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
         } else {
             // short rows: the planes are looked up per row (wave-uniform places only); the per-site reference bases and records,
             // which the lane-per-site and four-per-wave kernels touch with one site per lane, go through contiguous copies
-            if (!e->d_ref_cat) {
+            if (!e->d_ref_cat || !e->d_out_cat) {
+                if (e->d_ref_cat) (void)hipFree(e->d_ref_cat);
+                if (e->d_out_cat) (void)hipFree(e->d_out_cat);
+                e->d_ref_cat = nullptr; e->d_out_cat = nullptr;
                 BV_HIP(e, hipMalloc(&e->d_ref_cat, (size_t)e->cfg.max_sites + 256));
                 BV_HIP(e, hipMalloc(&e->d_out_cat, sizeof(bv_site_result) * (size_t)e->cfg.max_sites));
             }
@@ -998,7 +1037,7 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     if (t->mem_kind == BV_MEM_HOST) {
         HostPlane pl[5] = {{bs, S * P, nullptr}, {q, S * P, nullptr}, {mq, mq ? S * P : 0, nullptr},
                            {rp, rp ? S * P * 2 : 0, nullptr}, {gid, gid ? (size_t)t->n_samples : 0, nullptr}};
-        int rc = stage_host_planes(e, pl, 5, 0, &slot, nullptr);
+        int rc = stage_host_planes(e, pl, 5, 0, &slot, nullptr, st);
         if (rc != BV_OK) return rc;
         rc = stage_publish(e, slot, st);
         if (rc != BV_OK) return rc;
@@ -1068,7 +1107,7 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
         HostPlane pl[1] = {{ref_base, S, nullptr}};
         const size_t out_b = up(S * sizeof(bv_site_result)), gout_b = up(S * G * sizeof(bv_group_result));
         uint8_t *extra = nullptr;
-        int rc = stage_host_planes(e, pl, 1, out_b + gout_b, &slot, &extra);
+        int rc = stage_host_planes(e, pl, 1, out_b + gout_b, &slot, &extra, st);
         if (rc != BV_OK) return rc;
         rc = stage_publish(e, slot, st);
         if (rc != BV_OK) return rc;

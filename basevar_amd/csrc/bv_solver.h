@@ -180,6 +180,7 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
                                                    sv->ord, lane);
             bv_lrt_sync<0>();
             if (got == total) { B.ord = sv->ord; B.n_ord = (int)total; }
+            if (B.ord != nullptr && bv_hostlog_of(a.logmiss) == nullptr) flags |= BV_SITE_LOG_APPROX;  // loud: see basevar_amd.h
         }
         BvLrtOut L;
         // q0_mask: bases that hold a phred-0 call (1 - eps == 0) keep the generic EM path, because

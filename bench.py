@@ -182,6 +182,9 @@ def parity_on_sample(gpu, cpu):
 
 def main():
     args = parse()
+    # dmabuf IPC: RCCL across processes needs it on this driver -- also when a launcher other than self_launch() started the
+    # ranks (set before torch / HIP are loaded)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)  # does not return
     import numpy as np
@@ -347,10 +350,21 @@ def main():
         st_ms += s_; p1_ms += a1; p2_ms += a2; nsub += n_
     nvar = eng.last_variant_count()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # per-rank figures for rank 0's line: this rank's wall time of the timed region, its pass-1 fraction of the HBM peak, and
+    # what of its step was NOT kernels (the gather's exposed time + launch gaps)
+    my_p1_frac = (2.0 * Bl * N * args.steps / max(nsub, 1)) / max(p1_ms / max(nsub, 1) / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBS
+    my_exposed_ms = max(0.0, elapsed / args.steps * 1e3 - (p1_ms + p2_ms) / max(args.steps, 1))
+    mine = torch.tensor([elapsed, my_p1_frac, my_exposed_ms], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)] if dist_on else [mine]
     if dist_on:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        if backend == "nccl":
+            dist.all_gather(per_rank, mine)
+        else:
+            cpu_list = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(cpu_list, mine.cpu())
+            per_rank = cpu_list
+    per_rank = [[float(x) for x in t_.tolist()] for t_ in per_rank]
+    elapsed = max(r[0] for r in per_rank)
 
     if rank == 0:
         sites_per_s = world * Bl * args.steps / elapsed
@@ -364,7 +378,7 @@ def main():
         # planes; on long rows it is one kernel (st_avg_s == p1_avg_s)
         shape = (args.flags >> 8) & 0xF
         two_kernel = (shape == 0 and N <= 49152) or shape == 10
-        kernel_name = "bv_p1s_stream_kernel" if two_kernel else ("bv_pass1_fused_kernel" if (shape == 9 or (shape == 0 and N <= 49152)) else "bv_pass1_kernel")
+        kernel_name = "bv_p1s_stream_kernel" if two_kernel else ("bv_pass1_fused_kernel" if shape == 9 else "bv_pass1_kernel")
         achieved = algo_bytes / st_avg_s / 1e9
         # HBM bytes per launch of that kernel from the PMC counters: NOT measured in this run (counter collection needs
         # rocprofv3 around the process) but read from the committed record of the SAME kernel and configuration, if one
@@ -401,11 +415,23 @@ def main():
                 "rccl_ranks": (dist.get_world_size() if dist_on and backend == "nccl" else 0),
                 "dist_world_size": (dist.get_world_size() if dist_on else 1),
                 "variant_sites_last_batch": nvar, "gathered_records_ok": gathered_ok,
+                # 1: sites of <= 64 covered samples are replayed with the host libm's own log() (ties decided as the reference
+                # decides them); 0: the device library's log() (values within 1e-6, exact ties undecided, BV_SITE_LOG_APPROX)
+                "host_log_exact": int(eng.host_log_exact),
+                "per_rank": {"pass1_frac_min": min(r[1] for r in per_rank), "pass1_frac_max": max(r[1] for r in per_rank),
+                             "step_ms_min": min(r[0] for r in per_rank) / args.steps * 1e3,
+                             "step_ms_max": max(r[0] for r in per_rank) / args.steps * 1e3,
+                             # step time minus this rank's kernel time: launch gaps + what of the record gather is not hidden
+                             "exposed_ms_per_step_max": max(r[2] for r in per_rank)},
             },
             "roofline": {
+                # achieved / frac / avg_launch_ms describe the DOMINANT kernel named in `kernel` (long rows: all of pass 1;
+                # short rows: the streaming kernel of pass 1 -- the solve kernels read no planes); pass1_frac is all of pass 1
+                # over the same bytes and whole_path_frac both passes over section 8d's bytes: compare those across row lengths
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": kernel_name, "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel": kernel_name, "frac_covers": "streaming kernel of pass 1" if two_kernel else "pass 1",
+                "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": st_avg_s * 1e3, "pass1_avg_ms": p1_avg_s * 1e3,
                 "pass1_frac": algo_bytes / p1_avg_s / 1e9 / HBM_PEAK_GBS,  # all of pass 1 (streaming + solve kernels) over the same bytes
                 "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,

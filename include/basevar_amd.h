@@ -84,6 +84,10 @@ typedef enum bv_mem_kind {
 #define BV_SITE_RANKSUM 0x10u  /* mapq/rpr rank sums were computed (planes present)    */
 #define BV_SITE_SOR_OVERFLOW 0x20u /* int product in SOR exceeded 2^31 (basetype.cpp:286 is UB there) */
 #define BV_SITE_RPR_RANGE 0x40u    /* tile mode only: a read-position rank >= 1024 was seen; rpr_ranksum = NaN */
+#define BV_SITE_LOG_APPROX 0x80u   /* a site of <= 64 covered samples was replayed in the reference's per-sample order, but with the
+                                      device library's log() instead of the host libm's (bv_engine_host_log_exact() == 0: the host's
+                                      libm is not the glibc the restatement knows): where two allele subsets tie to the last bit the
+                                      pick may differ from the reference's; every value is still within 1e-6 */
 
 /* Input: SoA planes [n_sites][pitch], one row per genomic site, one cell per sample.
  * Replaces `struct BatchInfo` (src/basetype.h:25-43) for a whole batch of sites. */
@@ -158,6 +162,11 @@ typedef struct bv_group_result {
                                      pipeline of n chunks of consecutive sites over two streams (solve kernels of chunk c under the
                                      streaming kernel of chunk c + 1); 0 = the engine's default (by batch size), 1 = no pipeline.
                                      Records do not depend on n. */
+#define BV_FLAG_HOST_ORDERED 0x80u /* BV_MEM_HOST planes: the engine's copy stream waits for everything queued on the caller's `stream`
+                                     before it reads them (for callers that fill their pinned planes with asynchronous work on that
+                                     stream).  Default (flag clear): host planes must be COMPLETE in host memory when bv_engine_submit /
+                                     bv_engine_tiles_add / bv_engine_tiles_finish is called and stay untouched until bv_engine_wait --
+                                     the copies run on streams of the engine's own, ahead of `stream`, under earlier kernels */
 #define BV_FLAG_TILE_STATE 0x8u  /* tile mode: always accumulate per-site tallies (the fallback for jobs whose
                                     joined planes do not fit the HBM) instead of joining the tiles into rows */
 
@@ -191,6 +200,8 @@ int bv_engine_destroy(bv_engine *e);
  *   strand_bias (CVG and VCF flavours)            caller.cpp:1245, 1164
  *   3 x ref_vs_alt_ranksumtest                    caller.cpp:1151-1157
  *   per-group __gb() when slab->n_groups > 0      caller.cpp:756-759
+ * BV_MEM_HOST slabs: the planes must be fully written when the call is made and must not change before bv_engine_wait
+ *           returns (they are copied by the engine's own copy streams, not in `stream` order; BV_FLAG_HOST_ORDERED changes that).
  * `out`   : [n_sites] records, same mem_kind as the slab; a device buffer must be 16-byte aligned.
  * `gout`  : [n_sites][n_groups] records or NULL when n_groups == 0.
  * `stream`: hipStream_t to launch on, or NULL for the engine's own stream.  (NULL is also the handle of
@@ -235,8 +246,10 @@ int bv_engine_wait(bv_engine *e);
  *                          (5 B per cell: 82 GB for 16 Ki sites x 1 M samples) and finish() runs the ordinary
  *                          two passes on it -- results are those of bv_engine_submit on the joined rows, bit for bit;
  *   per-site tallies       when that slab does not fit (or with BV_FLAG_TILE_STATE): additive per-site state
- *                          (~30 KB per site), global atomics; equal results except that read-position ranks
- *                          >= 1024 are not supported there (BV_SITE_RPR_RANGE, rpr_ranksum = NaN). */
+ *                          (~30 KB per site), global atomics; equal results to 1e-6 except that (a) read-position ranks
+ *                          beyond the announced bound are not supported there (BV_SITE_RPR_RANGE, rpr_ranksum = NaN) and
+ *                          (b) it has no rows left at finish(), so sites of <= 64 covered samples are not replayed in the
+ *                          reference's per-sample order: where two allele subsets tie to the last bit, its pick may differ. */
 /* `with_ranks`: 0 = tiles carry no mapq/rpr planes; 1 = they do; a value > 1 also announces an upper bound on the
  * read-position ranks (read length), which only the per-site-tally realisation needs: it keeps exact tallies of ranks
  * below max(1024, with_ranks rounded up to 1024) and flags sites beyond that (BV_SITE_RPR_RANGE).  Host tiles go through

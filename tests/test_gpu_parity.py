@@ -48,9 +48,13 @@ def check(got, exp, gexp, margins=None, **kw):
     bad = {f: idx[~amb[idx]] for f, idx in bad.items()}
     bad = {f: idx for f, idx in bad.items() if idx.size}
     assert not bad, describe(bad, got.sites, exp)
-    # shallow sites and pop-groups replay the reference's per-sample order (bv_em_ordered), so a rounding-noise tie may only
-    # differ where log() itself differs by an ulp: observed ~1 site in 100,000 on tie-prone inputs
-    assert len(excused) <= max(1, len(exp) // 10000), "too many tie-excused sites: %d of %d" % (len(excused), len(exp))
+    # Shallow sites and pop-groups replay the reference's per-sample order (bv_em_ordered) with the host libm's own log():
+    # where that log was verified (bv_host_log_probe; the round-2 campaigns: 0 excused in 4.7 M tie-prone sites) NO site may
+    # need the excuse.  On another libm the device library's log() is ulps off and a rounding-noise tie may differ:
+    # ~1 site in 100,000 on tie-prone inputs.
+    from basevar_amd import _capi
+    allowed = 0 if _capi.load().bv_host_log_probe(None) == 1 else max(1, len(exp) // 10000)
+    assert len(excused) <= allowed, "too many tie-excused sites: %d of %d (allowed %d)" % (len(excused), len(exp), allowed)
     assert got.n_variant == int(((got.sites["status"] & 2) != 0).sum())
     return len(excused)
 
@@ -331,6 +335,65 @@ def test_synthetic_generator_and_full_size_properties(bv, restatement):
     check(r, exp, None)
     nvar = int(((sites["status"] & 2) != 0).sum())
     assert 0.2 * S < nvar < 0.45 * S  # 30 % of the synthetic sites carry an ALT allele
+    eng.close()
+
+
+def test_config3_full_batch_131072_sites_x_100k_samples(bv, restatement):
+    """BASELINE configs[2] at the batch bench.py times: 131,072 sites x 100,000 samples, generated on the device (65.6 GB of
+    planes).  Size-independent properties over the WHOLE batch -- depths against an independent torch count, strand tables
+    and depths adding up, site-range sharding invariance (three unequal shards == one submit, byte for byte) -- and 512 rows
+    spread over the batch against the reference's records (the real reference where oracle/_ref is present)."""
+    import torch
+    n, S = 100000, 131072
+    pitch = (n + 255) // 256 * 256
+    dev = torch.device("cuda:0")
+    free, _ = torch.cuda.mem_get_info()
+    if free < 5 * S * pitch + (4 << 30):
+        pytest.skip("needs %.0f GB of free HBM" % (5e-9 * S * pitch + 4))
+    bs = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    q = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    mq = torch.empty((S, pitch), dtype=torch.uint8, device=dev)
+    rp = torch.empty((S, pitch), dtype=torch.int16, device=dev)
+    ref = torch.empty(S, dtype=torch.uint8, device=dev)
+    bv.synth_fill(0, S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), mq.data_ptr(), rp.data_ptr(), seed=0xBA5E7A7)
+    torch.cuda.synchronize()
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    rec = bv.SITE_DTYPE.itemsize
+    out = torch.zeros(S * rec, dtype=torch.uint8, device=dev)
+    eng.submit_ptrs(S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(), mq.data_ptr(), rp.data_ptr())
+    eng.wait()
+    sites = out.cpu().numpy().view(bv.SITE_DTYPE)
+    # (1) integer depths of every site vs an independent torch count (in row blocks: the comparison mask is a plane of its own)
+    for r0 in range(0, S, 8192):
+        blk = bs[r0:r0 + 8192, :n] & 0x0B
+        for b in range(4):
+            assert np.array_equal((blk == b).sum(dim=1).cpu().numpy(), sites["depth"][r0:r0 + 8192, b]), (r0, b)
+        del blk
+    assert np.array_equal(sites["depth"].sum(axis=1), sites["total_depth"])
+    assert np.array_equal(sites["cvg_sb"].sum(axis=1), sites["total_depth"])
+    var = (sites["status"] & 2) != 0
+    assert (sites["status"][var] & 0x10).all()  # every variant site got its rank sums
+    assert 0.2 * S < var.sum() < 0.45 * S
+    # (2) sharding invariance: three unequal site ranges == the one submit, byte for byte
+    out2 = torch.zeros_like(out)
+    cuts = [0, 40000, 40000 + 65536, S]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        eng.submit_ptrs(hi - lo, n, pitch, bs[lo:].data_ptr(), q[lo:].data_ptr(), ref[lo:].data_ptr(), out2.data_ptr() + lo * rec,
+                        mq[lo:].data_ptr(), rp[lo:].data_ptr())
+        eng.wait()
+    assert torch.equal(out, out2)
+    # (3) 512 rows spread over the batch (21 does not divide the 20-site class cycle) against the reference
+    pick = (np.arange(512) * (S // 512) + np.arange(512) % 21).clip(0, S - 1)
+    ti = torch.from_numpy(pick).to(dev)
+    sub = {"base_strand": bs[ti].cpu().numpy(), "qual": q[ti].cpu().numpy(), "mapq": mq[ti].cpu().numpy(),
+           "rpr": rp[ti].cpu().numpy().view(np.uint16), "ref_base": ref[ti].cpu().numpy(), "n_samples": n}
+    exp, _ = restatement.run(sub, maf, n_threads=8)
+
+    class R:
+        pass
+    r = R(); r.sites = sites[pick]; r.groups = None; r.n_variant = int(((sites[pick]["status"] & 2) != 0).sum())
+    check(r, exp, None)
     eng.close()
 
 
