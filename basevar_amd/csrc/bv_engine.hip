@@ -236,6 +236,12 @@ struct bv_engine {
     bool tile_join = false;
     uint8_t *j_buf = nullptr;
     size_t j_bytes = 0, j_pitch = 0, j_o_q = 0, j_o_mq = 0, j_o_rp = 0, j_o_gid = 0;
+    // bv_engine_tiles_add_many: descriptor tables, a ring of pinned host + device buffers
+    static constexpr int kDescRing = 4;
+    BvTileScatterPlane *h_desc[kDescRing] = {}, *d_desc[kDescRing] = {};
+    hipEvent_t ev_desc[kDescRing] = {};
+    bool desc_used[kDescRing] = {};
+    unsigned desc_next = 0;
     mutable std::mutex mu;
     std::string err;
 };
@@ -571,6 +577,11 @@ int bv_engine_destroy(bv_engine *e) {
         if (sl.buf) (void)hipFree(sl.buf);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
         if (sl.freed) (void)hipEventDestroy(sl.freed);
+    }
+    for (int i = 0; i < bv_engine::kDescRing; ++i) {
+        if (e->h_desc[i]) (void)hipHostFree(e->h_desc[i]);
+        if (e->d_desc[i]) (void)hipFree(e->d_desc[i]);
+        if (e->ev_desc[i]) (void)hipEventDestroy(e->ev_desc[i]);
     }
     if (e->tile_state) (void)hipFree(e->tile_state);
     if (e->tile_maxr) (void)hipFree(e->tile_maxr);
@@ -959,7 +970,8 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
         }
         if (ok) {
             e->j_pitch = pitch; e->j_o_q = o_q; e->j_o_mq = o_mq; e->j_o_rp = o_rp; e->j_o_gid = o_gid;
-            BV_HIP(e, hipMemset(e->j_buf, 0x08, plane));           // every cell 'N' until its tile arrives
+            // (tiles fill the columns from the left in the order they are added; what a job leaves unfilled is set to 'N' at
+            // finish -- not the whole plane here: 8.6 GB of memset for 8 Ki sites x 1 M samples)
             BV_HIP(e, hipMemset(e->j_buf + o_gid, 0xFF, pitch));   // no pop-group
             e->tile_sites = n_sites; e->tile_groups = n_groups; e->tile_stride = 0;
             e->tile_samples_total = n_samples_total; e->tile_samples_seen = 0;
@@ -1085,6 +1097,120 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     return mark_done(e, st);
 }
 
+// Several tiles at once.  Device-resident tiles of a joined-rows job go to their columns in ONE launch per <= 256 tiles
+// (descriptor table in device memory); anything else -- host tiles, the per-site-tally realisation -- is added tile by tile.
+int bv_engine_tiles_add_many(bv_engine *e, uint32_t n_tiles, const bv_slab *tiles, void *stream_) {
+    if (!e || !tiles || n_tiles == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: null / empty argument");
+    if (!e->tile_open) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: call bv_engine_tiles_begin first");
+    bool one_launch = e->tile_join;
+    uint64_t seen = e->tile_samples_seen;
+    for (uint32_t k = 0; k < n_tiles; ++k) {  // the checks of bv_engine_tiles_add, for every tile before anything is queued
+        const bv_slab &t = tiles[k];
+        if (t.n_sites != e->tile_sites) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: tile n_sites differs from the job's");
+        if (t.n_samples == 0 || t.pitch < t.n_samples || (t.pitch & 15ull) || !t.base_strand || !t.qual)
+            return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: bad tile geometry or missing planes");
+        if (e->tile_ranks && (!t.mapq || !t.rpr)) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: job was opened with rank planes");
+        if (e->tile_groups && !t.group_id) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: job has groups, tile has no group_id");
+        seen += t.n_samples;
+        if (seen > e->tile_samples_total) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: more samples than announced");
+        one_launch = one_launch && t.mem_kind != BV_MEM_HOST;
+    }
+    if (!one_launch) {
+        for (uint32_t k = 0; k < n_tiles; ++k) {
+            int rc = bv_engine_tiles_add(e, &tiles[k], stream_);
+            if (rc != BV_OK) return rc;
+        }
+        return BV_OK;
+    }
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    {
+        int rc = use_stream(e, st);
+        if (rc != BV_OK) return rc;
+    }
+    const uint64_t JP = e->j_pitch;
+    for (uint32_t k0 = 0; k0 < n_tiles; k0 += BV_TILE_MANY_MAX) {
+        const uint32_t nk = n_tiles - k0 < (uint32_t)BV_TILE_MANY_MAX ? n_tiles - k0 : (uint32_t)BV_TILE_MANY_MAX;
+        const int slot = (int)(e->desc_next++ % bv_engine::kDescRing);
+        constexpr size_t kBytes = sizeof(BvTileScatterPlane) * 5 * BV_TILE_MANY_MAX;
+        if (!e->h_desc[slot]) {
+            BV_HIP(e, hipHostMalloc(&e->h_desc[slot], kBytes));
+            BV_HIP(e, hipMalloc(&e->d_desc[slot], kBytes));
+            BV_HIP(e, hipEventCreateWithFlags(&e->ev_desc[slot], hipEventDisableTiming));
+        }
+        if (e->desc_used[slot]) BV_HIP(e, hipEventSynchronize(e->ev_desc[slot]));  // the copy that last read this pinned table
+        // the usual job -- tiles of one width and pitch, every byte quantity a multiple of 8: whole destination rows are
+        // gathered across the tiles (bv_tile_join_rows_kernel); anything else: one descriptor per tile and plane
+        const bv_slab &t0 = tiles[k0];
+        bool uniform = !((t0.n_samples | t0.pitch | e->tile_samples_seen | JP) & 7u);
+        for (uint32_t i = 0; i < nk && uniform; ++i) {
+            const bv_slab &t = tiles[k0 + i];
+            uniform = t.n_samples == t0.n_samples && t.pitch == t0.pitch &&
+                      !(((uintptr_t)t.base_strand | (uintptr_t)t.qual | (uintptr_t)t.mapq | (uintptr_t)t.rpr | (uintptr_t)t.group_id) & 7u);
+        }
+        if (uniform) {
+            const uint8_t **tab = reinterpret_cast<const uint8_t **>(e->h_desc[slot]);  // [5][nk] pointers
+            for (uint32_t i = 0; i < nk; ++i) {
+                const bv_slab &t = tiles[k0 + i];
+                tab[0 * nk + i] = t.base_strand; tab[1 * nk + i] = t.qual; tab[2 * nk + i] = t.mapq;
+                tab[3 * nk + i] = reinterpret_cast<const uint8_t *>(t.rpr); tab[4 * nk + i] = t.group_id;
+            }
+            BV_HIP(e, hipMemcpyAsync(e->d_desc[slot], tab, sizeof(void *) * 5 * nk, hipMemcpyHostToDevice, st));
+            BV_HIP(e, hipEventRecord(e->ev_desc[slot], st));
+            e->desc_used[slot] = true;
+            const uint8_t *const *dtab = reinterpret_cast<const uint8_t *const *>(e->d_desc[slot]);
+            const uint64_t lo = e->tile_samples_seen;
+            auto join = [&](uint8_t *dst, int k, uint64_t scale, uint32_t n_rows) {
+                BvTileJoinArgs ja;
+                ja.dst = dst; ja.srcs = dtab + (size_t)k * nk; ja.dst_pitch = scale * JP; ja.src_pitch = scale * t0.pitch; ja.col_off = scale * lo;
+                ja.width_bytes = (uint32_t)(scale * t0.n_samples); ja.n_tiles = nk; ja.n_rows = n_rows;
+                bv_launch_tile_join_rows(ja, st);
+            };
+            join(e->j_buf, 0, 1, t0.n_sites);
+            join(e->j_buf + e->j_o_q, 1, 1, t0.n_sites);
+            if (e->tile_ranks) {
+                join(e->j_buf + e->j_o_mq, 2, 1, t0.n_sites);
+                join(e->j_buf + e->j_o_rp, 3, 2, t0.n_sites);
+            }
+            if (e->tile_groups) join(e->j_buf + e->j_o_gid, 4, 1, 1);
+            BV_HIP(e, hipGetLastError());
+            e->tile_samples_seen += (uint64_t)nk * t0.n_samples;
+            continue;
+        }
+        BvTileScatterPlane wide[5 * BV_TILE_MANY_MAX], narrow[5 * BV_TILE_MANY_MAX];
+        uint32_t nw = 0, nn = 0;
+        uint64_t uw = 0, un = 0;
+        for (uint32_t i = 0; i < nk; ++i) {
+            const bv_slab &t = tiles[k0 + i];
+            const uint64_t lo = e->tile_samples_seen, P = t.pitch;
+            auto plane = [&](uint8_t *dst, const void *src, uint64_t scale, uint32_t n_rows) {
+                BvTileScatterPlane p;
+                p.dst = dst; p.src = static_cast<const uint8_t *>(src); p.dst_pitch = scale * JP; p.src_pitch = scale * P; p.col_off = scale * lo;
+                p.width_bytes = (uint32_t)(scale * t.n_samples); p.n_rows = n_rows;
+                const bool w8 = !((p.dst_pitch | p.col_off | p.src_pitch | p.width_bytes | (uint64_t)(uintptr_t)p.dst | (uint64_t)(uintptr_t)p.src) & 7u);
+                if (w8) { wide[nw++] = p; const uint64_t u = (uint64_t)(p.width_bytes / 8u) * n_rows; if (u > uw) uw = u; }
+                else { narrow[nn++] = p; const uint64_t u = (uint64_t)p.width_bytes * n_rows; if (u > un) un = u; }
+            };
+            plane(e->j_buf, t.base_strand, 1, t.n_sites);
+            plane(e->j_buf + e->j_o_q, t.qual, 1, t.n_sites);
+            if (e->tile_ranks) {
+                plane(e->j_buf + e->j_o_mq, t.mapq, 1, t.n_sites);
+                plane(e->j_buf + e->j_o_rp, t.rpr, 2, t.n_sites);
+            }
+            if (e->tile_groups) plane(e->j_buf + e->j_o_gid, t.group_id, 1, 1);
+            e->tile_samples_seen += t.n_samples;
+        }
+        std::memcpy(e->h_desc[slot], wide, sizeof(BvTileScatterPlane) * nw);
+        std::memcpy(e->h_desc[slot] + nw, narrow, sizeof(BvTileScatterPlane) * nn);
+        BV_HIP(e, hipMemcpyAsync(e->d_desc[slot], e->h_desc[slot], sizeof(BvTileScatterPlane) * (nw + nn), hipMemcpyHostToDevice, st));
+        BV_HIP(e, hipEventRecord(e->ev_desc[slot], st));
+        e->desc_used[slot] = true;
+        bv_launch_tile_scatter_many(e->d_desc[slot], nw, nn, uw, un, st);
+        BV_HIP(e, hipGetLastError());
+    }
+    return mark_done(e, st);
+}
+
 int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result *out, bv_group_result *gout,
                            uint32_t mem_kind, void *stream_) {
     if (!e || !ref_base || !out) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_finish: null argument");
@@ -1121,6 +1247,8 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     }
     if (e->tile_join) {
         e->tile_open = false;
+        if (e->tile_samples_seen < e->tile_samples_total)  // samples announced but never delivered: uncovered cells
+            BV_HIP(e, hipMemset2DAsync(e->j_buf + e->tile_samples_seen, e->j_pitch, 0x08, e->tile_samples_total - e->tile_samples_seen, S, st));
         int rc = launch_passes(e, e->j_buf, e->j_buf + e->j_o_q, e->tile_ranks ? e->j_buf + e->j_o_mq : nullptr,
                                e->tile_ranks ? reinterpret_cast<const uint16_t *>(e->j_buf + e->j_o_rp) : nullptr, dref,
                                G ? e->j_buf + e->j_o_gid : nullptr, e->j_pitch, e->tile_sites, e->tile_samples_total, e->tile_groups,

@@ -192,6 +192,19 @@ struct BvTileScatterArgs {
     uint32_t n_planes, max_rows;
 };
 void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream);
+// the planes of MANY tiles in one launch (two: 8-byte and byte-wise planes), descriptors in device memory: `n_wide` planes that
+// move 8 bytes per thread first, then `n_narrow`; units_* = units of the largest plane of each kind
+#define BV_TILE_MANY_MAX 256  /* tiles per launch of bv_engine_tiles_add_many */
+// consecutive tiles of one width and pitch, one plane kind: row `r` of tile t goes to dst + r * dst_pitch + col_off + t * width_bytes
+struct BvTileJoinArgs {
+    uint8_t *dst;
+    const uint8_t *const *srcs;  // [n_tiles] device table: this plane of every tile
+    uint64_t dst_pitch, src_pitch, col_off;
+    uint32_t width_bytes, n_tiles, n_rows;  // all byte quantities multiples of 8
+};
+void bv_launch_tile_join_rows(const BvTileJoinArgs &a, hipStream_t stream);
+void bv_launch_tile_scatter_many(const BvTileScatterPlane *d_table, uint32_t n_wide, uint32_t n_narrow, uint64_t units_wide,
+                                 uint64_t units_narrow, hipStream_t stream);
 
 // host-callable launchers (defined next to the kernels)
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream);

@@ -307,7 +307,7 @@ void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, 
 // kernels handed over (BvPass2Args::gitems): one item per group of 16 lanes, bins in registers (bv_solver16.h).
 #define BV_P2G_NW 4
 #ifndef BV_P2G_OCC
-#define BV_P2G_OCC 4
+#define BV_P2G_OCC 3  /* 160 VGPRs, no spills; at 4 waves per SIMD (128 VGPRs) 28 registers spilled: equal at 1-2 groups, 19 % slower at 8 */
 #endif
 struct __attribute__((aligned(16))) BvP2gShared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];

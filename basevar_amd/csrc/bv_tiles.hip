@@ -253,6 +253,71 @@ void bv_launch_tile_scatter(const BvTileScatterArgs &a, hipStream_t stream) {
     }
 }
 
+// Many tiles, one launch: the plane descriptors come from a table in device memory, read through the constant address space
+// (scalar loads), blockIdx.y = descriptor.  A job of 200-sample tiles was launch-bound at one ~8 us launch per tile
+// (676 GB/s at 1 M samples, round 2).
+typedef const __attribute__((address_space(4))) BvTileScatterPlane *BvTileScatterPlaneC;
+template <typename UNIT>
+__global__ __launch_bounds__(256) void bv_tile_scatter_many_kernel(const BvTileScatterPlane *table) {
+    const BvTileScatterPlaneC p = (BvTileScatterPlaneC)(uintptr_t)table + blockIdx.y;
+    const uint32_t upr = p->width_bytes / (uint32_t)sizeof(UNIT), n_rows = p->n_rows;
+    if (upr == 0) return;
+    const uint8_t *src = p->src;
+    uint8_t *dst = p->dst + p->col_off;
+    const uint64_t sp = p->src_pitch, dp = p->dst_pitch;
+    // (a plane shorter than the launch's largest leaves its surplus blocks idle)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (uint64_t)upr * n_rows; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = i / upr, u = i % upr;
+        *reinterpret_cast<UNIT *>(dst + row * dp + u * sizeof(UNIT)) = *reinterpret_cast<const UNIT *>(src + row * sp + u * sizeof(UNIT));
+    }
+}
+void bv_launch_tile_scatter_many(const BvTileScatterPlane *d_table, uint32_t n_wide, uint32_t n_narrow, uint64_t units_wide,
+                                 uint64_t units_narrow, hipStream_t stream) {
+    // the table holds the 8-byte planes first, then the byte-wise ones; grid.x covers the largest plane of its kind, capped
+    // (grid-stride loop) so that a launch of many small planes is not a launch of many idle blocks
+    if (n_wide) {
+        uint64_t gx = (units_wide + 255u) / 256u;
+        if (gx > 2048u) gx = 2048u;
+        hipLaunchKernelGGL(bv_tile_scatter_many_kernel<uint64_t>, dim3((uint32_t)gx, n_wide), dim3(256), 0, stream, d_table);
+    }
+    if (n_narrow) {
+        uint64_t gx = (units_narrow + 255u) / 256u;
+        if (gx > 2048u) gx = 2048u;
+        hipLaunchKernelGGL(bv_tile_scatter_many_kernel<uint8_t>, dim3((uint32_t)gx, n_narrow), dim3(256), 0, stream, d_table + n_wide);
+    }
+}
+
+// The same for the usual job -- consecutive tiles of ONE width and pitch: a block writes 2 KiB of one ROW of the joined
+// plane, gathered from as many tiles as that spans (the tile of a destination byte is a division by the width), so the
+// writes are whole lines of the resident slab instead of 200-byte pieces a megabyte apart.
+#define BV_TILE_JOIN_ROWS 8  /* rows per block: a tile's rows are adjacent in memory (its pitch is its width rounded to 16), so the
+                                 reads of a block are runs of 8 x pitch bytes per tile, its writes 2 KiB runs per row */
+__global__ __launch_bounds__(256) void bv_tile_join_rows_kernel(BvTileJoinArgs a) {
+    // the pointer table is read through the constant address space (scalar loads); its entries are ordinary global pointers
+    typedef const uint8_t *BvSrcPtr;
+    typedef const __attribute__((address_space(4))) BvSrcPtr *SrcTabC;
+    const SrcTabC srcs = (SrcTabC)(uintptr_t)a.srcs;
+    const uint32_t row0 = blockIdx.y * BV_TILE_JOIN_ROWS;
+    const uint64_t span = (uint64_t)a.n_tiles * a.width_bytes;  // bytes of one destination row covered by this launch
+    for (uint64_t o = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 8u; o < span; o += (uint64_t)gridDim.x * 2048u) {
+        const uint32_t t = (uint32_t)(o / a.width_bytes), w = (uint32_t)(o - (uint64_t)t * a.width_bytes);
+        const uint8_t *src = srcs[t] + w;
+        uint64_t v[BV_TILE_JOIN_ROWS];
+#pragma unroll
+        for (int r = 0; r < BV_TILE_JOIN_ROWS; ++r)
+            if (row0 + r < a.n_rows) v[r] = *reinterpret_cast<const uint64_t *>(src + (uint64_t)(row0 + r) * a.src_pitch);
+#pragma unroll
+        for (int r = 0; r < BV_TILE_JOIN_ROWS; ++r)
+            if (row0 + r < a.n_rows) *reinterpret_cast<uint64_t *>(a.dst + (uint64_t)(row0 + r) * a.dst_pitch + a.col_off + o) = v[r];
+    }
+}
+void bv_launch_tile_join_rows(const BvTileJoinArgs &a, hipStream_t stream) {
+    const uint64_t span = (uint64_t)a.n_tiles * a.width_bytes;
+    uint32_t gx = (uint32_t)((span + 2047u) / 2048u);
+    if (gx > 64u) gx = 64u;  // (rows supply the parallelism)
+    hipLaunchKernelGGL(bv_tile_join_rows_kernel, dim3(gx, (a.n_rows + BV_TILE_JOIN_ROWS - 1) / BV_TILE_JOIN_ROWS), dim3(256), 0, stream, a);
+}
+
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream) {
     const uint64_t total = (uint64_t)a.n_sites * ((a.width + 15u) >> 4);
     hipLaunchKernelGGL(bv_tile_tally_kernel, dim3((uint32_t)((total + 255u) / 256u)), dim3(256), 0, stream, a);

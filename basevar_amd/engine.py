@@ -244,6 +244,14 @@ class BaseTypeEngine:
         self.wait()
         return BaseTypeBatch(out, gout, self.last_variant_count(), 0.0, 0.0)
 
+    def tiles_add_many(self, tiles, stream=0):
+        """tiles: list of _capi.Slab (one open tile job, bv_engine_tiles_begin): device-resident tiles of a joined-rows job go
+        to their columns in one launch per 256 tiles (bv_engine_tiles_add_many)."""
+        arr = (_capi.Slab * len(tiles))(*tiles)
+        rc = self._lib.bv_engine_tiles_add_many(self._h, len(tiles), arr, C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise RuntimeError("bv_engine_tiles_add_many failed (%d): %s" % (rc, self._err()))
+
     # ---- numpy slab (host memory; the engine stages it to HBM)
     def lrt(self, slab):
         """slab: dict of numpy planes as produced by basevar_amd.synth.make_slab()."""

@@ -586,6 +586,82 @@ def test_sample_axis_tiles_equal_rows(bv, restatement, n, width, groups, ranks, 
         assert np.array_equal(rows.sites[f], tiles.sites[f]), f
 
 
+@pytest.mark.parametrize("width", [200, 203], ids=["w200_8byte_units", "w203_bytewise"])
+def test_device_tiles_added_in_one_launch_equal_rows(bv, width):
+    """bv_engine_tiles_add_many: device-resident tiles moved by one launch per 256 tiles give the records of the row submit,
+    byte for byte (700 tiles: three launches; pop-groups and rank planes present; a ragged last tile)."""
+    import torch
+    from basevar_amd import _capi
+    n, S, G = 700 * width - 37, 96, 3
+    slab = make_slab(S, n, seed=411, coverage=0.06, n_groups=G)
+    maf = bv.min_af(n)
+    want = run_engine(bv, slab, maf)
+    dev = torch.device("cuda:0")
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    rc = eng._lib.bv_engine_tiles_begin(eng._h, S, n, G, 1)
+    assert rc == 0, eng._err()
+    P = (width + 15) // 16 * 16
+    keep, tiles = [], []
+    for lo in range(0, n, width):
+        w = min(width, n - lo)
+        def cut(a, dt, fill=0):
+            t = torch.full((S, P), fill, dtype=dt, device=dev)
+            t[:, :w] = torch.from_numpy(np.ascontiguousarray(a[:, lo:lo + w])).to(dev)
+            return t
+        tb = cut(slab["base_strand"], torch.uint8, 8); tq = cut(slab["qual"], torch.uint8)
+        tm = cut(slab["mapq"], torch.uint8); tr = cut(slab["rpr"].view(np.int16), torch.int16)
+        tg = torch.full((P,), 255, dtype=torch.uint8, device=dev)
+        tg[:w] = torch.from_numpy(np.ascontiguousarray(slab["group_id"][lo:lo + w])).to(dev)
+        keep.append((tb, tq, tm, tr, tg))
+        tiles.append(_capi.Slab(S, w, P, tb.data_ptr(), tq.data_ptr(), tm.data_ptr(), tr.data_ptr(), None, tg.data_ptr(), G, _capi.BV_MEM_DEVICE))
+    torch.cuda.synchronize()
+    eng.tiles_add_many(tiles)
+    ref = torch.from_numpy(np.ascontiguousarray(slab["ref_base"])).to(dev)
+    out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    gout = torch.zeros(S * G * bv.GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    rc = eng._lib.bv_engine_tiles_finish(eng._h, ref.data_ptr(), out.data_ptr(), gout.data_ptr(), _capi.BV_MEM_DEVICE, None)
+    assert rc == 0, eng._err()
+    eng.wait()
+    assert out.cpu().numpy().tobytes() == want.sites.tobytes()
+    assert gout.cpu().numpy().tobytes() == want.groups.tobytes()
+    eng.close()
+
+
+def test_tile_job_with_fewer_samples_than_announced(bv):
+    """A joined-rows job that delivers fewer samples than bv_engine_tiles_begin announced: the missing columns are uncovered
+    cells (the engine fills them at finish), i.e. the records are those of the row submit of the padded slab."""
+    import ctypes as C
+    from basevar_amd import _capi
+    S, n, missing, width = 48, 1000, 312, 250  # (n + missing: a multiple of 16, the padded slab is its own pitch)
+    slab = make_slab(S, n, seed=91, coverage=0.2, n_groups=0)
+    full = dict(slab)
+    for k, fill in (("base_strand", 8), ("qual", 0), ("mapq", 0), ("rpr", 0)):
+        full[k] = np.concatenate([slab[k][:, :n], np.full((S, missing), fill, dtype=slab[k].dtype)], axis=1)
+    full["n_samples"] = n + missing
+    maf = bv.min_af(n + missing)
+    want = run_engine(bv, full, maf)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    assert eng._lib.bv_engine_tiles_begin(eng._h, S, n + missing, 0, 1) == 0, eng._err()
+    keep = []
+    P = (width + 15) // 16 * 16
+    for lo in range(0, n, width):
+        planes = []
+        for k, dt, fill in (("base_strand", np.uint8, 8), ("qual", np.uint8, 0), ("mapq", np.uint8, 0), ("rpr", np.uint16, 0)):
+            a = np.full((S, P), fill, dtype=dt)
+            a[:, :width] = slab[k][:, lo:lo + width]
+            planes.append(a)
+        keep.append(planes)
+        t = _capi.Slab(S, width, P, planes[0].ctypes.data, planes[1].ctypes.data, planes[2].ctypes.data, planes[3].ctypes.data, None, None, 0,
+                       _capi.BV_MEM_HOST)
+        assert eng._lib.bv_engine_tiles_add(eng._h, C.byref(t), None) == 0, eng._err()
+    ref = np.ascontiguousarray(slab["ref_base"], dtype=np.uint8)
+    out = np.zeros(S, dtype=bv.SITE_DTYPE)
+    assert eng._lib.bv_engine_tiles_finish(eng._h, ref.ctypes.data, out.ctypes.data, None, _capi.BV_MEM_HOST, None) == 0, eng._err()
+    eng.wait()
+    assert out.tobytes() == want.sites.tobytes()
+    eng.close()
+
+
 def test_sample_axis_tiles_long_read_ranks(bv, restatement):
     """Ranks >= 1024: exact in the default (joined-rows) realisation of the tile mode, flagged in the per-site-tally
     fallback (BV_FLAG_TILE_STATE), whose layout cannot hold them."""
