@@ -104,6 +104,29 @@ public:
         std::memcpy(&rp_[off], rank, (size_t)n_ * sizeof(uint16_t));
         ref_.push_back(ref_code);
     }
+    // A row filled in place (batchfile_fast.hpp): begin_row() appends an all-'N' row and hands out its planes; commit_row()
+    // makes it a site, drop_row() takes it back.
+    struct Row {
+        uint8_t *cell, *phred, *mapq;
+        uint16_t *rank;
+    };
+    Row begin_row() {
+        const size_t off = (size_t)n_sites() * pitch_;
+        bs_.resize(off + pitch_, BV_CELL_N);
+        q_.resize(off + pitch_, 0);
+        mq_.resize(off + pitch_, 0);
+        rp_.resize(off + pitch_, 0);
+        std::memset(&bs_[off], BV_CELL_N, pitch_);
+        std::memset(&q_[off], 0, pitch_);
+        std::memset(&mq_[off], 0, pitch_);
+        std::memset(&rp_[off], 0, pitch_ * sizeof(uint16_t));
+        return Row{&bs_[off], &q_[off], &mq_[off], &rp_[off]};
+    }
+    void commit_row(uint8_t ref_code) { ref_.push_back(ref_code); }
+    void drop_row() {
+        const size_t off = (size_t)n_sites() * pitch_;
+        bs_.resize(off); q_.resize(off); mq_.resize(off); rp_.resize(off);
+    }
     const uint8_t *cell_row(size_t site) const { return &bs_[site * pitch_]; }
     const uint8_t *phred_row(size_t site) const { return &q_[site * pitch_]; }
 

@@ -12,7 +12,8 @@
 // src/basetype_caller.cpp:469-525).
 //
 //   bv_call --batchfiles a.bf.gz,b.bf.gz --output-vcf out.vcf --output-cvg out.cvg
-//           [--pop-group FILE] [--min-af 0.01] [--batch-sites N (default: min(4096, 2^26 / samples))]
+//           [--pop-group FILE] [--min-af 0.01] [--batch-sites N (default: 2^28 cells / samples, at most 65536)]
+//           [--parser fast|literal] [--timing FILE.json]
 //           [--gpus G] [--devices 0,1,... | --device 0]
 //           [--reference ref.fa --contig NAME:LENGTH ...]
 //   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END[,CHR:BEG-END...] [--mapq 10]
@@ -37,7 +38,10 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+
 #include "basetype_gpu.hpp"
+#include "batchfile_fast.hpp"
 #include "pileup.hpp"
 #include "vcf_emit.hpp"
 
@@ -109,6 +113,12 @@ private:
     std::condition_variable not_full_, not_empty_;
 };
 
+// Wall-clock seconds per stage, the way the reference prints its phases (src/basetype_caller.cpp:193-215, 625-632).
+struct StageClock {
+    double read = 0, parse = 0, engine = 0, emit = 0;  // engine: summed over the workers; the others run on one thread each
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+};
+
 [[noreturn]] void die(const std::string &m) {
     std::cerr << m << std::endl;
     std::exit(1);
@@ -118,7 +128,7 @@ private:
 
 int main(int argc, char **argv) {
     std::vector<std::string> batchfiles, bams;
-    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list, devices_arg;
+    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list, devices_arg, parser = "fast", timing_file;
     int mapq_thd = 10, threads = 1, n_gpus = 1;
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
@@ -133,6 +143,8 @@ int main(int argc, char **argv) {
         else if (a == "--pop-group") pop_group_file = next();
         else if (a == "--min-af") user_min_af = std::stof(next());
         else if (a == "--batch-sites") batch_sites = (uint32_t)std::stoul(next());
+        else if (a == "--parser") parser = next();
+        else if (a == "--timing") timing_file = next();
         else if (a == "--device") device = std::stoi(next());
         else if (a == "--gpus") n_gpus = std::stoi(next());
         else if (a == "--devices") devices_arg = next();
@@ -159,6 +171,7 @@ int main(int argc, char **argv) {
         }
     }
     if (!(user_min_af > 0.f)) die("[ERROR] --min-af must be > 0");  // the reference refuses it too (caller.cpp:73)
+    if (parser != "fast" && parser != "literal") die("[ERROR] --parser is fast or literal");
     if (n_gpus < 1) die("[ERROR] --gpus must be >= 1");
     // one engine per entry: --devices a,b,... (an ordinal may repeat: several engines on one GPU), else device, device+1, ...
     std::vector<int> devices;
@@ -233,11 +246,14 @@ int main(int argc, char **argv) {
     std::fwrite(hv.data(), 1, hv.size(), VCF);
     std::fwrite(hc.data(), 1, hc.size(), CVG);
 
-    // ---- batches are bounded by cells (2^26 cells = 5 x 64 MiB of planes), not by a site count that ignores the row
-    // length; per pending site the host keeps the slab row and a SiteText, nothing else
+    // ---- batches are bounded by cells (2^28 cells = 5 x 256 MiB of planes per batch in flight), not by a site count that
+    // ignores the row length: a launch carries ~0.1 ms of fill and drain whatever its size, so small batches run the engine
+    // in its worst regime (round 2's default was 671 sites at 100 k samples: 0.2 of the large-batch rate).  Per pending
+    // site the host keeps the slab row and a SiteText, nothing else.
     if (batch_sites == 0) {
-        const size_t by_cells = ((size_t)1 << 26) / std::max<size_t>(n_sample, 1);
-        batch_sites = (uint32_t)std::min<size_t>(4096, std::max<size_t>(by_cells, 1));
+        const size_t pitch = (n_sample + 255) / 256 * 256;
+        const size_t by_cells = ((size_t)1 << 28) / std::max<size_t>(pitch, 1);
+        batch_sites = (uint32_t)std::min<size_t>(65536, std::max<size_t>(by_cells, 64));
     }
 
     // ---- the pipeline: producer (this thread) -> G engine workers -> emitter, results written in batch order
@@ -245,6 +261,8 @@ int main(int argc, char **argv) {
     BatchQueue to_gpu(G + 1), to_emit(2 * G + 2);
     std::mutex err_mu;
     std::string first_error;
+    StageClock clk;
+    const double t_start = StageClock::now();
     auto fail = [&](const std::string &m) {
         std::lock_guard<std::mutex> g(err_mu);
         if (first_error.empty()) first_error = m;
@@ -258,7 +276,11 @@ int main(int argc, char **argv) {
             } catch (const std::exception &ex) { fail(ex.what()); }
             for (BatchPtr b; (b = to_gpu.pop());) {
                 if (engine) {
+                    const double t0 = StageClock::now();
                     try { b->result = engine->lrt(b->slab); } catch (const std::exception &ex) { b->error = ex.what(); }
+                    const double dt = StageClock::now() - t0;
+                    std::lock_guard<std::mutex> lk(err_mu);
+                    clk.engine += dt;
                 } else {
                     b->error = "no engine on device " + std::to_string(devices[g]);
                 }
@@ -275,6 +297,7 @@ int main(int argc, char **argv) {
                 Batch &d = *it->second;
                 if (!d.error.empty()) fail(d.error);
                 else {
+                    const double t0 = StageClock::now();
                     for (size_t i = 0; i < d.text.size(); ++i) {
                         const std::string c = bvamd::format_cvg_line(d.text[i], d.result.sites[i]);
                         std::fwrite(c.data(), 1, c.size(), CVG);
@@ -287,6 +310,7 @@ int main(int argc, char **argv) {
                         }
                     }
                     n_sites += d.text.size();
+                    clk.emit += StageClock::now() - t0;
                 }
                 waiting.erase(it);
                 ++next_seq;
@@ -323,6 +347,7 @@ int main(int argc, char **argv) {
                 const uint32_t end = (uint32_t)std::stoul(rg.substr(dash + 1));
                 if (fa_of != ref_id) { fa_seq = bvamd::load_fasta_sequence(reference, ref_id); fa_of = ref_id; }
                 if (beg < 1 || end < beg || end > fa_seq.size()) die("[ERROR] region outside " + ref_id);
+                const double tp0 = StageClock::now();
                 bvamd::pileup_region(bams, fa_seq, ref_id, beg, end, mapq_thd, true, threads, [&](const bvamd::PileupTile &t) {
                     size_t next_indel = 0;
                     for (uint32_t pos = t.beg; pos <= t.end && still_ok(); ++pos) {
@@ -341,22 +366,36 @@ int main(int argc, char **argv) {
                         if (cur->slab.n_sites() == batch_sites) ship();
                     }
                 });
+                clk.parse += StageClock::now() - tp0;
             }
         } else {
             // ---- one row from every batchfile per position (caller.cpp:586-611)
             std::vector<std::string> rows(batchfiles.size());
+            const bool fast = parser == "fast";
             for (; still_ok();) {
                 bool eof = false;
+                double t0 = StageClock::now();
                 for (size_t b = 0; b < batchfiles.size(); ++b) {
                     if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }
                     else if (!readers[b].getline(rows[b])) { eof = true; break; }
                 }
+                double t1 = StageClock::now();
+                clk.read += t1 - t0;
                 if (eof) break;
-                bvamd::BatchInfo bi;
-                if (!bvamd::parse_site_rows(rows, n_sample, bi)) continue;  // total depth 0, caller.cpp:718
                 if (!cur) fresh();
-                cur->slab.add_site(bi);
-                cur->text.push_back(bvamd::site_text_of(bi));
+                if (fast) {
+                    // the rows' bytes straight into the slab row (batchfile_fast.hpp)
+                    bvamd::SiteText st;
+                    if (bvamd::parse_site_rows_fast(rows, n_sample, cur->slab, st)) cur->text.push_back(std::move(st));
+                } else {
+                    // the reference's own steps: split -> BatchInfo -> slab row (batchfile.hpp)
+                    bvamd::BatchInfo bi;
+                    if (bvamd::parse_site_rows(rows, n_sample, bi)) {  // else total depth 0, caller.cpp:718
+                        cur->slab.add_site(bi);
+                        cur->text.push_back(bvamd::site_text_of(bi));
+                    }
+                }
+                clk.parse += StageClock::now() - t1;
                 if (cur->slab.n_sites() == batch_sites) ship();
             }
         }
@@ -369,7 +408,23 @@ int main(int argc, char **argv) {
     std::fclose(VCF);
     std::fclose(CVG);
     if (!first_error.empty()) die(first_error);
+    const double total = StageClock::now() - t_start;
     std::cout << "[INFO] bv_call: " << n_sites << " covered positions, " << n_variants << " VCF records, " << n_sample
               << " samples, " << group_names.size() << " groups, " << G << " engine(s)" << std::endl;
+    // stage seconds: read / parse+pack on the producer thread (BAM input: pileup + pack, all under "parse"), engine summed over
+    // the workers (staging copies + kernels + records back), emit on the emitter thread; the stages overlap, total is wall time
+    char line[512];
+    std::snprintf(line, sizeof line,
+                  "[INFO] -- %.3f s elapsed, %.1f sites/s: read %.3f s, parse+pack %.3f s (%s), engine %.3f s (%zu worker(s), batches of %u sites), emit %.3f s",
+                  total, total > 0 ? n_sites / total : 0.0, clk.read, clk.parse, from_bam ? "pileup" : parser.c_str(), clk.engine, G, batch_sites, clk.emit);
+    std::cout << line << std::endl;
+    if (!timing_file.empty()) {
+        std::ofstream tf(timing_file);
+        tf << "{\"sites\": " << n_sites << ", \"vcf_records\": " << n_variants << ", \"samples\": " << n_sample << ", \"engines\": " << G
+           << ", \"batch_sites\": " << batch_sites << ", \"input\": \"" << (from_bam ? "bam" : "batchfile") << "\", \"parser\": \""
+           << (from_bam ? "pileup" : parser) << "\", \"total_s\": " << total << ", \"sites_per_s\": " << (total > 0 ? n_sites / total : 0.0)
+           << ", \"read_s\": " << clk.read << ", \"parse_pack_s\": " << clk.parse << ", \"engine_s\": " << clk.engine
+           << ", \"emit_s\": " << clk.emit << "}\n";
+    }
     return 0;
 }

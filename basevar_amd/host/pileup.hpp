@@ -36,6 +36,9 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <sys/resource.h>
+
+#include <memory>
 #include <thread>
 #include <tuple>
 #include <vector>
@@ -177,14 +180,52 @@ inline void pileup_claim_read(const BamAlignment &al, const std::string &fa, uin
     }
 }
 
+// The samples' BAM readers, kept open across windows: opening one parses the header and loads the .bai, which the
+// reference pays per 500 kb step and file (caller.cpp:876-900) and round 2 paid per WINDOW and file -- at 10^5 samples a
+// window is 64 positions.  As many readers stay open as the process may hold descriptors (RLIMIT_NOFILE less a margin);
+// the samples beyond that are opened per window as before.  A sample is touched by one worker at a time, so its
+// reader needs no lock.
+class BamPool {
+public:
+    BamPool(const std::vector<std::string> &paths, bool use_index) : paths_(paths), use_index_(use_index), open_(paths.size()) {
+        struct rlimit rl;
+        size_t lim = 256;
+        if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY) lim = (size_t)rl.rlim_cur;
+        else if (getrlimit(RLIMIT_NOFILE, &rl) == 0) lim = 1u << 20;
+        keep_ = lim > 96 ? std::min(paths.size(), lim - 96) : 0;
+        if (const char *k = std::getenv("BASEVAR_AMD_BAM_KEEP")) keep_ = std::min(paths.size(), (size_t)std::strtoul(k, nullptr, 10));  // measurements: 0 = reopen per window
+    }
+    struct Handle {
+        BamFile *bf;
+        std::unique_ptr<BamFile> own;  // a reader of this window only (beyond the descriptors the pool may keep)
+    };
+    Handle get(size_t i) {
+        if (i < keep_) {
+            if (!open_[i]) open_[i].reset(new BamFile(paths_[i], use_index_));
+            return Handle{open_[i].get(), nullptr};
+        }
+        Handle h{nullptr, std::unique_ptr<BamFile>(new BamFile(paths_[i], use_index_))};
+        h.bf = h.own.get();
+        return h;
+    }
+    size_t size() const { return paths_.size(); }
+    size_t kept() const { return keep_; }
+private:
+    const std::vector<std::string> &paths_;
+    bool use_index_;
+    size_t keep_ = 0;
+    std::vector<std::unique_ptr<BamFile>> open_;
+};
+
 // All reads of one sample that touch the tile.  [gb, ge] as above.
-inline void pileup_one_sample(const std::string &path, const std::string &fa, int mapq_thd, uint32_t gb, uint32_t ge, bool use_index,
+inline void pileup_one_sample(BamPool &pool, const std::string &fa, int mapq_thd, uint32_t gb, uint32_t ge,
                               size_t sample, PileupTile &t, std::vector<uint8_t> &seen, std::vector<PileupTile::IndelToken> &indels) {
     std::fill(seen.begin(), seen.end(), (uint8_t)0);
     // the reference fetches its step +- 200 bp and keeps the reads that overlap the step; for a window inside the
     // step the reads that can claim one of its cells are those that overlap the window (+ 1 for a left anchor)
     const uint32_t lo = t.beg > PILEUP_PAD ? t.beg - PILEUP_PAD : 1, hi = t.end + PILEUP_PAD;
-    BamFile bf(path, use_index);
+    BamPool::Handle h = pool.get(sample);
+    BamFile &bf = *h.bf;
     if (!bf.fetch(bf.tid_of(t.ref_id), (int64_t)lo - 1, (int64_t)hi)) return;
     BamAlignment al;
     while (bf.next(al) >= 0) {
@@ -200,8 +241,8 @@ inline void pileup_one_sample(const std::string &path, const std::string &fa, in
 
 // The pileup of every sample over [beg, end] into `t`.  `region_beg`: where the caller's whole region starts -- the
 // reference's steps are laid out from there in units of 500 kb, and [beg, end] must lie inside one of them.
-inline void pileup_tile(const std::vector<std::string> &bams, const std::string &fa, const std::string &ref_id, uint32_t region_beg,
-                        uint32_t region_end, uint32_t beg, uint32_t end, int mapq_thd, bool use_index, int n_threads, PileupTile &t) {
+inline void pileup_tile(BamPool &bams, const std::string &fa, const std::string &ref_id, uint32_t region_beg,
+                        uint32_t region_end, uint32_t beg, uint32_t end, int mapq_thd, int n_threads, PileupTile &t) {
     const uint32_t gb = region_beg + (beg - region_beg) / PILEUP_STEP * PILEUP_STEP;
     const uint32_t ge = std::min(region_end, gb + PILEUP_STEP - 1);
     if (end > ge) throw std::runtime_error("[pileup_tile] a window must not cross the 500 kb step grid");
@@ -216,7 +257,7 @@ inline void pileup_tile(const std::vector<std::string> &bams, const std::string 
         std::vector<uint8_t> seen(t.rows());
         for (size_t i; (i = next.fetch_add(1)) < n;) {
             try {
-                pileup_one_sample(bams[i], fa, mapq_thd, gb, ge, use_index, i, t, seen, found[(size_t)w]);
+                pileup_one_sample(bams, fa, mapq_thd, gb, ge, i, t, seen, found[(size_t)w]);
             } catch (const std::exception &ex) {
                 std::lock_guard<std::mutex> g(mu);
                 if (err.empty()) err = ex.what();
@@ -248,12 +289,13 @@ template <typename Fn>
 inline void pileup_region(const std::vector<std::string> &bams, const std::string &fa, const std::string &ref_id, uint32_t beg,
                           uint32_t end, int mapq_thd, bool use_index, int n_threads, Fn fn, uint32_t window = 0) {
     if (window == 0) window = pileup_window(bams.size());
+    BamPool pool(bams, use_index);
     PileupTile t;
     for (uint32_t sb = beg; sb <= end; sb += PILEUP_STEP) {
         const uint32_t se = std::min(end, sb + PILEUP_STEP - 1);
         for (uint32_t wb = sb; wb <= se; wb += window) {
             const uint32_t we = std::min(se, wb + window - 1);
-            pileup_tile(bams, fa, ref_id, beg, end, wb, we, mapq_thd, use_index, n_threads, t);
+            pileup_tile(pool, fa, ref_id, beg, end, wb, we, mapq_thd, n_threads, t);
             fn(t);
             if (we == UINT32_MAX) return;
         }

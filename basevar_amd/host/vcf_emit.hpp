@@ -82,19 +82,35 @@ inline std::string format_vcf_line(const SiteText &st, const uint8_t *cell, cons
         cm_af.push_back(r.af[i]);
         cm_caf.push_back(r.caf[i]);
     }
-    // per-sample GT:AB:SO:BP, caller.cpp:1125-1145
-    std::vector<std::string> samples;
-    samples.reserve(n);
+    // per-sample GT:AB:SO:BP, caller.cpp:1125-1145 -- the same text the reference builds with a vector of strings and
+    // ngslib::join (one ostringstream per sample), appended directly: a VCF line is n_samples fields, and at 10^4 samples the
+    // emitter, not the engine, sets the pace of a run (profiles/r3_host_pipeline.txt).  std::to_string(1 - eps(q)) depends on
+    // the phred byte only: 256 strings, formed once.
+    static const std::vector<std::string> bp_text = [] {
+        std::vector<std::string> t(256);
+        for (int qv = 0; qv < 256; ++qv) t[(size_t)qv] = std::to_string(1.0 - std::exp(qv * EMIT_MLN10TO10));  // basetype.cpp:47-48
+        return t;
+    }();
+    std::string gt_of[4];
+    for (int b = 0; b < 4; ++b) {
+        const auto it = alt_gt.find(EMIT_BASES[b]);
+        gt_of[b] = it == alt_gt.end() ? "./." : it->second;
+    }
     const char upper_ref = (char)std::toupper((unsigned char)st.ref_base[0]);
+    std::string samples;
+    samples.reserve(n * 5);
     for (size_t i = 0; i < n; ++i) {
+        if (i) samples += '\t';
         if (!(cell[i] & BV_CELL_NOCALL)) {
-            const char fb = EMIT_BASES[cell[i] & 3];
-            if (alt_gt.find(fb) == alt_gt.end()) alt_gt[fb] = "./.";
-            const std::string gt = (fb == upper_ref) ? "0/." : alt_gt[fb];
-            const double epsilon = std::exp((int)phred[i] * EMIT_MLN10TO10);  // basetype.cpp:47-48 (quality char - 33)
-            samples.push_back(gt + ":" + fb + ":" + ((cell[i] & BV_CELL_REV) ? '-' : '+') + ":" + std::to_string(1.0 - epsilon));
+            const int bc = cell[i] & 3;
+            const char fb = EMIT_BASES[bc];
+            if (fb == upper_ref) samples += "0/."; else samples += gt_of[bc];
+            samples += ':'; samples += fb; samples += ':';
+            samples += (cell[i] & BV_CELL_REV) ? '-' : '+';
+            samples += ':';
+            samples += bp_text[phred[i]];
         } else {
-            samples.push_back("./.");
+            samples += "./.";
         }
     }
     const int mq_rank_sum = (int)r.mq_ranksum, read_pos_rank_sum = (int)r.rpr_ranksum, base_q_rank_sum = (int)r.bq_ranksum;
@@ -121,7 +137,7 @@ inline std::string format_vcf_line(const SiteText &st, const uint8_t *cell, cons
     }
     const std::string qs = (r.qual > EMIT_QUAL_THRESHOLD) ? "." : "LowQual";
     return st.ref_id + "\t" + std::to_string(st.ref_pos) + "\t.\t" + st.ref_base + "\t" + join(alt_bases, ",") + "\t" +
-           std::to_string(r.qual) + "\t" + qs + "\t" + join(info, ";") + "\tGT:AB:SO:BP\t" + join(samples, "\t") + "\n";
+           std::to_string(r.qual) + "\t" + qs + "\t" + join(info, ";") + "\tGT:AB:SO:BP\t" + samples + "\n";
 }
 
 // The same from a BatchInfo (the reference's per-site input): its tokens are packed into a slab row first.

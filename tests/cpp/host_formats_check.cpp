@@ -12,6 +12,7 @@
 
 #include "../../basevar_amd/host/basetype_gpu.hpp"
 #include "../../basevar_amd/host/vcf_emit.hpp"
+#include "../../basevar_amd/host/batchfile_fast.hpp"
 
 using namespace bvamd;
 
@@ -135,6 +136,100 @@ int main(int argc, char **argv) {
         threw = false;
         try { BatchInfo b; parse_site_rows({"chr1\t5\tA\t1\t60\tA\tI\t3\t+", "chr1\t6\tA\t1\t60\tA\tI\t3\t+"}, 2, b); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("same genome coordinate") != std::string::npos; }
         CHECK(threw, "coordinate mismatch -> error");
+    }
+
+    // ---- (2b) the byte-level reader (batchfile_fast.hpp) against the literal one (batchfile.hpp + SlabBuilder::add_site): the
+    // same slab row and SiteText, the same "skipped", or the same exception text -- on the valid rows above and on rows
+    // damaged at random (tokens dropped / doubled / emptied, characters replaced, columns removed, signs and junk in numbers)
+    {
+        struct Outcome {
+            int kind = 0;  // 0 row added, 1 skipped (depth 0), 2 threw
+            std::string what, planes, text;
+        };
+        auto snapshot = [&](const SlabBuilder &sb, const SiteText &t) {
+            Outcome o;
+            const bv_slab sl = sb.slab();
+            if (sl.n_sites) {
+                o.planes.assign((const char *)sl.base_strand, sl.pitch);
+                o.planes.append((const char *)sl.qual, sl.pitch);
+                o.planes.append((const char *)sl.mapq, sl.pitch);
+                o.planes.append((const char *)sl.rpr, sl.pitch * 2);
+                o.planes.push_back((char)sl.ref_base[0]);
+            }
+            o.text = t.ref_id + "|" + std::to_string(t.ref_pos) + "|" + t.ref_base + "|" + pack(t.indel_tokens);
+            return o;
+        };
+        auto literal = [&](const std::vector<std::string> &rows, size_t n) {
+            Outcome o;
+            try {
+                BatchInfo bi;
+                if (!parse_site_rows(rows, n, bi)) { o.kind = 1; return o; }
+                SlabBuilder sb((uint32_t)n);
+                sb.add_site(bi);
+                o = snapshot(sb, site_text_of(bi));
+            } catch (const std::exception &e) { o.kind = 2; o.what = e.what(); }
+            return o;
+        };
+        auto fast = [&](const std::vector<std::string> &rows, size_t n) {
+            Outcome o;
+            try {
+                SlabBuilder sb((uint32_t)n);
+                SiteText t;
+                if (!parse_site_rows_fast(rows, n, sb, t)) { o.kind = 1; CHECK(sb.n_sites() == 0 && sb.slab().n_sites == 0, "a skipped row leaves nothing"); return o; }
+                o = snapshot(sb, t);
+            } catch (const std::exception &e) { o.kind = 2; o.what = e.what(); }
+            return o;
+        };
+        size_t n_valid = 0, n_skipped = 0, n_threw = 0;
+        auto compare = [&](const std::vector<std::string> &rows, size_t n, const char *tag) {
+            const Outcome a = literal(rows, n), b = fast(rows, n);
+            // (std::stoi's own exception texts are the library's; the two readers call it on the same fields)
+            const bool same = a.kind == b.kind && a.what == b.what && a.planes == b.planes && (a.kind != 0 || a.text == b.text);
+            CHECK(same, "fast reader != literal reader (" << tag << "): kinds " << a.kind << "/" << b.kind << " [" << a.what << "] vs [" << b.what << "] rows[0]=" << rows[0].substr(0, 200));
+            (a.kind == 0 ? n_valid : a.kind == 1 ? n_skipped : n_threw)++;
+        };
+        for (const BatchInfo &bi : sites) {
+            std::vector<std::string> rows;
+            for (uint32_t b = 0; b < NBF; ++b) {
+                uint32_t first = b * (N / NBF), cnt = N / NBF, cov = 0;
+                for (uint32_t i = first; i < first + cnt; ++i) cov += bi.align_bases[i] != "N";
+                std::string row = format_batchfile_row(bi, first, cnt, cov);
+                row.pop_back();
+                rows.push_back(row);
+            }
+            compare(rows, N, "valid");
+            for (int rep = 0; rep < 40; ++rep) {  // damage
+                std::vector<std::string> bad = rows;
+                const int hits = 1 + (int)(rnd() % 3);
+                for (int hgt = 0; hgt < hits; ++hgt) {
+                    std::string &r = bad[rnd() % bad.size()];
+                    if (r.empty()) continue;
+                    const size_t at = rnd() % r.size();
+                    switch (rnd() % 9) {
+                        case 0: r.erase(at, 1 + rnd() % 3); break;
+                        case 1: r.insert(at, " "); break;
+                        case 2: r.insert(at, "\t"); break;
+                        case 3: r[at] = "ACGTN+-.!x5 \t-"[rnd() % 14]; break;
+                        case 4: r.insert(at, "-7"); break;
+                        case 5: r.insert(at, "99999999999"); break;
+                        case 6: { const size_t sp = r.find(' ', at); if (sp != std::string::npos) r.erase(at, sp - at); break; }
+                        case 7: { const size_t tb = r.rfind('\t'); if (tb != std::string::npos && (rnd() & 1)) r.erase(tb); break; }
+                        default: r.insert(at, "+ACG"); break;
+                    }
+                }
+                compare(bad, N, "damaged");
+            }
+        }
+        compare({"chr1\t5\tA\t1\t60"}, 1, "short row");
+        compare({"chr1\t5\tA\t1\t60\tA\tI\t3\t+", "chr1\t6\tA\t1\t60\tA\tI\t3\t+"}, 2, "coordinate mismatch");
+        compare({"chr1\t5\tA\t0\t60\tAC\tI\t3\tx"}, 1, "depth 0 hides a bad token");
+        compare({"chr1\t5\tA\t1\t60\tAC\tI\t3\tx"}, 1, "base token of two characters");
+        compare({"chr1\t5\tA\t1\t60\tR\tI\t3\t+"}, 1, "base outside ACGT");
+        compare({"chr1\t5\tA\t1\t60\tA\tI\t3\tx"}, 1, "strange strand");
+        compare({"chr1\t5\tA\t2\t60 \tA N\t I\t3 +4\t+ ."}, 2, "empty tokens");
+        compare({"chr1\t5\ta\t1\t-3\t+AT\t\t70000\t-"}, 1, "negative mapq, empty quality, rank past 16 bits");
+        std::cout << "FAST_READER_CASES valid " << n_valid << " skipped " << n_skipped << " threw " << n_threw << std::endl;
+        CHECK(n_valid > 100 && n_threw > 100, "the damaged rows exercise both outcomes");
     }
 
     // ---- (3) records from the oracle restatement -> lines

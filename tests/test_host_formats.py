@@ -100,6 +100,7 @@ def test_host_formats_harness(tmp_path, restatement):
     out = subprocess.run(args + [recs], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "PRIMITIVES_CHECKED 1" in out.stdout and "FAILS 0" in out.stdout
+    assert "FAST_READER_CASES" in out.stdout  # the byte-level batchfile reader against the literal one
     lines = out.stdout.split("\n")
     # headers
     cvg_h = lines[lines.index("CVG_HEADER_BEGIN") + 1:lines.index("CVG_HEADER_END")]
