@@ -17,6 +17,7 @@ BV_MAX_ALT = 4
 BV_MAX_GROUPS = 32
 BV_NO_GROUP = 0xFF
 BV_MEM_DEVICE, BV_MEM_HOST = 0, 1
+BV_FLAG_LANES = 0x10000000  # include/basevar_amd.h
 # bv_engine_config.flags (include/basevar_amd.h)
 BV_FLAG_TALLY_ONLY, BV_FLAG_SKIP_FISHER, BV_FLAG_SKIP_LRT, BV_FLAG_TILE_STATE, BV_FLAG_WAVE_SOLVER = 0x1, 0x2, 0x4, 0x8, 0x10
 BV_OK, BV_ERR_INVALID_ARG, BV_ERR_NO_DEVICE, BV_ERR_HIP, BV_ERR_TOO_LARGE, BV_ERR_SITE = 0, -1, -2, -3, -4, -5
@@ -59,7 +60,7 @@ class SynthParams(C.Structure):
 
 
 # every symbol include/basevar_amd.h declares
-EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_submit_many", "bv_engine_wait",
+EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_submit_many", "bv_engine_wait", "bv_engine_join",
            "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_add_many", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
            "bv_host_log_probe", "bv_host_log_eval", "bv_engine_host_log_exact", "bv_engine_host_log_eval",
@@ -98,6 +99,8 @@ def load():
     L.bv_engine_submit.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p, C.c_void_p, C.c_void_p]
     L.bv_engine_submit_many.restype = C.c_int
     L.bv_engine_submit_many.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Slab), C.POINTER(C.c_void_p), C.c_void_p]
+    L.bv_engine_join.restype = C.c_int
+    L.bv_engine_join.argtypes = [C.c_void_p, C.c_void_p]
     L.bv_engine_tiles_begin.restype = C.c_int
     L.bv_engine_tiles_begin.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.bv_engine_tiles_add.restype = C.c_int

@@ -236,6 +236,13 @@ struct bv_engine {
     bool tile_join = false;
     uint8_t *j_buf = nullptr;
     size_t j_bytes = 0, j_pitch = 0, j_o_q = 0, j_o_mq = 0, j_o_rp = 0, j_o_gid = 0;
+    // BV_FLAG_LANES: device-resident submits alternate between two child engines (streams and scratch of their own), so that
+    // the solve kernels of one submit run under the streaming kernels of the next; the parent runs no kernels then
+    bv_engine *lane[2] = {nullptr, nullptr};
+    unsigned lane_next = 0;
+    int last_lane = -1;
+    bool is_lane = false;
+    hipEvent_t ev_entry = nullptr;     // what a lane waits for: the caller's stream at the time of the submit
     // bv_engine_tiles_add_many: descriptor tables, a ring of pinned host + device buffers
     static constexpr int kDescRing = 4;
     BvTileScatterPlane *h_desc[kDescRing] = {}, *d_desc[kDescRing] = {};
@@ -485,16 +492,6 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
     BV_TRY(hipHostMalloc(&e->h_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks));
     std::memset(e->h_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks);
     BV_TRY(hipMemset(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks));
-    {
-        // the second stream carries short kernels that must get in beside long streaming kernels: highest queue priority
-        int least = 0, greatest = 0;
-        BV_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const char *pr = std::getenv("BASEVAR_AMD_AUX_PRIO");  // tuning: 0 = default priority
-        if (pr && pr[0] == '0') BV_TRY(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
-        else BV_TRY(hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, greatest));
-    }
-    for (auto &ev : e->ev_s) BV_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    for (auto &ev : e->ev_v) BV_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 
     // eps table with the host libm, exactly the reference's expression (basetype.cpp:47-48, :63)
     BvTables t;
@@ -539,6 +536,22 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
     }
     BV_TRY(hipMemcpy(e->d_tables, &t, sizeof(t), hipMemcpyHostToDevice));
 #undef BV_TRY
+    if (cfg->flags & BV_FLAG_LANES) {
+        // the two lanes now, not at their first submit: a process has few hardware queues and streams are dealt to them in
+        // the order they are created -- created late, the lanes landed on queues already carrying other streams
+        for (int k = 0; k < 2; ++k) {
+            bv_engine_config c = *cfg;
+            c.flags &= ~BV_FLAG_LANES;
+            const int rc = bv_engine_create(&c, &e->lane[k]);
+            if (rc != BV_OK) {
+                const std::string m = bv_last_error(nullptr);
+                bv_engine_destroy(e);
+                set_global_error("bv_engine_create: lane engine: " + m);
+                return rc;
+            }
+            e->lane[k]->is_lane = true;
+        }
+    }
     *out = e;
     return BV_OK;
 }
@@ -546,6 +559,11 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
 int bv_engine_destroy(bv_engine *e) {
     if (!e) return BV_OK;
     (void)hipSetDevice(e->cfg.device);
+    for (bv_engine *&l : e->lane) {
+        if (l) (void)bv_engine_destroy(l);
+        l = nullptr;
+    }
+    if (e->ev_entry) (void)hipEventDestroy(e->ev_entry);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipStream_t st : e->used_streams) (void)hipStreamSynchronize(st);
     if (e->aux) (void)hipStreamSynchronize(e->aux);
@@ -683,6 +701,13 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         if (H > bv_engine::kCtrBlocks) H = bv_engine::kCtrBlocks;
         while (H > 1u && n_sites / H < 256u) --H;
     }
+    if (H > 1u && !e->aux) {
+        // the second stream and its events exist only for engines that pipeline (a process has few hardware queues: every
+        // stream beyond them shares one)
+        BV_HIP(e, hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
+        for (auto &ev : e->ev_s) BV_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        for (auto &ev : e->ev_v) BV_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
     e->last_blocks = H;
     for (uint32_t c = 0; c < H; ++c)  // the per-launch lines of every block used (not the sticky error counters)
         BV_HIP(e, hipMemsetAsync(e->d_counters + (size_t)c * BV_CTR_WORDS, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));
@@ -799,6 +824,33 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: device record buffers must be 16-byte aligned");
 
     BV_HIP(e, hipSetDevice(e->cfg.device));
+    if ((e->cfg.flags & BV_FLAG_LANES) && !e->is_lane && slab->mem_kind != BV_MEM_HOST) {
+        // two lanes: this submit goes to the child engine whose turn it is, on that child's own stream, ordered behind what
+        // the caller's stream holds now; the caller's stream gets nothing back (bv_engine_join / bv_engine_wait)
+        const int k = (int)(e->lane_next++ & 1u);
+        if (!e->lane[k]) {
+            bv_engine_config c = e->cfg;
+            c.flags &= ~BV_FLAG_LANES;
+            int rc = bv_engine_create(&c, &e->lane[k]);
+            if (rc != BV_OK) return fail(e, rc, std::string("bv_engine_submit: lane engine: ") + bv_last_error(nullptr));
+            e->lane[k]->is_lane = true;
+        }
+        bv_engine *l = e->lane[k];
+        // (only if that stream holds unfinished work: recording an event on an idle stream and waiting for it on another cost
+        // 0.5-2 ms per submit on this stack -- measured, round 3 -- against ~10 us when the marker follows real work)
+        if (stream_ && hipStreamQuery((hipStream_t)stream_) != hipSuccess) {
+            (void)hipGetLastError();  // hipErrorNotReady is the answer, not an error
+            if (!e->ev_entry) BV_HIP(e, hipEventCreateWithFlags(&e->ev_entry, hipEventDisableTiming));
+            BV_HIP(e, hipEventRecord(e->ev_entry, (hipStream_t)stream_));
+            BV_HIP(e, hipStreamWaitEvent(l->stream, e->ev_entry, 0));
+        }
+        const int rc = bv_engine_submit(l, slab, out, gout, nullptr);
+        if (rc != BV_OK) return fail(e, rc, bv_last_error(l));
+        e->last_lane = k;
+        e->submitted = true;
+        return BV_OK;
+    }
+    e->last_lane = -1;
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
     {
         int rc = use_stream(e, st);
@@ -1288,6 +1340,12 @@ int bv_engine_wait(bv_engine *e) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_wait: null engine");
     if (!e->submitted) return BV_OK;
     BV_HIP(e, hipSetDevice(e->cfg.device));
+    for (bv_engine *l : e->lane) {
+        if (!l) continue;
+        const int rc = bv_engine_wait(l);
+        if (rc != BV_OK) return fail(e, rc, bv_last_error(l));
+    }
+    if (e->last_stream == nullptr && e->used_streams.empty()) return BV_OK;  // only lanes carried work
     // every stream that carried a submit since the last wait (submits of one engine are serialised through ev_done,
     // so the counters mirrored by the LAST submit are final once all of them have drained)
     for (hipStream_t st : e->used_streams) BV_HIP(e, hipStreamSynchronize(st));
@@ -1320,6 +1378,7 @@ int bv_engine_wait(bv_engine *e) {
 
 int bv_engine_kernel_ms(bv_engine *e, float *pass1_ms, float *pass2_ms) {
     if (!e || !e->submitted) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_kernel_ms: nothing submitted");
+    if (e->last_lane >= 0) return bv_engine_kernel_ms(e->lane[e->last_lane], pass1_ms, pass2_ms);
     if (e->last_slot < 0)
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_kernel_ms: the last job recorded no pass timings (per-site-tally tile job)");
     float a = 0.f, b = 0.f;
@@ -1339,6 +1398,8 @@ int bv_engine_timing_reset(bv_engine *e) {
     if (rc != BV_OK) return rc;
     e->acc1_ms = e->acc2_ms = e->acc_stream_ms = 0.;
     e->acc_n = 0;
+    for (bv_engine *l : e->lane)
+        if (l && (rc = bv_engine_timing_reset(l)) != BV_OK) return rc;
     return BV_OK;
 }
 
@@ -1347,9 +1408,17 @@ int bv_engine_timing_get(bv_engine *e, double *pass1_total_ms, double *pass2_tot
     BV_HIP(e, hipSetDevice(e->cfg.device));
     int rc = drain_timings(e, true);
     if (rc != BV_OK) return rc;
-    if (pass1_total_ms) *pass1_total_ms = e->acc1_ms;
-    if (pass2_total_ms) *pass2_total_ms = e->acc2_ms;
-    if (n_submits) *n_submits = e->acc_n;
+    double a1 = e->acc1_ms, a2 = e->acc2_ms;
+    uint32_t an = e->acc_n;
+    for (bv_engine *l : e->lane) {  // the lanes' submits are this engine's
+        if (!l) continue;
+        double x = 0, y = 0; uint32_t m = 0;
+        if ((rc = bv_engine_timing_get(l, &x, &y, &m)) != BV_OK) return rc;
+        a1 += x; a2 += y; an += m;
+    }
+    if (pass1_total_ms) *pass1_total_ms = a1;
+    if (pass2_total_ms) *pass2_total_ms = a2;
+    if (n_submits) *n_submits = an;
     return BV_OK;
 }
 
@@ -1359,10 +1428,31 @@ int bv_engine_timing_get_ex(bv_engine *e, double *stream_total_ms, double *pass1
     BV_HIP(e, hipSetDevice(e->cfg.device));
     int rc = drain_timings(e, true);
     if (rc != BV_OK) return rc;
-    if (stream_total_ms) *stream_total_ms = e->acc_stream_ms;
-    if (pass1_total_ms) *pass1_total_ms = e->acc1_ms;
-    if (pass2_total_ms) *pass2_total_ms = e->acc2_ms;
-    if (n_submits) *n_submits = e->acc_n;
+    double as = e->acc_stream_ms, a1 = e->acc1_ms, a2 = e->acc2_ms;
+    uint32_t an = e->acc_n;
+    for (bv_engine *l : e->lane) {
+        if (!l) continue;
+        double w = 0, x = 0, y = 0; uint32_t m = 0;
+        if ((rc = bv_engine_timing_get_ex(l, &w, &x, &y, &m)) != BV_OK) return rc;
+        as += w; a1 += x; a2 += y; an += m;
+    }
+    if (stream_total_ms) *stream_total_ms = as;
+    if (pass1_total_ms) *pass1_total_ms = a1;
+    if (pass2_total_ms) *pass2_total_ms = a2;
+    if (n_submits) *n_submits = an;
+    return BV_OK;
+}
+
+// Make `stream` wait for every submit issued so far.  Without BV_FLAG_LANES the submits already ran on the stream they
+// were given; with it they run on the lanes' own streams and a consumer ordered on a stream (a gather of the records,
+// a copy) calls this first.
+int bv_engine_join(bv_engine *e, void *stream_) {
+    if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_join: null engine");
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    for (bv_engine *l : e->lane)
+        if (l && l->ev_done_set) BV_HIP(e, hipStreamWaitEvent(st, l->ev_done, 0));
+    if (e->ev_done_set && st != e->last_stream) BV_HIP(e, hipStreamWaitEvent(st, e->ev_done, 0));
     return BV_OK;
 }
 
@@ -1403,6 +1493,7 @@ int bv_engine_host_log_eval(bv_engine *e, const double *x, double *y, uint32_t n
 
 int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant) {
     if (!e || !n_variant) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_last_variant_count: null argument");
+    if (e->last_lane >= 0) return bv_engine_last_variant_count(e->lane[e->last_lane], n_variant);
     uint32_t n = 0;
     for (uint32_t b = 0; b < e->last_blocks; ++b) n += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_VARIANTS];
     *n_variant = n;

@@ -126,6 +126,11 @@ class BaseTypeEngine:
         if rc != 0:
             raise RuntimeError("bv_engine_submit_many failed (%d): %s" % (rc, self._err()))
 
+    def join(self, stream=0):
+        """Make `stream` wait for every submit issued so far (needed with BV_FLAG_LANES: bv_engine_join)."""
+        if self._lib.bv_engine_join(self._h, C.c_void_p(stream) if stream else None) != 0:
+            raise RuntimeError("bv_engine_join: " + self._err())
+
     def stream_handle(self):
         """hipStream_t of the engine's own stream as an int (e.g. for torch.cuda.ExternalStream)."""
         return int(self._lib.bv_engine_stream(self._h) or 0)

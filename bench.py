@@ -54,6 +54,10 @@ def parse():
                          "batch runs under the stream of the next; 1 = one submit per batch")
     ap.add_argument("--streams", type=int, default=1,
                     help="engines/HIP streams used round-robin for consecutive batches (tails of one batch overlap the next)")
+    ap.add_argument("--lanes", type=int, default=1, choices=(1, 2),
+                    help="2: the engine runs consecutive submits on two internal lanes (BV_FLAG_LANES: a second stream and scratch "
+                         "set inside ONE engine), so the solve kernels of a batch run under the streaming kernels of the next; the "
+                         "timed region is still K back-to-back steps on resident batches")
     ap.add_argument("--groups", type=int, default=0,
                     help="diagnostic: G pop-groups (random membership, ~15 % of the samples in none): adds the per-group calls of pass 2")
     ap.add_argument("--with-tile-mode", action="store_true",
@@ -257,12 +261,13 @@ def main():
 
     ns = max(1, args.streams)
     engs = [basevar_amd.BaseTypeEngine(max_sites=Bl, min_af_value=maf, device=local_rank,
-                                       flags=(1 if args.tally_only else 0) | args.flags) for _ in range(ns)]
+                                       flags=(1 if args.tally_only else 0) | args.flags | (0x10000000 if args.lanes == 2 else 0))
+            for _ in range(ns)]
     eng = engs[0]
     rec = basevar_amd.SITE_DTYPE.itemsize
     # record buffers: one per stream at N = 1; a ring of 3 per rank at N > 1 so that the gather of
     # batch i (RCCL, asynchronous) overlaps the kernels of batches i+1 and i+2
-    depth = 3 if dist_on else ns
+    depth = 3 if dist_on else ns * args.lanes  # (submits in flight write distinct record buffers)
     gloo_host = dist_on and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
     outs = [torch.zeros(Bl * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
     houts = [torch.zeros(Bl * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None
@@ -305,8 +310,10 @@ def main():
                 engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                     mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
                                     group_id=gid.data_ptr() if G else 0, n_groups=G, gout=gouts[slot].data_ptr() if G else 0,
-                                    stream=streams[k].cuda_stream)
+                                    stream=(0 if os.environ.get("BASEVAR_BENCH_NULLSTREAM") else streams[k].cuda_stream))
             if gatherer is not None:
+                if args.lanes == 2:
+                    engs[k].join(streams[k].cuda_stream)  # the lanes run on streams of their own: order the gather behind them
                 if gloo_host:
                     houts[slot].copy_(out)
                     gatherer.issue(slot, houts[slot])
@@ -409,7 +416,7 @@ def main():
                                 "strong scaling: the job's %d-site batch split over the ranks" % (world * B)
                                 if args.scaling == "strong" else "weak scaling: per-GPU batch fixed",
                                 (1000000 + world * B - 1) // (world * B) if args.scaling == "strong" else (1000000 + B - 1) // B),
-                "samples": N, "batch_sites": B, "chain": K, "sites_per_launch": Bl, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
+                "samples": N, "batch_sites": B, "engine_lanes": args.lanes, "chain": K, "sites_per_launch": Bl, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
                 "parallelism": "site-sharded x%d, gather of %d-byte records to rank 0" % (world, rec),
                 "job_batch_sites": world * Bl, "backend": (backend if dist_on else None),
                 "rccl_ranks": (dist.get_world_size() if dist_on and backend == "nccl" else 0),

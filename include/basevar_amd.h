@@ -167,6 +167,13 @@ typedef struct bv_group_result {
                                      stream).  Default (flag clear): host planes must be COMPLETE in host memory when bv_engine_submit /
                                      bv_engine_tiles_add / bv_engine_tiles_finish is called and stay untouched until bv_engine_wait --
                                      the copies run on streams of the engine's own, ahead of `stream`, under earlier kernels */
+#define BV_FLAG_LANES 0x10000000u /* two lanes: device-resident submits (bv_engine_submit, BV_MEM_DEVICE) alternate between two internal
+                                     streams with a scratch set each, so that the kernels of consecutive submits overlap -- on short rows the
+                                     solve kernels of one batch (issue-bound, no HBM traffic) run under the streaming kernels of the next.
+                                     The `stream` argument then only ORDERS the submit behind the caller's earlier work on that stream; the
+                                     records are complete after bv_engine_wait(), or on a stream that called bv_engine_join() after the
+                                     submit.  The slabs and record buffers of submits in flight must be distinct.  Records do not depend
+                                     on the flag. */
 #define BV_FLAG_TILE_STATE 0x8u  /* tile mode: always accumulate per-site tallies (the fallback for jobs whose
                                     joined planes do not fit the HBM) instead of joining the tiles into rows */
 
@@ -220,6 +227,10 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
  * sites together; anything else is submitted slab by slab.  bv_engine_last_variant_count then counts the last launch.
  * Replaces nothing in the reference (its workers take one position at a time, basetype_caller.cpp:738-762). */
 int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, bv_site_result *const *outs, void *stream);
+
+/* Enqueue on `stream` (NULL: the engine's own) a wait for every submit issued so far.  Needed only with BV_FLAG_LANES (there
+ * the submits run on internal streams); otherwise a no-op for the stream the submits were given. */
+int bv_engine_join(bv_engine *e, void *stream);
 
 /* The engine's own HIP stream (hipStream_t), so that a caller can order other work on it -- e.g.
  * wrap it (torch.cuda.ExternalStream) and issue the RCCL gather of the records behind the kernels. */

@@ -533,6 +533,49 @@ def test_exact_tie_site_follows_the_reference_rounding(bv, restatement):
     assert got.sites["n_alt"][0] == 0
 
 
+@pytest.mark.parametrize("n", [9000, 70000], ids=["short_rows", "long_rows"])
+def test_two_lanes_give_the_records_of_one(bv, n):
+    """BV_FLAG_LANES: six device-resident submits in flight over the engine's two internal lanes (distinct slabs and record
+    buffers) give, after bv_engine_wait, the records of six plain submits byte for byte -- also with pop-groups, also when a
+    consumer stream is ordered behind them with bv_engine_join."""
+    import torch
+    from basevar_amd import _capi
+    dev = torch.device("cuda:0")
+    S, G = 700, 2
+    maf = bv.min_af(n)
+    slabs = [make_slab(S, n, seed=500 + i, coverage=0.07, n_groups=G, site_offset=13 * i) for i in range(6)]
+    want = [run_engine(bv, sl, maf) for sl in slabs]
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=_capi.BV_FLAG_LANES)
+    rec, grec = bv.SITE_DTYPE.itemsize, bv.GROUP_DTYPE.itemsize
+    keep, outs, gouts = [], [], []
+    side = torch.cuda.Stream()
+    copies = []
+    for sl in slabs:
+        t = {k: torch.from_numpy(np.ascontiguousarray(sl[k] if k != "rpr" else sl[k].view(np.int16))).to(dev)
+             for k in ("base_strand", "qual", "mapq", "rpr", "ref_base", "group_id")}
+        out = torch.zeros(S * rec, dtype=torch.uint8, device=dev)
+        gout = torch.zeros(S * G * grec, dtype=torch.uint8, device=dev)
+        keep.append(t); outs.append(out); gouts.append(gout)
+    torch.cuda.synchronize()
+    for t, out, gout in zip(keep, outs, gouts):
+        pitch = t["base_strand"].shape[1]
+        eng.submit_ptrs(S, n, pitch, t["base_strand"].data_ptr(), t["qual"].data_ptr(), t["ref_base"].data_ptr(), out.data_ptr(),
+                        t["mapq"].data_ptr(), t["rpr"].data_ptr(), group_id=t["group_id"].data_ptr(), n_groups=G, gout=gout.data_ptr())
+    # a consumer on another stream, ordered behind the submits by bv_engine_join
+    eng.join(side.cuda_stream)
+    with torch.cuda.stream(side):
+        copies = [o.clone() for o in outs]
+    side.synchronize()
+    for c, w in zip(copies, want):
+        assert c.cpu().numpy().tobytes() == w.sites.tobytes()
+    eng.wait()
+    for out, gout, w in zip(outs, gouts, want):
+        assert out.cpu().numpy().tobytes() == w.sites.tobytes()
+        assert gout.cpu().numpy().tobytes() == w.groups.tobytes()
+    assert eng.last_variant_count() == want[-1].n_variant
+    eng.close()
+
+
 def test_two_engines_on_two_host_threads(bv, restatement):
     """One engine per host thread (the reference runs one BaseType per ThreadPool worker,
     src/basetype_caller.cpp:485-510): concurrent submits must not interfere."""
