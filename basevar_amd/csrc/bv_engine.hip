@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <link.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -238,7 +239,9 @@ struct bv_engine {
     size_t j_bytes = 0, j_pitch = 0, j_o_q = 0, j_o_mq = 0, j_o_rp = 0, j_o_gid = 0;
     // BV_FLAG_LANES: device-resident submits alternate between two child engines (streams and scratch of their own), so that
     // the solve kernels of one submit run under the streaming kernels of the next; the parent runs no kernels then
-    bv_engine *lane[2] = {nullptr, nullptr};
+    static constexpr int kMaxLanes = 4;
+    bv_engine *lane[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+    int n_lanes = 2;                   // (BASEVAR_AMD_LANES: tuning runs)
     unsigned lane_next = 0;
     int last_lane = -1;
     bool is_lane = false;
@@ -539,7 +542,8 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
     if (cfg->flags & BV_FLAG_LANES) {
         // the two lanes now, not at their first submit: a process has few hardware queues and streams are dealt to them in
         // the order they are created -- created late, the lanes landed on queues already carrying other streams
-        for (int k = 0; k < 2; ++k) {
+        if (const char *nl = std::getenv("BASEVAR_AMD_LANES")) e->n_lanes = std::max(2, std::min((int)bv_engine::kMaxLanes, std::atoi(nl)));
+        for (int k = 0; k < e->n_lanes; ++k) {
             bv_engine_config c = *cfg;
             c.flags &= ~BV_FLAG_LANES;
             const int rc = bv_engine_create(&c, &e->lane[k]);
@@ -827,7 +831,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
     if ((e->cfg.flags & BV_FLAG_LANES) && !e->is_lane && slab->mem_kind != BV_MEM_HOST) {
         // two lanes: this submit goes to the child engine whose turn it is, on that child's own stream, ordered behind what
         // the caller's stream holds now; the caller's stream gets nothing back (bv_engine_join / bv_engine_wait)
-        const int k = (int)(e->lane_next++ & 1u);
+        const int k = (int)(e->lane_next++ % (unsigned)e->n_lanes);
         if (!e->lane[k]) {
             bv_engine_config c = e->cfg;
             c.flags &= ~BV_FLAG_LANES;

@@ -526,19 +526,10 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
 
 }
 
-// ---- every non-candidate site (hom-ref or uncovered), one lane per site.  A kernel of its own (as are the two phases of the
-// 16-lane solver below): each then runs out of a few KB of code -- as one kernel the three were 207 KB against an instruction
-// cache of 64 KB per pair of CUs.
-__global__ __launch_bounds__(256) void bv_p1s_simple_kernel(BvP1ShortArgs a) {
-    const uint32_t site = blockIdx.x * 256u + threadIdx.x;
-    if (site >= a.n_sites) return;
-    BvLnTab lnfact;
-    lnfact.t = a.tables->lnfact; lnfact.n = (int)a.tables->lnfact_n;
-    bv_p1s_simple_site(a, lnfact, site);
-}
-
-// ---- the ordinary candidates, four per wave: one site per group of 16 lanes (bv_solver16.h), in two kernels -- the LRT,
-// then everything that follows it.  Jobs (four sites of one list) are numbered with the sites of three or four active bases
+// ---- the ordinary candidates, four per wave: one site per group of 16 lanes (bv_solver16.h), in two phases -- the LRT,
+// then everything that follows it (bv_site_lrt_g16 / bv_site_tail_g16).  Measured as two kernels too (one per phase, and a third
+// for the non-candidates): 0.125 ms per 100 k sites against 0.105 ms for the one below -- two kernel boundaries and two tails more.
+// Jobs (four sites of one list) are numbered with the sites of three or four active bases
 // first (several times the EM runs: longest jobs first).  Jobs and workgroups are dealt to BV_TICKET_SLICES slices (job j and
 // workgroup w belong to slice j, w mod BV_TICKET_SLICES); a wave's first job is its rank in the slice, every further one is
 // drawn from the slice's ticket counter when the wave gets there -- no draw at the start of the kernel, where all waves
@@ -586,12 +577,15 @@ __device__ __forceinline__ BvP1sJob bv_p1s_job(const BvP1ShortArgs &a, uint32_t 
     return j;
 }
 
-__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_lrt16_kernel(BvP1ShortArgs a) {
+// One kernel: a wave takes a job through both phases (the LRT's results stay in registers), and when the jobs are gone it
+// takes blocks of 64 non-candidate sites, one per lane.  (lrt + tail + simple site: 60 KB of code, inside the instruction
+// cache of 64 KB per pair of CUs; round 2's kernel was 207 KB -- two inlined copies of the Fisher test, the log-factorial
+// series at ~60 call sites -- and 1.2 % of its instruction fetches missed.)
+__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolve16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_easy = a.counters[BV_CTR_EASY], n_easy3 = a.counters[BV_CTR_EASY3];
     const uint32_t n_jobs = ((n_easy + 3u) >> 2) + ((n_easy3 + 3u) >> 2);
-    if (blockIdx.x >= n_jobs) return;  // not even its first wave has a job
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE16_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
@@ -623,20 +617,37 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         uint32_t site = 0;
         if (jb.active) {
             site = jb.list[jb.idx];
-            const BvSiteSummary sm = a.summ[site];
-            uint32_t depth[4], total = 0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { depth[b] = sm.fwd[b] + sm.rev[b]; total += depth[b]; }
-            BvG16Bins B;
-            B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sa.loghit; B.logmiss = sa.logmiss;
-            B.pm = reinterpret_cast<double *>(scratch) + gl;
             const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+            uint32_t nb, badq;
+            BvG16Lrt pre;
+            {
+                // phase 1 needs the depths only: the strand totals are read again for phase 2 (eight registers that would
+                // otherwise sit through the EMs, in a kernel at its register limit)
+                const BvSiteSummary sm = a.summ[site];
+                uint32_t depth[4], total = 0;
 #pragma unroll
-            for (int s = 0; s < BV_G16_SLOTS; ++s) {
-                const uint32_t i = (uint32_t)(s * 16 + gl);
-                B.w[s] = i < sm.nb ? src[i] : 0u;
+                for (int b = 0; b < 4; ++b) { depth[b] = sm.fwd[b] + sm.rev[b]; total += depth[b]; }
+                nb = sm.nb;
+                badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
+                BvG16Bins B;
+                B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sa.loghit; B.logmiss = sa.logmiss;
+                B.pm = reinterpret_cast<double *>(scratch) + gl;
+#pragma unroll
+                for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                    const uint32_t i = (uint32_t)(s * 16 + gl);
+                    B.w[s] = i < nb ? src[i] : 0u;
+                }
+                variant = bv_site_lrt_g16(sa, site, depth, total, badq, B, scratch, lane, &pre);
             }
-            variant = bv_site_lrt_g16(sa, site, depth, total, (sm.flags & BV_SUM_BADQ) ? 1u : 0u, B, scratch, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record's first version is out before phase 2 patches it
+            BvSiteSums S;
+            {
+                const volatile BvSiteSummary *vs = &a.summ[site];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) { S.fwd[b] = vs->fwd[b]; S.rev[b] = vs->rev[b]; }
+            }
+            S.q0_mask = 0; S.nb = nb; S.badq = badq;
+            bv_site_tail_g16(sa, site, S, src, nb, scratch, lane, &pre);
         }
         // the wave's variant sites of this round, in group order
         const unsigned long long vm = __ballot(variant && gl == 0);
@@ -645,45 +656,13 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         if (n_vl > 60u) flush_vl();
     }
     if (n_vl) flush_vl();
-}
-
-#ifndef BV_P1S_TAIL16_OCC
-#define BV_P1S_TAIL16_OCC 4
-#endif
-__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_TAIL16_OCC) void bv_p1s_tail16_kernel(BvP1ShortArgs a) {
-    __shared__ BvP1sSolve16Shared sh;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t n_easy = a.counters[BV_CTR_EASY], n_easy3 = a.counters[BV_CTR_EASY3];
-    const uint32_t n_jobs = ((n_easy + 3u) >> 2) + ((n_easy3 + 3u) >> 2);
-    BvSolveArgs sa;
-    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
-    sa.min_af = a.min_af; sa.flags = a.flags;
-    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
-    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
-    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
-    const int grp = lane >> 4, gl = lane & 15;
-    uint32_t *scratch = sh.grp[wave][grp];
-    BvP1sTickets tk;
-    tk.init(a.counters + BV_CTR_TICKET_B, (uint32_t)wave);
-    for (; tk.job() < n_jobs; tk.next(lane)) {
-        const BvP1sJob jb = bv_p1s_job(a, tk.job(), n_easy, n_easy3, grp);
-        if (jb.active) {
-            const uint32_t site = jb.list[jb.idx];
-            const BvSiteSummary sm = a.summ[site];
-            BvSiteSums S;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
-            S.q0_mask = 0; S.nb = sm.nb;
-            S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
-            uint32_t w[BV_G16_SLOTS];
-            const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
-#pragma unroll
-            for (int s = 0; s < BV_G16_SLOTS; ++s) {
-                const uint32_t i = (uint32_t)(s * 16 + gl);
-                w[s] = i < sm.nb ? src[i] : 0u;
-            }
-            bv_site_tail_g16(sa, site, S, w, scratch, lane);
-        }
+    // ---- the non-candidate sites, one lane per site, in blocks of 64 drawn like the jobs
+    const uint32_t n_blocks = (a.n_sites + 63u) >> 6;
+    BvP1sTickets tb;
+    tb.init(a.counters + BV_CTR_TICKET_B, (uint32_t)wave);
+    for (; tb.job() < n_blocks; tb.next(lane)) {
+        const uint32_t site = tb.job() * 64u + (uint32_t)lane;
+        if (site < a.n_sites) bv_p1s_simple_site(a, sa.lnfact, site);
     }
 }
 
@@ -741,7 +720,6 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside_stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
-    hipLaunchKernelGGL(bv_p1s_simple_kernel, dim3((a.n_sites + 255u) / 256u), dim3(256), 0, stream, a);
     uint32_t grid = beside_stream ? cu : cu * 3u * (4u / BV_P1S_SOLVE_NW);  // 3 waves per SIMD (168 VGPRs)
     const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
     if (grid > need) grid = need > 0 ? need : 1;
@@ -751,9 +729,5 @@ void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside
     const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE16_NW - 1) / (4 * BV_P1S_SOLVE16_NW);  // four sites per wave
     if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
     if (cap && grid16 > cap) grid16 = cap;
-    hipLaunchKernelGGL(bv_p1s_lrt16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
-    uint32_t gridt = beside_stream ? cu : cu * (uint32_t)BV_P1S_TAIL16_OCC * (4u / BV_P1S_SOLVE16_NW);
-    if (gridt > need16) gridt = need16 > 0 ? need16 : 1;
-    if (cap && gridt > cap) gridt = cap;
-    hipLaunchKernelGGL(bv_p1s_tail16_kernel, dim3(gridt), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
+    hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
 }

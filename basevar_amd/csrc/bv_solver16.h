@@ -302,8 +302,8 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
     }
     const double n_cov = (double)total;
     const int m0 = m;
-    const double d0 = (double)depth[0] / n_cov, d1 = (double)depth[1] / n_cov, d2 = (double)depth[2] / n_cov,
-                 d3 = (double)depth[3] / n_cov;
+    // (the start frequencies depth / total are formed where a subset starts, basetype.cpp:99: four divisions per EM run
+    // instead of eight registers held through all of them -- the kernel sits at its register limit)
     double fr0 = 0., fr1 = 0., fr2 = 0., fr3 = 0.;  // active_bases_freq
     double lr_alt = 0., chi = 0.;
     for (int n = m0; n > 0; --n) {
@@ -338,8 +338,8 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
             for (int k = 0; k < m; ++k)
                 if (k != drop) in_set |= 1u << ((act >> (2 * k)) & 3);
             double f[4];
-            f[0] = (in_set & 1u) ? d0 : 0.; f[1] = (in_set & 2u) ? d1 : 0.;
-            f[2] = (in_set & 4u) ? d2 : 0.; f[3] = (in_set & 8u) ? d3 : 0.;
+            f[0] = (in_set & 1u) ? (double)depth[0] / n_cov : 0.; f[1] = (in_set & 2u) ? (double)depth[1] / n_cov : 0.;
+            f[2] = (in_set & 4u) ? (double)depth[2] / n_cov : 0.; f[3] = (in_set & 8u) ? (double)depth[3] / n_cov : 0.;
             double s = 0.;
             s += f[0]; s += f[1]; s += f[2]; s += f[3];
             double lr;
@@ -425,10 +425,17 @@ __device__ inline unsigned long long bv_ranksum_window_g16(uint32_t ref_v, uint3
 #define BV_G16_STASH_FIRST_SHIFT 20  /* bits 20-21: active_bases[0]        (BvLrtOut::first)  */
 #define BV_G16_STASH_MASK 0x00370000u
 
+// what phase 2 needs of phase 1, when both run in one kernel (else phase 2 reads it back from the record)
+struct BvG16Lrt {
+    uint32_t status;    // with the stash bits
+    uint32_t aw0, aw1;  // the record's bytes n_alt, alt[0..3] (+ n_em, em_iters): as stored at bv_site_result::n_alt
+    double chi2;
+};
+
 // Phase 1.  `scratch`: the group's BV_G16_GRP_WORDS words of LDS -- the EM's previous marginals (B.pm points into it), then
 // the staging of the record.  Returns whether the site is a variant site.
 __device__ inline bool bv_site_lrt_g16(const BvSolveArgs &a, uint32_t site, const uint32_t depth[4], uint32_t total, uint32_t badq,
-                                       const BvG16Bins &B, uint32_t *scratch, int lane) {
+                                       const BvG16Bins &B, uint32_t *scratch, int lane, BvG16Lrt *pre = nullptr) {
     const int gl = lane & 15;
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
     bv_site_result *res = reinterpret_cast<bv_site_result *>(scratch);
@@ -469,14 +476,21 @@ __device__ inline bool bv_site_lrt_g16(const BvSolveArgs &a, uint32_t site, cons
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     for (int i = gl; i < REC_WORDS; i += 16) reinterpret_cast<uint32_t *>(&a.out[site])[i] = scratch[i];
+    if (pre != nullptr) {
+        pre->status = flags;
+        pre->aw0 = scratch[offsetof(bv_site_result, n_alt) / 4];
+        pre->aw1 = scratch[offsetof(bv_site_result, n_alt) / 4 + 1];
+        pre->chi2 = L.chi2;
+    }
     return L.n_alt > 0;
 }
 
-// Phase 2.  `S`: the site's strand totals; `w`: its bins (bv_g16_bin layout; read only for variant sites); `cls`: the group's
-// scratch, here 2 x 128 REF / ALT counts per phred for the rank sum.  Everything it computes is patched into the record
-// phase 1 wrote, by the group's first lane.
-__device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const uint32_t w[BV_G16_SLOTS],
-                                        uint32_t *cls, int lane) {
+// Phase 2.  `S`: the site's strand totals; `bins` / `nb`: its exported bins in device memory (bv_g16_bin layout; read again
+// here, and only for variant sites, rather than kept in 8 registers across phase 1); `cls`: the group's scratch, here
+// 2 x 128 REF / ALT counts per phred for the rank sum.  Everything it computes is patched into the record phase 1 wrote,
+// by the group's first lane.
+__device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const uint32_t *bins, uint32_t nb,
+                                        uint32_t *cls, int lane, const BvG16Lrt *pre = nullptr) {
     const int gl = lane & 15;
     bv_site_result *rec = &a.out[site];
     uint32_t depth[4], total = 0;
@@ -488,8 +502,9 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
     int ref = a.ref_base[site];
     if (ref > 4) ref = 4;
     // what phase 1 left: status (with the stash), n_alt + alt[4] (8 bytes), chi2
-    const uint32_t st = rec->status;
-    const uint2 aw = *reinterpret_cast<const uint2 *>(&rec->n_alt);
+    const uint32_t st = pre ? pre->status : rec->status;
+    const uint2 aw = pre ? make_uint2(pre->aw0, pre->aw1) : *reinterpret_cast<const uint2 *>(&rec->n_alt);
+    const double chi2 = pre ? pre->chi2 : rec->chi2;
     const int n_alt = (int)(aw.x & 0xFFu);
     const int m = (int)((st >> BV_G16_STASH_M_SHIFT) & 7u), first = (int)((st >> BV_G16_STASH_FIRST_SHIFT) & 3u);
     uint32_t flags = st & ~BV_G16_STASH_MASK;
@@ -518,9 +533,9 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
             const double r = (double)bv_sel4u(depth, first) / (double)total;
             if (m == 1 && total > 10 && r > 0.5) qual = 5000.0;
 #ifdef BV_ABL16_NO_QUAL  /* attribution builds only */
-            else qual = rec->chi2;
+            else qual = chi2;
 #else
-            else qual = bv_qual_from_chi2(rec->chi2);
+            else qual = bv_qual_from_chi2(chi2);
 #endif
             double ad_sum = 0;
 #pragma unroll
@@ -547,7 +562,8 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int s = 0; s < BV_G16_SLOTS; ++s) {
-                const uint32_t ws = w[s];
+                const uint32_t i = (uint32_t)(s * 16 + gl);
+                const uint32_t ws = i < nb ? bins[i] : 0u;
                 if (ws & 0xFFFFu) {
                     const uint32_t q = (ws >> 16) & 127u, b = ws >> 23;
                     // bins are unique per (base, phred); several ALT bases can share a phred: add, one lane at a time per word

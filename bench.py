@@ -267,7 +267,7 @@ def main():
     rec = basevar_amd.SITE_DTYPE.itemsize
     # record buffers: one per stream at N = 1; a ring of 3 per rank at N > 1 so that the gather of
     # batch i (RCCL, asynchronous) overlaps the kernels of batches i+1 and i+2
-    depth = 3 if dist_on else ns * args.lanes  # (submits in flight write distinct record buffers)
+    depth = 3 if dist_on else ns * (args.lanes if args.lanes == 1 else 4)  # (submits in flight write distinct record buffers)
     gloo_host = dist_on and backend != "nccl"  # gloo has no GPU gather: stage through the host (test plumbing only)
     outs = [torch.zeros(Bl * rec, dtype=torch.uint8, device=dev) for _ in range(depth)]
     houts = [torch.zeros(Bl * rec, dtype=torch.uint8) for _ in range(depth)] if gloo_host else None

@@ -533,6 +533,25 @@ def test_exact_tie_site_follows_the_reference_rounding(bv, restatement):
     assert got.sites["n_alt"][0] == 0
 
 
+@pytest.mark.parametrize("groups", [0, 3], ids=["no_groups", "groups"])
+def test_chunk_pipeline_gives_the_records_of_the_plain_launch(bv, groups):
+    """BV_FLAG_SPLIT(n): a short-row batch cut into n chunks that go through the engine's two streams (measured slower than the
+    plain sequence and off by default) must still give every record of the plain launch byte for byte -- per-chunk
+    scratch slices, variant lists and counter blocks, pop-group items included."""
+    n, S = 9000, 3000
+    slab = make_slab(S, n, seed=808, coverage=0.08, n_groups=groups, site_offset=5)
+    maf = bv.min_af(n)
+    want = run_engine(bv, slab, maf)
+    for split in (2, 3, 5):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=split << 24)
+        got = eng.lrt(slab)
+        eng.close()
+        assert got.sites.tobytes() == want.sites.tobytes(), split
+        assert got.n_variant == want.n_variant
+        if groups:
+            assert got.groups.tobytes() == want.groups.tobytes(), split
+
+
 @pytest.mark.parametrize("n", [9000, 70000], ids=["short_rows", "long_rows"])
 def test_two_lanes_give_the_records_of_one(bv, n):
     """BV_FLAG_LANES: six device-resident submits in flight over the engine's two internal lanes (distinct slabs and record

@@ -4,7 +4,7 @@
 # For each configuration below: one un-profiled bench run (the JSON line), one `--kernel-trace --stats` run and two PMC
 # runs (FETCH_SIZE, WRITE_SIZE -- separate passes, no tracing beside them), all of the same bench command.
 # Back in the container:  python tools/summarize_profiles.py <tag>
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd "$(dirname "$0")/.."; ROOT=$PWD
 export TMPDIR=/tmp
 O=$ROOT/gpurun_out/prof_$TAG
@@ -15,10 +15,24 @@ run_cfg() {  # name, bench args
   echo "$*" > $O/$name.args
   timeout 600 python3 bench.py --no-cpu-baseline "$@" > $O/$name.bench.json 2> $O/$name.err
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$name.stats -- python3 bench.py --no-cpu-baseline --steps 5 --warmup 2 "$@" > /dev/null 2>> $O/$name.err
+  # per-dispatch rows of our kernels only (the summary groups calls by dispatch size); the full trace is not kept
+  for f in $(find $O/$name.stats -name '*kernel_trace.csv'); do
+    python3 - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+keep = [r for r in rows if r["Kernel_Name"].replace("void ", "").startswith("bv_") and "synth" not in r["Kernel_Name"]]
+if keep:
+    cols = [c for c in ("Kernel_Name", "Grid_Size_X", "Grid_Size", "Workgroup_Size_X", "Workgroup_Size", "LDS_Block_Size", "Start_Timestamp", "End_Timestamp") if c in keep[0]]
+    w = csv.DictWriter(open(sys.argv[1].replace("kernel_trace.csv", "bv_dispatches.csv"), "w"), fieldnames=cols)
+    w.writeheader()
+    for r in keep:
+        w.writerow({c: r[c] for c in cols})
+PY
+  done
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/$name.fetch -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > /dev/null 2>> $O/$name.err
   timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/$name.write -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > /dev/null 2>> $O/$name.err
   # keep only the CSVs that the summary reads (the merge back is capped at 64 MiB)
-  find $O/$name.stats $O/$name.fetch $O/$name.write -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
+  find $O/$name.stats $O/$name.fetch $O/$name.write -type f ! -name '*kernel_stats.csv' ! -name '*counter_collection.csv' ! -name '*bv_dispatches.csv' -delete 2>/dev/null
 }
 sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kernel, three passes
   local name=$1; shift
@@ -32,7 +46,8 @@ sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kern
 run_cfg n100k                                               # headline: bv_pass1_kernel<3,1>, bv_pass2_kernel<256,true,false>
 run_cfg n100k_groups2 --groups 2 --batch-sites 65536        # bv_pass2_kernel<256,true,true,false> + bv_p2g_solve16_kernel on long rows
 run_cfg n1M --samples 1000000 --batch-sites 16384 --steps 8 # the same kernels at 1 M samples
-run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_solve_kernel, bv_pass2_short_kernel
+run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_simple / solve / lrt16 / tail16 kernels, bv_pass2_dma_kernel
+run_cfg n10k_lanes2 --samples 10000 --batch-sites 100000 --lanes 2   # the same through the engine's two lanes (BV_FLAG_LANES)
 run_cfg n10k_524k --samples 10000 --batch-sites 524288
 run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_pass2_dma_kernel + bv_p2g_stream_kernel + bv_p2g_solve16/hard
 run_cfg n10k_groups1 --samples 10000 --batch-sites 100000 --groups 1

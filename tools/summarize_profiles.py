@@ -34,18 +34,35 @@ def newest(pattern):
     return sorted(hits, key=os.path.getmtime)[-1:] if hits else []
 
 
-def counters(dirpat):
+def grid_of(r):
+    return int(r.get("Grid_Size_X") or r.get("Grid_Size") or 0)
+
+
+def counters(dirpat, by_grid=False):
+    """average counter value per (kernel, counter) -- or per (kernel, grid size, counter): calls of one kernel with
+    different dispatch sizes are different workloads and must not be averaged together"""
     acc, cnt = collections.defaultdict(float), collections.Counter()
     for fn in glob.glob(dirpat, recursive=True):
         for r in csv.DictReader(open(fn)):
-            k = (short(r["Kernel_Name"]), r["Counter_Name"])
+            k = (short(r["Kernel_Name"]), grid_of(r), r["Counter_Name"]) if by_grid else (short(r["Kernel_Name"]), r["Counter_Name"])
             acc[k] += float(r["Counter_Value"])
             cnt[k] += 1
     return {k: acc[k] / cnt[k] for k in acc}
 
 
+def dispatch_groups(dirpat):
+    """{kernel: {grid size: [durations ns]}} from the per-dispatch rows collect_profiles.sh keeps"""
+    g = collections.defaultdict(lambda: collections.defaultdict(list))
+    for fn in glob.glob(dirpat, recursive=True):
+        for r in csv.DictReader(open(fn)):
+            g[short(r["Kernel_Name"])][grid_of(r)].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+    return g
+
+
 def algorithmic_bytes(kernel, cfg, nvar):
     B, N = cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"]
+    if cfg.get("tile_job"):
+        return None, "-"  # the tile job's finish runs the pass kernels on other rows than the bench batch: nothing attributed
     if kernel.startswith(("bv_pass1_kernel", "bv_pass1_fused_kernel", "bv_p1s_stream_kernel")):
         return 2.0 * B * N, "2 B/cell x %d sites x %d samples" % (B, N)
     per = None
@@ -70,7 +87,7 @@ def tkey(kernel, cfg):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
     src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
     names = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(src, "*.args")))
     out = {"tag": tag, "configs": {}}
@@ -91,6 +108,7 @@ def main():
             if t == "--groups": cfg["groups"] = int(toks[i + 1])
             if t == "--chain": cfg["chain"] = int(toks[i + 1])
             if t == "--no-rank-planes": cfg["ranks"] = False
+            if t == "--with-tile-mode": cfg["tile_job"] = True
         nvar = 0
         bj = os.path.join(src, name + ".bench.json")
         bench = None
@@ -109,6 +127,12 @@ def main():
                            "pct": float(r["Percentage"])}
         fetch = counters(os.path.join(src, name + ".fetch", "**", "*counter_collection.csv"))
         write = counters(os.path.join(src, name + ".write", "**", "*counter_collection.csv"))
+        # Calls of one kernel with different dispatch sizes (a tile job's finish beside the bench's own batches, a chunked or
+        # ragged last launch) are split: the stats row averages them, which is meaningless for a bytes-per-launch ratio.
+        groups = dispatch_groups(os.path.join(src, name + ".stats", "**", "*bv_dispatches.csv"))
+        fetch_g = counters(os.path.join(src, name + ".fetch", "**", "*counter_collection.csv"), by_grid=True)
+        write_g = counters(os.path.join(src, name + ".write", "**", "*counter_collection.csv"), by_grid=True)
+        mixed = {k for k, gs in groups.items() if len(gs) > 1}
         sq = {}
         for d in glob.glob(os.path.join(src, name + ".sq*")):
             sq.update(counters(os.path.join(d, "**", "*counter_collection.csv")))
@@ -122,6 +146,17 @@ def main():
                   "|---|---|---|---|---|---|---|---|---|"]
         for k, v in kern.items():
             if not k.startswith("bv_"):
+                continue
+            if k in mixed:
+                # one row per dispatch size; the algorithmic bytes (known for the bench's own batch only) are not attributed
+                for gsz in sorted(groups[k]):
+                    d = groups[k][gsz]
+                    fg, wg = fetch_g.get((k, gsz, "FETCH_SIZE")), write_g.get((k, gsz, "WRITE_SIZE"))
+                    hb = (2.0 * fg * 1024.0 if fg is not None else 0.0) + (wg * 1024.0 if wg is not None else 0.0)
+                    lines.append("| %s [grid %d] | %d | %.1f us | %s | %s | %s | (calls of several dispatch sizes: not attributed) | - | - |" % (
+                        k, gsz, len(d), sum(d) / len(d) / 1e3, "%.0f" % fg if fg is not None else "-", "%.0f" % wg if wg is not None else "-",
+                        "%.4g" % hb if fg is not None else "-"))
+                    v.setdefault("by_grid", {})[str(gsz)] = {"calls": len(d), "avg_ns": sum(d) / len(d), "FETCH_SIZE_KiB": fg, "WRITE_SIZE_KiB": wg}
                 continue
             f, w = fetch.get((k, "FETCH_SIZE")), write.get((k, "WRITE_SIZE"))
             hbm = (2.0 * f * 1024.0 if f is not None else 0.0) + (w * 1024.0 if w is not None else 0.0)
