@@ -46,7 +46,7 @@ sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kern
 run_cfg n100k                                               # headline: bv_pass1_kernel<3,1>, bv_pass2_kernel<256,true,false>
 run_cfg n100k_groups2 --groups 2 --batch-sites 65536        # bv_pass2_kernel<256,true,true,false> + bv_p2g_solve16_kernel on long rows
 run_cfg n1M --samples 1000000 --batch-sites 16384 --steps 8 # the same kernels at 1 M samples
-run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_simple / solve / lrt16 / tail16 kernels, bv_pass2_dma_kernel
+run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_solve_kernel + bv_p1s_solve16_kernel, bv_pass2_dma_kernel
 run_cfg n10k_lanes2 --samples 10000 --batch-sites 100000 --lanes 2   # the same through the engine's two lanes (BV_FLAG_LANES)
 run_cfg n10k_524k --samples 10000 --batch-sites 524288
 run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_pass2_dma_kernel + bv_p2g_stream_kernel + bv_p2g_solve16/hard
@@ -55,9 +55,10 @@ run_cfg n10k_noranks --samples 10000 --batch-sites 100000 --groups 2 --no-rank-p
 run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more than 7 groups: bv_pass2_kernel<256,true,true,false> + the group solve kernels
 run_cfg n100k_chain16 --batch-sites 8192 --chain 16                    # small batches chained: bv_pass1_kernel<3,1,true>
 run_cfg n100k_8192 --batch-sites 8192 --steps 20                       # ... and one launch per small batch
+run_cfg n100k_8192_lanes2 --batch-sites 8192 --steps 20 --lanes 2      # ... through the engine's two lanes
 run_cfg n10k_chain16 --samples 10000 --batch-sites 8192 --chain 16     # short rows chained: bv_p1s_stream_kernel<4,3,2,true>, bv_chain_* kernels
 run_cfg n10k_8192 --samples 10000 --batch-sites 8192 --steps 30
-run_cfg tiles_joined_1M --samples 1000000 --batch-sites 8192 --tile-sites 8192 --with-tile-mode --steps 2 --warmup 1   # bv_tile_scatter_kernel
+run_cfg tiles_joined_1M --samples 1000000 --batch-sites 8192 --tile-sites 8192 --with-tile-mode --steps 2 --warmup 1   # bv_tile_join_rows_kernel (bv_engine_tiles_add_many), bv_tile_scatter_kernel (tile by tile)
 run_cfg tiles_state_100k --samples 100000 --batch-sites 16384 --tile-sites 16384 --with-tile-mode --flags 8 --steps 2 --warmup 1   # bv_tile_tally_kernel, bv_tile_finish_kernel
 sq_cfg n10k --samples 10000 --batch-sites 100000
 sq_cfg n100k

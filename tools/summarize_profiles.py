@@ -145,7 +145,7 @@ def main():
         lines += ["| kernel | calls | avg duration | FETCH_SIZE KiB | WRITE_SIZE KiB | HBM bytes / launch | algorithmic bytes | traffic / algorithmic | frac of 8 TB/s |",
                   "|---|---|---|---|---|---|---|---|---|"]
         for k, v in kern.items():
-            if not k.startswith("bv_"):
+            if not k.startswith("bv_") or k.startswith("bv_synth"):  # (the bench's data generator is not part of the path)
                 continue
             if k in mixed:
                 # one row per dispatch size; the algorithmic bytes (known for the bench's own batch only) are not attributed
@@ -178,7 +178,7 @@ def main():
                     "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
                     "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)})
         lines.append("")
-        sqk = [k for k in kern if "sq" in kern[k]]
+        sqk = [k for k in kern if "sq" in kern[k] and not k.startswith("bv_synth")]
         if sqk:
             lines += ["SQ counters per launch (`rocprofv3 --pmc`, three passes):", "", "```"]
             for k in sqk:
