@@ -60,7 +60,7 @@ class SynthParams(C.Structure):
 
 
 # every symbol include/basevar_amd.h declares
-EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_submit_many", "bv_engine_wait", "bv_engine_join",
+EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_submit_many", "bv_engine_submit_many_g", "bv_engine_wait", "bv_engine_join",
            "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_add_many", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
            "bv_host_log_probe", "bv_host_log_eval", "bv_engine_host_log_exact", "bv_engine_host_log_eval",
@@ -99,6 +99,8 @@ def load():
     L.bv_engine_submit.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p, C.c_void_p, C.c_void_p]
     L.bv_engine_submit_many.restype = C.c_int
     L.bv_engine_submit_many.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Slab), C.POINTER(C.c_void_p), C.c_void_p]
+    L.bv_engine_submit_many_g.restype = C.c_int
+    L.bv_engine_submit_many_g.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Slab), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]
     L.bv_engine_join.restype = C.c_int
     L.bv_engine_join.argtypes = [C.c_void_p, C.c_void_p]
     L.bv_engine_tiles_begin.restype = C.c_int

@@ -630,9 +630,10 @@ int bv_engine_destroy(bv_engine *e) {
 // workers take one position at a time (basetype_caller.cpp:738-762).
 static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
-                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */) {
+                         bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */,
+                         bool chain_cat = false /* chained short rows: refb / dout are contiguous copies */) {
     const size_t S = n_sites, G = n_groups;
-    if (G) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));
+    if (G && chain == nullptr) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));  // (chained: per segment, by the caller)
 
     if (e->ring_count == bv_engine::kRing) {
         int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
@@ -658,6 +659,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
     a2.ch = chain;
+    a2.ch_cat = chain_cat ? 1u : 0u;
     bool gitems_all = true;  // the item scratch holds every (site, group) of this launch
     if (G && gid && dgout && !(e->cfg.flags & BV_FLAG_GROUP_INLINE)) {
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
@@ -668,13 +670,14 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         if (want > e->gitem_cap) {
             if (e->d_gitems) BV_HIP(e, hipFree(e->d_gitems));
             e->d_gitems = nullptr; e->gitem_cap = 0;
-            while (want >= 1024u) {
+            for (;;) {
                 if (hipMalloc(&e->d_gitems, sizeof(uint32_t) * BV_P2G_ITEM_WORDS * (size_t)want) == hipSuccess) {
                     e->gitem_cap = want;
                     break;
                 }
                 (void)hipGetLastError();
                 e->d_gitems = nullptr;
+                if (want < 1024u) break;  // no scratch at all: every group is solved inside the tally kernel
                 want /= 2u;
             }
         }
@@ -905,6 +908,13 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
 // ready should call -- the tail of every batch but the last hides under the next batch's stream.  Falls back to one
 // submit per slab whenever the chained kernels do not apply (short rows, pop-groups, host memory, a forced kernel shape).
 int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, bv_site_result *const *outs, void *stream_) {
+    return bv_engine_submit_many_g(e, n_slabs, slabs, outs, nullptr, stream_);
+}
+
+// The same with pop-groups: gouts[k] = slab k's [n_sites][n_groups] records (NULL array: no slab may have groups).  A queue
+// with groups chains when every slab names the SAME group_id array and group count (one cohort).
+int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, bv_site_result *const *outs,
+                            bv_group_result *const *gouts, void *stream_) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null engine");
     if (!slabs || !outs || n_slabs == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null / empty argument");
     bool chainable = n_slabs > 1 && ((e->cfg.flags >> 8) & 0xFu) == 0u;
@@ -916,18 +926,25 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
         if (!outs[k]) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null record buffer");
         if (s.n_sites == 0 || s.n_samples == 0 || s.pitch < s.n_samples || (s.pitch & 15ull) || !s.base_strand || !s.qual || !s.ref_base ||
             (s.mapq == nullptr) != (s.rpr == nullptr) || misaligned(s.base_strand) || misaligned(s.qual) || misaligned(s.mapq) ||
-            misaligned(s.rpr) || (s.mem_kind != BV_MEM_HOST && misaligned(outs[k])))
+            misaligned(s.rpr) || (s.mem_kind != BV_MEM_HOST && misaligned(outs[k])) || s.n_groups > BV_MAX_GROUPS)
             return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab fails the checks of bv_engine_submit");
+        if (s.n_groups > 0 && (!s.group_id || !gouts || !gouts[k]))
+            return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab with pop-groups needs group_id and its gouts[k] (bv_engine_submit_many_g)");
         if (s.n_sites > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_submit_many: a slab exceeds cfg.max_sites");
-        // (rows of up to 2048 samples and the diagnostic kernel choices take kernels that know no chain)
-        chainable = chainable && s.mem_kind != BV_MEM_HOST && s.n_groups == 0 && s.n_samples > 2048u && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP) &&
-                    s.n_samples == slabs[0].n_samples && s.pitch == slabs[0].pitch && (s.mapq == nullptr) == (slabs[0].mapq == nullptr);
+        // (host memory and the diagnostic kernel choices take kernels that know no chain; a queue is one cohort: one row
+        // length, one pitch, one set of planes, one group assignment)
+        chainable = chainable && s.mem_kind != BV_MEM_HOST && !(e->cfg.flags & (BV_FLAG_PASS2_SWEEP | BV_FLAG_GROUP_INLINE)) &&
+                    s.n_samples == slabs[0].n_samples && s.pitch == slabs[0].pitch && (s.mapq == nullptr) == (slabs[0].mapq == nullptr) &&
+                    s.n_groups == slabs[0].n_groups && (s.n_groups == 0 || s.group_id == slabs[0].group_id);
         total += s.n_sites;
     }
+    const uint32_t G = slabs[0].n_groups;
+    // pop-groups chain only when every (site, group) of a launch has an item in the scratch (no inline solves: their kernels
+    // would need the segment look-up too) -- checked per launch below through the 8 GiB cap of launch_passes
+    if (chainable && G && (uint64_t)std::min<uint64_t>(total, e->cfg.max_sites) * G * sizeof(uint32_t) * BV_P2G_ITEM_WORDS > (8192ull << 20)) chainable = false;
     if (!chainable) {
         for (uint32_t k = 0; k < n_slabs; ++k) {
-            if (slabs[k].n_groups != 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many takes no pop-groups (no gout): use bv_engine_submit");
-            int rc = bv_engine_submit(e, &slabs[k], outs[k], nullptr, stream_);
+            int rc = bv_engine_submit(e, &slabs[k], outs[k], slabs[k].n_groups ? gouts[k] : nullptr, stream_);
             if (rc != BV_OK) return rc;
         }
         return BV_OK;
@@ -940,8 +957,14 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
         if (rc != BV_OK) return rc;
     }
     e->host_out = nullptr; e->host_gout = nullptr;
+    e->last_lane = -1;
     const size_t P = slabs[0].pitch;
     const bool ranks = slabs[0].mapq != nullptr;
+    const uint8_t *gid = nullptr;
+    if (G) {
+        int rc = stage_group_ids(e, slabs[0].group_id, slabs[0].n_samples, false, st, &gid);
+        if (rc != BV_OK) return rc;
+    }
     // at most BV_MAX_CHAIN slabs per launch
     for (uint32_t k0 = 0; k0 < n_slabs; k0 += BV_MAX_CHAIN) {
         const uint32_t nk = n_slabs - k0 < (uint32_t)BV_MAX_CHAIN ? n_slabs - k0 : (uint32_t)BV_MAX_CHAIN;
@@ -956,11 +979,14 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
             ch.mapq[i] = ranks ? s.mapq - bias : nullptr; ch.rpr[i] = ranks ? s.rpr - bias : nullptr;
             ch.ref_base[i] = s.ref_base - first;
             ch.out[i] = outs[k0 + i] - first;
+            ch.gout[i] = G ? gouts[k0 + i] - (size_t)first * G : nullptr;
+            if (G) BV_HIP(e, hipMemsetAsync(gouts[k0 + i], 0, (size_t)s.n_sites * G * sizeof(bv_group_result), st));
             first += s.n_sites;
         }
         const bv_slab &s0 = slabs[k0];
+        bv_group_result *g0 = G ? gouts[k0] : nullptr;
         if (nk == 1) {
-            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, nullptr, P, first, s0.n_samples, 0, outs[k0], nullptr, st);
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, gid, P, first, s0.n_samples, G, outs[k0], g0, st);
             if (rc != BV_OK) return rc;
             continue;
         }
@@ -970,11 +996,12 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
         BV_HIP(e, hipMemcpyAsync(d_ch, &ch, sizeof(BvChain), hipMemcpyHostToDevice, st));
         if (s0.n_samples > BV_SHORT_ROW_MAX) {
             // long rows: every kernel looks its segment up per site (planes, reference bases, records)
-            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, nullptr, P, first, s0.n_samples, 0, outs[k0], nullptr, st, d_ch);
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, gid, P, first, s0.n_samples, G, outs[k0], g0, st, d_ch);
             if (rc != BV_OK) return rc;
         } else {
             // short rows: the planes are looked up per row (wave-uniform places only); the per-site reference bases and records,
             // which the lane-per-site and four-per-wave kernels touch with one site per lane, go through contiguous copies
+            // (the pop-group records are written once per (variant site, group): looked up where they are written)
             if (!e->d_ref_cat || !e->d_out_cat) {
                 if (e->d_ref_cat) (void)hipFree(e->d_ref_cat);
                 if (e->d_out_cat) (void)hipFree(e->d_out_cat);
@@ -984,7 +1011,7 @@ int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, 
             }
             bv_launch_chain_gather_ref(d_ch, first, e->d_ref_cat, st);
             BV_HIP(e, hipGetLastError());
-            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, e->d_ref_cat, nullptr, P, first, s0.n_samples, 0, e->d_out_cat, nullptr, st, d_ch);
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, e->d_ref_cat, gid, P, first, s0.n_samples, G, e->d_out_cat, g0, st, d_ch, true);
             if (rc != BV_OK) return rc;
             bv_launch_chain_scatter_out(d_ch, first, e->d_out_cat, st);
             BV_HIP(e, hipGetLastError());

@@ -37,6 +37,7 @@ struct BvChain {
     const uint8_t *bs[BV_MAX_CHAIN], *q[BV_MAX_CHAIN], *mapq[BV_MAX_CHAIN], *ref_base[BV_MAX_CHAIN];
     const uint16_t *rpr[BV_MAX_CHAIN];
     bv_site_result *out[BV_MAX_CHAIN];
+    bv_group_result *gout[BV_MAX_CHAIN];  // pop-group records, biased by -first x n_groups records; NULL without groups
 };
 #if defined(__HIPCC__)
 // The table is written by the host before the launch and never by a kernel: read it through the constant address space, so
@@ -93,7 +94,9 @@ struct BvPass2Args {
     uint32_t gitem_cap;       // (v = position in var_list) = BV_P2G_ITEM_WORDS words; items >= gitem_cap, or gitems == NULL:
                               // the tally kernel solves the group itself (one wave per group)
     const uint8_t *gidp;      // group_id prepared for bv_p2g_stream_kernel: g << 2, or 0x80 for "no group" (bv_launch_gid_prepare)
-    const BvChain *ch;        // device memory, or NULL.  Long rows without pop-groups only (bv_pass2_kernel<256, true, false>)
+    const BvChain *ch;        // device memory, or NULL: a chained launch -- planes (and gout) come per segment, biased
+    uint32_t ch_cat;          // chained short rows: ref_base / out are the engine's CONTIGUOUS copies, indexed with the global site
+                              // number as they are; else (long rows) they come per segment too
 };
 // item: [0] = number of bins | state, [1..4] = the group's ACGT depths, [5] = bases with a phred-0 call, [8..] = its bins
 // (valid phreds only, (base, phred) order): code << 16 | count for BV_P2G_PENDING items, code << 23 | count for BV_P2G_HARD ones

@@ -253,10 +253,12 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     if (v >= n_var) return;
     {
         const uint32_t site = a.var_list[v];
-        if (!GROUPS && a.ch != nullptr) {  // a chained launch: the segment's (biased) planes and records
+        if (a.ch != nullptr) {  // a chained launch: the segment's (biased) planes and records
             const BvChainC ch = bv_chain_const(a.ch);
             const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
-            a.bs = ch->bs[sg]; a.mapq = ch->mapq[sg]; a.rpr = ch->rpr[sg]; a.ref_base = ch->ref_base[sg]; a.out = ch->out[sg];
+            a.bs = ch->bs[sg]; a.q = ch->q[sg]; a.mapq = ch->mapq[sg]; a.rpr = ch->rpr[sg];
+            if (!a.ch_cat) { a.ref_base = ch->ref_base[sg]; a.out = ch->out[sg]; }
+            if (GROUPS) a.gout = ch->gout[sg];
         }
         // ---- what pass 1 decided for this site
         const bv_site_result *res = &a.out[site];
@@ -539,7 +541,13 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2S_WAVES, 4) void bv_pass2_short_kerne
         BvP2Ctx cx;
         cx.hm = hm; cx.hr = hr; cx.hg = nullptr;
         cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
-        bv_p2_sweep<BV_WAVE, true, true, false, BV_P2S_RW>(cx, a, site, lane);
+        BvPass2Args as = a;  // the sweeps index the planes with the site number themselves
+        if (a.ch != nullptr) {  // a chained launch (short rows: ref_base / out are contiguous): the segment's biased planes
+            const BvChainC ch = bv_chain_const(a.ch);
+            const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+            as.bs = ch->bs[sg]; as.mapq = ch->mapq[sg]; as.rpr = ch->rpr[sg];
+        }
+        bv_p2_sweep<BV_WAVE, true, true, false, BV_P2S_RW>(cx, as, site, lane);
         const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
         bv_lrt_sync<0>();
         {   // MQRankSum
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2S_WAVES, 4) void bv_pass2_short_kerne
                 }
                 bv_lrt_sync<0>();
                 cx.win_lo = win_lo + BV_P2S_RW;
-                bv_p2_sweep<BV_WAVE, true, false, false, BV_P2S_RW>(cx, a, site, lane);
+                bv_p2_sweep<BV_WAVE, true, false, false, BV_P2S_RW>(cx, as, site, lane);
                 bv_lrt_sync<0>();
             }
             const double ph = bv_ranksum_phred(twoR, n1, n2);

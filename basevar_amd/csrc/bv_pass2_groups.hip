@@ -62,11 +62,17 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GS_WAVES) void bv_p2g_stream_kernel(B
         return (uint32_t)(i < 64u ? __builtin_amdgcn_readlane((int)siteA, (int)i) : __builtin_amdgcn_readlane((int)siteB, (int)(i - 64u)));
     };
     uint32_t p_k = 0, p_j = 0, ring_w = 0, inflight = 0, blk0 = 0;  // prefetch cursor
+    const uint8_t *seg_bs = a.bs, *seg_q = a.q;  // a chained launch: the (biased) planes of the segment that holds the cursor's site
     auto issue = [&]() {
         if (p_k < mine) {
             const uint32_t site = site_of(p_k, blk0);
+            if (a.ch != nullptr && p_j == 0u) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, site);
+                seg_bs = ch->bs[sg]; seg_q = ch->q[sg];
+            }
             const size_t row = (size_t)site * a.pitch + (size_t)p_j * 1024u;
-            const uint8_t *pb = bv_uniform_ptr(a.bs + row), *pq = bv_uniform_ptr(a.q + row);
+            const uint8_t *pb = bv_uniform_ptr(seg_bs + row), *pq = bv_uniform_ptr(seg_q + row);
             const uint8_t *pg = bv_uniform_ptr(a.gidp + (size_t)p_j * 1024u);
             const uint32_t dst = ring_lds + ring_w * (BV_P2GS_SLOT_WORDS * 4u);
             if (p_j + 1u < n_slots || (uint32_t)lane < last_valid) {  // lanes past the row's end load nothing (lane 0 always loads)
@@ -241,8 +247,18 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GH_WAVES) void bv_p2g_hard_kernel(BvP
             const uint32_t nb = hdr & 0xFFFFu;
             const uint32_t v = idx / a.n_groups, g = idx - v * a.n_groups;
             const uint32_t site = a.var_list[v];
-            const bv_site_result *res = &a.out[site];
-            int ref = a.ref_base[site];
+            // a chained launch: the segment's records, reference bases, planes (the wave works on one item: uniform)
+            const bv_site_result *outp = a.out;
+            const uint8_t *refp = a.ref_base, *bsp = a.bs, *qp = a.q;
+            bv_group_result *goutp = a.gout;
+            if (a.ch != nullptr) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                if (!a.ch_cat) { outp = ch->out[sg]; refp = ch->ref_base[sg]; }
+                bsp = ch->bs[sg]; qp = ch->q[sg]; goutp = ch->gout[sg];
+            }
+            const bv_site_result *res = &outp[site];
+            int ref = refp[site];
             if (ref > 4) ref = 4;
             const int n_alt = res->n_alt;
             int comb = ref, nc = 1;  // caller.cpp:750-753: [toupper(REF)] + alts, 3 bits per entry
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GH_WAVES) void bv_p2g_hard_kernel(BvP
             B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.nb = (int)nb;
             B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss; B.ord = nullptr; B.n_ord = 0;
             if (hdr & BV_P2G_SHALLOW) {
-                const uint32_t got = bv_gather_ordered(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples,
+                const uint32_t got = bv_gather_ordered(bsp + (size_t)site * a.pitch, qp + (size_t)site * a.pitch, a.n_samples,
                                                        sh.ord[wave], lane, a.group_id, g);
                 bv_lrt_sync<0>();
                 if (got == gtotal) { B.ord = sh.ord[wave]; B.n_ord = (int)gtotal; }
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GH_WAVES) void bv_p2g_hard_kernel(BvP
                     gr.alt[k] = (k < L.n_alt) ? (uint8_t)bv_alt_at(L, k) : 0;
                     gr.af[k] = (k < L.n_alt) ? L.af[k] : 0.0;
                 }
-                a.gout[(size_t)site * a.n_groups + g] = gr;
+                goutp[(size_t)site * a.n_groups + g] = gr;
             }
             bv_lrt_sync<0>();
         }
@@ -335,8 +351,18 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         const uint32_t nb = hdr & 0xFFFFu;
         const uint32_t v = idx / a.n_groups, g = idx - v * a.n_groups;
         const uint32_t site = a.var_list[v];
-        const bv_site_result *res = &a.out[site];
-        int ref = a.ref_base[site];
+        // a chained launch: the segment's records and reference bases, looked up per group of 16 lanes (its site is its own)
+        const bv_site_result *outp = a.out;
+        const uint8_t *refp = a.ref_base;
+        bv_group_result *goutp = a.gout;
+        if (a.ch != nullptr) {
+            const BvChainC ch = bv_chain_const(a.ch);
+            const uint32_t sg = bv_chain_seg(ch, site);
+            if (!a.ch_cat) { outp = ch->out[sg]; refp = ch->ref_base[sg]; }
+            goutp = ch->gout[sg];
+        }
+        const bv_site_result *res = &outp[site];
+        int ref = refp[site];
         if (ref > 4) ref = 4;
         const int n_alt = res->n_alt;
         int comb = ref, nc = 1;  // caller.cpp:750-753: [toupper(REF)] + alts, 3 bits per entry
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
                 gr.alt[k] = (k < L.n_alt) ? (uint8_t)bv_alt_at(L, k) : 0;
                 gr.af[k] = (k < L.n_alt) ? L.af[k] : 0.0;
             }
-            a.gout[(size_t)site * a.n_groups + g] = gr;
+            goutp[(size_t)site * a.n_groups + g] = gr;
         }
     }
 }

@@ -112,17 +112,21 @@ class BaseTypeEngine:
         if rc != 0:
             raise RuntimeError("bv_engine_submit failed (%d): %s" % (rc, self._err()))
 
-    def submit_many_ptrs(self, n_samples, pitch, slabs, stream=0):
-        """Several device-resident slabs as ONE launch per pass (bv_engine_submit_many).  `slabs`: a sequence of
-        (n_sites, base_strand, qual, ref_base, out, mapq, rpr) with device pointers as ints (mapq = rpr = 0: no rank sums)."""
+    def submit_many_ptrs(self, n_samples, pitch, slabs, stream=0, group_id=0, n_groups=0, gouts=None):
+        """Several device-resident slabs as ONE launch per pass (bv_engine_submit_many / _g).  `slabs`: a sequence of
+        (n_sites, base_strand, qual, ref_base, out, mapq, rpr) with device pointers as ints (mapq = rpr = 0: no rank sums);
+        pop-groups: one `group_id` array for the whole queue, `gouts[k]` = slab k's group records."""
         n = len(slabs)
         arr = (_capi.Slab * n)()
         outs = (C.c_void_p * n)()
+        gp = (C.c_void_p * n)() if n_groups else None
         for k, (n_sites, bs, q, ref, out, mq, rp) in enumerate(slabs):
             arr[k] = _capi.Slab(int(n_sites), int(n_samples), int(pitch), bs or None, q or None, mq or None, rp or None, ref or None,
-                                None, 0, _capi.BV_MEM_DEVICE)
+                                group_id or None, int(n_groups), _capi.BV_MEM_DEVICE)
             outs[k] = out
-        rc = self._lib.bv_engine_submit_many(self._h, n, arr, outs, stream or None)
+            if n_groups:
+                gp[k] = gouts[k]
+        rc = self._lib.bv_engine_submit_many_g(self._h, n, arr, outs, gp, stream or None)
         if rc != 0:
             raise RuntimeError("bv_engine_submit_many failed (%d): %s" % (rc, self._err()))
 

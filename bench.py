@@ -286,7 +286,7 @@ def main():
         gen = torch.Generator(device="cpu").manual_seed(args.seed & 0xFFFF)
         g = torch.randint(0, G + 1, (pitch,), generator=gen, dtype=torch.int64)
         gid = torch.where(g == G, torch.full_like(g, 255), g).to(torch.uint8).to(dev)
-        gouts = [torch.zeros(B * G * basevar_amd.GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(depth)]
+        gouts = [torch.zeros(Bl * G * basevar_amd.GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(depth)]
 
     def step(i):
         bs, q, mq, rp, ref = batches[i % nb]
@@ -305,7 +305,8 @@ def main():
                     sb, sq, smq, srp, sref = batches[(i * K + j) % nb]
                     segs.append((B, sb.data_ptr(), sq.data_ptr(), sref.data_ptr(), out.data_ptr() + j * B * rec,
                                  smq.data_ptr() if ranks else 0, srp.data_ptr() if ranks else 0))
-                engs[k].submit_many_ptrs(N, pitch, segs, stream=streams[k].cuda_stream)
+                engs[k].submit_many_ptrs(N, pitch, segs, stream=streams[k].cuda_stream, group_id=gid.data_ptr() if G else 0, n_groups=G,
+                                         gouts=[gouts[slot].data_ptr() + j * B * G * basevar_amd.GROUP_DTYPE.itemsize for j in range(K)] if G else None)
             else:
                 engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                     mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,

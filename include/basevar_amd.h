@@ -218,15 +218,20 @@ int bv_engine_destroy(bv_engine *e);
 int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out,
                      bv_group_result *gout, void *stream);
 
-/* n_slabs device-resident slabs as ONE launch per pass: equivalent to n_slabs calls of bv_engine_submit (no pop-groups:
- * gout is not taken), but the persistent kernels draw their sites across the whole queue, so the fixed tail of a launch --
- * the solve of its last deep sites, ~0.1 ms during which the chip has nothing left to stream -- is paid once per queue, not
- * once per slab.  Meant for hosts that hold several small batches (a few thousand sites each): 8,192-site batches run at
- * the rate of one large batch (100 k samples: 14.9 -> 20 M sites/s; 10 k samples: 52 -> 143 M).  Chained, 16 slabs per
- * launch, when the slabs are BV_MEM_DEVICE, share n_samples (> 2048) and pitch, have no groups and at most cfg.max_sites
- * sites together; anything else is submitted slab by slab.  bv_engine_last_variant_count then counts the last launch.
+/* n_slabs device-resident slabs as ONE launch per pass: equivalent to n_slabs calls of bv_engine_submit, but the persistent
+ * kernels draw their sites across the whole queue, so the fixed tail of a launch -- the solve of its last deep sites, ~0.1 ms
+ * during which the chip has nothing left to stream -- is paid once per queue, not once per slab.  Meant for hosts that hold
+ * several small batches (a few thousand sites each): 8,192-site batches run at the rate of one large batch (100 k samples:
+ * 14.9 -> 20 M sites/s; 10 k samples: 52 -> 143 M).  Chained, 16 slabs per launch, when the slabs are BV_MEM_DEVICE, share
+ * n_samples, pitch, the presence of rank planes and the pop-group assignment (the same group_id array and n_groups), and
+ * have at most cfg.max_sites sites together; anything else is submitted slab by slab.  bv_engine_last_variant_count then
+ * counts the last launch.  Every record is byte-identical to the one a submit of its own slab writes.
+ * bv_engine_submit_many takes slabs without pop-groups; bv_engine_submit_many_g also takes gouts[k] = slab k's
+ * [n_sites][n_groups] records (NULL entries for slabs without groups).
  * Replaces nothing in the reference (its workers take one position at a time, basetype_caller.cpp:738-762). */
 int bv_engine_submit_many(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, bv_site_result *const *outs, void *stream);
+int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs, bv_site_result *const *outs,
+                            bv_group_result *const *gouts, void *stream);
 
 /* Enqueue on `stream` (NULL: the engine's own) a wait for every submit issued so far.  Needed only with BV_FLAG_LANES (there
  * the submits run on internal streams); otherwise a no-op for the stream the submits were given. */

@@ -918,14 +918,18 @@ def test_tile_job_interleaved_with_row_submits_and_abandoned_jobs(bv, restatemen
     eng.close()
 
 
-@pytest.mark.parametrize("n,flags", [(60000, 0), (6000, 0), (6000, 1 << 16), (70, 0)],
-                         ids=["long_rows", "short_rows", "short_rows_one_workgroup", "shallow_rows"])
-def test_chained_submit_equals_separate_submits(bv, n, flags):
-    """bv_engine_submit_many: several device slabs, one launch per pass (the site tickets / site ranges span the queue) --
+@pytest.mark.parametrize("n,flags,groups", [(60000, 0, 0), (6000, 0, 0), (6000, 1 << 16, 0), (70, 0, 0), (1500, 0, 0),
+                                            (60000, 0, 3), (6000, 0, 3), (6000, 1 << 16, 2), (6000, 0, 9), (1500, 0, 2), (70, 0, 2)],
+                         ids=["long_rows", "short_rows", "short_rows_one_workgroup", "shallow_rows", "rows_of_1500",
+                              "long_rows_groups", "short_rows_groups", "short_rows_groups_one_workgroup", "short_rows_9_groups",
+                              "rows_of_1500_groups", "shallow_rows_groups"])
+def test_chained_submit_equals_separate_submits(bv, n, flags, groups):
+    """bv_engine_submit_many(_g): several device slabs, one launch per pass (the site tickets / site ranges span the queue) --
     every record must be the one a submit of its own slab writes (byte for byte: which workgroup solves a site has no
     influence).  Long rows: every kernel looks its segment up per site; short rows: planes per row, reference bases and
     records through the engine's contiguous copies (with BV_FLAG_GRID_LIMIT(1) every wave walks sites of many segments);
-    70-sample rows take the plain submits (no chained kernels there)."""
+    rows of <= 2048 samples and pop-groups (one cohort: one group_id array for the queue; the streaming group tally, the
+    workgroup-per-row kernels, the four-per-wave and the one-wave group solvers) chain too since round 3."""
     import torch
     sizes = [96, 17, 200, 64, 1, 130, 48, 77, 33, 120, 5, 5, 60, 41, 9, 88, 150, 3, 70]  # 19 slabs: two chained launches (16 + 3)
     slabs = [make_slab(s, n, seed=300 + k, coverage=(0.05 + 0.02 * (k % 3)) if n > 1000 else 0.4,
@@ -939,32 +943,47 @@ def test_chained_submit_equals_separate_submits(bv, n, flags):
     maf = bv.min_af(n)
     dev = torch.device("cuda", 0)
     eng = bv.BaseTypeEngine(max_sites=sum(sizes), min_af_value=maf, device=0, flags=flags)
-    rec = bv.SITE_DTYPE.itemsize
-    keep, segs, outs = [], [], []
+    rec, grec = bv.SITE_DTYPE.itemsize, bv.GROUP_DTYPE.itemsize
+    gid_t = None
+    if groups:
+        rng = np.random.default_rng(n + groups)
+        g = rng.integers(0, groups + 1, size=slabs[0]["pitch"]).astype(np.uint8)
+        g[g == groups] = 255  # in no group
+        if groups >= 2:
+            g[: n // 3][g[: n // 3] == 1] = 255  # one shallow group (the one-wave group solver)
+        gid_t = torch.from_numpy(g).to(dev)
+    keep, segs, outs, gouts = [], [], [], []
     for sl in slabs:
         t = [torch.from_numpy(np.ascontiguousarray(sl[k])).to(dev) for k in ("base_strand", "qual", "ref_base", "mapq")]
         t.append(torch.from_numpy(np.ascontiguousarray(sl["rpr"]).view(np.int16)).to(dev))
         out = torch.zeros(sl["n_sites"] * rec, dtype=torch.uint8, device=dev)
-        keep.append(t); outs.append(out)
+        gout = torch.full((max(1, sl["n_sites"] * groups * grec),), 0xEE, dtype=torch.uint8, device=dev)
+        keep.append(t); outs.append(out); gouts.append(gout)
         segs.append((sl["n_sites"], t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr(), t[3].data_ptr(), t[4].data_ptr()))
     torch.cuda.synchronize()
-    eng.submit_many_ptrs(n, slabs[0]["pitch"], segs)
+    eng.submit_many_ptrs(n, slabs[0]["pitch"], segs, group_id=gid_t.data_ptr() if groups else 0, n_groups=groups,
+                         gouts=[g_.data_ptr() for g_ in gouts])
     eng.wait()
     chained = [o.cpu().numpy().view(bv.SITE_DTYPE).copy() for o in outs]
+    gchained = [g_.cpu().numpy().copy() for g_ in gouts]
     n_var_chain = eng.last_variant_count()
     eng.close()
     eng = bv.BaseTypeEngine(max_sites=sum(sizes), min_af_value=maf, device=0)  # the single submits: default launch shapes
     total_var = 0
     for k, sl in enumerate(slabs):
         outs[k].zero_()
-        eng.submit_ptrs(sl["n_sites"], n, sl["pitch"], segs[k][1], segs[k][2], segs[k][3], segs[k][4], segs[k][5], segs[k][6])
+        gouts[k].fill_(0x77)
+        eng.submit_ptrs(sl["n_sites"], n, sl["pitch"], segs[k][1], segs[k][2], segs[k][3], segs[k][4], segs[k][5], segs[k][6],
+                        group_id=gid_t.data_ptr() if groups else 0, n_groups=groups, gout=gouts[k].data_ptr() if groups else 0)
         eng.wait()
         single = outs[k].cpu().numpy().view(bv.SITE_DTYPE)
         assert single.tobytes() == chained[k].tobytes(), "slab %d" % k
+        if groups:
+            assert gouts[k].cpu().numpy().tobytes() == gchained[k].tobytes(), "pop-group records of slab %d" % k
         total_var += int(((single["status"] & 2) != 0).sum())
     assert total_var > 100
-    if n > 2048:  # the last chained launch held slabs 16, 17 and 18
-        assert n_var_chain == sum(int(((c["status"] & 2) != 0).sum()) for c in chained[16:])
+    # the last chained launch held slabs 16, 17 and 18
+    assert n_var_chain == sum(int(((c["status"] & 2) != 0).sum()) for c in chained[16:])
     eng.close()
 
 
