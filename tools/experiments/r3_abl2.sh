@@ -1,0 +1,15 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
+OUT=gpurun_out/r3_abl2.txt; : > $OUT
+run() { # lib args...
+  lib=$1; shift
+  BASEVAR_AMD_LIB=$PWD/basevar_amd/lib/$lib timeout 300 python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 "$@" 2>>gpurun_out/r3_abl2.err | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('%-28s %-44s sites/s %.4g ms/step %.4f stream %.4f | solve %.4f | pass2 %.4f' % ('$lib', '$*', d['value'], d['ms_per_step'], r['avg_launch_ms'], r['pass1_avg_ms']-r['avg_launch_ms'], r['pass2_avg_launch_ms']))" >> $OUT
+}
+for lib in "$@"; do
+  run $lib --samples 10000 --batch-sites 100000 --flags $(( (1 << 24) ))
+  run $lib --samples 10000 --batch-sites 100000 --flags $(( (1 << 24) | 2 ))
+done
+cat $OUT
