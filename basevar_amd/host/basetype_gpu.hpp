@@ -127,8 +127,30 @@ public:
         const size_t off = (size_t)n_sites() * pitch_;
         bs_.resize(off); q_.resize(off); mq_.resize(off); rp_.resize(off);
     }
+    // All rows of `o` (same sample count), behind this builder's: blocks of sites parsed by several threads into builders
+    // of their own are joined in site order this way (bv_call).
+    void append(const SlabBuilder &o) {
+        if (o.n_ != n_) throw std::runtime_error("[ERROR] SlabBuilder::append: different sample counts");
+        bs_.insert(bs_.end(), o.bs_.begin(), o.bs_.end());
+        q_.insert(q_.end(), o.q_.begin(), o.q_.end());
+        mq_.insert(mq_.end(), o.mq_.begin(), o.mq_.end());
+        rp_.insert(rp_.end(), o.rp_.begin(), o.rp_.end());
+        ref_.insert(ref_.end(), o.ref_.begin(), o.ref_.end());
+    }
+    // the first `k` rows of `o` only
+    void append_first(const SlabBuilder &o, size_t k) {
+        if (o.n_ != n_) throw std::runtime_error("[ERROR] SlabBuilder::append: different sample counts");
+        bs_.insert(bs_.end(), o.bs_.begin(), o.bs_.begin() + k * pitch_);
+        q_.insert(q_.end(), o.q_.begin(), o.q_.begin() + k * pitch_);
+        mq_.insert(mq_.end(), o.mq_.begin(), o.mq_.begin() + k * pitch_);
+        rp_.insert(rp_.end(), o.rp_.begin(), o.rp_.begin() + k * pitch_);
+        ref_.insert(ref_.end(), o.ref_.begin(), o.ref_.begin() + k);
+    }
     const uint8_t *cell_row(size_t site) const { return &bs_[site * pitch_]; }
     const uint8_t *phred_row(size_t site) const { return &q_[site * pitch_]; }
+    const uint8_t *mapq_row(size_t site) const { return &mq_[site * pitch_]; }
+    const uint16_t *rank_row(size_t site) const { return &rp_[site * pitch_]; }
+    uint8_t ref_code(size_t site) const { return ref_[site]; }
 
     void set_groups(const std::vector<uint8_t> &group_id, uint32_t n_groups) {
         gid_ = group_id;

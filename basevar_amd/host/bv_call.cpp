@@ -119,6 +119,17 @@ struct StageClock {
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 };
 
+// fn(i) for i in [0, n) on up to `threads` threads (contiguous ranges; the caller's thread takes the first)
+template <typename Fn>
+void parallel_ranges(size_t n, int threads, Fn fn) {
+    const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), n));
+    if (nt <= 1) { fn(0, 0, n); return; }
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back([&, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
+    fn(0, 0, n / nt);
+    for (auto &th : pool) th.join();
+}
+
 [[noreturn]] void die(const std::string &m) {
     std::cerr << m << std::endl;
     std::exit(1);
@@ -298,16 +309,25 @@ int main(int argc, char **argv) {
                 if (!d.error.empty()) fail(d.error);
                 else {
                     const double t0 = StageClock::now();
-                    for (size_t i = 0; i < d.text.size(); ++i) {
-                        const std::string c = bvamd::format_cvg_line(d.text[i], d.result.sites[i]);
-                        std::fwrite(c.data(), 1, c.size(), CVG);
-                        if (d.result.has_variant(i)) {
-                            const std::string v = bvamd::format_vcf_line(d.text[i], d.slab.cell_row(i), d.slab.phred_row(i), n_sample,
-                                                                         d.result.sites[i],
-                                                                         group_names.empty() ? nullptr : &d.result.group(i, 0), group_names);
-                            std::fwrite(v.data(), 1, v.size(), VCF);
-                            ++n_variants;
+                    // the lines of a batch are formatted by `--thread` threads (ranges of consecutive sites, a text buffer each)
+                    // and written in site order
+                    const size_t nt = (size_t)std::max(1, threads);
+                    std::vector<std::string> cvg_txt(nt), vcf_txt(nt);
+                    std::vector<size_t> nv(nt, 0);
+                    parallel_ranges(d.text.size(), threads, [&](size_t t, size_t lo, size_t hi) {
+                        for (size_t i = lo; i < hi; ++i) {
+                            cvg_txt[t] += bvamd::format_cvg_line(d.text[i], d.result.sites[i]);
+                            if (d.result.has_variant(i)) {
+                                vcf_txt[t] += bvamd::format_vcf_line(d.text[i], d.slab.cell_row(i), d.slab.phred_row(i), n_sample, d.result.sites[i],
+                                                                     group_names.empty() ? nullptr : &d.result.group(i, 0), group_names);
+                                ++nv[t];
+                            }
                         }
+                    });
+                    for (size_t t = 0; t < nt; ++t) {
+                        std::fwrite(cvg_txt[t].data(), 1, cvg_txt[t].size(), CVG);
+                        std::fwrite(vcf_txt[t].data(), 1, vcf_txt[t].size(), VCF);
+                        n_variants += nv[t];
                     }
                     n_sites += d.text.size();
                     clk.emit += StageClock::now() - t0;
@@ -370,33 +390,106 @@ int main(int argc, char **argv) {
             }
         } else {
             // ---- one row from every batchfile per position (caller.cpp:586-611)
-            std::vector<std::string> rows(batchfiles.size());
             const bool fast = parser == "fast";
-            for (; still_ok();) {
-                bool eof = false;
-                double t0 = StageClock::now();
-                for (size_t b = 0; b < batchfiles.size(); ++b) {
-                    if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }
-                    else if (!readers[b].getline(rows[b])) { eof = true; break; }
-                }
-                double t1 = StageClock::now();
-                clk.read += t1 - t0;
-                if (eof) break;
-                if (!cur) fresh();
-                if (fast) {
-                    // the rows' bytes straight into the slab row (batchfile_fast.hpp)
-                    bvamd::SiteText st;
-                    if (bvamd::parse_site_rows_fast(rows, n_sample, cur->slab, st)) cur->text.push_back(std::move(st));
-                } else {
-                    // the reference's own steps: split -> BatchInfo -> slab row (batchfile.hpp)
-                    bvamd::BatchInfo bi;
-                    if (bvamd::parse_site_rows(rows, n_sample, bi)) {  // else total depth 0, caller.cpp:718
-                        cur->slab.add_site(bi);
-                        cur->text.push_back(bvamd::site_text_of(bi));
+            const size_t NB = batchfiles.size();
+            if (threads <= 1 || !fast) {
+                std::vector<std::string> rows(NB);
+                for (; still_ok();) {
+                    bool eof = false;
+                    double t0 = StageClock::now();
+                    for (size_t b = 0; b < NB; ++b) {
+                        if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }
+                        else if (!readers[b].getline(rows[b])) { eof = true; break; }
                     }
+                    double t1 = StageClock::now();
+                    clk.read += t1 - t0;
+                    if (eof) break;
+                    if (!cur) fresh();
+                    if (fast) {
+                        // the rows' bytes straight into the slab row (batchfile_fast.hpp)
+                        bvamd::SiteText st;
+                        if (bvamd::parse_site_rows_fast(rows, n_sample, cur->slab, st)) cur->text.push_back(std::move(st));
+                    } else {
+                        // the reference's own steps: split -> BatchInfo -> slab row (batchfile.hpp)
+                        bvamd::BatchInfo bi;
+                        if (bvamd::parse_site_rows(rows, n_sample, bi)) {  // else total depth 0, caller.cpp:718
+                            cur->slab.add_site(bi);
+                            cur->text.push_back(bvamd::site_text_of(bi));
+                        }
+                    }
+                    clk.parse += StageClock::now() - t1;
+                    if (cur->slab.n_sites() == batch_sites) ship();
                 }
-                clk.parse += StageClock::now() - t1;
-                if (cur->slab.n_sites() == batch_sites) ship();
+            } else {
+                // ---- `--thread T`: blocks of sites.  The files are read by T threads (every thread its files, a block of lines
+                // each), then the block's sites are parsed by T threads (every thread a range of consecutive sites into a slab
+                // builder of its own, with the byte-level reader unchanged) and joined in site order: same rows, and the error
+                // of the first offending site in site order, as the site-by-site loop.
+                const size_t R = std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << 24) / std::max<size_t>(n_sample, 1)));
+                std::vector<std::vector<std::string>> lines(NB, std::vector<std::string>(R));
+                std::vector<size_t> got(NB, 0);
+                struct Part {
+                    std::unique_ptr<bvamd::SlabBuilder> slab;
+                    std::vector<bvamd::SiteText> text;
+                    std::string error;
+                    size_t error_site = (size_t)-1;
+                };
+                bool at_eof = false;
+                while (still_ok() && !at_eof) {
+                    double t0 = StageClock::now();
+                    parallel_ranges(NB, threads, [&](size_t, size_t lo, size_t hi) {
+                        for (size_t b = lo; b < hi; ++b) {
+                            size_t k = 0;
+                            if (have_row[b]) { lines[b][k++] = first_row[b]; have_row[b] = false; }
+                            while (k < R && readers[b].getline(lines[b][k])) ++k;
+                            got[b] = k;
+                        }
+                    });
+                    size_t n_blk = R;
+                    for (size_t b = 0; b < NB; ++b) n_blk = std::min(n_blk, got[b]);
+                    if (n_blk < R) at_eof = true;  // a file ran out: the sites every file still has, then stop (caller.cpp:589-601)
+                    double t1 = StageClock::now();
+                    clk.read += t1 - t0;
+                    if (n_blk == 0) break;
+                    std::vector<Part> parts((size_t)std::max(1, threads));
+                    parallel_ranges(n_blk, threads, [&](size_t t, size_t lo, size_t hi) {
+                        Part &p = parts[t];
+                        p.slab.reset(new bvamd::SlabBuilder((uint32_t)n_sample));
+                        std::vector<std::string> rows(NB);
+                        for (size_t r = lo; r < hi; ++r) {
+                            for (size_t b = 0; b < NB; ++b) rows[b].swap(lines[b][r]);
+                            try {
+                                bvamd::SiteText st;
+                                if (bvamd::parse_site_rows_fast(rows, n_sample, *p.slab, st)) p.text.push_back(std::move(st));
+                            } catch (const std::exception &ex) {
+                                p.error = ex.what(); p.error_site = r;
+                                return;  // the sites before r of this range are in p; nothing after r counts
+                            }
+                        }
+                    });
+                    // join in site order; the first error in site order ends the run (what precedes it in the block is kept)
+                    for (Part &p : parts) {
+                        if (!p.slab) continue;
+                        size_t done = 0;
+                        const size_t have = p.slab->n_sites();
+                        while (done < have) {
+                            if (!cur) fresh();
+                            const size_t room = batch_sites - cur->slab.n_sites(), take = std::min(room, have - done);
+                            if (done == 0 && take == have) cur->slab.append(*p.slab);
+                            else {
+                                bvamd::SlabBuilder piece((uint32_t)n_sample);
+                                // (rare: a part straddles a batch boundary -- copy it row range by row range)
+                                for (size_t i = done; i < done + take; ++i) piece.add_row(p.slab->cell_row(i), p.slab->phred_row(i), p.slab->mapq_row(i), p.slab->rank_row(i), p.slab->ref_code(i));
+                                cur->slab.append(piece);
+                            }
+                            for (size_t i = done; i < done + take; ++i) cur->text.push_back(std::move(p.text[i]));
+                            done += take;
+                            if (cur->slab.n_sites() == batch_sites) ship();
+                        }
+                        if (!p.error.empty()) throw std::runtime_error(p.error);
+                    }
+                    clk.parse += StageClock::now() - t1;
+                }
             }
         }
         ship();

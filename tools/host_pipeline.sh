@@ -47,4 +47,10 @@ for p in literal fast; do
   cat $W/b.json >> $OUT
 done
 cmp $W/b_literal.vcf $W/b_fast.vcf && cmp $W/b_literal.cvg $W/b_fast.cvg && say "outputs of the two readers: byte-identical ($(wc -l < $W/b_fast.vcf) VCF lines, $(wc -l < $W/b_fast.cvg) CVG lines)"
+for t in 4 16; do
+  say "-- parser fast, --thread $t (files read and sites parsed in blocks by $t threads, lines formatted by $t threads)"
+  $CALL --batchfiles $BF --output-vcf $W/b_t.vcf --output-cvg $W/b_t.cvg --parser fast --thread $t --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
+  cat $W/b.json >> $OUT
+  cmp $W/b_t.vcf $W/b_fast.vcf && cmp $W/b_t.cvg $W/b_fast.cvg && say "outputs with --thread $t: byte-identical to one thread"
+done
 rm -rf $W
