@@ -23,7 +23,7 @@ class _Got:
 
 
 def lrt_chained(eng, slab, rng):
-    """The slab cut into 2-5 row ranges, uploaded, and submitted as ONE chained launch (CAMPAIGN_CHAIN=1; no pop-groups)."""
+    """The slab cut into 2-5 row ranges, uploaded, and submitted as ONE chained launch (CAMPAIGN_CHAIN=1; pop-groups too)."""
     import torch
     dev = torch.device("cuda", 0)
     S, n, pitch = slab["n_sites"], slab["n_samples"], slab["pitch"]
@@ -31,6 +31,10 @@ def lrt_chained(eng, slab, rng):
     t["rpr"] = torch.from_numpy(np.ascontiguousarray(slab["rpr"]).view(np.int16)).to(dev)
     rec = basevar_amd.SITE_DTYPE.itemsize
     out = torch.zeros(S * rec, dtype=torch.uint8, device=dev)
+    G = int(slab.get("n_groups", 0) or 0)
+    grec = basevar_amd.GROUP_DTYPE.itemsize
+    gid = torch.from_numpy(np.ascontiguousarray(slab["group_id"])).to(dev) if G else None
+    gout = torch.zeros(max(1, S * G * grec), dtype=torch.uint8, device=dev)
     k = int(rng.integers(2, 6))
     cuts = sorted(set([0, S] + [int(c) for c in rng.integers(1, max(2, S), size=k - 1)]))
     segs = []
@@ -38,11 +42,12 @@ def lrt_chained(eng, slab, rng):
         segs.append((hi - lo, t["base_strand"][lo].data_ptr(), t["qual"][lo].data_ptr(), t["ref_base"][lo:].data_ptr(),
                      out.data_ptr() + lo * rec, t["mapq"][lo].data_ptr(), t["rpr"][lo].data_ptr()))
     torch.cuda.synchronize()
-    eng.submit_many_ptrs(n, pitch, segs)
+    eng.submit_many_ptrs(n, pitch, segs, group_id=gid.data_ptr() if G else 0, n_groups=G,
+                         gouts=[gout.data_ptr() + lo * G * grec for lo in cuts[:-1]] if G else None)
     eng.wait()
     g = _Got()
     g.sites = out.cpu().numpy().view(basevar_amd.SITE_DTYPE)
-    g.groups = None
+    g.groups = gout.cpu().numpy()[:S * G * grec].view(basevar_amd.GROUP_DTYPE).reshape(S, G) if G else None
     g.n_variant = int(((g.sites["status"] & 2) != 0).sum())
     return g
 
@@ -73,8 +78,8 @@ def main():
         slab = make_slab(sites, n, seed=int(rng.integers(1 << 30)), coverage=cov, qual_mean=qm, qual_sd=9.0,
                          qual_min=1, qual_max=60, n_groups=ng, class_af=classes, ref_n_frac=0.03)
         maf = res.min_af(n, float(rng.choice([0.01, 0.001])))
-        eng = basevar_amd.BaseTypeEngine(sites, maf)
-        if os.environ.get("CAMPAIGN_CHAIN") == "1" and ng == 0:
+        eng = basevar_amd.BaseTypeEngine(sites, maf, flags=int(os.environ.get("CAMPAIGN_FLAGS", "0"), 0))
+        if os.environ.get("CAMPAIGN_CHAIN") == "1":
             got = lrt_chained(eng, slab, rng)  # the same rows as 2-5 slabs through bv_engine_submit_many
         else:
             got = eng.lrt(slab)

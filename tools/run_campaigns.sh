@@ -1,0 +1,16 @@
+#!/bin/bash
+# the differential campaigns of a round against the real reference: tools/run_campaigns.sh <tag> [rounds per campaign]
+cd "$(dirname "$0")/.."; mkdir -p gpurun_out
+TAG=${1:-r3}; R=${2:-30}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
+run() { echo "### $1" >> $OUT; shift; env "$@" timeout 1500 python3 tools/diff_campaign.py $R 2>&1 | grep -E "TOTAL|tie-excused site [0-9]|MISMATCH|mismatching fields [1-9]" >> $OUT; }
+run "default shapes, seed 11" CAMPAIGN_SEED=11
+run "default shapes, seed 12" CAMPAIGN_SEED=12
+run "default shapes, seed 13" CAMPAIGN_SEED=13
+run "shallow rows (ties), seed 21" CAMPAIGN_SHALLOW=1 CAMPAIGN_SEED=21
+run "shallow rows (ties), seed 22" CAMPAIGN_SHALLOW=1 CAMPAIGN_SEED=22
+run "chained launches incl. pop-groups, seed 31" CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=31
+run "chained launches incl. pop-groups, seed 32" CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=32
+run "chained + shallow, seed 33" CAMPAIGN_CHAIN=1 CAMPAIGN_SHALLOW=1 CAMPAIGN_SEED=33
+run "chunk pipeline BV_FLAG_SPLIT(3), seed 41" CAMPAIGN_FLAGS=$((3 << 24)) CAMPAIGN_SEED=41
+run "wave solver only (BV_FLAG_WAVE_SOLVER), seed 51" CAMPAIGN_FLAGS=16 CAMPAIGN_SEED=51
+cat $OUT
