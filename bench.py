@@ -447,6 +447,9 @@ def main():
                 # (pass 2 also re-reads the call byte of variant rows: its own traffic is 4 B/cell)
                 "whole_path_GBps": (1.0 + 1.5 * fvar) * algo_bytes / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9,
                 "whole_path_frac": (1.0 + 1.5 * fvar) * algo_bytes / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                # the same bytes over the WALL time of a step on this rank (launch gaps and, with --lanes 2 / --streams 2, the
+                # overlap of consecutive submits included: the per-submit kernel times above then count co-running kernels twice)
+                "whole_path_frac_wall": (1.0 + 1.5 * fvar) * algo_bytes * max(nsub, 1) / args.steps / max(per_rank[0][0] / args.steps, 1e-12) / 1e9 / HBM_PEAK_GBS,
             },
         }
         if world == 1:
