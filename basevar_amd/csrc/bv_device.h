@@ -974,10 +974,11 @@ __device__ __noinline__ int bv_em_ordered(const uint16_t *ord, int n, const doub
 // ------------------------------------------------------------------ LRT
 // BaseType::lrt + _f, src/basetype.cpp:105-199.  The EM runs of one level (the n-subsets of
 // the current active set, Combinations order: external/combinations.h:55-69) are independent.
-//   NW >= 1: "block mode" -- the runs of a level are dealt to the NW waves of the workgroup,
-//            results meet in LDS behind __syncthreads(); every thread then replays the cheap,
-//            uniform argmin / threshold decision.  (Kept for workgroup-wide callers; the
-//            shipped kernels use wave mode.)
+//   NW >= 1: "team mode" -- the runs of a level are dealt to NW cooperating waves of a workgroup (NOT necessarily all of
+//            its waves: no s_barrier); results meet in LDS behind a counting barrier in `sh` (which must then be a
+//            BvLrtTeamShared shared by the team), every wave replays the cheap, uniform argmin / threshold decision.
+//            Each run is the same one-wave arithmetic as in wave mode, so the outcome is bit-identical to it.
+//            (Used at the tail of a long-row launch, bv_pass1.hip: the idle tally waves join the solver wave.)
 //   NW == 0: "wave mode"  -- the calling wave does every run itself (used for the pop-group
 //            calls of pass 2, where each wave owns a different group); `sh` is wave-private.
 struct BvLrtShared {
@@ -1010,13 +1011,31 @@ __device__ __forceinline__ uint32_t bv_sel4u(const uint32_t v[4], int i) {
 
 template <int NW>
 __device__ __forceinline__ void bv_lrt_sync() {
-    if (NW > 0) {
-        __syncthreads();
-    } else {
-        // same wave writes (lane 0) then reads (all lanes): LDS is in-order per wave; just
-        // stop the compiler from moving the accesses across this point
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    static_assert(NW == 0, "team mode synchronises through bv_team_barrier");
+    // same wave writes (lane 0) then reads (all lanes): LDS is in-order per wave; just
+    // stop the compiler from moving the accesses across this point
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Team mode: the LRT scratch plus a counting barrier for the NW waves of the team.  `bar` counts arrivals since the
+// team's owner last zeroed it (before it hands out a site); every spin is bounded like the kernel's other hand-offs.
+struct BvLrtTeamShared {
+    BvLrtShared lrt;  // first member: bv_lrt() receives &team->lrt
+    uint32_t bar;
+    uint32_t *err;    // a.counters + BV_CTR_TIMEOUT
+};
+__device__ __forceinline__ void bv_team_barrier(BvLrtShared *sh, uint32_t target, int lane) {
+    BvLrtTeamShared *t = reinterpret_cast<BvLrtTeamShared *>(sh);
+    // one arrival per wave; its earlier LDS writes are ahead of the atomic in the wave's in-order LDS queue
+    if (lane == 0) __hip_atomic_fetch_add(&t->bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(&t->bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 24)) {
+            atomicOr(t->err, 1u);
+            break;
+        }
     }
 }
 
@@ -1060,6 +1079,7 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
     double lr_alt = 0., chi = 0.;
     bool have_single = false;  // sh->single[] holds the closed-form log-likelihoods of the single-base subsets
     int par = 0;
+    uint32_t team_epoch = 0;  // team mode: barriers passed for this site
     // n == m0: F_m over the full active set (basetype.cpp:144); n < m0: the loop of :151-169,
     // whose bound is the ORIGINAL size while the subsets are drawn from the current set.
     for (int n = m0; n > 0; --n) {
@@ -1081,7 +1101,7 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             int it;
             if (B.ord != nullptr && s != 0.) {
                 it = bv_em_ordered(B.ord, B.n_ord, B.hit, B.miss, f, &lr, lane, bv_hostlog_of(B.logmiss));
-            } else if (NW == 0 && B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
+            } else if (B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
                 // A single-base subset {b} with every likelihood positive: the reference's EM needs no arithmetic.  Its
                 // first e_step gives every sample the posterior L/L == 1.0 for b, the m_step f_b == n/n == 1.0, and from
                 // then on every marginal is the likelihood itself (lh * 1.0), so the reported log-likelihood is
@@ -1113,11 +1133,13 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
                     }
                     a_ = bv_wave_sum(a_);
                     bv_wave_sum4(g0, g1, g2, g3, g0, g1, g2, g3);
+                    // (team mode: every wave that meets a single-base subset computes the four sums itself and reads back
+                    // its own stores -- the other waves write the same values -- so no team barrier is needed here)
                     if (lane == 0) {
                         sh->single[0] = a_ + g0; sh->single[1] = a_ + g1;
                         sh->single[2] = a_ + g2; sh->single[3] = a_ + g3;
                     }
-                    bv_lrt_sync<NW>();
+                    bv_lrt_sync<0>();
                     have_single = true;
                 }
                 const int b1 = __builtin_ctz(in_set);
@@ -1142,7 +1164,8 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
                 sh->iters[par][c] = (s == 0.) ? -it - 1 : it;  // negative marks basetype.cpp:113-115
             }
         }
-        bv_lrt_sync<NW>();
+        if (NW > 0) bv_team_barrier(sh, (uint32_t)NW * (++team_epoch), lane);
+        else bv_lrt_sync<0>();
         int i_min = 0;
         double chi_min = 0.;
         for (int c = 0; c < ncomb; ++c) {

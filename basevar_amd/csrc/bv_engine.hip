@@ -1367,6 +1367,35 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
 
 void *bv_engine_stream(bv_engine *e) { return e ? (void *)e->stream : nullptr; }
 
+#ifdef BV_TEAM_DEBUG
+// the stamps of bv_pass1_kernel's team form (see BV_TEAM_STAMP in bv_pass1.hip): distribution over the workgroups, and per XCD
+static void bv_team_debug_report(const uint32_t *h) {
+    fprintf(stderr, "[team debug] team jobs %u (mean %.0f cycles)  solo solves %u (mean %.0f cycles)\n", h[BV_CTR_CANDS],
+            h[BV_CTR_CANDS] ? 64.0 * h[BV_CTR_CANDS + 1] / h[BV_CTR_CANDS] : 0., h[BV_CTR_EASY3],
+            h[BV_CTR_EASY3] ? 64.0 * h[BV_CTR_EASY3 + 1] / h[BV_CTR_EASY3] : 0.);
+    const uint32_t *d = h + BV_CTR_WORDS;
+    const char *nm[6] = {"entry", "start barrier passed", "first row begins", "tally waves done", "phred tables in LDS", "solver wave done"};
+    uint32_t t0 = 0; bool any = false;
+    for (int b = 0; b < 640; ++b)
+        if (d[b * 8] && (!any || (int32_t)(d[b * 8] - t0) < 0)) { t0 = d[b * 8]; any = true; }
+    if (!any) return;
+    for (int j = 0; j < 6; ++j) {
+        std::vector<double> v; double sum[8] = {}; uint32_t cnt[8] = {};
+        for (int b = 0; b < 640; ++b) {
+            if (!d[b * 8]) continue;
+            const double t = (double)(int32_t)(d[b * 8 + j] - t0) * 0.01;
+            v.push_back(t); sum[d[b * 8 + 7] & 7u] += t; cnt[d[b * 8 + 7] & 7u]++;
+        }
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        fprintf(stderr, "[team debug] %-22s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f us | mean per XCD:", nm[j], v[0], v[n / 10], v[n / 2],
+                v[n * 9 / 10], v[n - 1]);
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", cnt[x] ? sum[x] / cnt[x] : 0.);
+        fprintf(stderr, "\n");
+    }
+}
+#endif
+
 int bv_engine_wait(bv_engine *e) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_wait: null engine");
     if (!e->submitted) return BV_OK;
@@ -1384,6 +1413,9 @@ int bv_engine_wait(bv_engine *e) {
     e->used_streams.push_back(e->last_stream);
     uint32_t timed_out = 0, zero_freq = 0;
     for (uint32_t b = 0; b < bv_engine::kCtrBlocks; ++b) {
+#ifdef BV_TEAM_DEBUG
+        if (b == 0) bv_team_debug_report(e->h_counters);
+#endif
         timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
         zero_freq += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ];
     }

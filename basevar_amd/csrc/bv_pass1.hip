@@ -163,28 +163,194 @@ __device__ __forceinline__ void bv_add_flag(uint32_t *flag, int lane) {
     if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int NTALLY, int NSOLVE, bool CHAIN = false>
+// ------------------------------------------------------------------------------ the tail of a launch: team solves
+// When a workgroup has streamed its last row, its tally waves used to exit while the solver wave worked through what was
+// left in the ring -- a whole solve (8 EM runs, two Fisher tests, QUAL, a rank sum: 40-70 us on one wave at 10^5
+// samples) with the HBM pipes empty.  On a 131,072-site batch that is 1-2 % of the launch; on a single 8,192-site batch it
+// was 23 % (0.363 ms against 0.280 ms for the tally alone).  In the TEAM form of the kernel the tally waves stay: waves
+// 0 .. NTALLY-2 join the solver wave for the LRT (bv_lrt's team mode: the EM runs of a level are independent,
+// basetype.cpp:151-169), the last tally wave runs the site's Fisher tests (the CVG one needs nothing from the LRT; the
+// VCF one starts the moment the ALT set is known) while the solver wave does QUAL and the base-quality rank sum.  Every
+// run is the same one-wave arithmetic whoever executes it, so records are byte-identical to the plain form
+// (tests/test_gpu_parity.py::test_team_tail_...).  Hand-offs are LDS flags with bounded spins, like the rest of the kernel.
+struct __attribute__((aligned(16))) BvTeam {
+    BvLrtTeamShared lrt;  // LRT scratch + counting barrier of the team
+    uint32_t helpers;     // tally waves that have finished streaming and wait for team jobs
+    uint32_t last_site;   // the last site this workgroup streams (set by the lead tally wave once it knows)
+    uint32_t gen;         // team jobs handed out so far (the job's number, from 1)
+    uint32_t site, buf;   // the job; site == 0xFFFFFFFF: no more jobs
+    uint32_t done;        // helper completions, NTALLY per job
+    uint32_t fv_go, f_done;  // == job number once the VCF table is posted / the Fisher results are
+    uint32_t vtab[4], ntab;
+    uint32_t f_flags;
+    double c_fs, c_sor, v_fs, v_sor;
+};
+#define BV_TEAM_NO_SITE 0xFFFFFFFEu
+#ifndef BV_TEAM_MAX_SITES
+#define BV_TEAM_MAX_SITES 32768
+#endif
+
+template <bool TEAM>
+__device__ __forceinline__ BvTeam *bv_team_lds() {
+    __shared__ BvTeam tm;
+    return &tm;
+}
+template <>
+__device__ __forceinline__ BvTeam *bv_team_lds<false>() {
+    return nullptr;
+}
+
+// bv_site_solve's work policy on the solver wave of a team job (role 0)
+template <int NLRT>
+struct BvTeamWork {
+    BvTeam *tm;
+    uint32_t job;
+    uint32_t *err;
+    mutable bool posted = false;
+    __device__ __forceinline__ void post(const uint32_t v[4], int ntab, int lane) const {
+        if (lane == 0) {
+            tm->vtab[0] = v[0]; tm->vtab[1] = v[1]; tm->vtab[2] = v[2]; tm->vtab[3] = v[3];
+            tm->ntab = (uint32_t)ntab;
+        }
+        bv_set_flag(&tm->fv_go, job);
+        posted = true;
+    }
+    __device__ __forceinline__ void lrt(const BvBins &B, const uint32_t depth[4], uint32_t total, int nspec, int ref,
+                                        double min_af, BvLrtShared *, int lane, BvLrtOut &L, uint32_t q0_mask) const {
+        bv_lrt<NLRT>(B, depth, total, 0 | (1 << 3) | (2 << 6) | (3 << 9), nspec, ref, min_af, &tm->lrt.lrt, 0, lane, L, q0_mask);
+    }
+    __device__ __forceinline__ void tables_known(const uint32_t v[4], int ntab, int lane) const { post(v, ntab, lane); }
+    __device__ __forceinline__ void strand_bias(const uint32_t[4], const uint32_t v[4], int ntab, int lane, const BvLnTab &,
+                                                double &c_fs, double &c_sor, double &v_fs, double &v_sor,
+                                                uint32_t &flags) const {
+        if (!posted) post(v, ntab, lane);  // not a variant site: only the CVG table
+        bv_wait_flag(&tm->f_done, job, err);
+        c_fs = tm->c_fs; c_sor = tm->c_sor;
+        if (ntab == 2) { v_fs = tm->v_fs; v_sor = tm->v_sor; }
+        flags |= tm->f_flags;
+    }
+};
+
+// Which sites a team takes: deep ones (the shallow-site replay, bv_em_ordered, is one wave's job) of a normal launch.
+__device__ __forceinline__ bool bv_team_takes(uint32_t flags, const BvSiteSums &S) {
+    const uint32_t total = S.fwd[0] + S.fwd[1] + S.fwd[2] + S.fwd[3] + S.rev[0] + S.rev[1] + S.rev[2] + S.rev[3];
+    return total > (uint32_t)BV_ORD_MAX && !(flags & (BV_FLAG_TALLY_ONLY | BV_FLAG_SKIP_LRT | BV_FLAG_SKIP_FISHER));
+}
+
+// A tally wave's part in one team job.  role 1 .. NLRT-1: LRT; role NLRT: the Fisher tests.
+template <int NLRT>
+__device__ __forceinline__ void bv_team_help(const BvSolveArgs &a, uint32_t site, int role, uint32_t job, uint32_t *hist,
+                                             uint32_t *bin_code, uint32_t *bin_cnt, BvTeam *tm, const double *tab_hit,
+                                             const double *tab_miss, int lane) {
+    BvSiteSums S;
+    S.q0_mask = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+        if (hist[b << 8] + hist[(b | 4) << 8]) S.q0_mask |= 1u << b;
+    // (the bins are re-derived by every team wave: the same values land in the same words, no hand-off needed)
+    bv_prologue_wave<false>(hist, bin_code, bin_cnt, lane, S.fwd, S.rev, &S.nb, &S.badq);
+    bv_lrt_sync<0>();
+    uint32_t depth[4], total = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        depth[b] = S.fwd[b] + S.rev[b];
+        total += depth[b];
+    }
+    int ref = a.ref_base[site];
+    if (ref > 4) ref = 4;
+    if (role < NLRT) {
+        BvBins B;
+        B.code = bin_code; B.cnt = bin_cnt; B.skip_mask = 0u; B.hit = tab_hit; B.miss = tab_miss;
+        B.loghit = a.loghit; B.logmiss = a.logmiss;
+        B.nb = (int)S.nb;
+        B.ord = nullptr; B.n_ord = 0;
+        BvLrtOut L;
+        bv_lrt<NLRT>(B, depth, total, 0 | (1 << 3) | (2 << 6) | (3 << 9), 4, ref, a.min_af, &tm->lrt.lrt, role, lane, L, S.q0_mask);
+    } else {
+        uint32_t t[4] = {0, 0, 0, 0};  // CVG table: alt = every non-ref base (caller.cpp:1236-1245)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b == ref) { t[0] += S.fwd[b]; t[1] += S.rev[b]; } else { t[2] += S.fwd[b]; t[3] += S.rev[b]; }
+        }
+        uint32_t fl = 0;
+#pragma unroll 1
+        for (int k = 0; k < 2; ++k) {
+            if (k) {
+                bv_wait_flag(&tm->fv_go, job, tm->lrt.err);
+                if (tm->ntab != 2u) break;
+                t[0] = tm->vtab[0]; t[1] = tm->vtab[1]; t[2] = tm->vtab[2]; t[3] = tm->vtab[3];
+            }
+            double fs, sor;
+            bv_strand_bias_wave(t[0], t[1], t[2], t[3], lane, a.lnfact, &fs, &sor, &fl);
+            if (lane == 0) {
+                if (k) { tm->v_fs = fs; tm->v_sor = sor; } else { tm->c_fs = fs; tm->c_sor = sor; }
+            }
+        }
+        if (lane == 0) tm->f_flags = fl;
+        bv_set_flag(&tm->f_done, job);
+    }
+    bv_add_flag(&tm->done, lane);
+}
+
+// -DBV_TEAM_DEBUG (tools/experiments/r3_team_debug.sh): every workgroup of the team form stamps s_memrealtime (100 MHz) at six
+// points of its life into the engine's spare counter blocks, the solver wave counts team jobs / solo solves and their cycles;
+// bv_engine_wait prints the distribution.  This is how the start and the tail of a launch were taken apart.
+#ifdef BV_TEAM_DEBUG
+#define BV_TEAM_STAMP_INIT()                                                                                               \
+    uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 640u ? blockIdx.x : 639u) * 8u; /* counter blocks 1.. are free */ \
+    if (TEAM && tid == 0) dbg_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */
+#define BV_TEAM_STAMP(COND, SLOT)                                                   \
+    do {                                                                            \
+        if (TEAM && (COND)) dbg_[SLOT] = (uint32_t)__builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define BV_TEAM_STAMP_INIT() do { } while (0)
+#define BV_TEAM_STAMP(COND, SLOT) do { } while (0)
+#endif
+
+template <int NTALLY, int NSOLVE, bool CHAIN = false, bool TEAM = false>
 __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel(BvPass1Args a) {
+    static_assert(!TEAM || NSOLVE == 1, "the team form has one solver wave");
     constexpr int NT = BV_WAVE * (NTALLY + NSOLVE);
     constexpr int NBUF = NSOLVE + BV_RING_EXTRA;  // the tally may run BV_RING_EXTRA sites ahead of a slow (variant-site) solve
     __shared__ BvPass1Shared<NBUF, NSOLVE> sh;
+    BvTeam *const tm = bv_team_lds<TEAM>();
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+    BV_TEAM_STAMP_INIT();
+    BV_TEAM_STAMP(tid == 0, 0);  // entry
     // one-time set-up by the whole workgroup: zero the ring, copy the phred tables
     {
         uint4 *h4 = reinterpret_cast<uint4 *>(&sh.hist[0][0]);
         for (int i = tid; i < NBUF * BV_H2_WORDS / 4; i += NT) h4[i] = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < BV_QBINS; i += NT) {
-            sh.tab_hit[i] = a.tables->hit[i];
-            sh.tab_miss[i] = a.tables->miss[i];
+        if (!TEAM) {
+            for (int i = tid; i < BV_QBINS; i += NT) {
+                sh.tab_hit[i] = a.tables->hit[i];
+                sh.tab_miss[i] = a.tables->miss[i];
+            }
         }
         if (tid < NBUF) {
             sh.published[tid] = 0u;
             sh.filled[tid] = 0u;
             sh.drained[tid] = 0u;
         }
+        if (TEAM && tid == 0) {
+            tm->helpers = 0u; tm->last_site = BV_TEAM_NO_SITE; tm->gen = 0u; tm->done = 0u; tm->fv_go = 0u; tm->f_done = 0u;
+            tm->lrt.bar = 0u; tm->lrt.err = &a.counters[BV_CTR_TIMEOUT];
+        }
     }
     __syncthreads();
+    BV_TEAM_STAMP(tid == 0, 1);  // start barrier passed
+
+    BvSolveArgs sa;  // the solver wave's; in the team form the tally waves fill theirs when they turn helpers
+#define BV_FILL_SOLVE_ARGS()                                                                              \
+    do {                                                                                                  \
+        sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;     \
+        sa.min_af = a.min_af; sa.flags = a.flags;                                                         \
+        sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;                            \
+        sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;                                     \
+        sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;                         \
+    } while (0)
 
     // Sites are handed out by a global ticket counter (a.counters[BV_CTR_TICKET], zeroed by the engine before
     // the launch): a workgroup that drew cheap hom-ref sites simply draws more, so the persistent
@@ -197,16 +363,37 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
         // work, so reserving more would lengthen the drain), 4 for short rows (one atomic per site on a single
         // address saturates at ~85 M/s).
         const uint32_t chunk = a.n_samples > 16384u ? 1u : 4u;
-        uint32_t next = 0, cur = 0, end = 0;
-        if (wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
+        // Team form: (1) a workgroup's FIRST ticket is its own index -- no atomic: the persistent grid starts all at once and
+        // 1,024 draws on one address take 12 us (measured: first rows began 3-30 us after the launch); the counter hands
+        // out the tickets from gridDim.x * chunk on.  (2) The next ticket is drawn ahead, under the current row's stream,
+        // only while the ring has room for it: a workgroup whose solver is a full ring behind would otherwise sit on a
+        // reserved site that any other workgroup could have started at once (measured on 8,192-site launches: the last
+        // tally ended 85 us after the first workgroup had run out of work).
+        const uint32_t t0 = TEAM ? gridDim.x * chunk : 0u;
+        uint32_t next = TEAM ? blockIdx.x * chunk : 0u, cur = 0, end = 0;
+        bool have = true;  // `next` holds a ticket
+        if (!TEAM && wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
         for (uint32_t k = 0;; ++k) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             uint32_t site;
             if (wave == 0) {
                 if (cur == end) {
+                    if (TEAM && !have) {  // nothing was reserved: wait for room, then draw
+                        bv_wait_flag(&sh.drained[buf], gen, &a.counters[BV_CTR_TIMEOUT]);
+                        if (lane == 0) next = t0 + atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
+                    }
                     cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
                     end = cur + chunk;
-                    if (cur < a.n_sites && lane == 0)
+                    if (TEAM) {
+                        if (cur < a.n_sites) {
+                            const uint32_t nk = k + chunk;  // the slot of the next draw's first row
+                            // (not under the very first row either: the grid starts in step, the burst of draws would return
+                            // -- in order -- ahead of every workgroup's first loads)
+                            have = k != 0 && __builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sh.drained[nk % NBUF], __ATOMIC_RELAXED,
+                                                                                                  __HIP_MEMORY_SCOPE_WORKGROUP)) == (int)(nk / NBUF);
+                            if (have && lane == 0) next = t0 + atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
+                        }
+                    } else if (cur < a.n_sites && lane == 0)
                         next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);  // in flight under these rows' stream
                 }
                 site = cur < a.n_sites ? cur : 0xFFFFFFFFu;
@@ -237,32 +424,127 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                 const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
                 pb = ch->bs[sg]; pq = ch->q[sg];
             }
+            BV_TEAM_STAMP(wave == 0 && lane == 0 && k == 0, 2);  // first row begins
             bv_tally_row_wave<NTALLY>(pb + (size_t)site * a.pitch, pq + (size_t)site * a.pitch, a.n_samples,
                                       sh.hist[buf], wave, lane);
+            if (TEAM && wave == 0) {
+                // Was that this workgroup's last row?  (The next ticket was drawn a row ago and has long arrived.)  The solver
+                // wave then waits the microsecond it takes the tally waves to report as helpers instead of starting alone.
+                if (cur == end && !have && cur < a.n_sites) {
+                    // nothing reserved (first row, or the ring was full when this row began): draw now if there is room
+                    const uint32_t nk = k + 1u;
+                    if (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sh.drained[nk % NBUF], __ATOMIC_RELAXED,
+                                                                              __HIP_MEMORY_SCOPE_WORKGROUP)) == (int)(nk / NBUF)) {
+                        if (lane == 0) next = t0 + atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
+                        have = true;
+                    }
+                }
+                bool last = cur >= a.n_sites;
+                if (!last && cur == end && have) last = (uint32_t)__builtin_amdgcn_readfirstlane((int)next) >= a.n_sites;
+                if (last && lane == 0) tm->last_site = site;
+            }
             bv_add_flag(&sh.filled[buf], lane);  // release: this wave's ds_add of the row are done
+        }
+        if (TEAM) {
+            // ------------------------------------------------ the tail: help the solver wave with what is left in the ring
+            BV_TEAM_STAMP(wave == 0 && lane == 0, 3);  // tally waves done
+            BV_FILL_SOLVE_ARGS();  // (here, not at the start: the table pointers are loads the first row must not wait for)
+            bv_add_flag(&tm->helpers, lane);
+            for (uint32_t job = 1;; ++job) {
+                bv_wait_flag(&tm->gen, job, &a.counters[BV_CTR_TIMEOUT]);
+                const uint32_t site = tm->site, buf = tm->buf;
+                if (site == 0xFFFFFFFFu) break;
+                if (CHAIN && a.ch != nullptr) {
+                    const BvChainC ch = bv_chain_const(a.ch);
+                    const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                    sa.ref_base = ch->ref_base[sg];
+                }
+                bv_team_help<NTALLY>(sa, site, wave + 1, job, sh.hist[buf], sh.sv[0].bin_code, sh.sv[0].bin_cnt, tm,
+                                     sh.tab_hit, sh.tab_miss, lane);
+            }
         }
     } else {
         // ------------------------------------------------ solver waves
         const int s = wave - NTALLY;
-        BvSolveArgs sa;
-        sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
-        sa.min_af = a.min_af; sa.flags = a.flags;
-    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
-    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
-    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
+        BV_FILL_SOLVE_ARGS();
+#undef BV_FILL_SOLVE_ARGS
+        if (TEAM) {
+            // The phred tables are the solver's (and, later, its helpers'): fetched here, under the first row's stream.  Behind
+            // the workgroup's start barrier they held every tally wave back by one loaded-memory latency (measured: 2 us on
+            // the XCD that starts first, 5-12 us on the other seven -- 1,024 workgroups already have 50 MB of row loads queued).
+            for (int i = lane; i < BV_QBINS; i += BV_WAVE) {
+                sh.tab_hit[i] = a.tables->hit[i];
+                sh.tab_miss[i] = a.tables->miss[i];
+            }
+            bv_lrt_sync<0>();
+            BV_TEAM_STAMP(lane == 0, 4);  // phred tables in LDS
+        }
+        uint32_t jobs = 0;  // team jobs handed out
         for (uint32_t k = (uint32_t)s;; k += NSOLVE) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             bv_wait_flag(&sh.filled[buf], (gen + 1u) * NTALLY, &a.counters[BV_CTR_TIMEOUT]);
             const uint32_t site = sh.site_of[buf];
-            if (site == 0xFFFFFFFFu) break;
+            if (site == 0xFFFFFFFFu) {
+                BV_TEAM_STAMP(lane == 0, 5);  // solver wave done
+                if (TEAM) {  // release the helpers
+                    if (lane == 0) tm->site = 0xFFFFFFFFu;
+                    bv_set_flag(&tm->gen, jobs + 1u);
+                }
+                break;
+            }
             if (CHAIN && a.ch != nullptr) {
                 const BvChainC ch = bv_chain_const(a.ch);
                 const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
                 sa.ref_base = ch->ref_base[sg]; sa.out = ch->out[sg]; sa.bs = ch->bs[sg]; sa.q = ch->q[sg];
             }
-            bv_solve_site_wave<false>(sa, site, (BV_LDS uint32_t *)sh.hist[buf], (BV_LDS uint32_t *)sh.sv[s].bin_code,
-                                      (BV_LDS uint32_t *)sh.sv[s].bin_cnt, (BV_LDS BvSolverScratch *)&sh.sv[s].sc,
-                                      (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
+            if (TEAM) {
+                uint32_t *hist = sh.hist[buf], *bin_code = sh.sv[s].bin_code, *bin_cnt = sh.sv[s].bin_cnt;
+                BvSolverScratch *sv = &sh.sv[s].sc;
+                constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+                if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&sv->res)[lane] = 0u;
+                BvSiteSums S;
+                S.q0_mask = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (hist[b << 8] + hist[(b | 4) << 8]) S.q0_mask |= 1u << b;
+                bv_prologue_wave<false>(hist, bin_code, bin_cnt, lane, S.fwd, S.rev, &S.nb, &S.badq);
+                bv_lrt_sync<0>();
+                BvHqFromHist hq{hist};
+                bool team = bv_team_takes(sa.flags, S);
+                if (team) {
+                    team = __hip_atomic_load(&tm->helpers, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)NTALLY;
+                    if (!team && tm->last_site == site) {  // they are on their way
+                        bv_wait_flag(&tm->helpers, (uint32_t)NTALLY, &a.counters[BV_CTR_TIMEOUT]);
+                        team = true;
+                    }
+                }
+#ifdef BV_TEAM_DEBUG
+                const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+                if (team) {
+                    ++jobs;
+                    if (lane == 0) { tm->site = site; tm->buf = buf; tm->lrt.bar = 0u; }
+                    bv_set_flag(&tm->gen, jobs);
+                    BvTeamWork<NTALLY> work;
+                    work.tm = tm; work.job = jobs; work.err = &a.counters[BV_CTR_TIMEOUT];
+                    bv_site_solve<false, BvHqFromHist, false, BvTeamWork<NTALLY>>(sa, site, S, bin_code, bin_cnt, hq, sv, sh.tab_hit,
+                                                                                 sh.tab_miss, lane, work);
+                    bv_wait_flag(&tm->done, jobs * (uint32_t)NTALLY, &a.counters[BV_CTR_TIMEOUT]);  // nobody reads the slot any more
+                } else {
+                    bv_site_solve<false>(sa, site, S, bin_code, bin_cnt, hq, sv, sh.tab_hit, sh.tab_miss, lane);
+                }
+#ifdef BV_TEAM_DEBUG
+                if (lane == 0) {  // (long rows leave the short-row list counters free)
+                    const uint32_t dt = (uint32_t)((__builtin_readcyclecounter() - t0_) >> 6);
+                    atomicAdd(&a.counters[team ? BV_CTR_CANDS : BV_CTR_EASY3], 1u);
+                    atomicAdd(&a.counters[(team ? BV_CTR_CANDS : BV_CTR_EASY3) + 1], dt);
+                }
+#endif
+            } else {
+                bv_solve_site_wave<false>(sa, site, (BV_LDS uint32_t *)sh.hist[buf], (BV_LDS uint32_t *)sh.sv[s].bin_code,
+                                          (BV_LDS uint32_t *)sh.sv[s].bin_cnt, (BV_LDS BvSolverScratch *)&sh.sv[s].sc,
+                                          (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
+            }
             // hand the slot back, zeroed
             uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[buf]);
 #pragma unroll
@@ -372,7 +654,7 @@ static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
     hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_FUSED_WAVES), 0, stream, a);
 }
 
-template <int NTALLY, int NSOLVE>
+template <int NTALLY, int NSOLVE, bool TEAM = false>
 static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
     // never more than there are sites.
@@ -380,9 +662,15 @@ static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + BV_RING_EXTRA, NSOLVE>));
     uint32_t grid = (a.n_cu ? a.n_cu : 256u) * (by_vgpr < by_lds ? by_vgpr : by_lds);
     if (grid > a.n_sites) grid = a.n_sites;
-    // (the chained form is an instantiation of its own: the headline kernel keeps its register allocation)
-    if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, true>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
-    else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, false>), dim3(grid), dim3(64 * (NTALLY + NSOLVE)), 0, stream, a);
+    // (the chained and the team forms are instantiations of their own: the headline kernel keeps its register allocation)
+    const dim3 block(64 * (NTALLY + NSOLVE));
+    if constexpr (TEAM) {
+        if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, true, true>), dim3(grid), block, 0, stream, a);
+        else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, false, true>), dim3(grid), block, 0, stream, a);
+    } else {
+        if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, true>), dim3(grid), block, 0, stream, a);
+        else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, false>), dim3(grid), block, 0, stream, a);
+    }
 }
 
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
@@ -399,8 +687,11 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
         default: break;
     }
     if (a.n_samples > 49152u) {  // measured crossover of the two kernels: ~50 k samples per row
-        // long rows: several tally waves share a row (short per-site latency => short tail)
-        bv_launch_pass1_cfg<3, 1>(a, stream);
+        // long rows: several tally waves share a row (short per-site latency => short tail).  Up to BV_TEAM_MAX_SITES per
+        // launch the team form is used: the last solves of a workgroup are spread over its idle tally waves (the tail is
+        // ~40 us shorter; past 32 rows per workgroup that is under 3 % and the plain form keeps its tuned code).
+        if (a.n_sites <= (uint32_t)BV_TEAM_MAX_SITES) bv_launch_pass1_cfg<3, 1, true>(a, stream);
+        else bv_launch_pass1_cfg<3, 1>(a, stream);
     } else {
         // short rows: solve-bound -> every wave tallies and solves its own site
         bv_launch_pass1_fused(a, stream);

@@ -118,6 +118,29 @@ struct BvSiteSums {
     uint32_t q0_mask;  // bit b: base b has a phred-0 call
 };
 
+// WHO runs a site's EM runs and its two Fisher tests.  BvSoloWork: the calling wave itself (every kernel; the arithmetic of a
+// site is defined by this form).  bv_pass1.hip adds a team form for the last sites of a long-row launch, where the same
+// one-wave runs are dealt to the workgroup's idle waves -- same values, shorter critical path.
+struct BvSoloWork {
+    __device__ __forceinline__ void lrt(const BvBins &B, const uint32_t depth[4], uint32_t total, int nspec, int ref,
+                                        double min_af, BvLrtShared *sh, int lane, BvLrtOut &L, uint32_t q0_mask) const {
+        bv_lrt<0>(B, depth, total, /*A,C,G,T*/ 0 | (1 << 3) | (2 << 6) | (3 << 9), nspec, ref, min_af, sh, 0, lane, L, q0_mask);
+    }
+    // the VCF table is known (ntab == 2: it differs from the CVG table and needs its own test)
+    __device__ __forceinline__ void tables_known(const uint32_t[4], int, int) const {}
+    // FS / SOR of the CVG table c[] and, if ntab == 2, of the VCF table v[] ({ref_fwd, ref_rev, alt_fwd, alt_rev})
+    __device__ __forceinline__ void strand_bias(const uint32_t c[4], const uint32_t v[4], int ntab, int lane, const BvLnTab &T,
+                                                double &c_fs, double &c_sor, double &v_fs, double &v_sor,
+                                                uint32_t &flags) const {
+#pragma unroll 1
+        for (int t = 0; t < ntab; ++t) {
+            double fs, sor;
+            bv_strand_bias_wave(t ? v[0] : c[0], t ? v[1] : c[1], t ? v[2] : c[2], t ? v[3] : c[3], lane, T, &fs, &sor, &flags);
+            if (t) { v_fs = fs; v_sor = sor; } else { c_fs = fs; c_sor = sor; }
+        }
+    }
+};
+
 // Everything the reference computes for one site, on one wave, from the site's totals, its compacted bins
 // (bin_code / bin_cnt, layout given by ALIAS) and the merged (base, phred) counts `hq`.
 // Register-pressure note: this body sits inside the persistent loop of the kernel.  With
@@ -128,10 +151,10 @@ struct BvSiteSums {
 // DEFER_LIST: the caller appends variant sites to var_list itself, in batches (one returning atomic per SITE on the single
 // counter address serialises at ~88 M/s: 0.23 ms per 20 k variant sites, measured in the short-row solve kernel).
 // Returns whether the site is a variant site.
-template <bool ALIAS, class HQ, bool DEFER_LIST = false>
+template <bool ALIAS, class HQ, bool DEFER_LIST = false, class WORK = BvSoloWork>
 __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, uint32_t *bin_code,
                                               uint32_t *bin_cnt, const HQ &hq, BvSolverScratch *sv, const double *tab_hit,
-                                              const double *tab_miss, int lane) {
+                                              const double *tab_miss, int lane, const WORK &work = WORK()) {
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
     uint32_t *res_words = reinterpret_cast<uint32_t *>(&sv->res);
     uint32_t depth[4], total = 0;
@@ -185,8 +208,7 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
         BvLrtOut L;
         // q0_mask: bases that hold a phred-0 call (1 - eps == 0) keep the generic EM path, because
         // the reference's 0/0 there yields NaN frequencies that must be reproduced
-        bv_lrt<0>(B, depth, total, /*A,C,G,T*/ 0 | (1 << 3) | (2 << 6) | (3 << 9), (a.flags & BV_FLAG_SKIP_LRT) ? 0 : 4, ref,
-                  a.min_af, &sv->lrt, 0, lane, L, q0_mask);
+        work.lrt(B, depth, total, (a.flags & BV_FLAG_SKIP_LRT) ? 0 : 4, ref, a.min_af, &sv->lrt, lane, L, q0_mask);
         if (L.zero_freq) flags |= BV_SITE_ZERO_FREQ;
 
         double bq_ranksum = qnan;
@@ -240,6 +262,10 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
                 else if ((alt_mask >> b) & 1u) { v_af += fwd[b]; v_ar += rev[b]; }
             }
             have_var = true;
+            {
+                const uint32_t vt[4] = {v_rf, v_rr, v_af, v_ar};
+                work.tables_known(vt, (v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar) ? 1 : 2, lane);
+            }
             // base-quality rank sum from the (base, phred) counts this pass already holds (caller.cpp:1157)
 #ifndef BV_ABL_NO_BQ
             {
@@ -271,12 +297,9 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
             const int ntab = (have_var && !same) ? 2 : 1;
 #endif
             double c_fs = 0, c_sor = 0, v_fs = 0, v_sor = 0;
-#pragma unroll 1
-            for (int t = 0; t < ntab; ++t) {
-                double fs, sor;
-                bv_strand_bias_wave(t ? v_rf : c_rf, t ? v_rr : c_rr, t ? v_af : c_af, t ? v_ar : c_ar, lane, a.lnfact, &fs, &sor,
-                                    &flags);
-                if (t) { v_fs = fs; v_sor = sor; } else { c_fs = fs; c_sor = sor; }
+            {
+                const uint32_t ct[4] = {c_rf, c_rr, c_af, c_ar}, vt[4] = {v_rf, v_rr, v_af, v_ar};
+                work.strand_bias(ct, vt, ntab, lane, a.lnfact, c_fs, c_sor, v_fs, v_sor, flags);
             }
             if (same) { v_fs = c_fs; v_sor = c_sor; }
             if (lane == 0) {

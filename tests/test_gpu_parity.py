@@ -552,6 +552,31 @@ def test_chunk_pipeline_gives_the_records_of_the_plain_launch(bv, groups):
             assert got.groups.tobytes() == want.groups.tobytes(), split
 
 
+@pytest.mark.parametrize("S", [640, 3000, 9000], ids=["one_row_per_workgroup", "three_rows", "nine_rows"])
+def test_team_tail_gives_the_records_of_the_plain_kernel(bv, restatement, S):
+    """Long rows, launches of up to 32,768 sites: the last solves of a workgroup are spread over its idle tally waves (EM runs
+    of an LRT level on three waves, the Fisher tests on a fourth -- bv_pass1.hip, team form).  Whoever runs them, the records
+    are those of the plain kernel (shape 1: <3 tally, 1 solver>, no team) byte for byte, and those of the reference.
+    640 sites = one row per workgroup: every deep site is a team job.  Shallow sites (<= 64 covered samples, replayed in
+    sample order by one wave) and empty ones stay with the solver wave."""
+    n = 52000
+    slab = make_slab(S, n, seed=4242 + S, coverage=0.06, site_offset=3)
+    # a few rows made shallow / empty / phred-0 so that both kinds of site meet the tail
+    slab["base_strand"][5, :] = 0x08
+    slab["base_strand"][7, 40:] = 0x08
+    slab["qual"][9, :200] = 0
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=1 << 8)
+    plain = eng.lrt(slab)
+    eng.close()
+    assert got.sites.tobytes() == plain.sites.tobytes()
+    assert got.n_variant == plain.n_variant
+    if S <= 640:
+        exp, gexp, margins = oracle_run(restatement, slab, maf)
+        check(got, exp, gexp, margins)
+
+
 @pytest.mark.parametrize("n", [9000, 70000], ids=["short_rows", "long_rows"])
 def test_two_lanes_give_the_records_of_one(bv, n):
     """BV_FLAG_LANES: six device-resident submits in flight over the engine's two internal lanes (distinct slabs and record
