@@ -1368,6 +1368,41 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
 void *bv_engine_stream(bv_engine *e) { return e ? (void *)e->stream : nullptr; }
 
 #ifdef BV_TEAM_DEBUG
+// bv_p1s_stream_kernel (short rows): when each wave finished its static range of sites, per XCD
+static void bv_stream_debug_report(const uint32_t *h) {
+    const uint32_t *d = h + BV_CTR_WORDS;
+    uint32_t t0 = 0; bool any = false;
+    for (int b = 0; b < 512; ++b)
+        if (d[4096 + b] && (!any || (int32_t)(d[4096 + b] - t0) < 0)) { t0 = d[4096 + b]; any = true; }
+    if (!any) return;
+    std::vector<double> v;
+    struct Acc { double sum = 0; uint32_t n = 0; };
+    Acc by_xcc[8], by_wave[4], by_simd[4], by_cu[16], by_se[8], by_slot[16];
+    for (int w = 0; w < 2048; ++w) {
+        if (!d[w] || !d[4096 + w / 4]) continue;
+        const double t = (double)(int32_t)(d[w] - t0) * 0.01;
+        const uint32_t hw = d[2048 + w];
+        v.push_back(t);
+        auto add = [&](Acc &a) { a.sum += t; a.n++; };
+        add(by_xcc[d[4608 + w / 4] & 7u]); add(by_wave[w & 3]); add(by_simd[(hw >> 4) & 3u]); add(by_cu[(hw >> 8) & 15u]); add(by_se[(hw >> 13) & 7u]);
+        add(by_slot[hw & 15u]);
+    }
+    if (v.empty()) return;
+    std::sort(v.begin(), v.end());
+    const size_t n = v.size();
+    fprintf(stderr, "[stream debug] wave done min %.1f p10 %.1f p25 %.1f p50 %.1f p75 %.1f p90 %.1f max %.1f us (%zu waves)\n", v[0], v[n / 10], v[n / 4],
+            v[n / 2], v[n * 3 / 4], v[n * 9 / 10], v[n - 1], n);
+    auto show = [&](const char *nm, Acc *a, int k) {
+        fprintf(stderr, "[stream debug] mean by %-12s:", nm);
+        for (int i = 0; i < k; ++i) if (a[i].n) fprintf(stderr, " %d:%.0f(%u)", i, a[i].sum / a[i].n, a[i].n);
+        fprintf(stderr, "\n");
+    };
+    show("XCD", by_xcc, 8); show("wave of group", by_wave, 4); show("SIMD", by_simd, 4); show("CU id", by_cu, 16); show("SE/SH bits", by_se, 8);
+    show("wave slot", by_slot, 16);
+}
+#endif
+
+#ifdef BV_TEAM_DEBUG
 // the stamps of bv_pass1_kernel's team form (see BV_TEAM_STAMP in bv_pass1.hip): distribution over the workgroups, and per XCD
 static void bv_team_debug_report(const uint32_t *h) {
     fprintf(stderr, "[team debug] team jobs %u (mean %.0f cycles)  solo solves %u (mean %.0f cycles)\n", h[BV_CTR_CANDS],
@@ -1414,7 +1449,8 @@ int bv_engine_wait(bv_engine *e) {
     uint32_t timed_out = 0, zero_freq = 0;
     for (uint32_t b = 0; b < bv_engine::kCtrBlocks; ++b) {
 #ifdef BV_TEAM_DEBUG
-        if (b == 0) bv_team_debug_report(e->h_counters);
+        if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 1u) bv_stream_debug_report(e->h_counters);
+        else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 2u) bv_team_debug_report(e->h_counters);
 #endif
         timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
         zero_freq += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ];

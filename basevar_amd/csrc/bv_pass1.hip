@@ -298,6 +298,7 @@ __device__ __forceinline__ void bv_team_help(const BvSolveArgs &a, uint32_t site
 #ifdef BV_TEAM_DEBUG
 #define BV_TEAM_STAMP_INIT()                                                                                               \
     uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 640u ? blockIdx.x : 639u) * 8u; /* counter blocks 1.. are free */ \
+    if (TEAM && tid == 0 && blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 2u; /* whose stamps these are */                       \
     if (TEAM && tid == 0) dbg_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20) /* XCC_ID */
 #define BV_TEAM_STAMP(COND, SLOT)                                                   \
     do {                                                                            \

@@ -38,10 +38,13 @@
 
 
 // ------------------------------------------------------------------------------ streaming kernel
+#define BV_S_REFCAP 4096                     /* sites of a workgroup's range handled per pass (their reference bases sit in LDS) */
 template <int NW, int K, int U>
 struct __attribute__((aligned(16))) BvP1sStreamShared {
     uint32_t hist[NW][BV_S_HWORDS + BV_S_OVF + 8];     // per wave: [(rev<<2)|base][phred < 128], then the overflow rows
     uint32_t ring[NW][K][U * BV_S_SLOT_WORDS];         // per wave: K slots of U x (1 KiB calls + 1 KiB phreds)
+    uint8_t refl[BV_S_REFCAP];                         // reference bases of the workgroup's current sites
+    uint32_t cursor;                                   // sites of the current pass handed out so far
 };
 
 // One slot of one row: tally its 64 x 16 cells into the wave's histogram.
@@ -95,28 +98,71 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
     uint32_t *hist = sh.hist[wave];
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(bv_lds_u32 *)sh.ring[wave][0]);
     const uint32_t *ring = sh.ring[wave][0];
+    const uint32_t cursor_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.cursor;
     {
         uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
         for (int i = 0; i < (BV_S_HWORDS + BV_S_OVF + 8) / 4 / BV_WAVE + 1; ++i)
             if (i * BV_WAVE + lane < (BV_S_HWORDS + BV_S_OVF + 8) / 4) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
     }
-    // this wave's contiguous site range
-    const uint64_t n_waves = (uint64_t)gridDim.x * NW, gw = (uint64_t)blockIdx.x * NW + (uint64_t)wave;
-    const uint32_t s0 = (uint32_t)((uint64_t)a.n_sites * gw / n_waves), s1 = (uint32_t)((uint64_t)a.n_sites * (gw + 1) / n_waves);
-    if (s0 >= s1) return;
+    // The WORKGROUP owns a contiguous range of sites; its waves draw chunks of C consecutive sites from a cursor in LDS.
+    // (Each wave used to own a fixed range of its own.  Measured with per-wave time stamps: of the two waves that share a
+    // SIMD the one in wave slot 0 -- the older one, which the issue arbiter prefers -- was done after 303 us, the one in
+    // slot 1 after 360 us, and the kernel lasted as long as the slower half.  Drawing the work in small chunks lets the
+    // favoured waves take more of it; an LDS atomic per chunk does not touch vmcnt, so the ring keeps its counted waits.)
+    const uint32_t B0 = (uint32_t)((uint64_t)a.n_sites * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)a.n_sites * (blockIdx.x + 1) / gridDim.x);
+#ifdef BV_TEAM_DEBUG  /* per-wave end stamps, per-workgroup start stamp and XCD (tools/experiments/r3_team_debug.sh) */
+    const uint32_t gw = blockIdx.x * NW + (uint32_t)wave;
+    uint32_t *dbg_ = a.counters + BV_CTR_WORDS;
+    if (gridDim.x * NW <= 2048u) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) dbg_[5150] = 1u;  // whose stamps these are
+        if (threadIdx.x == 0) { dbg_[4096 + blockIdx.x] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[4608 + blockIdx.x] = __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+        if (lane == 0) dbg_[2048 + gw] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+    }
+#endif
     const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 64u * U - 1u) / (64u * U);
     const int tail = (int)(a.n_samples & 15u);
     const uint32_t voff = (uint32_t)lane * 16u;
     const uint32_t last_valid = n_chunks - (n_slots - 1u) * 64u * U;  // chunks of a row's last slot that lie inside the row
+    // a chunk is at least K slots long, so the loads in flight never reach past the chunk after the one being tallied
+    uint32_t C = 1u;  // = ceil(K / n_slots), without a division (its VALU expansion would drag the ring's scalar state into VGPRs)
+    while (C * n_slots < (uint32_t)K) ++C;
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
 
-    // prefetch cursor: the next slot to request
-    uint32_t p_site = s0, p_j = 0, ring_w = 0, inflight = 0;
+    uint32_t ring_w = 0, ring_r = 0, inflight = 0;
+    uint32_t cand = 0, n_cand = 0;  // lane k: the k-th wave-solver candidate of this wave since the last flush
+    uint32_t easy = 0, n_easy = 0;  // the same for the candidates of the 16-lane solver (<= 2 active bases)
+    uint32_t easy3 = 0, n_easy3 = 0;  //                                                  (>= 3 active bases)
+#pragma unroll 1
+    for (uint32_t e0 = B0; e0 < B1; e0 += (uint32_t)BV_S_REFCAP) {  // one pass unless the workgroup has more than BV_S_REFCAP sites
+    const uint32_t e1 = (B1 - e0 > (uint32_t)BV_S_REFCAP) ? e0 + (uint32_t)BV_S_REFCAP : B1;
+    __syncthreads();  // (a later pass: every wave is done with refl and the cursor)
+    for (uint32_t i = 0; i < e1 - e0; i += BV_WAVE * NW)  // (uniform trip count: a divergent loop here makes the compiler treat the ring state as per-lane)
+        if (i + threadIdx.x < e1 - e0) sh.refl[i + threadIdx.x] = a.ref_base[e0 + i + threadIdx.x];
+    if (threadIdx.x == 0) sh.cursor = 0u;
+    __syncthreads();
+
+    // prefetch cursor: the next slot to request, inside the chunk [p_site, p_end)
+    uint32_t p_site = 0, p_end = 0, p_j = 0;
+    // the chunk being tallied and the one after it (drawn by the prefetch side, which runs ahead)
+    uint32_t c_site = 0, c_end = 0, n_site = 0, n_end = 0;
+    // bit 0: no chunks left to draw; bit 1: [c_site, c_end) is valid; bit 2: [n_site, n_end) is valid.  (One word, not three
+    // bools: the optimiser merged the bools' stores into one store through a selected pointer, which kept them -- and with
+    // them everything the prefetch step computes -- in scratch memory and VGPRs.)
+    uint32_t st = 0;
+    constexpr uint32_t P_DONE = 1u, C_HAVE = 2u, N_HAVE = 4u;
     const uint8_t *seg_bs = a.bs, *seg_q = a.q;  // CHAIN: the (biased) planes of the segment that holds p_site
-    auto issue = [&]() {
-        if (p_site < s1) {
+    auto issue = [&]() __attribute__((always_inline)) {  // (out of line its captured state would live in scratch memory)
+        if (p_site == p_end) {
+            if (st & P_DONE) return;
+            const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, C);
+            if (c >= e1 - e0) { st |= P_DONE; return; }
+            p_site = e0 + c; p_end = (e1 - p_site > C) ? p_site + C : e1; p_j = 0;
+            if (!(st & C_HAVE)) { c_site = p_site; c_end = p_end; st |= C_HAVE; }
+            else { n_site = p_site; n_end = p_end; st |= N_HAVE; }
+        }
+        {
             if (CHAIN && p_j == 0u) {
                 const BvChainC ch = bv_chain_const(a.ch);
                 const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)p_site));
@@ -145,21 +191,10 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 #pragma unroll 1
     for (int k = 0; k < K; ++k) issue();
 
-    uint32_t ring_r = 0;
-    uint32_t cand = 0, n_cand = 0;  // lane k: the k-th wave-solver candidate of this wave since the last flush
-    uint32_t easy = 0, n_easy = 0;  // the same for the candidates of the 16-lane solver (<= 2 active bases)
-    uint32_t easy3 = 0, n_easy3 = 0;  //                                                  (>= 3 active bases)
-    uint32_t refv = 0;              // lane i: ref_base of site blk0 + i
-    uint32_t blk0 = s0;
 #pragma unroll 1
-    for (uint32_t site = s0; site < s1; ++site) {
-        if (site == blk0) {
-            // reference bases of the next 64 sites (the wait for this load also drains the ring: once per 64 sites)
-            refv = (site + (uint32_t)lane < s1) ? (uint32_t)a.ref_base[site + (uint32_t)lane] : 4u;
-            // pass the value through an asm statement: the compiler waits for the load HERE, not (with vmcnt(0), draining the
-            // ring) in front of every later use of the register
-            asm volatile("" : "+v"(refv)::"memory");
-        }
+    while (st & C_HAVE) {
+#pragma unroll 1
+    for (uint32_t site = c_site; site < c_end; ++site) {
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
             // the oldest slot in flight has landed once at most 2 (K - 1) younger loads are outstanding
@@ -233,7 +268,7 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             const bool act = (double)bv_sel4u(depth, bsel) / (int)total >= a.min_af;  // basetype.cpp:137, one base per lane
             const uint32_t act_mask = (uint32_t)(__ballot(act) & 0xFull);
             n_active = (uint32_t)__popc(act_mask);
-            int ref = __builtin_amdgcn_readlane((int)refv, (int)(site - blk0));
+            int ref = __builtin_amdgcn_readfirstlane((int)sh.refl[site - e0]);
             if (ref > 4) ref = 4;
             const bool one_ref = act_mask != 0u && (act_mask & (act_mask - 1u)) == 0u && ref < 4 && act_mask == (1u << ref);
             is_cand = !one_ref || (q0_mask & act_mask) != 0u;
@@ -297,8 +332,7 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
         }
         bv_lrt_sync<0>();
-        if (site + 1u == blk0 + 64u) blk0 += 64u;
-        if (n_cand == 64u || (site + 1u == s1 && n_cand != 0u)) {
+        if (n_cand == 64u) {
             // flush this wave's candidates: one atomic reserves their places in the list
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_CANDS], n_cand);
@@ -306,21 +340,47 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             if ((uint32_t)lane < n_cand) a.cand_list[base + (uint32_t)lane] = cand;
             n_cand = 0;
         }
-        if (n_easy == 64u || (site + 1u == s1 && n_easy != 0u)) {
+        if (n_easy == 64u) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_EASY], n_easy);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if ((uint32_t)lane < n_easy) a.easy_list[base + (uint32_t)lane] = easy;
             n_easy = 0;
         }
-        if (n_easy3 == 64u || (site + 1u == s1 && n_easy3 != 0u)) {
+        if (n_easy3 == 64u) {
             uint32_t base = 0;
             if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_EASY3], n_easy3);
             base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
             if ((uint32_t)lane < n_easy3) a.easy3_list[base + (uint32_t)lane] = easy3;
             n_easy3 = 0;
         }
+    }  // sites of the chunk
+        if (st & N_HAVE) { c_site = n_site; c_end = n_end; st &= ~N_HAVE; }
+        else st &= ~C_HAVE;
+    }  // chunks
+    }  // passes
+    // what is left of this wave's candidate lists (the wait for an atomic's return drains the ring: empty by now)
+    if (n_cand != 0u) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_CANDS], n_cand);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint32_t)lane < n_cand) a.cand_list[base + (uint32_t)lane] = cand;
     }
+    if (n_easy != 0u) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_EASY], n_easy);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint32_t)lane < n_easy) a.easy_list[base + (uint32_t)lane] = easy;
+    }
+    if (n_easy3 != 0u) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_EASY3], n_easy3);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if ((uint32_t)lane < n_easy3) a.easy3_list[base + (uint32_t)lane] = easy3;
+    }
+#ifdef BV_TEAM_DEBUG
+    if (gridDim.x * NW <= 2048u && lane == 0) dbg_[gw] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------ per-lane Fisher test
@@ -706,13 +766,20 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     switch ((a.flags >> 12) & 0xFu) {
         case 1: return bv_launch_p1s_stream_cfg<4, 3>(a, stream, 4);   // 16 waves/CU, 2 slots in flight each
         case 2: return bv_launch_p1s_stream_cfg<4, 6>(a, stream, 2);   //  8 waves/CU, 5 slots in flight each
+        case 3: return bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);  // the default's slots, two workgroups of 4 waves per CU
         case 6: return bv_launch_p1s_stream_cfg<4, 4, 1>(a, stream, 2);  // slots of 1 KiB per plane:  8 waves/CU, 6 KiB in flight each
         case 8: return bv_launch_p1s_stream_cfg<4, 2, 2>(a, stream, 3);  //                          12 waves/CU, 4 KiB in flight each
         default: break;
     }
     // default: slots of 2 KiB per plane, 3 slots per wave (8 KiB in flight), 8 waves per CU: measured best (+4-5 % over 1 KiB
     // slots; 4 slots of 2 KiB or 8 of 1 KiB need 82 KB of LDS per workgroup -- one workgroup per CU, 0.43 of peak)
-    bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);
+    // One workgroup of 8 waves per CU (not two of 4): the waves of a workgroup share its sites through the LDS cursor, and the
+    // two waves that share a SIMD -- the arbiter's favourite and the other -- must be in the same workgroup for that to even
+    // them out.
+    // (With BV_FLAG_LANES the kernels of the other lane run beside this one: a workgroup that needs 136 KB of LDS would wait for a
+    // whole CU to drain -- measured 89 M sites/s against 165 M -- so two workgroups of 4 waves there, each balancing only itself.)
+    if (a.flags & BV_FLAG_LANES) bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);
+    else bv_launch_p1s_stream_cfg<8, 3, 2>(a, stream, 1);
 }
 // `beside_stream`: the kernels will run beside a streaming kernel (the next chunk's pass 1 or an earlier chunk's pass 2) whose
 // two workgroups per CU leave 28-32 KB of LDS: grids of ONE workgroup per CU then -- with more, whatever starts in the

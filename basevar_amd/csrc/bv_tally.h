@@ -109,6 +109,25 @@ __device__ __forceinline__ void bv_glds16(uint32_t lds_dst, const uint8_t *base,
                  : "v"(voff), "s"(lds_dst), "s"(base)
                  : "memory");
 }
+// One wave-level fetch-and-add on an LDS word, result in an SGPR.  Done by lane 0 alone inside the asm statement, so the
+// compiler sees no divergent branch (an `if (lane == 0)` around an atomic inside the streaming kernel's prefetch step made
+// it keep the whole ring state in VGPRs) and no vector-memory operation (lgkmcnt only).
+__device__ __forceinline__ uint32_t bv_lds_fetch_add_wave(uint32_t lds_addr, uint32_t v) {
+    uint32_t r, t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %[t], %[val]\n\t"
+        "ds_add_rtn_u32 %[t], %[adr], %[t]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[r], %[t]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "=&s"(r), [t] "=&v"(t), [sv] "=&s"(sv)
+        : [adr] "v"(lds_addr), [val] "s"(v)
+        : "memory");
+    return r;
+}
 // a pointer the compiler knows to be wave-uniform (the "s" operand above)
 __device__ __forceinline__ const uint8_t *bv_uniform_ptr(const uint8_t *p) {
     const uint64_t v = (uint64_t)(uintptr_t)p;
