@@ -124,6 +124,21 @@ def test_short_row_kernel_variants_agree(bv, restatement, flags):
     assert np.allclose(ref_run.sites["qual"], got.sites["qual"], rtol=1e-9, atol=0, equal_nan=True)
 
 
+def test_streaming_kernel_range_larger_than_its_reference_base_buffer(bv):
+    """The short-row streaming kernel keeps the reference bases of a workgroup's sites in LDS, 4,096 at a time; a workgroup with
+    more sites than that goes through its range in passes (barrier, refill, cursor reset).  BV_FLAG_GRID_LIMIT(1): one
+    workgroup, 9,500 sites = three passes; every record must equal the ordinary launch's (whose workgroups hold ~40 sites)."""
+    n, S = 700, 9500
+    slab = make_slab(S, n, seed=4096, coverage=0.15, ref_n_frac=0.02, site_offset=7)
+    maf = bv.min_af(n)
+    want = run_engine(bv, slab, maf)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=1 << 16)
+    got = eng.lrt(slab)
+    eng.close()
+    assert got.sites.tobytes() == want.sites.tobytes()
+    assert got.n_variant == want.n_variant and got.n_variant > 100
+
+
 def test_short_row_kernels_with_many_sites_per_wave(bv, restatement):
     """BV_FLAG_GRID_LIMIT(1): one workgroup per short-row kernel, so that 3,000 sites walk the paths a large batch takes -- more
     than 64 sites per wave in the streaming kernel (reference bases and candidate lists in blocks of 64), list flushes of the
