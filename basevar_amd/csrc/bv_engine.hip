@@ -1408,6 +1408,7 @@ static void bv_team_debug_report(const uint32_t *h) {
     fprintf(stderr, "[team debug] team jobs %u (mean %.0f cycles)  solo solves %u (mean %.0f cycles)\n", h[BV_CTR_CANDS],
             h[BV_CTR_CANDS] ? 64.0 * h[BV_CTR_CANDS + 1] / h[BV_CTR_CANDS] : 0., h[BV_CTR_EASY3],
             h[BV_CTR_EASY3] ? 64.0 * h[BV_CTR_EASY3 + 1] / h[BV_CTR_EASY3] : 0.);
+    fprintf(stderr, "[team debug] tally waves waiting for a free ring slot: %.0f cycles per workgroup (sum over its rows)\n", 64.0 * h[BV_CTR_EASY] / 1024.0);
     const uint32_t *d = h + BV_CTR_WORDS;
     const char *nm[6] = {"entry", "start barrier passed", "first row begins", "tally waves done", "phred tables in LDS", "solver wave done"};
     uint32_t t0 = 0; bool any = false;

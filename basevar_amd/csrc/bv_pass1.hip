@@ -399,7 +399,13 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                 }
                 site = cur < a.n_sites ? cur : 0xFFFFFFFFu;
                 ++cur;
+#ifdef BV_TEAM_DEBUG
+                const unsigned long long tw_ = __builtin_readcyclecounter();
+#endif
                 bv_wait_flag(&sh.drained[buf], gen, &a.counters[BV_CTR_TIMEOUT]);  // the solver has re-zeroed this slot
+#ifdef BV_TEAM_DEBUG  /* cycles the tally waves of this workgroup stood still because the ring was full */
+                if (TEAM && lane == 0) atomicAdd(&a.counters[BV_CTR_EASY], (uint32_t)((__builtin_readcyclecounter() - tw_) >> 6));
+#endif
                 if (lane == 0) sh.site_of[buf] = site;
                 bv_set_flag(&sh.published[buf], gen + 1u);
             } else {
