@@ -187,7 +187,7 @@ struct __attribute__((aligned(16))) BvTeam {
 };
 #define BV_TEAM_NO_SITE 0xFFFFFFFEu
 #ifndef BV_TEAM_MAX_SITES
-#define BV_TEAM_MAX_SITES 32768
+#define BV_TEAM_MAX_SITES 65536
 #endif
 
 template <bool TEAM>
@@ -695,8 +695,8 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
     }
     if (a.n_samples > 49152u) {  // measured crossover of the two kernels: ~50 k samples per row
         // long rows: several tally waves share a row (short per-site latency => short tail).  Up to BV_TEAM_MAX_SITES per
-        // launch the team form is used: the last solves of a workgroup are spread over its idle tally waves (the tail is
-        // ~40 us shorter; past 32 rows per workgroup that is under 3 % and the plain form keeps its tuned code).
+        // launch the team form is used: the last solves of a workgroup are spread over its idle tally waves (8,192 sites:
+        // 0.351 -> 0.327 ms, 65,536: ~1 %; the 131,072-site launch measures the same either way and keeps the plain form).
         if (a.n_sites <= (uint32_t)BV_TEAM_MAX_SITES) bv_launch_pass1_cfg<3, 1, true>(a, stream);
         else bv_launch_pass1_cfg<3, 1>(a, stream);
     } else {

@@ -569,7 +569,7 @@ def test_chunk_pipeline_gives_the_records_of_the_plain_launch(bv, groups):
 
 @pytest.mark.parametrize("S", [640, 3000, 9000], ids=["one_row_per_workgroup", "three_rows", "nine_rows"])
 def test_team_tail_gives_the_records_of_the_plain_kernel(bv, restatement, S):
-    """Long rows, launches of up to 32,768 sites: the last solves of a workgroup are spread over its idle tally waves (EM runs
+    """Long rows, launches of up to 65,536 sites: the last solves of a workgroup are spread over its idle tally waves (EM runs
     of an LRT level on three waves, the Fisher tests on a fourth -- bv_pass1.hip, team form).  Whoever runs them, the records
     are those of the plain kernel (shape 1: <3 tally, 1 solver>, no team) byte for byte, and those of the reference.
     640 sites = one row per workgroup: every deep site is a team job.  Shallow sites (<= 64 covered samples, replayed in
