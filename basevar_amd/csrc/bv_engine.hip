@@ -1403,6 +1403,31 @@ static void bv_stream_debug_report(const uint32_t *h) {
 #endif
 
 #ifdef BV_TEAM_DEBUG
+// bv_p1s_solve16_kernel: wave 0 of every workgroup
+static void bv_solve16_debug_report(const uint32_t *h) {
+    const uint32_t *d = h + BV_CTR_WORDS;
+    uint32_t t0 = 0; bool any = false;
+    for (int b = 0; b < 768; ++b)
+        if (d[b * 6] && (!any || (int32_t)(d[b * 6] - t0) < 0)) { t0 = d[b * 6]; any = true; }
+    if (!any) return;
+    const char *nm[5] = {"entry", "set-up done", "first job done", "jobs done", "end (filler blocks done)"};
+    for (int j = 0; j < 5; ++j) {
+        std::vector<double> v;
+        for (int b = 0; b < 768; ++b) if (d[b * 6] && d[b * 6 + j]) v.push_back((double)(int32_t)(d[b * 6 + j] - t0) * 0.01);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        fprintf(stderr, "[solve16 debug] %-26s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f p99 %6.1f max %6.1f us (%zu workgroups)\n", nm[j], v[0], v[n / 10], v[n / 2],
+                v[n * 9 / 10], v[n * 99 / 100], v[n - 1], n);
+    }
+    std::vector<uint32_t> nj;
+    for (int b = 0; b < 768; ++b) if (d[b * 6]) nj.push_back(d[b * 6 + 5]);
+    std::sort(nj.begin(), nj.end());
+    fprintf(stderr, "[solve16 debug] jobs per wave: min %u p50 %u max %u; lists: easy %u, easy3 %u sites\n", nj[0], nj[nj.size() / 2], nj.back(), h[BV_CTR_EASY], h[BV_CTR_EASY3]);
+}
+#endif
+
+#ifdef BV_TEAM_DEBUG
 // the stamps of bv_pass1_kernel's team form (see BV_TEAM_STAMP in bv_pass1.hip): distribution over the workgroups, and per XCD
 static void bv_team_debug_report(const uint32_t *h) {
     fprintf(stderr, "[team debug] team jobs %u (mean %.0f cycles)  solo solves %u (mean %.0f cycles)\n", h[BV_CTR_CANDS],
@@ -1452,6 +1477,7 @@ int bv_engine_wait(bv_engine *e) {
 #ifdef BV_TEAM_DEBUG
         if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 1u) bv_stream_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 2u) bv_team_debug_report(e->h_counters);
+        else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 3u) bv_solve16_debug_report(e->h_counters);
 #endif
         timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
         zero_freq += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ];

@@ -644,6 +644,12 @@ __device__ __forceinline__ BvP1sJob bv_p1s_job(const BvP1ShortArgs &a, uint32_t 
 __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolve16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef BV_SOLVE16_DEBUG  /* wave 0 of every workgroup: entry, set-up done, first job done, jobs done, end; jobs taken */
+    uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 768u ? blockIdx.x : 767u) * 6u;
+    uint32_t njobs_ = 0;
+    if (tid == 0 && blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 3u;
+    if (tid == 0) dbg_[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     const uint32_t n_easy = a.counters[BV_CTR_EASY], n_easy3 = a.counters[BV_CTR_EASY3];
     const uint32_t n_jobs = ((n_easy + 3u) >> 2) + ((n_easy3 + 3u) >> 2);
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE16_NW) {
@@ -651,6 +657,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         sh.tab_miss[i] = a.tables->miss[i];
     }
     __syncthreads();
+#ifdef BV_SOLVE16_DEBUG
+    if (tid == 0) dbg_[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
     BvSolveArgs sa;
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = a.flags;
@@ -673,6 +682,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
     tk.init(a.counters + BV_CTR_TICKET_A, (uint32_t)wave);
     for (; tk.job() < n_jobs; tk.next(lane)) {
         const BvP1sJob jb = bv_p1s_job(a, tk.job(), n_easy, n_easy3, grp);
+        // (s_setprio for the jobs of three or four active bases -- the kernel's critical path, one runs 50-83 us of the kernel's
+        // 94 -- was measured: no change; their time is dependent-latency, not lost issue slots)
         bool variant = false;
         uint32_t site = 0;
         if (jb.active) {
@@ -714,8 +725,15 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         if (variant && gl == 0) vl[n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
         n_vl += (uint32_t)__popcll(vm);
         if (n_vl > 60u) flush_vl();
+#ifdef BV_SOLVE16_DEBUG
+        if (tid == 0 && njobs_ == 0) dbg_[2] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        ++njobs_;
+#endif
     }
     if (n_vl) flush_vl();
+#ifdef BV_SOLVE16_DEBUG
+    if (tid == 0) { dbg_[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[5] = njobs_; }
+#endif
     // ---- the non-candidate sites, one lane per site, in blocks of 64 drawn like the jobs
     const uint32_t n_blocks = (a.n_sites + 63u) >> 6;
     BvP1sTickets tb;
@@ -724,6 +742,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         const uint32_t site = tb.job() * 64u + (uint32_t)lane;
         if (site < a.n_sites) bv_p1s_simple_site(a, sa.lnfact, site);
     }
+#ifdef BV_SOLVE16_DEBUG
+    if (tid == 0) dbg_[4] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------ chained launches (bv_engine_submit_many)
