@@ -797,10 +797,10 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     // One workgroup of 8 waves per CU (not two of 4): the waves of a workgroup share its sites through the LDS cursor, and the
     // two waves that share a SIMD -- the arbiter's favourite and the other -- must be in the same workgroup for that to even
     // them out.
-    // (With BV_FLAG_LANES the kernels of the other lane run beside this one: a workgroup that needs 136 KB of LDS would wait for a
-    // whole CU to drain -- measured 89 M sites/s against 165 M -- so two workgroups of 4 waves there, each balancing only itself.)
-    if (a.flags & BV_FLAG_LANES) bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);
-    else bv_launch_p1s_stream_cfg<8, 3, 2>(a, stream, 1);
+    // (Also under BV_FLAG_LANES, where the other lane's kernels run beside this one.  Measured there, interleaved A/B: this
+    // shape 170.5 M sites/s, two workgroups of 4 waves with fixed ranges 167-171 M, two of 4 with the cursor 157 M; both of
+    // the first two fall into a slow interleaving now and then -- 111-133 M in one run of four.)
+    bv_launch_p1s_stream_cfg<8, 3, 2>(a, stream, 1);
 }
 // `beside_stream`: the kernels will run beside a streaming kernel (the next chunk's pass 1 or an earlier chunk's pass 2) whose
 // two workgroups per CU leave 28-32 KB of LDS: grids of ONE workgroup per CU then -- with more, whatever starts in the
