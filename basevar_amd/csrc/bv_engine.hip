@@ -180,6 +180,10 @@ struct bv_engine {
     // Counter blocks (BV_CTR_* words each, bv_kernels.h): a launch that is cut into chunks (short rows, launch_passes)
     // gives every chunk a block of its own; everything else uses block 0.
     static constexpr uint32_t kCtrBlocks = 8;
+#ifdef BV_TL_DEBUG
+    uint32_t *d_tl = nullptr;          // [512][8] kernel start / end stamps per submit
+    uint32_t tl_n = 0;
+#endif
     uint32_t *d_counters = nullptr;    // [kCtrBlocks][BV_CTR_WORDS]
     uint32_t *h_counters = nullptr;    // pinned host mirror
     uint32_t last_blocks = 1;          // blocks the last launch used (their VARIANTS words add up to its variant count)
@@ -657,6 +661,11 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
+#ifdef BV_TL_DEBUG
+    if (!e->d_tl) { BV_HIP(e, hipMalloc(&e->d_tl, 512 * 8 * sizeof(uint32_t))); BV_HIP(e, hipMemset(e->d_tl, 0, 512 * 8 * sizeof(uint32_t))); }
+    uint32_t *tl_rec = e->d_tl + 8 * (e->tl_n++ % 512u);
+    a2.tl = tl_rec;
+#endif
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
     a2.ch = chain;
     a2.ch_cat = chain_cat ? 1u : 0u;
@@ -743,6 +752,9 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
             BvP1ShortArgs s1;
             s1.bs = bs + (size_t)c0 * P; s1.q = q + (size_t)c0 * P; s1.ref_base = refb + c0; s1.pitch = P; s1.n_sites = nc; s1.n_samples = n_samples;
+#ifdef BV_TL_DEBUG
+            s1.tl = tl_rec;
+#endif
             s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout + c0;
             s1.var_list = e->d_var_list + c0; s1.counters = e->d_counters + (size_t)c * BV_CTR_WORDS;
             s1.summ = e->d_summ + c0; s1.bins = e->d_bins + (size_t)c0 * BV_S_BIN_STRIDE;
@@ -1474,6 +1486,17 @@ int bv_engine_wait(bv_engine *e) {
     e->used_streams.push_back(e->last_stream);
     uint32_t timed_out = 0, zero_freq = 0;
     for (uint32_t b = 0; b < bv_engine::kCtrBlocks; ++b) {
+#ifdef BV_TL_DEBUG
+        if (b == 0 && e->d_tl && e->tl_n) {
+            std::vector<uint32_t> tl(512 * 8);
+            (void)hipMemcpy(tl.data(), e->d_tl, tl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
+            const uint32_t n = std::min(e->tl_n, 512u);
+            for (uint32_t i = (n > 24 ? n - 24 : 0); i < n; ++i) {
+                const uint32_t *r = &tl[8 * i];
+                fprintf(stderr, "[timeline] engine %p submit %u: stream %u %u  solve16 %u %u  pass2 %u %u\n", (void *)e, i, ~r[0], r[1], ~r[2], r[3], ~r[4], r[5]);
+            }
+        }
+#endif
 #ifdef BV_TEAM_DEBUG
         if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 1u) bv_stream_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 2u) bv_team_debug_report(e->h_counters);

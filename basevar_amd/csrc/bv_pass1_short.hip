@@ -93,6 +93,9 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 #ifdef BV_STREAM_PRIO
     __builtin_amdgcn_s_setprio(BV_STREAM_PRIO);  // beside the solve kernels of the previous chunk: the stream goes first
 #endif
+#ifdef BV_TL_DEBUG
+    BV_TL_START(a.tl, 0);
+#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *hist = sh.hist[wave];
@@ -381,6 +384,9 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 #ifdef BV_TEAM_DEBUG
     if (gridDim.x * NW <= 2048u && lane == 0) dbg_[gw] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef BV_TL_DEBUG
+    BV_TL_END(a.tl, 0);
+#endif
 }
 
 // ------------------------------------------------------------------------------ per-lane Fisher test
@@ -644,6 +650,9 @@ __device__ __forceinline__ BvP1sJob bv_p1s_job(const BvP1ShortArgs &a, uint32_t 
 __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolve16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef BV_TL_DEBUG
+    BV_TL_START(a.tl, 1);
+#endif
 #ifdef BV_SOLVE16_DEBUG  /* wave 0 of every workgroup: entry, set-up done, first job done, jobs done, end; jobs taken */
     uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 768u ? blockIdx.x : 767u) * 6u;
     uint32_t njobs_ = 0;
@@ -745,6 +754,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
 #ifdef BV_SOLVE16_DEBUG
     if (tid == 0) dbg_[4] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef BV_TL_DEBUG
+    BV_TL_END(a.tl, 1);
+#endif
 }
 
 // ------------------------------------------------------------------------------ chained launches (bv_engine_submit_many)
@@ -798,8 +810,8 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     // two waves that share a SIMD -- the arbiter's favourite and the other -- must be in the same workgroup for that to even
     // them out.
     // (Also under BV_FLAG_LANES, where the other lane's kernels run beside this one.  Measured there, interleaved A/B: this
-    // shape 170.5 M sites/s, two workgroups of 4 waves with fixed ranges 167-171 M, two of 4 with the cursor 157 M; both of
-    // the first two fall into a slow interleaving now and then -- 111-133 M in one run of four.)
+    // shape 170.5 M sites/s, two workgroups of 4 waves with fixed ranges 167-171 M, two of 4 with the cursor 157 M; about one
+    // bench process in ten ran at 89-133 M with either of the first two, cause not found: DESIGN 4.2c.)
     bv_launch_p1s_stream_cfg<8, 3, 2>(a, stream, 1);
 }
 // `beside_stream`: the kernels will run beside a streaming kernel (the next chunk's pass 1 or an earlier chunk's pass 2) whose

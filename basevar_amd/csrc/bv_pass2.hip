@@ -609,6 +609,9 @@ struct __attribute__((aligned(16))) BvPass2DmaShared {
 
 __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvPass2Args a) {
     __shared__ BvPass2DmaShared sh;
+#ifdef BV_TL_DEBUG
+    BV_TL_START(a.tl, 2);
+#endif
 #ifdef BV_STREAM_PRIO
     __builtin_amdgcn_s_setprio(BV_STREAM_PRIO);
 #endif
@@ -847,6 +850,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
         }
         bv_lrt_sync<0>();
     }
+#ifdef BV_TL_DEBUG
+    BV_TL_END(a.tl, 2);
+#endif
 }
 
 size_t bv_pass2_lds_bytes(uint32_t n_groups) { return (size_t)n_groups * 512u * sizeof(uint32_t); }
