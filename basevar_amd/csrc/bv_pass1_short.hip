@@ -824,10 +824,12 @@ void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside
     const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
     if (grid > need) grid = need > 0 ? need : 1;
     if (cap && grid > cap) grid = cap;
-    hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
     uint32_t grid16 = beside_stream ? cu : cu * (uint32_t)BV_P1S_SOLVE16_OCC * (4u / BV_P1S_SOLVE16_NW);
     const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE16_NW - 1) / (4 * BV_P1S_SOLVE16_NW);  // four sites per wave
     if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
     if (cap && grid16 > cap) grid16 = cap;
     hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
+    // the wave-solver kernel second: most batches give it nothing to do, and behind the streaming kernel it only delayed the
+    // kernel that has (interleaved A/B, 100 k sites x 10 k samples: 157.3 -> 158.25 M sites/s); the two are independent
+    hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
 }
