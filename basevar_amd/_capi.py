@@ -17,7 +17,8 @@ BV_MAX_ALT = 4
 BV_MAX_GROUPS = 32
 BV_NO_GROUP = 0xFF
 BV_MEM_DEVICE, BV_MEM_HOST = 0, 1
-BV_FLAG_LANES = 0x10000000  # include/basevar_amd.h
+BV_FLAG_LANES = 0x10000000
+BV_FLAG_SPARSE_TIMING = 0x20000000  # include/basevar_amd.h
 # bv_engine_config.flags (include/basevar_amd.h)
 BV_FLAG_TALLY_ONLY, BV_FLAG_SKIP_FISHER, BV_FLAG_SKIP_LRT, BV_FLAG_TILE_STATE, BV_FLAG_WAVE_SOLVER = 0x1, 0x2, 0x4, 0x8, 0x10
 BV_OK, BV_ERR_INVALID_ARG, BV_ERR_NO_DEVICE, BV_ERR_HIP, BV_ERR_TOO_LARGE, BV_ERR_SITE = 0, -1, -2, -3, -4, -5

@@ -203,6 +203,7 @@ struct bv_engine {
     hipEvent_t ring[kRing][4] = {};    // per-submit events: start, end of pass 1, end of pass 2, [3] end of the streaming kernel of pass 1
     int ring_head = 0, ring_count = 0; // pending (not yet accumulated) triplets
     int last_slot = -1;
+    uint32_t n_launches = 0;           // launches since creation (BV_FLAG_SPARSE_TIMING times every eighth)
     double acc1_ms = 0., acc2_ms = 0., acc_stream_ms = 0.;
     // short rows (bv_pass1_short.hip): HBM scratch between the streaming kernel and the solve kernel
     BvSiteSummary *d_summ = nullptr;
@@ -646,15 +647,24 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     const size_t S = n_sites, G = n_groups;
     if (G && chain == nullptr) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));  // (chained: per segment, by the caller)
 
-    if (e->ring_count == bv_engine::kRing) {
-        int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
-        if (rc != BV_OK) return rc;
+    // Per-pass timing: four event records per launch (start, end of the streaming kernel, end of pass 1, end of pass 2).  They are
+    // not free -- each is a packet the next kernel queues behind: ~15 us per launch together (measured: 100 k sites x 10 k samples
+    // 158.4 -> 162.4 M sites/s without them, 8,192-site batches 56.7 -> 63.0 M) -- so BV_FLAG_SPARSE_TIMING records them for one
+    // launch in eight; the averages of bv_engine_timing_get then rest on those launches.
+    const bool timed = !(e->cfg.flags & BV_FLAG_SPARSE_TIMING) || ((e->cfg.flags >> 24) & 0xFu) > 1u || (e->n_launches % 8u) == 0u;
+    e->n_launches += 1;
+    hipEvent_t *ev = nullptr;
+    if (timed) {
+        if (e->ring_count == bv_engine::kRing) {
+            int rc = drain_timings(e, true);  // ring full: fold the oldest submits first
+            if (rc != BV_OK) return rc;
+        }
+        const int slot = e->ring_head;
+        e->ring_head = (e->ring_head + 1) % bv_engine::kRing;
+        e->ring_count += 1;
+        e->last_slot = slot;
+        ev = e->ring[slot];
     }
-    const int slot = e->ring_head;
-    e->ring_head = (e->ring_head + 1) % bv_engine::kRing;
-    e->ring_count += 1;
-    e->last_slot = slot;
-    hipEvent_t *ev = e->ring[slot];
     // Short rows take the two-kernel form of pass 1 (bv_pass1_short.hip); bits 8-11 of the flags force a kernel for
     // tuning runs (9: the one-kernel short-row form; 1, 2, 5: a long-row workgroup shape).
     const uint32_t shape = (e->cfg.flags >> 8) & 0xFu;
@@ -755,7 +765,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         return c >= H ? n_sites : (uint32_t)(((uint64_t)n_sites * c / H) & ~(uint64_t)63);
     };
 
-    BV_HIP(e, hipEventRecord(ev[0], st));
+    if (ev) BV_HIP(e, hipEventRecord(ev[0], st));
     if (two_kernel) {
         if (n_sites > e->short_sites) {
             // scratch between the kernels, grown to the largest short-row submit seen: 48 B + 2 KiB + 12 B per site
@@ -793,7 +803,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
                 BV_HIP(e, hipGetLastError());
                 BV_HIP(e, hipEventRecord(e->ev_v[c], e->aux));
             } else {
-                BV_HIP(e, hipEventRecord(ev[3], st));
+                if (ev) BV_HIP(e, hipEventRecord(ev[3], st));
                 bv_launch_p1s_solve(s1, st);
                 BV_HIP(e, hipGetLastError());
             }
@@ -802,7 +812,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             BV_HIP(e, hipEventRecord(ev[3], st));      // the last streaming kernel
             BV_HIP(e, hipEventRecord(ev[1], e->aux));  // the last solve kernel: end of pass 1
         } else {
-            BV_HIP(e, hipEventRecord(ev[1], st));
+            if (ev) BV_HIP(e, hipEventRecord(ev[1], st));
         }
     } else {
         BvPass1Args a1;
@@ -812,8 +822,8 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         a1.ch = chain;
         bv_launch_pass1(a1, st);
         BV_HIP(e, hipGetLastError());
-        BV_HIP(e, hipEventRecord(ev[3], st));
-        BV_HIP(e, hipEventRecord(ev[1], st));
+        if (ev) BV_HIP(e, hipEventRecord(ev[3], st));
+        if (ev) BV_HIP(e, hipEventRecord(ev[1], st));
     }
 
     for (uint32_t c = 0; c < H; ++c) {
@@ -832,7 +842,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         bv_launch_p2g_solve16(ac, st);
         BV_HIP(e, hipGetLastError());
     }
-    BV_HIP(e, hipEventRecord(ev[2], st));
+    if (ev) BV_HIP(e, hipEventRecord(ev[2], st));
 
     if (rotate) e->ctr_mirror_stale = true;  // mirrored by bv_engine_wait
     else BV_HIP(e, hipMemcpyAsync(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks, hipMemcpyDeviceToHost, st));

@@ -58,6 +58,9 @@ def parse():
                     help="2: the engine runs consecutive submits on two internal lanes (BV_FLAG_LANES: a second stream and scratch "
                          "set inside ONE engine), so the solve kernels of a batch run under the streaming kernels of the next; the "
                          "timed region is still K back-to-back steps on resident batches")
+    ap.add_argument("--sparse-timing", action="store_true",
+                    help="BV_FLAG_SPARSE_TIMING: the engine records its per-pass timing events for one launch in eight (the four "
+                         "events cost ~15 us per launch); the kernel averages of the line then rest on those launches")
     ap.add_argument("--groups", type=int, default=0,
                     help="diagnostic: G pop-groups (random membership, ~15 % of the samples in none): adds the per-group calls of pass 2")
     ap.add_argument("--with-tile-mode", action="store_true",
@@ -261,7 +264,7 @@ def main():
 
     ns = max(1, args.streams)
     engs = [basevar_amd.BaseTypeEngine(max_sites=Bl, min_af_value=maf, device=local_rank,
-                                       flags=(1 if args.tally_only else 0) | args.flags | (0x10000000 if args.lanes == 2 else 0))
+                                       flags=(1 if args.tally_only else 0) | args.flags | (0x10000000 if args.lanes == 2 else 0) | (0x20000000 if args.sparse_timing else 0))
             for _ in range(ns)]
     eng = engs[0]
     rec = basevar_amd.SITE_DTYPE.itemsize
@@ -360,8 +363,12 @@ def main():
 
     # per-rank figures for rank 0's line: this rank's wall time of the timed region, its pass-1 fraction of the HBM peak, and
     # what of its step was NOT kernels (the gather's exposed time + launch gaps)
-    my_p1_frac = (2.0 * Bl * N * args.steps / max(nsub, 1)) / max(p1_ms / max(nsub, 1) / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBS
-    my_exposed_ms = max(0.0, elapsed / args.steps * 1e3 - (p1_ms + p2_ms) / max(args.steps, 1))
+    # nsub: launches that carried timing events (all of them unless --sparse-timing); n_launch: launches of the timed region
+    if args.sparse_timing and K > 16:
+        raise SystemExit("--sparse-timing: at most 16 batches per step (one launch per step)")
+    n_launch = args.steps if args.sparse_timing else nsub
+    my_p1_frac = (2.0 * Bl * N * args.steps / max(n_launch, 1)) / max(p1_ms / max(nsub, 1) / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBS
+    my_exposed_ms = max(0.0, elapsed / args.steps * 1e3 - (p1_ms + p2_ms) / max(nsub, 1) * n_launch / max(args.steps, 1))
     mine = torch.tensor([elapsed, my_p1_frac, my_exposed_ms], dtype=torch.float64, device=dev)
     per_rank = [mine.clone() for _ in range(world)] if dist_on else [mine]
     if dist_on:
@@ -381,7 +388,7 @@ def main():
         st_avg_s = st_ms / max(nsub, 1) / 1e3
         # pass 1: u8 call + u8 phred per cell of every batch of a launch (a chain longer than the engine's queue is
         # split into several launches: bytes of the timed region / its launches)
-        algo_bytes = 2.0 * Bl * N * args.steps / max(nsub, 1)
+        algo_bytes = 2.0 * Bl * N * args.steps / max(n_launch, 1)
         # the dominant (HBM-bound) kernel: on short rows pass 1 is a streaming kernel + a solve kernel that reads no
         # planes; on long rows it is one kernel (st_avg_s == p1_avg_s)
         shape = (args.flags >> 8) & 0xF
@@ -404,7 +411,7 @@ def main():
             except Exception:
                 traffic = traffic_source = None
         # variant fraction of the last launch (a chained launch counts its whole queue)
-        fvar = nvar / max(1.0, Bl * args.steps / max(nsub, 1))
+        fvar = nvar / max(1.0, Bl * args.steps / max(n_launch, 1))
         line = {
             "metric": "genomic sites/sec through basetype caller at N samples",
             "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -442,14 +449,14 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_launch_ms": st_avg_s * 1e3, "pass1_avg_ms": p1_avg_s * 1e3,
                 "pass1_frac": algo_bytes / p1_avg_s / 1e9 / HBM_PEAK_GBS,  # all of pass 1 (streaming + solve kernels) over the same bytes
-                "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": nsub,
+                "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": n_launch, "launches_timed": nsub,
                 # BASELINE.md section 3's whole-path figure: S*N*(2 + 3 f_var) bytes over both kernels' time
                 # (pass 2 also re-reads the call byte of variant rows: its own traffic is 4 B/cell)
                 "whole_path_GBps": (1.0 + 1.5 * fvar) * algo_bytes / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9,
                 "whole_path_frac": (1.0 + 1.5 * fvar) * algo_bytes / max(p1_avg_s + p2_avg_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
                 # the same bytes over the WALL time of a step on this rank (launch gaps and, with --lanes 2 / --streams 2, the
                 # overlap of consecutive submits included: the per-submit kernel times above then count co-running kernels twice)
-                "whole_path_frac_wall": (1.0 + 1.5 * fvar) * algo_bytes * max(nsub, 1) / args.steps / max(per_rank[0][0] / args.steps, 1e-12) / 1e9 / HBM_PEAK_GBS,
+                "whole_path_frac_wall": (1.0 + 1.5 * fvar) * algo_bytes * max(n_launch, 1) / args.steps / max(per_rank[0][0] / args.steps, 1e-12) / 1e9 / HBM_PEAK_GBS,
             },
         }
         if world == 1:

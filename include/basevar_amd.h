@@ -174,6 +174,10 @@ typedef struct bv_group_result {
                                      records are complete after bv_engine_wait(), or on a stream that called bv_engine_join() after the
                                      submit.  The slabs and record buffers of submits in flight must be distinct.  Records do not depend
                                      on the flag. */
+#define BV_FLAG_SPARSE_TIMING 0x20000000u /* the per-pass timing events (bv_engine_timing_get, bv_engine_kernel_ms) are recorded for one
+                                             launch in eight only: four event records cost ~15 us per launch, which a host that queues
+                                             small batches back to back notices (8,192 sites x 10 k samples: +11 % sites/s).
+                                             bv_engine_kernel_ms then reports the last TIMED launch.  Records do not depend on the flag. */
 #define BV_FLAG_TILE_STATE 0x8u  /* tile mode: always accumulate per-site tallies (the fallback for jobs whose
                                     joined planes do not fit the HBM) instead of joining the tiles into rows */
 

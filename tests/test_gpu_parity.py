@@ -592,6 +592,26 @@ def test_team_tail_gives_the_records_of_the_plain_kernel(bv, restatement, S):
         check(got, exp, gexp, margins)
 
 
+def test_sparse_timing_keeps_records_and_reports_the_timed_launches(bv):
+    """BV_FLAG_SPARSE_TIMING: timing events on one launch in eight.  Twenty submits (the counter blocks go round twice and a
+    half): every record equals the fully timed engine's, the variant count is the last submit's, and the timing averages rest
+    on the three timed launches."""
+    from basevar_amd import _capi
+    n, S = 6000, 900
+    slabs = [make_slab(S, n, seed=700 + i, coverage=0.07, site_offset=i) for i in range(4)]
+    maf = bv.min_af(n)
+    want = [run_engine(bv, sl, maf) for sl in slabs]
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=_capi.BV_FLAG_SPARSE_TIMING)
+    eng.timing_reset()
+    for i in range(20):
+        got = eng.lrt(slabs[i % 4])
+        assert got.sites.tobytes() == want[i % 4].sites.tobytes(), i
+        assert got.n_variant == want[i % 4].n_variant, i
+    s_ms, p1_ms, p2_ms, n_timed = eng.timing_get_ex()
+    eng.close()
+    assert n_timed == 3 and p1_ms > 0 and s_ms > 0
+
+
 @pytest.mark.parametrize("n", [9000, 70000], ids=["short_rows", "long_rows"])
 def test_two_lanes_give_the_records_of_one(bv, n):
     """BV_FLAG_LANES: six device-resident submits in flight over the engine's two internal lanes (distinct slabs and record
