@@ -170,6 +170,8 @@ struct bv_engine {
     hipEvent_t ev_host = nullptr;      // BV_FLAG_HOST_ORDERED: what the copy stream waits for before it reads host planes
     hipEvent_t ev_done = nullptr;      // end of the last submit: a submit on ANOTHER stream waits for it (shared scratch)
     bool ev_done_set = false;
+    bool done_pending = false;         // the last submit's end is not recorded in ev_done yet (flush_done)
+    hipStream_t done_stream = nullptr;
     uint32_t n_cu = 256;               // hipDeviceProp_t::multiProcessorCount
     int host_log_exact = 0;            // 1: the device replays shallow sites with the host libm's log(), verified bit-exact
     uint8_t *d_gid = nullptr;          // engine-owned copy of group_id, padded to 16 bytes with BV_NO_GROUP
@@ -316,17 +318,33 @@ namespace {
 // The engine's scratch (variant list, counters, staging) is shared by its submits, so work of one engine is
 // serialised even when the caller alternates streams: a submit on a stream other than the previous one first
 // waits for the end of the previous submit.  Every stream used is remembered for bv_engine_wait.
+int flush_done(bv_engine *e) {
+    if (e->done_pending) {
+        BV_HIP(e, hipEventRecord(e->ev_done, e->done_stream));
+        e->done_pending = false;
+        e->ev_done_set = true;
+    }
+    return BV_OK;
+}
 int use_stream(bv_engine *e, hipStream_t st) {
     bool seen = false;
     for (hipStream_t u : e->used_streams) seen |= (u == st);
     if (!seen) e->used_streams.push_back(st);
-    if (e->ev_done_set && st != e->last_stream) BV_HIP(e, hipStreamWaitEvent(st, e->ev_done, 0));
+    if (st != e->last_stream) {
+        int rc = flush_done(e);
+        if (rc != BV_OK) return rc;
+        if (e->ev_done_set) BV_HIP(e, hipStreamWaitEvent(st, e->ev_done, 0));
+    }
     e->last_stream = st;
     return BV_OK;
 }
+// The end of a submit is marked lazily: the event is recorded only when somebody needs it -- a submit on another stream,
+// bv_engine_join -- and then on the stream that carried the submit (whatever the caller queued there since is waited for too:
+// conservative, never wrong).  A host that keeps to one stream pays for no event at all (an event record behind every submit
+// was one more packet in front of the next submit's first kernel).
 int mark_done(bv_engine *e, hipStream_t st) {
-    BV_HIP(e, hipEventRecord(e->ev_done, st));
-    e->ev_done_set = true;
+    e->done_pending = true;
+    e->done_stream = st;
     return BV_OK;
 }
 // group ids as the kernels read them: 16-byte chunks up to round_up(n_samples, 16) -- the ABI promises only
@@ -1519,6 +1537,7 @@ int bv_engine_wait(bv_engine *e) {
     for (hipStream_t st : e->used_streams) BV_HIP(e, hipStreamSynchronize(st));
     e->used_streams.clear();
     e->used_streams.push_back(e->last_stream);
+    e->done_pending = false; e->ev_done_set = false;  // everything submitted so far has finished: nothing left to order behind
     if (e->ctr_mirror_stale) {  // (the streams are idle: a plain copy)
         BV_HIP(e, hipMemcpy(e->h_counters, e->d_counters, sizeof(uint32_t) * BV_CTR_WORDS * bv_engine::kCtrBlocks, hipMemcpyDeviceToHost));
         e->ctr_mirror_stale = false;
@@ -1638,9 +1657,17 @@ int bv_engine_join(bv_engine *e, void *stream_) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_join: null engine");
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
-    for (bv_engine *l : e->lane)
-        if (l && l->ev_done_set) BV_HIP(e, hipStreamWaitEvent(st, l->ev_done, 0));
-    if (e->ev_done_set && st != e->last_stream) BV_HIP(e, hipStreamWaitEvent(st, e->ev_done, 0));
+    for (bv_engine *l : e->lane) {
+        if (!l) continue;
+        int rc = flush_done(l);
+        if (rc != BV_OK) return fail(e, rc, bv_last_error(l));
+        if (l->ev_done_set) BV_HIP(e, hipStreamWaitEvent(st, l->ev_done, 0));
+    }
+    if (st != e->last_stream) {
+        int rc = flush_done(e);
+        if (rc != BV_OK) return rc;
+        if (e->ev_done_set) BV_HIP(e, hipStreamWaitEvent(st, e->ev_done, 0));
+    }
     return BV_OK;
 }
 
