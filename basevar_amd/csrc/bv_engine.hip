@@ -1551,7 +1551,7 @@ int bv_engine_wait(bv_engine *e) {
             const uint32_t n = std::min(e->tl_n, 512u);
             for (uint32_t i = (n > 24 ? n - 24 : 0); i < n; ++i) {
                 const uint32_t *r = &tl[8 * i];
-                fprintf(stderr, "[timeline] engine %p submit %u: stream %u %u  solve16 %u %u  pass2 %u %u\n", (void *)e, i, ~r[0], r[1], ~r[2], r[3], ~r[4], r[5]);
+                fprintf(stderr, "[timeline] engine %p submit %u: stream %u %u  solve16 %u %u  pass2 %u %u  wave-solver %u %u\n", (void *)e, i, ~r[0], r[1], ~r[2], r[3], ~r[4], r[5], ~r[6], r[7]);
             }
         }
 #endif

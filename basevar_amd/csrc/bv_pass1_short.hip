@@ -514,6 +514,10 @@ struct __attribute__((aligned(16))) BvP1sSolveShared {
 __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolveShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef BV_TL_DEBUG
+    BV_TL_START(a.tl, 3);
+    BV_TL_END(a.tl, 3);  // (an empty workgroup leaves at once: the last stamp is the kernel's end for our purpose)
+#endif
     // most batches have few such candidates, or none: a workgroup that gets none leaves at once (the kernel runs on the
     // engine's second stream, beside a streaming kernel that keeps the memory system busy)
     if (blockIdx.x * BV_P1S_SOLVE_NW >= a.counters[BV_CTR_CANDS]) return;
