@@ -655,6 +655,44 @@ def test_two_lanes_give_the_records_of_one(bv, n):
     eng.close()
 
 
+@pytest.mark.parametrize("n", [9000, 70000], ids=["short_rows", "long_rows"])
+def test_one_engine_on_alternating_streams(bv, n):
+    """Submits of ONE engine on two caller streams in turn (no lanes): the engine shares its scratch between them, so a submit
+    on another stream than the previous one is ordered behind it (the end-of-submit event is recorded lazily, at that moment);
+    a consumer stream is ordered behind everything with bv_engine_join.  Ten submits without a wait: the counter blocks go
+    round; records and the last variant count are those of separate runs."""
+    import torch
+    dev = torch.device("cuda:0")
+    S = 600
+    maf = bv.min_af(n)
+    slabs = [make_slab(S, n, seed=900 + i, coverage=0.07, site_offset=7 * i) for i in range(5)]
+    want = [run_engine(bv, sl, maf) for sl in slabs]
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    rec = bv.SITE_DTYPE.itemsize
+    keep, outs = [], []
+    for i in range(10):
+        sl = slabs[i % 5]
+        t = {k: torch.from_numpy(np.ascontiguousarray(sl[k] if k != "rpr" else sl[k].view(np.int16))).to(dev)
+             for k in ("base_strand", "qual", "mapq", "rpr", "ref_base")}
+        keep.append(t); outs.append(torch.zeros(S * rec, dtype=torch.uint8, device=dev))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for i, (t, out) in enumerate(zip(keep, outs)):
+        pitch = t["base_strand"].shape[1]
+        eng.submit_ptrs(S, n, pitch, t["base_strand"].data_ptr(), t["qual"].data_ptr(), t["ref_base"].data_ptr(), out.data_ptr(),
+                        t["mapq"].data_ptr(), t["rpr"].data_ptr(), stream=streams[(i // 2) % 2].cuda_stream)  # A A B B A A ...
+    side = torch.cuda.Stream()
+    eng.join(side.cuda_stream)
+    with torch.cuda.stream(side):
+        copies = [o.clone() for o in outs]
+    side.synchronize()
+    for i, c in enumerate(copies):
+        assert c.cpu().numpy().tobytes() == want[i % 5].sites.tobytes(), i
+    eng.wait()
+    assert eng.last_variant_count() == want[9 % 5].n_variant
+    eng.close()
+
+
 def test_two_engines_on_two_host_threads(bv, restatement):
     """One engine per host thread (the reference runs one BaseType per ThreadPool worker,
     src/basetype_caller.cpp:485-510): concurrent submits must not interfere."""
