@@ -309,8 +309,12 @@ __device__ __forceinline__ void bv_team_help(const BvSolveArgs &a, uint32_t site
 #define BV_TEAM_STAMP(COND, SLOT) do { } while (0)
 #endif
 
-template <int NTALLY, int NSOLVE, bool CHAIN = false, bool TEAM = false>
+// MODE 0: the plain form.  MODE 1: the team form (its ticket rules + the helpers).  MODE 2: the team form's ticket rules and
+// start-up alone (first ticket = workgroup index, no ticket reserved while the solver is behind, phred tables fetched by the
+// solver wave) -- for measuring them apart from the helpers.
+template <int NTALLY, int NSOLVE, bool CHAIN = false, int MODE = 0>
 __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel(BvPass1Args a) {
+    constexpr bool TEAM = MODE == 1, TK = MODE != 0;
     static_assert(!TEAM || NSOLVE == 1, "the team form has one solver wave");
     constexpr int NT = BV_WAVE * (NTALLY + NSOLVE);
     constexpr int NBUF = NSOLVE + BV_RING_EXTRA;  // the tally may run BV_RING_EXTRA sites ahead of a slow (variant-site) solve
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
     {
         uint4 *h4 = reinterpret_cast<uint4 *>(&sh.hist[0][0]);
         for (int i = tid; i < NBUF * BV_H2_WORDS / 4; i += NT) h4[i] = make_uint4(0, 0, 0, 0);
-        if (!TEAM) {
+        if (!TK) {
             for (int i = tid; i < BV_QBINS; i += NT) {
                 sh.tab_hit[i] = a.tables->hit[i];
                 sh.tab_miss[i] = a.tables->miss[i];
@@ -370,22 +374,22 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
         // only while the ring has room for it: a workgroup whose solver is a full ring behind would otherwise sit on a
         // reserved site that any other workgroup could have started at once (measured on 8,192-site launches: the last
         // tally ended 85 us after the first workgroup had run out of work).
-        const uint32_t t0 = TEAM ? gridDim.x * chunk : 0u;
-        uint32_t next = TEAM ? blockIdx.x * chunk : 0u, cur = 0, end = 0;
+        const uint32_t t0 = TK ? gridDim.x * chunk : 0u;
+        uint32_t next = TK ? blockIdx.x * chunk : 0u, cur = 0, end = 0;
         bool have = true;  // `next` holds a ticket
-        if (!TEAM && wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
+        if (!TK && wave == 0 && lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
         for (uint32_t k = 0;; ++k) {
             const uint32_t buf = k % NBUF, gen = k / NBUF;
             uint32_t site;
             if (wave == 0) {
                 if (cur == end) {
-                    if (TEAM && !have) {  // nothing was reserved: wait for room, then draw
+                    if (TK && !have) {  // nothing was reserved: wait for room, then draw
                         bv_wait_flag(&sh.drained[buf], gen, &a.counters[BV_CTR_TIMEOUT]);
                         if (lane == 0) next = t0 + atomicAdd(&a.counters[BV_CTR_TICKET], chunk);
                     }
                     cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
                     end = cur + chunk;
-                    if (TEAM) {
+                    if (TK) {
                         if (cur < a.n_sites) {
                             const uint32_t nk = k + chunk;  // the slot of the next draw's first row
                             // (not under the very first row either: the grid starts in step, the burst of draws would return
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
         const int s = wave - NTALLY;
         BV_FILL_SOLVE_ARGS();
 #undef BV_FILL_SOLVE_ARGS
-        if (TEAM) {
+        if (TK) {
             // The phred tables are the solver's (and, later, its helpers'): fetched here, under the first row's stream.  Behind
             // the workgroup's start barrier they held every tally wave back by one loaded-memory latency (measured: 2 us on
             // the XCD that starts first, 5-12 us on the other seven -- 1,024 workgroups already have 50 MB of row loads queued).
@@ -661,7 +665,7 @@ static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
     hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_FUSED_WAVES), 0, stream, a);
 }
 
-template <int NTALLY, int NSOLVE, bool TEAM = false>
+template <int NTALLY, int NSOLVE, int MODE = 0>
 static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
     // never more than there are sites.
@@ -671,9 +675,9 @@ static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
     if (grid > a.n_sites) grid = a.n_sites;
     // (the chained and the team forms are instantiations of their own: the headline kernel keeps its register allocation)
     const dim3 block(64 * (NTALLY + NSOLVE));
-    if constexpr (TEAM) {
-        if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, true, true>), dim3(grid), block, 0, stream, a);
-        else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, false, true>), dim3(grid), block, 0, stream, a);
+    if constexpr (MODE != 0) {
+        if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, true, MODE>), dim3(grid), block, 0, stream, a);
+        else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, false, MODE>), dim3(grid), block, 0, stream, a);
     } else {
         if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, true>), dim3(grid), block, 0, stream, a);
         else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, false>), dim3(grid), block, 0, stream, a);
@@ -697,8 +701,10 @@ void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
         // long rows: several tally waves share a row (short per-site latency => short tail).  Up to BV_TEAM_MAX_SITES per
         // launch the team form is used: the last solves of a workgroup are spread over its idle tally waves (8,192 sites:
         // 0.351 -> 0.327 ms, 65,536: ~1 %; the 131,072-site launch measures the same either way and keeps the plain form).
-        if (a.n_sites <= (uint32_t)BV_TEAM_MAX_SITES) bv_launch_pass1_cfg<3, 1, true>(a, stream);
-        else bv_launch_pass1_cfg<3, 1>(a, stream);
+        // Larger launches take the team form's ticket rules and start-up without its helpers (MODE 2): 14 interleaved A/B runs at
+        // 131,072 sites x 100 k samples, pass 1 4.17 -> 4.12 ms (-1.1 %); with the helpers too (MODE 1) it measured 0.5 % slower there.
+        if (a.n_sites <= (uint32_t)BV_TEAM_MAX_SITES) bv_launch_pass1_cfg<3, 1, 1>(a, stream);
+        else bv_launch_pass1_cfg<3, 1, 2>(a, stream);
     } else {
         // short rows: solve-bound -> every wave tallies and solves its own site
         bv_launch_pass1_fused(a, stream);

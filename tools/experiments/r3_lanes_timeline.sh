@@ -2,7 +2,7 @@
 # usage: r3_lanes_timeline.sh [runs]   -- prints, per run, sites/s and the last submits of both lanes on one time axis (us)
 export BASEVAR_AMD_LIB=$PWD/basevar_amd/lib/libbasevar_amd_tl.so
 for rep in $(seq 1 ${1:-6}); do
-  python bench.py --steps 30 --warmup 5 --samples 10000 --batch-sites 100000 --no-cpu-baseline --lanes 2 > /tmp/tl_out.txt 2> /tmp/tl_err.txt
+  python bench.py --steps 30 --warmup 5 --samples 10000 --batch-sites 100000 --no-cpu-baseline --lanes 2 $TL_EXTRA > /tmp/tl_out.txt 2> /tmp/tl_err.txt
   python - <<'PY'
 import json,re
 d=json.loads([l for l in open('/tmp/tl_out.txt') if l.startswith('{')][0])
