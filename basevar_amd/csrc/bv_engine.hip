@@ -203,6 +203,7 @@ struct bv_engine {
     hipEvent_t ev_s[kCtrBlocks] = {}, ev_v[kCtrBlocks] = {};  // per chunk: streaming kernel done / solve kernels done
     static constexpr int kRing = 256;
     hipEvent_t ring[kRing][4] = {};    // per-submit events: start, end of pass 1, end of pass 2, [3] end of the streaming kernel of pass 1
+    bool ring_one_kernel[kRing] = {};  // pass 1 was ONE kernel (long rows): [3] was not recorded, its time is [0] -> [1]
     int ring_head = 0, ring_count = 0; // pending (not yet accumulated) triplets
     int last_slot = -1;
     uint32_t n_launches = 0;           // launches since creation (BV_FLAG_SPARSE_TIMING times every eighth)
@@ -302,7 +303,8 @@ int drain_timings(bv_engine *e, bool block) {
         float a = 0.f, b = 0.f, c = 0.f;
         BV_HIP(e, hipEventElapsedTime(&a, t[0], t[1]));
         BV_HIP(e, hipEventElapsedTime(&b, t[1], t[2]));
-        BV_HIP(e, hipEventElapsedTime(&c, t[0], t[3]));
+        if (e->ring_one_kernel[slot]) c = a;
+        else BV_HIP(e, hipEventElapsedTime(&c, t[0], t[3]));
         e->acc1_ms += a;
         e->acc2_ms += b;
         e->acc_stream_ms += c;
@@ -682,6 +684,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         e->ring_count += 1;
         e->last_slot = slot;
         ev = e->ring[slot];
+        e->ring_one_kernel[slot] = false;
     }
     // Short rows take the two-kernel form of pass 1 (bv_pass1_short.hip); bits 8-11 of the flags force a kernel for
     // tuning runs (9: the one-kernel short-row form; 1, 2, 5: a long-row workgroup shape).
@@ -833,6 +836,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             if (ev) BV_HIP(e, hipEventRecord(ev[1], st));
         }
     } else {
+        if (ev) e->ring_one_kernel[e->last_slot] = true;
         BvPass1Args a1;
         a1.bs = bs; a1.q = q; a1.ref_base = refb; a1.pitch = P; a1.n_sites = n_sites;
         a1.n_samples = n_samples; a1.flags = e->cfg.flags; a1.min_af = e->cfg.min_af; a1.tables = e->d_tables; a1.out = dout;
@@ -840,8 +844,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         a1.ch = chain;
         bv_launch_pass1(a1, st);
         BV_HIP(e, hipGetLastError());
-        if (ev) BV_HIP(e, hipEventRecord(ev[3], st));
-        if (ev) BV_HIP(e, hipEventRecord(ev[1], st));
+        if (ev) BV_HIP(e, hipEventRecord(ev[1], st));  // (one kernel: no separate event for "the streaming kernel")
     }
 
     for (uint32_t c = 0; c < H; ++c) {
