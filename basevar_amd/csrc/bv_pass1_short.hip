@@ -12,10 +12,11 @@
 //                          summary (strand x base totals, flags); only sites that need the EM -- more than one active
 //                          base, a non-reference base, a phred-0 call, a deep strand table -- also export their
 //                          compacted (base, phred) bins and go on the candidate list.
-//   bv_p1s_solve_kernel    (a) every non-candidate site (hom-ref, or uncovered) is finished ONE LANE PER SITE: the
-//                          work there is scalar per site (depths, one small Fisher test), and a whole wave per
-//                          site repeated it 64 times over;  (b) every candidate gets a whole wave and the full
-//                          solver of bv_solver.h on its bins (EM / LRT / QUAL / both Fisher tests / BaseQ rank sum).
+//   bv_p1s_solve16_kernel  (a) the candidates only the wave solver takes (shallow sites, phred-0 calls, > 128 bins) get a whole
+//                          wave and the full solver of bv_solver.h on their bins; (b) the ordinary candidates are solved four
+//                          per wave, one per group of 16 lanes (bv_solver16.h); (c) every non-candidate site (hom-ref, or
+//                          uncovered) is finished ONE LANE PER SITE: the work there is scalar per site (depths, one small
+//                          Fisher test), and a whole wave per site repeated it 64 times over.
 //
 // Reference functions realised: those of bv_pass1.hip (src/basetype.cpp:22-295, src/algorithm.h:44-255,
 // htslib/kfunc.c:39-143,197-313); results are bit-identical to the one-kernel form for candidates (same bins, same
@@ -502,99 +503,7 @@ __device__ __forceinline__ void bv_p1s_simple_site(const BvP1ShortArgs &a, const
 }
 
 // Candidates that need the wave solver (shallow sites, phred-0 calls, > 128 bins, min_af <= 0): one wave per site.
-#define BV_P1S_SOLVE_NW 2
-#define BV_P1S_RAW_WORDS (2 * BV_SLOTS * BV_WAVE + 4 * 128)  /* 1280 words of per-wave scratch */
-struct __attribute__((aligned(16))) BvP1sSolveShared {
-    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    // per wave: bin codes [384], bin counts [384], merged (base, phred) counts [4][128]
-    uint32_t raw[BV_P1S_SOLVE_NW][BV_P1S_RAW_WORDS];
-    BvSolverScratch sc[BV_P1S_SOLVE_NW];
-};
-
-__global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kernel(BvP1ShortArgs a) {
-    __shared__ BvP1sSolveShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef BV_TL_DEBUG
-    BV_TL_START(a.tl, 3);
-    BV_TL_END(a.tl, 3);  // (an empty workgroup leaves at once: the last stamp is the kernel's end for our purpose)
-#endif
-    // most batches have few such candidates, or none: a workgroup that gets none leaves at once (the kernel runs on the
-    // engine's second stream, beside a streaming kernel that keeps the memory system busy)
-    if (blockIdx.x * BV_P1S_SOLVE_NW >= a.counters[BV_CTR_CANDS]) return;
-    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE_NW) {
-        sh.tab_hit[i] = a.tables->hit[i];
-        sh.tab_miss[i] = a.tables->miss[i];
-    }
-    __syncthreads();  // the only workgroup-wide barrier: from here the waves never meet
-    BvSolveArgs sa;
-    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
-    sa.min_af = a.min_af; sa.flags = a.flags;
-    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
-    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
-    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
-    const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE_NW, gw = blockIdx.x * BV_P1S_SOLVE_NW + (uint32_t)wave;
-
-    const uint32_t n_cand = a.counters[BV_CTR_CANDS];
-    uint32_t *bin_code = sh.raw[wave], *bin_cnt = sh.raw[wave] + BV_SLOTS * BV_WAVE, *hq = sh.raw[wave] + 2 * BV_SLOTS * BV_WAVE;
-    BvSolverScratch *sv = &sh.sc[wave];
-    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
-    uint32_t vlist = 0, n_vlist = 0;  // lane k: the k-th variant site of this wave since the last flush
-    auto flush_variants = [&]() {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_VARIANTS], n_vlist);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if ((uint32_t)lane < n_vlist) a.var_list[base + (uint32_t)lane] = vlist;
-        n_vlist = 0;
-    };
-    // Candidates are dealt round-robin, not drawn from a ticket counter: a single-address atomic serves ~88 M draws/s,
-    // and at ~25 k candidates per 100 k sites the draws alone took 0.28 ms (measured) -- longer than the solves.
-    for (uint32_t t = gw; t < n_cand; t += n_waves) {
-        const uint32_t site = a.cand_list[t];
-        const BvSiteSummary sm = a.summ[site];
-        BvSiteSums S;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
-        S.q0_mask = sm.flags & BV_SUM_Q0_MASK;
-        S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
-        if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&sv->res)[lane] = 0u;
-        {
-            uint4 *z = reinterpret_cast<uint4 *>(hq);
-#pragma unroll
-            for (int i = 0; i < 4 * 128 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
-        }
-        bv_lrt_sync<0>();
-        // exported bins -> merged counts for the rank sum (all of them) and the EM's bins (phred <= 93), order kept
-        const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
-        uint32_t nb = 0;
-        for (uint32_t i0 = 0; i0 < sm.nb; i0 += BV_WAVE) {
-            const uint32_t i = i0 + (uint32_t)lane;
-            const bool have = i < sm.nb;
-            const uint32_t w = have ? src[i] : 0u;
-            const uint32_t code = w >> 16, cnt = w & 0xFFFFu;
-            if (have) hq[code] = cnt;
-            const bool valid = have && (code & 127u) < BV_NQ_VALID;
-            const unsigned long long m = __ballot(valid);
-            const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (valid) { bin_code[pos] = code; bin_cnt[pos] = cnt; }
-            nb += (uint32_t)__popcll(m);
-        }
-        S.nb = nb;
-        bv_lrt_sync<0>();
-        BvHqMerged H{hq};
-        if (a.ch != nullptr) {  // chained launch: the ordered gather of a shallow site reads the segment's (biased) planes
-            const BvChainC ch = bv_chain_const(a.ch);
-            const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
-            sa.bs = ch->bs[sg]; sa.q = ch->q[sg];
-        }
-        if (bv_site_solve<false, BvHqMerged, true>(sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
-            vlist = ((uint32_t)lane == n_vlist) ? site : vlist;
-            if (++n_vlist == 64u) flush_variants();
-        }
-        bv_lrt_sync<0>();
-    }
-    if (n_vlist) flush_variants();
-
-}
+#define BV_P1S_RAW_WORDS (2 * BV_SLOTS * BV_WAVE + 4 * 128)  /* the wave solver's per-wave bins: codes [384], counts [384], merged counts [4][128] */
 
 // ---- the ordinary candidates, four per wave: one site per group of 16 lanes (bv_solver16.h), in two phases -- the LRT,
 // then everything that follows it (bv_site_lrt_g16 / bv_site_tail_g16).  Measured as two kernels too (one per phase, and a third
@@ -607,9 +516,18 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE_NW, 3) void bv_p1s_solve_kern
 #ifndef BV_P1S_SOLVE16_NW
 #define BV_P1S_SOLVE16_NW 4
 #endif
+// per wave: the four groups' scratch of the 16-lane solver -- or, while the wave works off the (rare) candidates that need the
+// wave solver, that solver's bins and scratch in the same bytes
+union __attribute__((aligned(16))) BvP1sWaveScratch {
+    uint32_t grp[4][BV_G16_GRP_WORDS];  // per group: bv_site_lrt_g16 / bv_site_tail_g16
+    struct {
+        uint32_t raw[BV_P1S_RAW_WORDS];  // bin codes [384], bin counts [384], merged (base, phred) counts [4][128]
+        BvSolverScratch sc;
+    } w;
+};
 struct __attribute__((aligned(16))) BvP1sSolve16Shared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    uint32_t grp[BV_P1S_SOLVE16_NW][4][BV_G16_GRP_WORDS];  // per group: the solver's scratch (bv_site_lrt_g16 / bv_site_tail_g16)
+    BvP1sWaveScratch ws[BV_P1S_SOLVE16_NW];
     uint32_t vl[BV_P1S_SOLVE16_NW][64];                    // the wave's variant sites since the last flush
 };
 #ifndef BV_P1S_SOLVE16_OCC
@@ -680,7 +598,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
     sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
     const int grp = lane >> 4, gl = lane & 15;
-    uint32_t *scratch = sh.grp[wave][grp], *vl = sh.vl[wave];
+    uint32_t *scratch = sh.ws[wave].grp[grp], *vl = sh.vl[wave];
     uint32_t n_vl = 0;  // variant sites in vl[]
     auto flush_vl = [&]() {
         uint32_t base = 0;
@@ -691,6 +609,63 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         bv_lrt_sync<0>();
         n_vl = 0;
     };
+    // ---- first the candidates only the wave solver takes (shallow sites replayed in sample order, phred-0 calls, more than 128
+    // bins, min_af <= 0): none in most batches, all of them in a cohort of <= 64 samples.  Dealt round-robin over the grid's waves;
+    // one wave, one site, the solver of bv_solver.h on the exported bins.  (A kernel of their own until round 3: mostly empty, it
+    // still cost a launch, a kernel boundary and -- beside the other lane's kernels -- 50-110 us of workgroups queueing to leave.)
+    {
+        const uint32_t n_cand = a.counters[BV_CTR_CANDS];
+        const uint32_t n_waves = gridDim.x * BV_P1S_SOLVE16_NW, gw = blockIdx.x * BV_P1S_SOLVE16_NW + (uint32_t)wave;
+        uint32_t *bin_code = sh.ws[wave].w.raw, *bin_cnt = bin_code + BV_SLOTS * BV_WAVE, *hq = bin_code + 2 * BV_SLOTS * BV_WAVE;
+        BvSolverScratch *sv = &sh.ws[wave].w.sc;
+        constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+#pragma unroll 1
+        for (uint32_t t = gw; t < n_cand; t += n_waves) {
+            const uint32_t site = a.cand_list[t];
+            const BvSiteSummary sm = a.summ[site];
+            BvSiteSums S;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { S.fwd[b] = sm.fwd[b]; S.rev[b] = sm.rev[b]; }
+            S.q0_mask = sm.flags & BV_SUM_Q0_MASK;
+            S.badq = (sm.flags & BV_SUM_BADQ) ? 1u : 0u;
+            if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&sv->res)[lane] = 0u;
+            {
+                uint4 *z = reinterpret_cast<uint4 *>(hq);
+#pragma unroll
+                for (int i = 0; i < 4 * 128 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+            }
+            bv_lrt_sync<0>();
+            // exported bins -> merged counts for the rank sum (all of them) and the EM's bins (phred <= 93), order kept
+            const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+            uint32_t nb = 0;
+            for (uint32_t i0 = 0; i0 < sm.nb; i0 += BV_WAVE) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const bool have = i < sm.nb;
+                const uint32_t w = have ? src[i] : 0u;
+                const uint32_t code = w >> 16, cnt = w & 0xFFFFu;
+                if (have) hq[code] = cnt;
+                const bool valid = have && (code & 127u) < BV_NQ_VALID;
+                const unsigned long long m = __ballot(valid);
+                const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (valid) { bin_code[pos] = code; bin_cnt[pos] = cnt; }
+                nb += (uint32_t)__popcll(m);
+            }
+            S.nb = nb;
+            bv_lrt_sync<0>();
+            BvHqMerged H{hq};
+            if (a.ch != nullptr) {  // chained launch: the ordered gather of a shallow site reads the segment's (biased) planes
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+                sa.bs = ch->bs[sg]; sa.q = ch->q[sg];
+            }
+            if (bv_site_solve<false, BvHqMerged, true>(sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
+                if (lane == 0) vl[n_vl] = site;
+                if (++n_vl > 60u) flush_vl();
+            }
+            bv_lrt_sync<0>();
+        }
+        if (n_vl) flush_vl();  // (the groups' scratch starts clean of the list logic either way; the flush keeps the phases apart)
+    }
     BvP1sTickets tk;
     tk.init(a.counters + BV_CTR_TICKET_A, (uint32_t)wave);
     for (; tk.job() < n_jobs; tk.next(lane)) {
@@ -824,16 +799,9 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
 void bv_launch_p1s_solve(const BvP1ShortArgs &a, hipStream_t stream, bool beside_stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
-    uint32_t grid = beside_stream ? cu : cu * 3u * (4u / BV_P1S_SOLVE_NW);  // 3 waves per SIMD (168 VGPRs)
-    const uint32_t need = (a.n_sites + BV_P1S_SOLVE_NW - 1) / BV_P1S_SOLVE_NW;
-    if (grid > need) grid = need > 0 ? need : 1;
-    if (cap && grid > cap) grid = cap;
     uint32_t grid16 = beside_stream ? cu : cu * (uint32_t)BV_P1S_SOLVE16_OCC * (4u / BV_P1S_SOLVE16_NW);
     const uint32_t need16 = (a.n_sites + 4 * BV_P1S_SOLVE16_NW - 1) / (4 * BV_P1S_SOLVE16_NW);  // four sites per wave
     if (grid16 > need16) grid16 = need16 > 0 ? need16 : 1;
     if (cap && grid16 > cap) grid16 = cap;
     hipLaunchKernelGGL(bv_p1s_solve16_kernel, dim3(grid16), dim3(BV_WAVE * BV_P1S_SOLVE16_NW), 0, stream, a);
-    // the wave-solver kernel second: most batches give it nothing to do, and behind the streaming kernel it only delayed the
-    // kernel that has (interleaved A/B, 100 k sites x 10 k samples: 157.3 -> 158.25 M sites/s); the two are independent
-    hipLaunchKernelGGL(bv_p1s_solve_kernel, dim3(grid), dim3(BV_WAVE * BV_P1S_SOLVE_NW), 0, stream, a);
 }

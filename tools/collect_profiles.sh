@@ -46,7 +46,7 @@ sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kern
 run_cfg n100k                                               # headline: bv_pass1_kernel<3,1>, bv_pass2_kernel<256,true,false>
 run_cfg n100k_groups2 --groups 2 --batch-sites 65536        # bv_pass2_kernel<256,true,true,false> + bv_p2g_solve16_kernel on long rows
 run_cfg n1M --samples 1000000 --batch-sites 16384 --steps 8 # the same kernels at 1 M samples
-run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_solve_kernel + bv_p1s_solve16_kernel, bv_pass2_dma_kernel
+run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_stream_kernel, bv_p1s_solve16_kernel, bv_pass2_dma_kernel
 run_cfg n10k_lanes2 --samples 10000 --batch-sites 100000 --lanes 2   # the same through the engine's two lanes (BV_FLAG_LANES)
 run_cfg n10k_524k --samples 10000 --batch-sites 524288
 run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_pass2_dma_kernel + bv_p2g_stream_kernel + bv_p2g_solve16/hard
