@@ -789,8 +789,8 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
     // two waves that share a SIMD -- the arbiter's favourite and the other -- must be in the same workgroup for that to even
     // them out.
     // (Also under BV_FLAG_LANES, where the other lane's kernels run beside this one.  Measured there, interleaved A/B: this
-    // shape 170.5 M sites/s, two workgroups of 4 waves with fixed ranges 167-171 M, two of 4 with the cursor 157 M; about one
-    // bench process in ten ran at 89-133 M with either of the first two, cause not found: DESIGN 4.2c.)
+    // shape 170.5 M sites/s, two workgroups of 4 waves with fixed ranges 167-171 M, two of 4 with the cursor 157 M; 176-178 M
+    // since the wave-solver candidates moved into the solve kernel: DESIGN 4.2c.)
     bv_launch_p1s_stream_cfg<8, 3, 2>(a, stream, 1);
 }
 // `beside_stream`: the kernels will run beside a streaming kernel (the next chunk's pass 1 or an earlier chunk's pass 2) whose
