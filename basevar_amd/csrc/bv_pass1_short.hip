@@ -779,6 +779,10 @@ void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
         case 1: return bv_launch_p1s_stream_cfg<4, 3>(a, stream, 4);   // 16 waves/CU, 2 slots in flight each
         case 2: return bv_launch_p1s_stream_cfg<4, 6>(a, stream, 2);   //  8 waves/CU, 5 slots in flight each
         case 3: return bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);  // the default's slots, two workgroups of 4 waves per CU
+        // fewer waves per CU, to leave the other lane's solve (37.5 KB) / pass-2 (64 KB) workgroups room beside a streaming one --
+        // measured: 6 waves 0.449 ms per 100 k sites (8 waves: 0.363), 153 M sites/s with two lanes (8 waves: 177); 5 waves 0.511 ms, 140 M
+        case 4: return bv_launch_p1s_stream_cfg<6, 3, 2>(a, stream, 1);
+        case 5: return bv_launch_p1s_stream_cfg<5, 3, 2>(a, stream, 1);
         case 6: return bv_launch_p1s_stream_cfg<4, 4, 1>(a, stream, 2);  // slots of 1 KiB per plane:  8 waves/CU, 6 KiB in flight each
         case 8: return bv_launch_p1s_stream_cfg<4, 2, 2>(a, stream, 3);  //                          12 waves/CU, 4 KiB in flight each
         default: break;
