@@ -815,6 +815,14 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             s1.summ = e->d_summ + c0; s1.bins = e->d_bins + (size_t)c0 * BV_S_BIN_STRIDE;
             s1.cand_list = e->d_cand_list + c0; s1.easy_list = e->d_easy_list + c0; s1.easy3_list = e->d_easy3_list + c0;
             s1.ch = chain;
+            // rows of at least three 4 KiB slots: both halves of pass 1 as ONE persistent kernel (bv_pass1_fused.hip: solver
+            // waves beside the streaming waves of every workgroup); bits 12-15 of the flags = 9 keep the two-kernel form (A/B)
+            if (H == 1u && ((e->cfg.flags >> 12) & 0xFu) == 0u && bv_p1s_fused_takes(s1)) {
+                if (ev) e->ring_one_kernel[e->last_slot] = true;
+                bv_launch_p1s_fused(s1, st);
+                BV_HIP(e, hipGetLastError());
+                continue;
+            }
             bv_launch_p1s_stream(s1, st);
             BV_HIP(e, hipGetLastError());
             if (H > 1u) {

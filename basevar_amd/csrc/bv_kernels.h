@@ -235,3 +235,6 @@ bool bv_p2g_all_items(const BvPass2Args &a);
 bool bv_p2g_streams(const BvPass2Args &a);  // whether bv_launch_pass2 takes the LDS-DMA group tally (needs a.gidp)
 void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, uint32_t n_groups, hipStream_t stream);
 size_t bv_pass2_lds_bytes(uint32_t n_groups);
+// short rows of at least three 4 KiB slots, not chained: pass 1 as ONE persistent kernel (bv_pass1_fused.hip)
+bool bv_p1s_fused_takes(const BvP1ShortArgs &a);
+void bv_launch_p1s_fused(const BvP1ShortArgs &a, hipStream_t stream);

@@ -1,0 +1,703 @@
+// bv_pass1_fused.hip -- pass 1 for short rows (4,097 .. 49,152 samples per site) as ONE persistent kernel.
+//
+// bv_pass1_short.hip runs pass 1 as a streaming kernel followed by a solve kernel: while the first runs the chip's vector
+// units are ~40 % busy, while the second runs HBM is idle, and the second's 0.10 ms per 100 k sites (16 % of the step at
+// 10 k samples) is fully exposed.  Here both are roles of one workgroup of 12 waves (one per CU, three per SIMD):
+//
+//   waves 0-7  (stream)  draw sites from the workgroup's cursor and stream their rows through private LDS rings filled
+//                        by LDS-DMA, exactly one site per draw, three 4 KiB slots in flight per wave across row
+//                        boundaries.  The per-slot control is straight-line scalar code (two asm blocks: a full slot, a
+//                        row's last slot with two precomputed exec masks) -- the streaming kernel of bv_pass1_short.hip
+//                        spends ~110 scalar instructions and ~15 branches per slot on the same job.  Per row: the
+//                        strand x base totals, the candidate test, ONE 48-byte summary store; a candidate's bins leave
+//                        through a 512-byte LDS stage as two 64-lane stores.  A row's stores are counted: the three slot
+//                        waits that follow it allow exactly that many more operations outstanding (s_waitcnt vmcnt(8 + S)),
+//                        so a candidate row no longer drains the ring.
+//   waves 8-11 (solve)   take the candidates from two queues in LDS (three or four active bases first), four sites per
+//                        wave on 16-lane groups (bv_solver16.h), and finish the non-candidate sites one lane per site in
+//                        blocks of 64 as soon as every streaming wave has passed them.
+//   at the end           a streaming wave that finds the cursor exhausted joins the solvers with its ring as scratch; only
+//                        these waves (12 KiB each) take the candidates that need the wave solver of bv_solver.h (shallow
+//                        sites, phred-0 calls, more than 128 bins).
+//
+// Hand-off.  A row's summary and bins go to HBM scratch as before; they are PUBLISHED (queue entry / the wave's `pub` mark in
+// LDS) one row later, behind an s_waitcnt that covers exactly the stores of that row (vmcnt counts in issue order), and read
+// by the solvers through the L2 (sc1 loads; summaries of neighbouring sites share lines).  Producer and consumer are waves
+// of one CU: one L2, no cross-XCD visibility involved.  Streaming waves never wait for solver waves except on a full queue.
+//
+// Reference functions realised: those of bv_pass1_short.hip (src/basetype.cpp:22-295, src/algorithm.h:44-255,
+// htslib/kfunc.c:39-143,197-313); every record is byte-identical to the two-kernel form's (same bins, same order, same
+// solver code).  HBM-bound by design (2 B per cell, each byte read once); no MFMA (categorical tallies).
+#define BV_LNFACT_TABLE_ONLY 1  /* rows of at most 65,535 samples: see bv_lnfact */
+#include "bv_kernels.h"
+
+#include "bv_solver.h"
+#include "bv_solver16.h"
+#include "bv_tally.h"
+
+#include "bv_short.h"
+
+#define BV_F_NS 8                         /* streaming waves per workgroup */
+#ifndef BV_F_NV
+#define BV_F_NV 4                         /* dedicated solver waves per workgroup */
+#endif
+static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody must be emptying it");
+#define BV_F_NW (BV_F_NS + BV_F_NV)
+#define BV_F_K 3                          /* ring slots per streaming wave */
+#define BV_F_SLOT_WORDS 1024              /* 2 KiB of calls, then 2 KiB of phreds */
+#define BV_F_QCAP 256                     /* entries per queue (ring buffers) */
+#define BV_F_EMPTY 0xFFFFFFFFu
+// control words in LDS
+#define BV_FC_CURSOR 0                    /* sites of the workgroup's range handed out so far */
+#define BV_FC_Q3_TAIL 1                   /* candidates with >= 3 active bases: reserved / claimed positions */
+#define BV_FC_Q3_HEAD 2
+#define BV_FC_Q2_TAIL 3                   /* candidates with <= 2 active bases */
+#define BV_FC_Q2_HEAD 4
+#define BV_FC_QH_TAIL 5                   /* candidates for the wave solver: entries of the workgroup's slice of cand_list (HBM) */
+#define BV_FC_QH_HEAD 6
+#define BV_FC_BLK_HEAD 7                  /* blocks of 64 sites (non-candidates) claimed */
+#define BV_FC_NDONE 8                     /* streaming waves that have published their last row */
+
+union __attribute__((aligned(16))) BvFusedRing {
+    uint32_t slot[BV_F_K][BV_F_SLOT_WORDS];
+    struct {                                  // once the wave has stopped streaming
+        BvP1sWaveScratch ws;
+        uint32_t vl[64];
+    } solve;
+};
+struct __attribute__((aligned(16))) BvFusedShared {
+    uint32_t hist[BV_F_NS][BV_S_HWORDS + BV_S_OVF + 8];  // per streaming wave: [(rev<<2)|base][phred < 128], overflow rows
+    BvFusedRing ring[BV_F_NS];
+    uint32_t grp[BV_F_NV > 0 ? BV_F_NV : 1][4][BV_G16_GRP_WORDS];  // the solver waves' group scratches
+    uint32_t vl[BV_F_NV > 0 ? BV_F_NV : 1][64];          // ... and their variant sites since the last flush
+    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    uint32_t stage[BV_F_NS][128];                        // a candidate's compacted bins on their way out
+    uint32_t q3[BV_F_QCAP], q2[BV_F_QCAP];
+    uint32_t pub[BV_F_NS];                               // every row of wave w below site pub[w] is published
+    uint32_t ctl[16];
+};
+static_assert(sizeof(BvFusedShared) <= 160 * 1024, "one workgroup per CU must fit the LDS");
+static_assert(sizeof(BvFusedRing) == sizeof(uint32_t) * BV_F_K * BV_F_SLOT_WORDS, "the solver scratch must fit the ring");
+
+// ---- LDS-DMA of one slot: 2 KiB of calls to d0, 2 KiB of phreds to d0 + 2 KiB; four 1 KiB pieces, always four (the
+// counted waits rely on it).  M0 is written inside the statement; the s_add between the write and the load is the wait state.
+__device__ __forceinline__ void bv_f_glds_full(uint32_t d0, const uint8_t *pb, const uint8_t *pq, uint32_t va, uint32_t vb) {
+    uint32_t keep, t;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b32 m0, %[d0]\n\t"
+        "s_add_u32 %[t], %[d0], 0x400\n\t"
+        "global_load_lds_dwordx4 %[va], %[pb] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_add_u32 %[t], %[d0], 0x800\n\t"
+        "global_load_lds_dwordx4 %[vb], %[pb] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_add_u32 %[t], %[d0], 0xc00\n\t"
+        "global_load_lds_dwordx4 %[va], %[pq] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vb], %[pq] nt\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [t] "=&s"(t)
+        : [d0] "s"(d0), [pb] "s"(pb), [pq] "s"(pq), [va] "v"(va), [vb] "v"(vb)
+        : "memory", "scc");
+}
+// A row's last slot: lanes past the row's end load nothing (mA: first KiB, mB: second KiB).  A second KiB that lies wholly
+// past the end is "loaded" by lane 0 alone from the slot's first bytes (mB = 1, vbl = va): its cells are masked in the tally.
+__device__ __forceinline__ void bv_f_glds_last(uint32_t d0, const uint8_t *pb, const uint8_t *pq, uint32_t va, uint32_t vbl,
+                                               unsigned long long mA, unsigned long long mB) {
+    uint32_t keep, t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, %[mA]\n\t"
+        "s_mov_b32 m0, %[d0]\n\t"
+        "s_add_u32 %[t], %[d0], 0x800\n\t"
+        "global_load_lds_dwordx4 %[va], %[pb] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_add_u32 %[t], %[d0], 0x400\n\t"
+        "global_load_lds_dwordx4 %[va], %[pq] nt\n\t"
+        "s_mov_b64 exec, %[mB]\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_add_u32 %[t], %[d0], 0xc00\n\t"
+        "global_load_lds_dwordx4 %[vbl], %[pb] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[vbl], %[pq] nt\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
+        : [d0] "s"(d0), [pb] "s"(pb), [pq] "s"(pq), [va] "v"(va), [vbl] "v"(vbl), [mA] "s"(mA), [mB] "s"(mB)
+        : "memory", "scc");
+}
+// a reference base through the scalar cache (lgkmcnt: a vector load would sit in the vmcnt queue of the ring)
+typedef const __attribute__((address_space(4))) uint32_t *bv_c32;
+__device__ __forceinline__ uint32_t bv_f_ref_scalar(const uint8_t *ref_base, uint32_t site) {
+    const uintptr_t p = (uintptr_t)ref_base + site;
+    const uint32_t w = *(bv_c32)(p & ~(uintptr_t)3);
+    return (w >> (8u * (uint32_t)(p & 3))) & 0xFFu;
+}
+__device__ __forceinline__ uint32_t bv_f_lds_read_u(const uint32_t *p) {  // p: a word of the kernel's __shared__ block
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const volatile __attribute__((address_space(3))) uint32_t *)p);
+}
+__device__ __forceinline__ uint32_t bv_f_keep_mask(int kept) {  // dword mask of the first `kept` bytes
+    return kept >= 4 ? 0xFFFFFFFFu : (kept <= 0 ? 0u : (1u << (8 * kept)) - 1u);
+}
+
+// the cells of two 16-byte chunks per lane (first and second KiB of a slot) -> the wave's histogram
+__device__ __forceinline__ void bv_f_tally2(bv_u32x4 vbA, bv_u32x4 vqA, bv_u32x4 vbB, bv_u32x4 vqB, uint32_t *hist, uint32_t one) {
+    // A phred byte >= 128 (invalid input) would carry into its neighbour under the shift below: such a slot takes the
+    // exact cell-by-cell path (wave-uniform branch; never taken on valid data).
+    const uint32_t hi = ((vqA.x | vqA.y | vqA.z) | (vqA.w | vqB.x | vqB.y) | (vqB.z | vqB.w)) & 0x80808080u;
+    if (__builtin_expect(__ballot(hi != 0u) != 0ull, 0)) {
+        const uint32_t wb[8] = {vbA.x, vbA.y, vbA.z, vbA.w, vbB.x, vbB.y, vbB.z, vbB.w};
+        const uint32_t wq[8] = {vqA.x, vqA.y, vqA.z, vqA.w, vqB.x, vqB.y, vqB.z, vqB.w};
+#pragma unroll 1
+        for (int j = 0; j < 32; ++j) {
+            const uint32_t c = (wb[j >> 2] >> (8 * (j & 3))) & 0xFFu, p = (wq[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            if (c < 8u) atomicAdd(p < 128u ? &hist[(c << 7) | p] : &hist[BV_S_HWORDS + c], 1u);
+        }
+        return;
+    }
+    // X = call << 8 | phred << 1 = twice the word index of the 8 x 128 histogram; call < 8 <=> X < 0x800
+    vqA.x <<= 1; vqA.y <<= 1; vqA.z <<= 1; vqA.w <<= 1;
+    vqB.x <<= 1; vqB.y <<= 1; vqB.z <<= 1; vqB.w <<= 1;
+    bv_tally_chunk<1>(vbA, vqA, hist, one);
+    bv_tally_chunk<1>(vbB, vqB, hist, one);
+}
+
+// ------------------------------------------------------------------------------ the solver side
+struct BvFusedSolver {
+    BvSolveArgs sa;
+    uint32_t *grp;   // this wave's four group scratches (LDS)
+    uint32_t *vl;    // this wave's variant sites since the last flush (LDS)
+    uint32_t n_vl;
+    BvP1sWaveScratch *big;  // the wave solver's scratch, or NULL: this wave cannot take the hard candidates
+};
+__device__ __forceinline__ void bv_f_flush_vl(const BvP1ShortArgs &a, BvFusedSolver &v, int lane) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&a.counters[BV_CTR_VARIANTS], v.n_vl);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    bv_lrt_sync<0>();
+    if ((uint32_t)lane < v.n_vl) a.var_list[base + (uint32_t)lane] = v.vl[lane];
+    bv_lrt_sync<0>();
+    v.n_vl = 0;
+}
+// claim up to `most` entries of a queue: returns the number claimed (0: none there, or another wave was faster) and the
+// first position
+__device__ __forceinline__ uint32_t bv_f_claim(uint32_t *ctl, int tail_i, int head_i, uint32_t most, uint32_t &first, int lane) {
+    const uint32_t h = bv_f_lds_read_u(&ctl[head_i]), t = bv_f_lds_read_u(&ctl[tail_i]);
+    if (h == t) return 0u;
+    uint32_t n = t - h;
+    if (n > most) n = most;
+    uint32_t old = 0;
+    if (lane == 0) old = atomicCAS(&ctl[head_i], h, h + n);
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    first = h;
+    return old == h ? n : 0u;
+}
+// the entry at `pos` (its producer reserved the position before writing it: wait for the site number), handed back empty
+__device__ __forceinline__ uint32_t bv_f_take(uint32_t *q, uint32_t pos) {
+    volatile __attribute__((address_space(3))) uint32_t *e = (volatile __attribute__((address_space(3))) uint32_t *)q + (pos & (BV_F_QCAP - 1u));
+    uint32_t s = *e;
+    while (s == BV_F_EMPTY) { __builtin_amdgcn_s_sleep(1); s = *e; }
+    *e = BV_F_EMPTY;
+    return s;
+}
+
+// four candidates, one per group of 16 lanes: positions first .. first + n - 1 of queue q
+__device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t *q, uint32_t first,
+                                           uint32_t n, int lane) {
+    const int grp = lane >> 4, gl = lane & 15;
+    uint32_t *scratch = v.grp + grp * BV_G16_GRP_WORDS;
+    bool variant = false;
+    uint32_t site = 0;
+    if ((uint32_t)grp < n) {
+        site = bv_f_take(q, first + (uint32_t)grp);
+        const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+        uint32_t nb, badq;
+        BvG16Lrt pre;
+        uint4 s0, s1, s2;
+        bv_load3_l2(&a.summ[site], s0, s1, s2);
+        {
+            uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+            const uint32_t total = depth[0] + depth[1] + depth[2] + depth[3];
+            nb = s2.x;
+            badq = (s2.y & BV_SUM_BADQ) ? 1u : 0u;
+            BvG16Bins B;
+            B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = v.sa.loghit; B.logmiss = v.sa.logmiss;
+            B.pm = reinterpret_cast<double *>(scratch) + gl;
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t i = (uint32_t)(s * 16 + gl);
+                B.w[s] = i < nb ? src[i] : 0u;
+            }
+            variant = bv_site_lrt_g16(v.sa, site, depth, total, badq, B, scratch, lane, &pre);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record's first version is out before phase 2 patches it
+        BvSiteSums S;
+        // phase 2 needs the strand totals: read again (eight registers that would otherwise sit through the EMs)
+        bv_load3_l2(&a.summ[site], s0, s1, s2);
+        S.fwd[0] = s0.x; S.fwd[1] = s0.y; S.fwd[2] = s0.z; S.fwd[3] = s0.w;
+        S.rev[0] = s1.x; S.rev[1] = s1.y; S.rev[2] = s1.z; S.rev[3] = s1.w;
+        S.q0_mask = 0; S.nb = nb; S.badq = badq;
+        bv_site_tail_g16(v.sa, site, S, src, nb, scratch, lane, &pre);
+    }
+    const unsigned long long vm = __ballot(variant && gl == 0);
+    if (variant && gl == 0) v.vl[v.n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
+    v.n_vl += (uint32_t)__popcll(vm);
+    if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
+}
+// one candidate that needs the wave solver (shallow site: ordered replay; phred-0 calls; more than 128 bins; min_af <= 0)
+__device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t site, int lane) {
+    uint32_t *bin_code = v.big->w.raw, *bin_cnt = bin_code + BV_SLOTS * BV_WAVE, *hq = bin_code + 2 * BV_SLOTS * BV_WAVE;
+    BvSolverScratch *sv = &v.big->w.sc;
+    constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
+    uint4 s0, s1, s2;
+    bv_load3_l2(&a.summ[site], s0, s1, s2);
+    BvSiteSums S;
+    S.fwd[0] = s0.x; S.fwd[1] = s0.y; S.fwd[2] = s0.z; S.fwd[3] = s0.w;
+    S.rev[0] = s1.x; S.rev[1] = s1.y; S.rev[2] = s1.z; S.rev[3] = s1.w;
+    const uint32_t sm_nb = s2.x;
+    S.q0_mask = s2.y & BV_SUM_Q0_MASK;
+    S.badq = (s2.y & BV_SUM_BADQ) ? 1u : 0u;
+    if (lane < REC_WORDS) reinterpret_cast<uint32_t *>(&sv->res)[lane] = 0u;
+    {
+        uint4 *z = reinterpret_cast<uint4 *>(hq);
+#pragma unroll
+        for (int i = 0; i < 4 * 128 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+    }
+    bv_lrt_sync<0>();
+    // exported bins -> merged counts for the rank sum (all of them) and the EM's bins (phred <= 93), order kept
+    const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+    uint32_t nb = 0;
+    for (uint32_t i0 = 0; i0 < sm_nb; i0 += BV_WAVE) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const bool have = i < sm_nb;
+        const uint32_t w = have ? src[i] : 0u;
+        const uint32_t code = w >> 16, cnt = w & 0xFFFFu;
+        if (have) hq[code] = cnt;
+        const bool valid = have && (code & 127u) < BV_NQ_VALID;
+        const unsigned long long m = __ballot(valid);
+        const uint32_t pos = nb + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (valid) { bin_code[pos] = code; bin_cnt[pos] = cnt; }
+        nb += (uint32_t)__popcll(m);
+    }
+    S.nb = nb;
+    bv_lrt_sync<0>();
+    BvHqMerged H{hq};
+    if (bv_site_solve<false, BvHqMerged, true>(v.sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
+        if (lane == 0) v.vl[v.n_vl] = site;
+        if (++v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
+    }
+    bv_lrt_sync<0>();
+}
+
+// The solver loop of one wave: candidates with three or four active bases first (the longest jobs), then the others, then
+// (waves with the big scratch) the wave-solver candidates, then blocks of 64 non-candidate sites that every streaming wave
+// has passed.  Ends when the streaming waves are done and nothing is left.
+__device__ __forceinline__ void bv_f_solver_loop(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t B1,
+                                                 int lane) {
+    const uint32_t n_blocks = (B1 - B0 + 63u) >> 6;
+#pragma unroll 1
+    for (;;) {
+        uint32_t first, n;
+        if ((n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, 4u, first, lane)) != 0u) { bv_f_job16(a, sh, v, sh.q3, first, n, lane); continue; }
+        if ((n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, 4u, first, lane)) != 0u) { bv_f_job16(a, sh, v, sh.q2, first, n, lane); continue; }
+        // (read before the block test: once every streaming wave is done, every block is ready)
+        const uint32_t n_done = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]);
+        if (v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
+            (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, first, lane)) != 0u) {
+            // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
+            const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[B0 + first]));
+            bv_f_job_hard(a, sh, v, site, lane);
+            continue;
+        }
+        {
+            const uint32_t bh = bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]);
+            if (bh < n_blocks) {
+                uint32_t ready = n_blocks;
+                if (n_done < (uint32_t)BV_F_NS) {
+                    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int w = 0; w < BV_F_NS; ++w) {
+                        const uint32_t p = bv_f_lds_read_u(&sh.pub[w]);
+                        m = p < m ? p : m;
+                    }
+                    ready = m >= B1 ? n_blocks : ((m - B0) >> 6);
+                }
+                if (bh < ready) {
+                    uint32_t old = 0;
+                    if (lane == 0) old = atomicCAS(&sh.ctl[BV_FC_BLK_HEAD], bh, bh + 1u);
+                    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                    if (old == bh) {
+                        const uint32_t site = B0 + bh * 64u + (uint32_t)lane;
+                        if (site < B1) bv_p1s_simple_site<true>(a, v.sa.lnfact, site);
+                    }
+                    continue;
+                }
+            }
+        }
+        if (n_done == (uint32_t)BV_F_NS) {
+            // nothing was claimable a moment ago and no producer is left: done, unless a queue got its last entries in between
+            const bool q_left = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) ||
+                                bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) ||
+                                (v.big != nullptr && bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD])) ||
+                                bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks;
+            if (!q_left) break;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (v.n_vl) bv_f_flush_vl(a, v, lane);
+}
+
+// ------------------------------------------------------------------------------ the streaming side
+// publish a row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic, one
+// LDS write (the slot is free once its last consumer has handed it back empty).  Candidates of the wave solver: a place in the
+// workgroup's slice of cand_list in HBM (unbounded: they are taken up only when every streaming wave is done, see
+// bv_f_solver_loop, so no streaming wave ever waits on them); that store is one more in the vmcnt queue than the slot waits
+// allow for -- a conservative wait, never a wrong one.
+typedef volatile __attribute__((address_space(3))) uint32_t bv_lds_vu32;
+__device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, int lane) {
+    const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)tail, 1u);
+    bv_lds_vu32 *e = q + (pos & (BV_F_QCAP - 1u));
+    // (a slot still occupied: the solvers are BV_F_QCAP candidates behind -- they never wait for a streaming wave, so this ends)
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*e) != BV_F_EMPTY) __builtin_amdgcn_s_sleep(8);
+    if (lane == 0) *e = site;
+}
+__device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, uint32_t site, uint32_t kind, int lane) {
+    if (kind < 2u) return;
+    if (kind == 4u) {
+        const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QH_TAIL], 1u);
+        if (lane == 0) a.cand_list[B0 + pos] = site;
+    } else if (kind == 3u) {
+        bv_f_push((bv_lds_vu32 *)sh.q3, (bv_lds_u32 *)&sh.ctl[BV_FC_Q3_TAIL], site, lane);
+    } else {
+        bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, lane);
+    }
+}
+
+__device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFusedShared &sh, const int wave, const int lane,
+                                                 const uint32_t B0, const uint32_t B1) {
+    uint32_t *hist = sh.hist[wave];
+    uint32_t *stage = sh.stage[wave];
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(bv_lds_u32 *)sh.ring[wave].slot[0]);
+    const uint32_t *ring = sh.ring[wave].slot[0];
+    const uint32_t cursor_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_CURSOR];
+    // ---- the geometry of a row (the same for every row)
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 127u) >> 7;  // 16-byte chunks; slots of 128 chunks
+    const int tail = (int)(a.n_samples & 15u);
+    const uint32_t last_valid = n_chunks - (n_slots - 1u) * 128u;  // chunks of a row's last slot that lie inside the row: 1 .. 128
+    const uint32_t va = (uint32_t)lane * 16u, vb = va + 1024u;
+    const uint32_t vbl = last_valid > 64u ? vb : va;
+    const unsigned long long mA = last_valid >= 64u ? ~0ull : ((1ull << last_valid) - 1ull);
+    const unsigned long long mB = last_valid > 64u ? (last_valid >= 128u ? ~0ull : ((1ull << (last_valid - 64u)) - 1ull)) : 1ull;
+    // the last slot's cells past the row's end are forced to 'N': per lane and dword, the mask of the bytes that stay
+    uint32_t keepA[4], keepB[4];
+    {
+        const uint32_t cA = (uint32_t)lane, cB = 64u + (uint32_t)lane;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int partial = tail ? tail - 4 * d : 4;
+            keepA[d] = cA >= last_valid ? 0u : ((cA == last_valid - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
+            keepB[d] = cB >= last_valid ? 0u : ((cB == last_valid - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
+        }
+    }
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+
+    // ---- prefetch side: the next slot to request
+    const uint8_t *pb = a.bs, *pq = a.q;
+    uint32_t p_left = 0;               // slots of the prefetch row still to request
+    uint32_t ring_w = 0, ring_r = 0, inflight = 0;
+    // rows drawn: the one being tallied and the one after it (the prefetch runs at most one row ahead: n_slots >= BV_F_K)
+    uint32_t c_site = 0, c_ref = 0, n_site = 0, n_ref = 0;
+    uint32_t st = 0;
+    constexpr uint32_t P_DONE = 1u, C_HAVE = 2u, N_HAVE = 4u;
+    auto issue = [&]() __attribute__((always_inline)) {
+        if (p_left == 0u) {
+            if (st & P_DONE) return;
+            const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, 1u);
+            if (c >= B1 - B0) { st |= P_DONE; return; }
+            const uint32_t s = B0 + c;
+            const uint32_t r = bv_f_ref_scalar(a.ref_base, s);
+            const uint64_t off = (uint64_t)s * a.pitch;
+            pb = bv_uniform_ptr(a.bs + off); pq = bv_uniform_ptr(a.q + off);
+            p_left = n_slots;
+            if (!(st & C_HAVE)) { c_site = s; c_ref = r; st |= C_HAVE; }
+            else { n_site = s; n_ref = r; st |= N_HAVE; }
+        }
+        const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
+        if (p_left > 1u) {
+            bv_f_glds_full(d0, pb, pq, va, vb);
+            pb += 2048; pq += 2048;
+        } else {
+            bv_f_glds_last(d0, pb, pq, va, vbl, mA, mB);  // (the next row comes from a draw)
+        }
+        --p_left;
+        ring_w = (ring_w + 1u == (uint32_t)BV_F_K) ? 0u : ring_w + 1u;
+        ++inflight;
+    };
+#pragma unroll 1
+    for (int k = 0; k < BV_F_K; ++k) issue();
+
+    // the previous row of this wave: published once its stores are known to be complete
+    uint32_t prev_site = 0, prev_kind = 0;  // kind 0: none; 1: not a candidate; 2 / 3: queue q2 / q3; 4: wave solver
+    uint32_t wsel = 0;                      // stores of the previous row still to be allowed for in the slot waits: 0 none / unknown, 1, 3
+#pragma unroll 1
+    while (st & C_HAVE) {
+        const uint32_t site = c_site;
+#pragma unroll 1
+        for (uint32_t j = 0; j < n_slots; ++j) {
+            // The oldest slot in flight has landed once at most 8 younger loads are outstanding -- plus, for the three waits
+            // that follow a row's epilogue, that row's S stores, which are younger than the slot waited for (vmcnt counts in
+            // issue order).  Unknown S, or fewer than K slots in flight: the conservative wait.
+            if (inflight != (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (j >= 3u || wsel == 0u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (wsel == 1u) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            const uint32_t *rs = ring + ring_r * BV_F_SLOT_WORDS + lane * 4;
+            bv_u32x4 vbA = *reinterpret_cast<const bv_u32x4 *>(rs);
+            bv_u32x4 vbB = *reinterpret_cast<const bv_u32x4 *>(rs + 256);
+            bv_u32x4 vqA = *reinterpret_cast<const bv_u32x4 *>(rs + 512);
+            bv_u32x4 vqB = *reinterpret_cast<const bv_u32x4 *>(rs + 768);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers: the slot may be refilled
+            ring_r = (ring_r + 1u == (uint32_t)BV_F_K) ? 0u : ring_r + 1u;
+            --inflight;
+            issue();
+            if (j + 1u == n_slots) {
+                const uint32_t N4 = 0x08080808u;
+                vbA.x = (vbA.x & keepA[0]) | (N4 & ~keepA[0]); vbA.y = (vbA.y & keepA[1]) | (N4 & ~keepA[1]);
+                vbA.z = (vbA.z & keepA[2]) | (N4 & ~keepA[2]); vbA.w = (vbA.w & keepA[3]) | (N4 & ~keepA[3]);
+                vbB.x = (vbB.x & keepB[0]) | (N4 & ~keepB[0]); vbB.y = (vbB.y & keepB[1]) | (N4 & ~keepB[1]);
+                vbB.z = (vbB.z & keepB[2]) | (N4 & ~keepB[2]); vbB.w = (vbB.w & keepB[3]) | (N4 & ~keepB[3]);
+                // (stale phred bytes of lanes that loaded nothing must not look like invalid input)
+                vqA.x &= keepA[0]; vqA.y &= keepA[1]; vqA.z &= keepA[2]; vqA.w &= keepA[3];
+                vqB.x &= keepB[0]; vqB.y &= keepB[1]; vqB.z &= keepB[2]; vqB.w &= keepB[3];
+            }
+            bv_f_tally2(vbA, vqA, vbB, vqB, hist, one);
+        }
+        bv_lrt_sync<0>();
+
+        // ---- the previous row's stores are older than the (at most) K slots in flight: wait for exactly them, publish it
+        if (prev_kind != 0u) {
+            if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+            if (lane == 0) sh.pub[wave] = site;  // every row of this wave below the current one is out
+        }
+
+        // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
+        uint32_t c[4][2], facc[4], racc[4];
+        bool bad = false;
+        uint32_t q0_mask = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+#pragma unroll
+            for (int qr = 0; qr < 2; ++qr) {
+                const int q = (qr << 6) | lane;
+                const uint32_t f = hist[(b << 7) | q], r = hist[((b | 4) << 7) | q];
+                c[b][qr] = f + r;
+                if (qr == 0) { facc[b] = f; racc[b] = r; } else { facc[b] += f; racc[b] += r; }
+                if (qr == 1) bad |= (c[b][qr] != 0u) && (q >= BV_NQ_VALID);
+            }
+            if (__builtin_amdgcn_readfirstlane((int)c[b][0]) != 0) q0_mask |= 1u << b;
+        }
+        uint32_t fwd[4], rev[4];
+        {
+            const uint32_t vv[8] = {facc[0], facc[1], facc[2], facc[3], racc[0], racc[1], racc[2], racc[3]};
+            uint32_t t[8];
+            bv_wave_sum8_u32(vv, t, lane);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { fwd[b] = t[b]; rev[b] = t[4 + b]; }
+        }
+        uint32_t badq = (__ballot(bad) != 0ull) ? 1u : 0u;
+        {
+            uint32_t ovf_any = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t of = hist[BV_S_HWORDS + b], orv = hist[BV_S_HWORDS + 4 + b];
+                fwd[b] += of; rev[b] += orv;
+                ovf_any |= of | orv;
+            }
+            if (ovf_any) badq = 1u;
+        }
+        uint32_t depth[4], total = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { depth[b] = fwd[b] + rev[b]; total += depth[b]; }
+
+        // ---- candidate or not (as bv_p1s_stream_kernel): not a candidate = nothing covered, or exactly one active base
+        // (basetype.cpp:135-139), it is the reference base, none of its calls has phred 0, and the all-sites strand table is shallow
+        bool is_cand = false;
+        uint32_t n_active = 0;
+        if (total != 0u && !(a.flags & BV_FLAG_TALLY_ONLY)) {
+            const int bsel = lane & 3;
+            const bool act = (double)bv_sel4u(depth, bsel) / (int)total >= a.min_af;  // basetype.cpp:137, one base per lane
+            const uint32_t act_mask = (uint32_t)(__ballot(act) & 0xFull);
+            n_active = (uint32_t)__popc(act_mask);
+            int ref = (int)c_ref;
+            if (ref > 4) ref = 4;
+            const bool one_ref = act_mask != 0u && (act_mask & (act_mask - 1u)) == 0u && ref < 4 && act_mask == (1u << ref);
+            is_cand = !one_ref || (q0_mask & act_mask) != 0u;
+            if (!is_cand) {
+                // Fisher tables of (ref_fwd, ref_rev, alt_fwd, alt_rev): imax - imin + 1 (kfunc.c:253-257)
+                const uint32_t rf = bv_sel4u(fwd, ref), rr = bv_sel4u(rev, ref);
+                const uint32_t af = fwd[0] + fwd[1] + fwd[2] + fwd[3] - rf;
+                const int n1_ = (int)(rf + rr), n_1 = (int)(rf + af), n = (int)total;
+                const int imax = n_1 < n1_ ? n_1 : n1_;
+                int imin = n1_ + n_1 - n;
+                if (imin < 0) imin = 0;
+                is_cand = (imax - imin + 1) > BV_S_SIMPLE_MAX_TABLES;
+            }
+        }
+        uint32_t nb = 0, kind = 1u, n_stores = 1u;
+        if (is_cand) {
+            // every non-empty (base, phred < 128) bin, in (base, phred) order -- the order of bv_prologue_wave
+            unsigned long long m[8];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                for (int qr = 0; qr < 2; ++qr) {
+                    m[b * 2 + qr] = __ballot(c[b][qr] != 0u);
+                    nb += (uint32_t)__popcll(m[b * 2 + qr]);
+                }
+            }
+            // four per wave (bv_solver16.h) unless the site needs what only the wave solver has: the ordered replay of a
+            // shallow site, the literal 0/0 arithmetic of phred-0 calls or of min_af <= 0, or more than 128 bins
+            const bool is_easy = q0_mask == 0u && total > (uint32_t)BV_ORD_MAX && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 &&
+                                 !(a.flags & BV_FLAG_WAVE_SOLVER);
+            kind = is_easy ? (n_active <= 2u ? 2u : 3u) : 4u;
+            uint32_t *dst = a.bins + (size_t)site * BV_S_BIN_STRIDE;
+            uint32_t pos0 = 0;
+            if (is_easy) {
+                // through the LDS stage: two 64-lane stores whatever the number of bins (words past it are never read)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int qr = 0; qr < 2; ++qr) {
+                        const int q = (qr << 6) | lane;
+                        const unsigned long long mm = m[b * 2 + qr];
+                        const uint32_t pos = pos0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                        if (c[b][qr] != 0u) stage[pos] = ((((uint32_t)b << 7) | (uint32_t)q) << 16) | c[b][qr];
+                        pos0 += (uint32_t)__popcll(mm);
+                    }
+                }
+                bv_lrt_sync<0>();
+                const uint32_t w0 = stage[lane], w1 = stage[64 + lane];
+                dst[lane] = w0;
+                dst[64 + lane] = w1;
+                n_stores = 3u;
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+#pragma unroll
+                    for (int qr = 0; qr < 2; ++qr) {
+                        const int q = (qr << 6) | lane;
+                        const unsigned long long mm = m[b * 2 + qr];
+                        const uint32_t pos = pos0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                        if (c[b][qr] != 0u) dst[pos] = ((((uint32_t)b << 7) | (uint32_t)q) << 16) | c[b][qr];
+                        pos0 += (uint32_t)__popcll(mm);
+                    }
+                }
+                n_stores = 0u;  // not counted: the waits that follow are the conservative ones
+            }
+        }
+        {
+            // 48-byte summary: 12 lanes, one dword each
+            const uint32_t fl = q0_mask | (badq ? BV_SUM_BADQ : 0u) | (is_cand ? BV_SUM_CAND : 0u);
+            uint32_t w = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                w = (lane == b) ? fwd[b] : w;
+                w = (lane == 4 + b) ? rev[b] : w;
+            }
+            w = (lane == 8) ? nb : w;
+            w = (lane == 9) ? fl : w;
+            if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
+        }
+        // ---- hand the histogram back, zeroed
+        {
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+            for (int i = 0; i < BV_S_HWORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+            if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        bv_lrt_sync<0>();
+        prev_site = site;
+        prev_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+        wsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_stores);
+        if (st & N_HAVE) { c_site = n_site; c_ref = n_ref; st &= ~N_HAVE; }
+        else st &= ~C_HAVE;
+    }
+    // ---- this wave's last row, and the end of its streaming
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (prev_kind != 0u) bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a cand_list entry of the last row)
+    if (lane == 0) {
+        sh.pub[wave] = 0xFFFFFFFFu;
+        atomicAdd(&sh.ctl[BV_FC_NDONE], 1u);
+    }
+}
+
+__global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1ShortArgs a) {
+    __shared__ BvFusedShared sh;
+#ifdef BV_TL_DEBUG
+    BV_TL_START(a.tl, 0);
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t B0 = (uint32_t)((uint64_t)a.n_sites * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)a.n_sites * (blockIdx.x + 1) / gridDim.x);
+    // ---- set-up: histograms zeroed, queues empty, tables in LDS; nothing is in flight yet, so a plain barrier is fine
+    if (wave < BV_F_NS) {
+        uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[wave]);
+#pragma unroll
+        for (int i = 0; i < (BV_S_HWORDS + BV_S_OVF + 8) / 4 / BV_WAVE + 1; ++i)
+            if (i * BV_WAVE + lane < (BV_S_HWORDS + BV_S_OVF + 8) / 4) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+    }
+    for (int i = tid; i < BV_F_QCAP; i += BV_WAVE * BV_F_NW) { sh.q3[i] = BV_F_EMPTY; sh.q2[i] = BV_F_EMPTY; }
+    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_F_NW) {
+        sh.tab_hit[i] = a.tables->hit[i];
+        sh.tab_miss[i] = a.tables->miss[i];
+    }
+    if (tid < 16) sh.ctl[tid] = 0u;
+    if (tid < BV_F_NS) sh.pub[tid] = B0;
+    __syncthreads();
+
+    if (wave < BV_F_NS) bv_f_stream_role(a, sh, wave, lane, B0, B1);
+
+    BvFusedSolver v;
+    v.sa.ref_base = a.ref_base; v.sa.out = a.out; v.sa.var_list = a.var_list; v.sa.counters = a.counters;
+    v.sa.min_af = a.min_af; v.sa.flags = a.flags;
+    v.sa.lnfact.t = a.tables->lnfact; v.sa.lnfact.n = (int)a.tables->lnfact_n;
+    v.sa.loghit = a.tables->loghit; v.sa.logmiss = a.tables->logmiss;
+    v.sa.bs = a.bs; v.sa.q = a.q; v.sa.pitch = a.pitch; v.sa.n_samples = a.n_samples;
+    v.n_vl = 0;
+    if (wave < BV_F_NS) {
+        v.grp = &sh.ring[wave].solve.ws.grp[0][0]; v.vl = sh.ring[wave].solve.vl; v.big = &sh.ring[wave].solve.ws;
+    } else {
+        v.grp = &sh.grp[wave - BV_F_NS][0][0]; v.vl = sh.vl[wave - BV_F_NS]; v.big = nullptr;
+    }
+    bv_f_solver_loop(a, sh, v, B0, B1, lane);
+#ifdef BV_TL_DEBUG
+    BV_TL_END(a.tl, 0);
+#endif
+}
+
+// ------------------------------------------------------------------------------ launcher
+bool bv_p1s_fused_takes(const BvP1ShortArgs &a) {
+    // rows of at least BV_F_K slots (the prefetch then never runs more than one row ahead); chained launches keep the
+    // two-kernel form (their planes come per segment)
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 127u) >> 7;
+    return a.ch == nullptr && n_slots >= (uint32_t)BV_F_K && a.n_samples <= BV_SHORT_ROW_MAX;
+}
+void bv_launch_p1s_fused(const BvP1ShortArgs &a, hipStream_t stream) {
+    const uint32_t cu = a.n_cu ? a.n_cu : 256u;
+    uint32_t grid = cu;
+    const uint32_t need = (a.n_sites + BV_F_NS - 1) / BV_F_NS;  // at least one site per streaming wave
+    if (grid > need) grid = need > 0 ? need : 1;
+    const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
+    if (cap && grid > cap) grid = cap;
+    hipLaunchKernelGGL(bv_p1s_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_F_NW), 0, stream, a);
+}
