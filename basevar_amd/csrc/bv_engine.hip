@@ -1479,6 +1479,40 @@ static void bv_stream_debug_report(const uint32_t *h) {
 #endif
 
 #ifdef BV_TEAM_DEBUG
+// bv_p1s_fused_kernel: per workgroup, when its streaming waves were done, what was left for the solvers then, when it ended
+static void bv_fused_debug_report(const uint32_t *h) {
+    const uint32_t *d = h + BV_CTR_WORDS;
+    uint32_t t0 = 0; bool any = false;
+    for (int b = 0; b < 512; ++b)
+        if (d[b * 8] && (!any || (int32_t)(d[b * 8] - t0) < 0)) { t0 = d[b * 8]; any = true; }
+    if (!any) return;
+    const char *nm[4] = {"entry", "first streaming wave done", "last streaming wave done", "workgroup done"};
+    for (int j = 0; j < 4; ++j) {
+        std::vector<double> v; double sum[8] = {}; uint32_t cnt[8] = {};
+        for (int b = 0; b < 512; ++b) {
+            if (!d[b * 8] || !d[b * 8 + j]) continue;
+            const double t = (double)(int32_t)(d[b * 8 + j] - t0) * 0.01;
+            v.push_back(t); sum[d[b * 8 + 7] & 7u] += t; cnt[d[b * 8 + 7] & 7u]++;
+        }
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        fprintf(stderr, "[fused debug] %-26s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f us | mean per XCD:", nm[j], v[0], v[n / 10], v[n / 2],
+                v[n * 9 / 10], v[n - 1]);
+        for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", cnt[x] ? sum[x] / cnt[x] : 0.);
+        fprintf(stderr, "\n");
+    }
+    const char *qn[3] = {"q3 entries", "q2 entries", "blocks of 64"};
+    for (int j = 0; j < 3; ++j) {
+        std::vector<uint32_t> v;
+        for (int b = 0; b < 512; ++b) if (d[b * 8]) v.push_back(d[b * 8 + 4 + j]);
+        std::sort(v.begin(), v.end());
+        fprintf(stderr, "[fused debug] left when the last streaming wave was done, %-12s: min %u p50 %u p90 %u max %u\n", qn[j], v[0], v[v.size() / 2],
+                v[v.size() * 9 / 10], v.back());
+    }
+}
+#endif
+#ifdef BV_TEAM_DEBUG
 // bv_p1s_solve16_kernel: wave 0 of every workgroup
 static void bv_solve16_debug_report(const uint32_t *h) {
     const uint32_t *d = h + BV_CTR_WORDS;
@@ -1570,6 +1604,7 @@ int bv_engine_wait(bv_engine *e) {
         if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 1u) bv_stream_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 2u) bv_team_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 3u) bv_solve16_debug_report(e->h_counters);
+        else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 4u) bv_fused_debug_report(e->h_counters);
 #endif
         timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
         zero_freq += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ];

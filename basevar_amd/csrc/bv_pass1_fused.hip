@@ -47,6 +47,9 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_F_SLOT_WORDS 1024              /* 2 KiB of calls, then 2 KiB of phreds */
 #define BV_F_QCAP 256                     /* entries per queue (ring buffers) */
 #define BV_F_EMPTY 0xFFFFFFFFu
+#ifndef BV_F_MIN_JOB
+#define BV_F_MIN_JOB 4u                   /* sites per job of the 16-lane solver while rows are still streaming */
+#endif
 // control words in LDS
 #define BV_FC_CURSOR 0                    /* sites of the workgroup's range handed out so far */
 #define BV_FC_Q3_TAIL 1                   /* candidates with >= 3 active bases: reserved / claimed positions */
@@ -186,9 +189,9 @@ __device__ __forceinline__ void bv_f_flush_vl(const BvP1ShortArgs &a, BvFusedSol
 }
 // claim up to `most` entries of a queue: returns the number claimed (0: none there, or another wave was faster) and the
 // first position
-__device__ __forceinline__ uint32_t bv_f_claim(uint32_t *ctl, int tail_i, int head_i, uint32_t most, uint32_t &first, int lane) {
+__device__ __forceinline__ uint32_t bv_f_claim(uint32_t *ctl, int tail_i, int head_i, uint32_t least, uint32_t most, uint32_t &first, int lane) {
     const uint32_t h = bv_f_lds_read_u(&ctl[head_i]), t = bv_f_lds_read_u(&ctl[tail_i]);
-    if (h == t) return 0u;
+    if (t - h < least) return 0u;
     uint32_t n = t - h;
     if (n > most) n = most;
     uint32_t old = 0;
@@ -303,12 +306,20 @@ __device__ __forceinline__ void bv_f_solver_loop(const BvP1ShortArgs &a, BvFused
 #pragma unroll 1
     for (;;) {
         uint32_t first, n;
-        if ((n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, 4u, first, lane)) != 0u) { bv_f_job16(a, sh, v, sh.q3, first, n, lane); continue; }
-        if ((n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, 4u, first, lane)) != 0u) { bv_f_job16(a, sh, v, sh.q2, first, n, lane); continue; }
-        // (read before the block test: once every streaming wave is done, every block is ready)
+        // (read before everything else: once every streaming wave is done, every block is ready and no queue grows any more)
         const uint32_t n_done = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]);
+        // While rows are still streaming only FULL jobs are taken (four sites): a wave that runs off with the one candidate
+        // that has just arrived spends a whole job on it, and the queue behind it grows -- the solver waves have ~60 % of the
+        // streaming time's worth of work when every job is full.
+        const uint32_t least = n_done == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
+        {
+            uint32_t *q = sh.q3;
+            n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, least, 4u, first, lane);
+            if (n == 0u) { q = sh.q2; n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, least, 4u, first, lane); }
+            if (n != 0u) { bv_f_job16(a, sh, v, q, first, n, lane); continue; }   // (ONE call site: the solver is ~50 KB of code)
+        }
         if (v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
-            (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, first, lane)) != 0u) {
+            (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, 1u, first, lane)) != 0u) {
             // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
             const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[B0 + first]));
             bv_f_job_hard(a, sh, v, site, lane);
@@ -637,7 +648,19 @@ __device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFused
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a cand_list entry of the last row)
     if (lane == 0) {
         sh.pub[wave] = 0xFFFFFFFFu;
+#ifdef BV_TEAM_DEBUG  /* per workgroup: first / last streaming wave done, and what was left to solve then */
+        const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u;
+        if (atomicAdd(&sh.ctl[BV_FC_NDONE], 1u) == 0u) dbg_[1] = now;
+        else if (sh.ctl[BV_FC_NDONE] == (uint32_t)BV_F_NS) {
+            dbg_[2] = now;
+            dbg_[4] = sh.ctl[BV_FC_Q3_TAIL] - sh.ctl[BV_FC_Q3_HEAD];
+            dbg_[5] = sh.ctl[BV_FC_Q2_TAIL] - sh.ctl[BV_FC_Q2_HEAD];
+            dbg_[6] = ((B1 - B0 + 63u) >> 6) - sh.ctl[BV_FC_BLK_HEAD];
+        }
+#else
         atomicAdd(&sh.ctl[BV_FC_NDONE], 1u);
+#endif
     }
 }
 
@@ -663,9 +686,25 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     }
     if (tid < 16) sh.ctl[tid] = 0u;
     if (tid < BV_F_NS) sh.pub[tid] = B0;
+#ifdef BV_TEAM_DEBUG
+    if (tid == 0) {
+        uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u;
+        dbg_[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[3] = 0u;
+        dbg_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+        if (blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 4u;  // whose stamps these are
+    }
+#endif
     __syncthreads();
 
-    if (wave < BV_F_NS) bv_f_stream_role(a, sh, wave, lane, B0, B1);
+    if (wave < BV_F_NS) {
+#ifdef BV_F_STREAM_PRIO
+        __builtin_amdgcn_s_setprio(BV_F_STREAM_PRIO);
+#endif
+        bv_f_stream_role(a, sh, wave, lane, B0, B1);
+#ifdef BV_F_STREAM_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
 
     BvFusedSolver v;
     v.sa.ref_base = a.ref_base; v.sa.out = a.out; v.sa.var_list = a.var_list; v.sa.counters = a.counters;
@@ -680,6 +719,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         v.grp = &sh.grp[wave - BV_F_NS][0][0]; v.vl = sh.vl[wave - BV_F_NS]; v.big = nullptr;
     }
     bv_f_solver_loop(a, sh, v, B0, B1, lane);
+#ifdef BV_TEAM_DEBUG
+    if (lane == 0) atomicMax(&a.counters[BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u + 3u], (uint32_t)__builtin_amdgcn_s_memrealtime());
+#endif
 #ifdef BV_TL_DEBUG
     BV_TL_END(a.tl, 0);
 #endif
