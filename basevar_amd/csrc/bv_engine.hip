@@ -786,6 +786,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         return c >= H ? n_sites : (uint32_t)(((uint64_t)n_sites * c / H) & ~(uint64_t)63);
     };
 
+    bool pass2_fused = false;  // pass 1's kernel has streamed the pass-2 rows too (bv_pass1_fused.hip)
     if (ev) BV_HIP(e, hipEventRecord(ev[0], st));
     if (two_kernel) {
         if (n_sites > e->short_sites) {
@@ -817,8 +818,16 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             s1.ch = chain;
             // rows of at least three 4 KiB slots: both halves of pass 1 as ONE persistent kernel (bv_pass1_fused.hip: solver
             // waves beside the streaming waves of every workgroup); bits 12-15 of the flags = 9 keep the two-kernel form (A/B)
-            if (H == 1u && ((e->cfg.flags >> 12) & 0xFu) == 0u && bv_p1s_fused_takes(s1)) {
+            s1.mapq = nullptr; s1.rpr = nullptr;
+            const uint32_t tune = (e->cfg.flags >> 12) & 0xFu;
+            if (H == 1u && (tune == 0u || tune == 10u) && bv_p1s_fused_takes(s1)) {
                 if (ev) e->ring_one_kernel[e->last_slot] = true;
+                // without pop-groups the same kernel streams the variant sites' rank-sum rows too (pass 2); bits 12-15 = 10 keep
+                // pass 2 a launch of its own (A/B)
+                if (tune == 0u && G == 0 && mq != nullptr && rp != nullptr && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP)) {
+                    s1.mapq = mq; s1.rpr = rp;
+                    pass2_fused = true;
+                }
                 bv_launch_p1s_fused(s1, st);
                 BV_HIP(e, hipGetLastError());
                 continue;
@@ -865,6 +874,12 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             ac.ref_base = refb + c0; ac.n_sites = nc; ac.out = dout + c0; ac.gout = dgout ? dgout + (size_t)c0 * G : nullptr;
             ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
             if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * G * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * G); }
+        }
+        if (pass2_fused) {
+            // what is left of pass 2: the rows whose ranks did not fit the fused kernel's 256-rank window (long reads), listed in
+            // easy_list / counted in the BV_CTR_CANDS line -- normally none, and the launch ends at once
+            ac.var_list = e->d_easy_list;
+            ac.counters = ac.counters + BV_CTR_CANDS;
         }
         bv_launch_pass2(ac, st);
         BV_HIP(e, hipGetLastError());

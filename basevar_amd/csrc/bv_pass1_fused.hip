@@ -37,6 +37,8 @@
 
 #include "bv_short.h"
 
+#include <type_traits>
+
 #define BV_F_NS 8                         /* streaming waves per workgroup */
 #ifndef BV_F_NV
 #define BV_F_NV 4                         /* dedicated solver waves per workgroup */
@@ -44,9 +46,18 @@
 static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody must be emptying it");
 #define BV_F_NW (BV_F_NS + BV_F_NV)
 #define BV_F_K 3                          /* ring slots per streaming wave */
-#define BV_F_SLOT_WORDS 1024              /* 2 KiB of calls, then 2 KiB of phreds */
-#define BV_F_QCAP 256                     /* entries per queue (ring buffers) */
+#define BV_F_SLOT_WORDS 1024              /* pass-1 rows: 2 KiB of calls, 2 KiB of phreds; pass-2 rows: 1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks */
+#define BV_F_QCAP 256                     /* entries per candidate queue (ring buffers) */
+#define BV_F_QVCAP 128                    /* entries of the variant queue */
+#define BV_F_QV_HIGH 64u                  /* from this many waiting variant rows on, a streaming wave takes one before its next pass-1 row */
 #define BV_F_EMPTY 0xFFFFFFFFu
+// Issue priority of a wave while it solves (s_setprio; streaming: 0).  The solver's chains of dependent FP64 operations lose
+// 2-3 x beside two streaming waves per SIMD at equal priority (jobs of 35-65 us took 100-195 us, measured from the queue
+// lengths at the end of the pass-1 rows: 28 candidates waiting); at priority 3 the solver waves keep up (1 waiting) and the
+// streaming waves, which wait on memory most of the time, lose ~4 %.
+#ifndef BV_F_SOLVER_PRIO
+#define BV_F_SOLVER_PRIO 3
+#endif
 #ifndef BV_F_MIN_JOB
 #define BV_F_MIN_JOB 4u                   /* sites per job of the 16-lane solver while rows are still streaming */
 #endif
@@ -59,56 +70,69 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_FC_QH_TAIL 5                   /* candidates for the wave solver: entries of the workgroup's slice of cand_list (HBM) */
 #define BV_FC_QH_HEAD 6
 #define BV_FC_BLK_HEAD 7                  /* blocks of 64 sites (non-candidates) claimed */
-#define BV_FC_NDONE 8                     /* streaming waves that have published their last row */
+#define BV_FC_NDONE 8                     /* streaming waves that have published their last pass-1 row */
+#define BV_FC_QV_TAIL 9                   /* variant sites whose rank-sum rows (pass 2) are to be streamed */
+#define BV_FC_QV_HEAD 10
+#define BV_FC_BUSY 11                     /* solver jobs in flight (each may still add to the variant queue) */
+// a streaming wave's flags that outlive a call of bv_f_stream_until_idle
+#define BV_FS_P_DONE 1u                   /* no row will ever come again */
+#define BV_FS_CUR_DONE 8u                 /* the cursor is exhausted */
+#define BV_FS_P1_FIN 16u                  /* the wave's last pass-1 row is published, the wave counted in NDONE */
+// kinds of rows in a streaming wave's ring
+#define BV_FK_P1 1u                       /* calls + phreds of a site: the pass-1 tally */
+#define BV_FK_P2 2u                       /* calls + mapq + ranks of a variant site: the two rank sums of pass 2 */
 
 union __attribute__((aligned(16))) BvFusedRing {
     uint32_t slot[BV_F_K][BV_F_SLOT_WORDS];
-    struct {                                  // once the wave has stopped streaming
+    struct {                                  // while the wave has no row in flight
         BvP1sWaveScratch ws;
         uint32_t vl[64];
     } solve;
 };
 struct __attribute__((aligned(16))) BvFusedShared {
-    uint32_t hist[BV_F_NS][BV_S_HWORDS + BV_S_OVF + 8];  // per streaming wave: [(rev<<2)|base][phred < 128], overflow rows
+    uint32_t hist[BV_F_NS][BV_S_HWORDS + BV_S_OVF + 8];  // per streaming wave: [(rev<<2)|base][phred < 128], overflow rows; pass-2 rows: hm[2][256], hr[2][256]
     BvFusedRing ring[BV_F_NS];
-    uint32_t grp[BV_F_NV > 0 ? BV_F_NV : 1][4][BV_G16_GRP_WORDS];  // the solver waves' group scratches
-    uint32_t vl[BV_F_NV > 0 ? BV_F_NV : 1][64];          // ... and their variant sites since the last flush
+    uint32_t grp[BV_F_NV][4][BV_G16_GRP_WORDS];          // the solver waves' group scratches
+    uint32_t vl[BV_F_NV][64];                            // ... and their variant sites since the last flush
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
     uint32_t stage[BV_F_NS][128];                        // a candidate's compacted bins on their way out
     uint32_t q3[BV_F_QCAP], q2[BV_F_QCAP];
-    uint32_t pub[BV_F_NS];                               // every row of wave w below site pub[w] is published
+    uint32_t qv[BV_F_QVCAP][4];                          // site, class table, n_ref | n_alt << 16, 2-bit lut
+    uint32_t pub[BV_F_NS];                               // every pass-1 row of wave w below site pub[w] is published
     uint32_t ctl[16];
 };
 static_assert(sizeof(BvFusedShared) <= 160 * 1024, "one workgroup per CU must fit the LDS");
 static_assert(sizeof(BvFusedRing) == sizeof(uint32_t) * BV_F_K * BV_F_SLOT_WORDS, "the solver scratch must fit the ring");
 
-// ---- LDS-DMA of one slot: 2 KiB of calls to d0, 2 KiB of phreds to d0 + 2 KiB; four 1 KiB pieces, always four (the
+// ---- LDS-DMA of one slot: four 1 KiB pieces (64 lanes x 16 bytes from p_i + v_i) to d0, d0 + 1 KiB, ..., always four (the
 // counted waits rely on it).  M0 is written inside the statement; the s_add between the write and the load is the wait state.
-__device__ __forceinline__ void bv_f_glds_full(uint32_t d0, const uint8_t *pb, const uint8_t *pq, uint32_t va, uint32_t vb) {
+__device__ __forceinline__ void bv_f_glds4(uint32_t d0, const uint8_t *p0, uint32_t v0, const uint8_t *p1, uint32_t v1,
+                                           const uint8_t *p2, uint32_t v2, const uint8_t *p3, uint32_t v3) {
     uint32_t keep, t;
     asm volatile(
         "s_mov_b32 %[keep], m0\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[va], %[pb] nt\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[vb], %[pb] nt\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[va], %[pq] nt\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[vb], %[pq] nt\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t)
-        : [d0] "s"(d0), [pb] "s"(pb), [pq] "s"(pq), [va] "v"(va), [vb] "v"(vb)
+        : [d0] "s"(d0), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3)
         : "memory", "scc");
 }
-// A row's last slot: lanes past the row's end load nothing (mA: first KiB, mB: second KiB).  A second KiB that lies wholly
-// past the end is "loaded" by lane 0 alone from the slot's first bytes (mB = 1, vbl = va): its cells are masked in the tally.
-__device__ __forceinline__ void bv_f_glds_last(uint32_t d0, const uint8_t *pb, const uint8_t *pq, uint32_t va, uint32_t vbl,
-                                               unsigned long long mA, unsigned long long mB) {
+// A row's last slot: lanes past the row's end load nothing (mA: pieces 0 and 2, mB: pieces 1 and 3 -- never empty: a piece
+// that lies wholly past the end is "loaded" by lane 0 alone from valid bytes of the slot; its cells are masked in the tally).
+__device__ __forceinline__ void bv_f_glds4_masked(uint32_t d0, const uint8_t *p0, uint32_t v0, const uint8_t *p1, uint32_t v1,
+                                                  const uint8_t *p2, uint32_t v2, const uint8_t *p3, uint32_t v3,
+                                                  unsigned long long mA, unsigned long long mB) {
     uint32_t keep, t;
     unsigned long long sv;
     asm volatile(
@@ -117,22 +141,42 @@ __device__ __forceinline__ void bv_f_glds_last(uint32_t d0, const uint8_t *pb, c
         "s_mov_b64 exec, %[mA]\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[va], %[pb] nt\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[va], %[pq] nt\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[vbl], %[pb] nt\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[vbl], %[pq] nt\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
-        : [d0] "s"(d0), [pb] "s"(pb), [pq] "s"(pq), [va] "v"(va), [vbl] "v"(vbl), [mA] "s"(mA), [mB] "s"(mB)
+        : [d0] "s"(d0), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3),
+          [mA] "s"(mA), [mB] "s"(mB)
         : "memory", "scc");
+}
+// One wave-level compare-and-swap on an LDS word by lane 0, the old value in an SGPR (no divergent branch, no vector-memory
+// operation: see bv_lds_fetch_add_wave)
+__device__ __forceinline__ uint32_t bv_f_lds_cas_wave(uint32_t lds_addr, uint32_t expect, uint32_t desired) {
+    uint32_t r, tc, td;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %[tc], %[cmp]\n\t"
+        "v_mov_b32 %[td], %[val]\n\t"
+        "ds_cmpst_rtn_b32 %[tc], %[adr], %[tc], %[td]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[r], %[tc]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "=&s"(r), [tc] "=&v"(tc), [td] "=&v"(td), [sv] "=&s"(sv)
+        : [adr] "v"(lds_addr), [cmp] "s"(expect), [val] "s"(desired)
+        : "memory");
+    return r;
 }
 // a reference base through the scalar cache (lgkmcnt: a vector load would sit in the vmcnt queue of the ring)
 typedef const __attribute__((address_space(4))) uint32_t *bv_c32;
@@ -177,6 +221,7 @@ struct BvFusedSolver {
     uint32_t *vl;    // this wave's variant sites since the last flush (LDS)
     uint32_t n_vl;
     BvP1sWaveScratch *big;  // the wave solver's scratch, or NULL: this wave cannot take the hard candidates
+    bool fuse2;      // variant sites also go to the workgroup's variant queue (their pass-2 rows are streamed by this kernel)
 };
 __device__ __forceinline__ void bv_f_flush_vl(const BvP1ShortArgs &a, BvFusedSolver &v, int lane) {
     uint32_t base = 0;
@@ -187,8 +232,8 @@ __device__ __forceinline__ void bv_f_flush_vl(const BvP1ShortArgs &a, BvFusedSol
     bv_lrt_sync<0>();
     v.n_vl = 0;
 }
-// claim up to `most` entries of a queue: returns the number claimed (0: none there, or another wave was faster) and the
-// first position
+// claim `least` to `most` entries of a queue: returns the number claimed (0: too few there, or another wave was faster) and
+// the first position
 __device__ __forceinline__ uint32_t bv_f_claim(uint32_t *ctl, int tail_i, int head_i, uint32_t least, uint32_t most, uint32_t &first, int lane) {
     const uint32_t h = bv_f_lds_read_u(&ctl[head_i]), t = bv_f_lds_read_u(&ctl[tail_i]);
     if (t - h < least) return 0u;
@@ -208,6 +253,36 @@ __device__ __forceinline__ uint32_t bv_f_take(uint32_t *q, uint32_t pos) {
     *e = BV_F_EMPTY;
     return s;
 }
+// What the rank sums of pass 2 need of a variant site (bv_pass2_dma_kernel forms the same from the record): the class of
+// every base -- byte b of L: 0x80 REF, 0x81 ALT, 0xFF neither (caller.cpp:1151-1157) --, the 2-bit form of it for the window
+// sweeps, and the REF / ALT depths.  aw0 / aw1: the record's bytes n_alt, alt[0..3] as stored at bv_site_result::n_alt.
+__device__ __forceinline__ void bv_f_p2_facts(int ref, const uint32_t depth[4], uint32_t aw0, uint32_t aw1, uint32_t &L, uint32_t &n12,
+                                              uint32_t &lut) {
+    L = 0xFFFFFFFFu; lut = 0xAAu;
+    uint32_t n1 = 0, n2 = 0;
+    const int n_alt = (int)(aw0 & 0xFFu);
+    if (ref < 4) { L = (L & ~(0xFFu << (8 * ref))) | (0x80u << (8 * ref)); lut &= ~(3u << (2 * ref)); n1 = bv_sel4u(depth, ref); }
+#pragma unroll
+    for (int t = 0; t < BV_MAX_ALT; ++t) {
+        if (t < n_alt) {
+            const int b = (int)((t < 3 ? (aw0 >> (8 * (t + 1))) : aw1) & 3u);
+            L = (L & ~(0xFFu << (8 * b))) | (0x81u << (8 * b));
+            lut = (lut & ~(3u << (2 * b))) | (1u << (2 * b));
+            n2 += bv_sel4u(depth, b);
+        }
+    }
+    n12 = n1 | (n2 << 16);  // both at most the row length (<= 49,152)
+}
+// a variant site into the workgroup's variant queue (one lane; its record is complete in memory)
+__device__ __forceinline__ void bv_f_push_variant(BvFusedShared &sh, uint32_t site, uint32_t L, uint32_t n12, uint32_t lut) {
+    const uint32_t pos = atomicAdd(&sh.ctl[BV_FC_QV_TAIL], 1u);
+    volatile __attribute__((address_space(3))) uint32_t *e =
+        (volatile __attribute__((address_space(3))) uint32_t *)&sh.qv[pos & (BV_F_QVCAP - 1u)][0];
+    // (a slot still occupied: BV_F_QVCAP variant rows are waiting -- from BV_F_QV_HIGH on the streaming waves take them first)
+    while (e[0] != BV_F_EMPTY) __builtin_amdgcn_s_sleep(8);
+    e[1] = L; e[2] = n12; e[3] = lut;
+    e[0] = site;  // (LDS operations of one wave execute in order: the entry is whole when its site number appears)
+}
 
 // four candidates, one per group of 16 lanes: positions first .. first + n - 1 of queue q
 __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t *q, uint32_t first,
@@ -215,7 +290,7 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     const int grp = lane >> 4, gl = lane & 15;
     uint32_t *scratch = v.grp + grp * BV_G16_GRP_WORDS;
     bool variant = false;
-    uint32_t site = 0;
+    uint32_t site = 0, pL = 0, pn12 = 0, plut = 0;
     if ((uint32_t)grp < n) {
         site = bv_f_take(q, first + (uint32_t)grp);
         const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
@@ -246,10 +321,21 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
         S.rev[0] = s1.x; S.rev[1] = s1.y; S.rev[2] = s1.z; S.rev[3] = s1.w;
         S.q0_mask = 0; S.nb = nb; S.badq = badq;
         bv_site_tail_g16(v.sa, site, S, src, nb, scratch, lane, &pre);
+        if (variant && v.fuse2) {
+            const uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+            int ref = v.sa.ref_base[site];
+            if (ref > 4) ref = 4;
+            bv_f_p2_facts(ref, depth, pre.aw0, pre.aw1, pL, pn12, plut);
+        }
     }
     const unsigned long long vm = __ballot(variant && gl == 0);
     if (variant && gl == 0) v.vl[v.n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
     v.n_vl += (uint32_t)__popcll(vm);
+    if (v.fuse2 && vm != 0ull) {
+        // the records are complete (the rank sums' waves add to them: BV_SITE_RANKSUM is OR-ed into the status stored above)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (variant && gl == 0) bv_f_push_variant(sh, site, pL, pn12, plut);
+    }
     if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
 }
 // one candidate that needs the wave solver (shallow site: ordered replay; phred-0 calls; more than 128 bins; min_af <= 0)
@@ -292,84 +378,95 @@ __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedSha
     BvHqMerged H{hq};
     if (bv_site_solve<false, BvHqMerged, true>(v.sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
         if (lane == 0) v.vl[v.n_vl] = site;
-        if (++v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
+        ++v.n_vl;
+        if (v.fuse2) {
+            // the facts from the record as stored (read back through the L2: its stores are complete behind the wait)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            uint4 r0, r1, r2;
+            bv_load3_l2(&a.out[site], r0, r1, r2);  // depth[4]; total, status, cvg_sb[0..1]; cvg_sb[2..3], cvg_fs
+            const uint32_t *rw = reinterpret_cast<const uint32_t *>(&a.out[site].n_alt);
+            const uint32_t aw0 = __builtin_nontemporal_load(rw), aw1 = __builtin_nontemporal_load(rw + 1);
+            const uint32_t depth[4] = {r0.x, r0.y, r0.z, r0.w};
+            int ref = v.sa.ref_base[site];
+            if (ref > 4) ref = 4;
+            uint32_t pL, pn12, plut;
+            bv_f_p2_facts(ref, depth, aw0, aw1, pL, pn12, plut);
+            if (lane == 0) bv_f_push_variant(sh, site, pL, pn12, plut);
+        }
+        if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
     }
     bv_lrt_sync<0>();
 }
 
-// The solver loop of one wave: candidates with three or four active bases first (the longest jobs), then the others, then
-// (waves with the big scratch) the wave-solver candidates, then blocks of 64 non-candidate sites that every streaming wave
-// has passed.  Ends when the streaming waves are done and nothing is left.
-__device__ __forceinline__ void bv_f_solver_loop(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t B1,
-                                                 int lane) {
+// One unit of solver work, in this order: a job of candidates with three or four active bases (the longest jobs), a job of
+// the others, (waves with the big scratch, once every streaming wave is past its last pass-1 row) a wave-solver candidate,
+// a block of 64 non-candidate sites that every streaming wave has passed.  Returns 1: did something; 0: nothing to do right
+// now; 2: nothing left to do, ever (no streaming wave will publish another pass-1 row, queues and blocks are empty -- jobs of
+// other waves may still be running).
+__device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t B1,
+                                                     int lane) {
     const uint32_t n_blocks = (B1 - B0 + 63u) >> 6;
-#pragma unroll 1
-    for (;;) {
-        uint32_t first, n;
-        // (read before everything else: once every streaming wave is done, every block is ready and no queue grows any more)
-        const uint32_t n_done = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]);
-        // While rows are still streaming only FULL jobs are taken (four sites): a wave that runs off with the one candidate
-        // that has just arrived spends a whole job on it, and the queue behind it grows -- the solver waves have ~60 % of the
-        // streaming time's worth of work when every job is full.
-        const uint32_t least = n_done == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
-        {
-            uint32_t *q = sh.q3;
-            n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, least, 4u, first, lane);
-            if (n == 0u) { q = sh.q2; n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, least, 4u, first, lane); }
-            if (n != 0u) { bv_f_job16(a, sh, v, q, first, n, lane); continue; }   // (ONE call site: the solver is ~50 KB of code)
-        }
-        if (v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
+    uint32_t first, n;
+    // (read before everything else: once every streaming wave is done, every block is ready and no candidate queue grows any more)
+    const uint32_t n_done = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]);
+    // While rows are still streaming only FULL jobs are taken (four sites): a wave that runs off with the one candidate
+    // that has just arrived spends a whole job on it, and the queue behind it grows -- the solver waves have ~60 % of the
+    // streaming time's worth of work when every job is full.
+    const uint32_t least = n_done == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
+    {
+        // a job in flight is counted BEFORE its entries leave the queue (a wave that finds the queues empty and no job
+        // counted knows that no variant site is still to come)
+        if (lane == 0) atomicAdd(&sh.ctl[BV_FC_BUSY], 1u);
+        uint32_t *q = sh.q3;
+        n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, least, 4u, first, lane);
+        if (n == 0u) { q = sh.q2; n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, least, 4u, first, lane); }
+        if (n != 0u) bv_f_job16(a, sh, v, q, first, n, lane);   // (ONE call site: the solver is ~50 KB of code)
+        if (n == 0u && v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
             (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, 1u, first, lane)) != 0u) {
             // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
             const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[B0 + first]));
             bv_f_job_hard(a, sh, v, site, lane);
-            continue;
         }
-        {
-            const uint32_t bh = bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]);
-            if (bh < n_blocks) {
-                uint32_t ready = n_blocks;
-                if (n_done < (uint32_t)BV_F_NS) {
-                    uint32_t m = 0xFFFFFFFFu;
+        if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
+        if (n != 0u) return 1;
+    }
+    {
+        const uint32_t bh = bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]);
+        if (bh < n_blocks) {
+            uint32_t ready = n_blocks;
+            if (n_done < (uint32_t)BV_F_NS) {
+                uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int w = 0; w < BV_F_NS; ++w) {
-                        const uint32_t p = bv_f_lds_read_u(&sh.pub[w]);
-                        m = p < m ? p : m;
-                    }
-                    ready = m >= B1 ? n_blocks : ((m - B0) >> 6);
+                for (int w = 0; w < BV_F_NS; ++w) {
+                    const uint32_t p = bv_f_lds_read_u(&sh.pub[w]);
+                    m = p < m ? p : m;
                 }
-                if (bh < ready) {
-                    uint32_t old = 0;
-                    if (lane == 0) old = atomicCAS(&sh.ctl[BV_FC_BLK_HEAD], bh, bh + 1u);
-                    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-                    if (old == bh) {
-                        const uint32_t site = B0 + bh * 64u + (uint32_t)lane;
-                        if (site < B1) bv_p1s_simple_site<true>(a, v.sa.lnfact, site);
-                    }
-                    continue;
+                ready = m >= B1 ? n_blocks : ((m - B0) >> 6);
+            }
+            if (bh < ready) {
+                uint32_t old = 0;
+                if (lane == 0) old = atomicCAS(&sh.ctl[BV_FC_BLK_HEAD], bh, bh + 1u);
+                old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+                if (old == bh) {
+                    const uint32_t site = B0 + bh * 64u + (uint32_t)lane;
+                    if (site < B1) bv_p1s_simple_site<true>(a, v.sa.lnfact, site);
                 }
+                return 1;
             }
         }
-        if (n_done == (uint32_t)BV_F_NS) {
-            // nothing was claimable a moment ago and no producer is left: done, unless a queue got its last entries in between
-            const bool q_left = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) ||
-                                bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) ||
-                                (v.big != nullptr && bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD])) ||
-                                bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks;
-            if (!q_left) break;
-            continue;
-        }
-        __builtin_amdgcn_s_sleep(8);
     }
-    if (v.n_vl) bv_f_flush_vl(a, v, lane);
+    if (n_done == (uint32_t)BV_F_NS) {
+        // nothing was claimable a moment ago and no producer is left: done, unless a queue got its last entries in between
+        const bool q_left = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) ||
+                            bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) ||
+                            (v.big != nullptr && bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD])) ||
+                            bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks;
+        if (!q_left && v.n_vl) bv_f_flush_vl(a, v, lane);
+        return q_left ? 1 : 2;
+    }
+    return 0;
 }
-
 // ------------------------------------------------------------------------------ the streaming side
-// publish a row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic, one
-// LDS write (the slot is free once its last consumer has handed it back empty).  Candidates of the wave solver: a place in the
-// workgroup's slice of cand_list in HBM (unbounded: they are taken up only when every streaming wave is done, see
-// bv_f_solver_loop, so no streaming wave ever waits on them); that store is one more in the vmcnt queue than the slot waits
-// allow for -- a conservative wait, never a wrong one.
 typedef volatile __attribute__((address_space(3))) uint32_t bv_lds_vu32;
 __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, int lane) {
     const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)tail, 1u);
@@ -378,6 +475,11 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
     while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*e) != BV_F_EMPTY) __builtin_amdgcn_s_sleep(8);
     if (lane == 0) *e = site;
 }
+// publish a pass-1 row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic,
+// one LDS write (the slot is free once its last consumer has handed it back empty).  Candidates of the wave solver: a place in
+// the workgroup's slice of cand_list in HBM (unbounded: they are taken up only when every streaming wave is past its last
+// pass-1 row, see bv_f_solver_step, so no streaming wave ever waits on them); that store is one more in the vmcnt queue than
+// the slot waits allow for -- a conservative wait, never a wrong one.
 __device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, uint32_t site, uint32_t kind, int lane) {
     if (kind < 2u) return;
     if (kind == 4u) {
@@ -389,117 +491,278 @@ __device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShar
         bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, lane);
     }
 }
+// pass-2 results of up to 64 rows of one wave, one row per lane: the two rank sums as exact integers, turned into phred values
+// (erfc, log10: scalar work per site) and stored for all of them at once
+struct BvFusedStash {
+    uint32_t site, n12;
+    unsigned long long tw_m, tw_r;
+    uint32_t n;  // rows held (wave-uniform)
+};
+__device__ __forceinline__ void bv_f_stash_flush(const BvP1ShortArgs &a, BvFusedStash &t, int lane) {
+    if ((uint32_t)lane < t.n) {
+        const unsigned long long n1 = t.n12 & 0xFFFFu, n2 = t.n12 >> 16;
+        const double ph_m = bv_ranksum_phred(t.tw_m, n1, n2), ph_r = bv_ranksum_phred(t.tw_r, n1, n2);
+        a.out[t.site].mq_ranksum = ph_m;
+        a.out[t.site].rpr_ranksum = ph_r;
+        atomicOr(&a.out[t.site].status, BV_SITE_RANKSUM);
+    }
+    t.n = 0;
+}
 
-__device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFusedShared &sh, const int wave, const int lane,
-                                                 const uint32_t B0, const uint32_t B1) {
+// Streams rows until none is in flight and none can be drawn right now.  `st_io`: the wave's flags that outlive a call (cursor
+// exhausted / last pass-1 row published / no row will ever come again).  On return the ring is idle (it can serve as solver
+// scratch), no pass-1 row of this wave is unpublished and the pass-2 results of its rows are stored.
+//
+// NOT inlined.  Inlined into the kernel's loop beside the solver (which wants all of its 168 registers), the allocator parked
+// this loop's lane constants in scratch memory: a scratch load behind an s_waitcnt vmcnt(0) -- a drained ring -- per row.  As a
+// function of its own it has a register allocation of its own.  What it needs arrives so that everything stays what it is in
+// a kernel: the argument block is read from the kernel's own kernarg segment (scalar loads, wave-uniform by construction; its
+// pointers are marked as device memory), the LDS block comes as an LDS ADDRESS and is turned back into a pointer here (a generic
+// pointer handed across a call would make every access a flat one), the lane number is formed here.
+#define BV_F_GLOBAL(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
+template <bool FUSE2>
+__device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
+                                                                     uint32_t B1_, uint32_t st_in_) {
+    const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
+    const int wave = __builtin_amdgcn_readfirstlane((int)wave_);
+    const uint32_t B0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B0_), B1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B1_);
+    uint32_t st_io = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_in_);
+    BvFusedShared &sh = *(BvFusedShared *)(__attribute__((address_space(3))) BvFusedShared *)(uintptr_t)sh_lds;
+    BvP1ShortArgs a;
+    {
+        // (the kernel hands its kernarg segment pointer over: the intrinsic itself read null in this function)
+        const uint64_t kp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ka_hi_) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ka_lo_);
+        const __attribute__((address_space(4))) BvP1ShortArgs *ka = (const __attribute__((address_space(4))) BvP1ShortArgs *)(uintptr_t)kp;
+        a.bs = BV_F_GLOBAL(const uint8_t, ka->bs); a.q = BV_F_GLOBAL(const uint8_t, ka->q); a.ref_base = BV_F_GLOBAL(const uint8_t, ka->ref_base);
+        a.pitch = ka->pitch; a.n_sites = ka->n_sites; a.n_samples = ka->n_samples; a.flags = ka->flags; a.n_cu = ka->n_cu;
+        a.min_af = ka->min_af; a.tables = BV_F_GLOBAL(const BvTables, ka->tables); a.out = BV_F_GLOBAL(bv_site_result, ka->out);
+        a.var_list = BV_F_GLOBAL(uint32_t, ka->var_list); a.counters = BV_F_GLOBAL(uint32_t, ka->counters);
+        a.summ = BV_F_GLOBAL(BvSiteSummary, ka->summ); a.bins = BV_F_GLOBAL(uint32_t, ka->bins);
+        a.cand_list = BV_F_GLOBAL(uint32_t, ka->cand_list); a.easy_list = BV_F_GLOBAL(uint32_t, ka->easy_list);
+        a.easy3_list = BV_F_GLOBAL(uint32_t, ka->easy3_list); a.ch = nullptr;
+        a.mapq = BV_F_GLOBAL(const uint8_t, ka->mapq); a.rpr = BV_F_GLOBAL(const uint16_t, ka->rpr);
+#ifdef BV_TL_DEBUG
+        a.tl = nullptr;
+#endif
+    }
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     uint32_t *hist = sh.hist[wave];
     uint32_t *stage = sh.stage[wave];
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(bv_lds_u32 *)sh.ring[wave].slot[0]);
     const uint32_t *ring = sh.ring[wave].slot[0];
     const uint32_t cursor_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_CURSOR];
-    // ---- the geometry of a row (the same for every row)
-    const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 127u) >> 7;  // 16-byte chunks; slots of 128 chunks
+    const uint32_t qvhead_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QV_HEAD];
+    // ---- the geometry of a row (the same for every row of a kind)
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4;  // 16-byte chunks of a plane's row
     const int tail = (int)(a.n_samples & 15u);
-    const uint32_t last_valid = n_chunks - (n_slots - 1u) * 128u;  // chunks of a row's last slot that lie inside the row: 1 .. 128
+    // pass-1 rows: slots of 128 chunks (2 KiB of calls + 2 KiB of phreds)
+    const uint32_t n_slots1 = (n_chunks + 127u) >> 7;
+    const uint32_t last1 = n_chunks - (n_slots1 - 1u) * 128u;  // chunks of a row's last slot that lie inside the row: 1 .. 128
     const uint32_t va = (uint32_t)lane * 16u, vb = va + 1024u;
-    const uint32_t vbl = last_valid > 64u ? vb : va;
-    const unsigned long long mA = last_valid >= 64u ? ~0ull : ((1ull << last_valid) - 1ull);
-    const unsigned long long mB = last_valid > 64u ? (last_valid >= 128u ? ~0ull : ((1ull << (last_valid - 64u)) - 1ull)) : 1ull;
+    const uint32_t vbl = last1 > 64u ? vb : va;
+    const unsigned long long mA1 = last1 >= 64u ? ~0ull : ((1ull << last1) - 1ull);
+    const unsigned long long mB1 = last1 > 64u ? (last1 >= 128u ? ~0ull : ((1ull << (last1 - 64u)) - 1ull)) : 1ull;
+    // pass-2 rows: slots of 64 chunks (1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks: 32 bytes per lane in two pieces)
+    const uint32_t n_slots2 = (n_chunks + 63u) >> 6;
+    const uint32_t last2 = n_chunks - (n_slots2 - 1u) * 64u;   // 1 .. 64
+    const uint32_t vr0 = (uint32_t)lane * 32u, vr1 = vr0 + 16u;
+    const unsigned long long mA2 = last2 >= 64u ? ~0ull : ((1ull << last2) - 1ull);
     // the last slot's cells past the row's end are forced to 'N': per lane and dword, the mask of the bytes that stay
-    uint32_t keepA[4], keepB[4];
+    uint32_t keepA[4], keepB[4], keep2[4];
     {
         const uint32_t cA = (uint32_t)lane, cB = 64u + (uint32_t)lane;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int partial = tail ? tail - 4 * d : 4;
-            keepA[d] = cA >= last_valid ? 0u : ((cA == last_valid - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
-            keepB[d] = cB >= last_valid ? 0u : ((cB == last_valid - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
+            keepA[d] = cA >= last1 ? 0u : ((cA == last1 - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
+            keepB[d] = cB >= last1 ? 0u : ((cB == last1 - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
+            keep2[d] = cA >= last2 ? 0u : ((cA == last2 - 1u) ? bv_f_keep_mask(partial) : 0xFFFFFFFFu);
         }
     }
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
 
     // ---- prefetch side: the next slot to request
-    const uint8_t *pb = a.bs, *pq = a.q;
-    uint32_t p_left = 0;               // slots of the prefetch row still to request
+    const uint8_t *p0 = a.bs, *p1 = a.q, *p2 = a.q;  // pass 1: calls, phreds; pass 2: calls, mapq, ranks
+    uint32_t p_left = 0, p_kind = 0;    // slots of the prefetch row still to request; its kind
     uint32_t ring_w = 0, ring_r = 0, inflight = 0;
-    // rows drawn: the one being tallied and the one after it (the prefetch runs at most one row ahead: n_slots >= BV_F_K)
-    uint32_t c_site = 0, c_ref = 0, n_site = 0, n_ref = 0;
-    uint32_t st = 0;
-    constexpr uint32_t P_DONE = 1u, C_HAVE = 2u, N_HAVE = 4u;
+    // rows drawn: the one being tallied and the one after it (the prefetch runs at most one row ahead: every row has >= BV_F_K slots)
+    // x / y: pass 1: reference base / -; pass 2: class table / n_ref | n_alt << 16; z: pass 2: the sweeps' 2-bit table
+    uint32_t c_site = 0, c_kind = 0, c_x = 0, c_y = 0, c_z = 0, n_site = 0, n_kind = 0, n_x = 0, n_y = 0, n_z = 0;
+    uint32_t st = st_io;
+    constexpr uint32_t P_DONE = BV_FS_P_DONE, C_HAVE = 2u, N_HAVE = 4u, CUR_DONE = BV_FS_CUR_DONE, P1_FIN = BV_FS_P1_FIN;
     auto issue = [&]() __attribute__((always_inline)) {
         if (p_left == 0u) {
             if (st & P_DONE) return;
-            const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, 1u);
-            if (c >= B1 - B0) { st |= P_DONE; return; }
-            const uint32_t s = B0 + c;
-            const uint32_t r = bv_f_ref_scalar(a.ref_base, s);
+            uint32_t s = 0, kind = 0, x = 0, y = 0, z = 0;
+            // the next row: a pass-1 row while the cursor has any -- unless the variant queue is filling up (the solvers wait
+            // on a full one) --, else a variant site's pass-2 row
+            bool p2_first = false;
+            if (FUSE2 && !(st & CUR_DONE))
+                p2_first = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) >= BV_F_QV_HIGH;
+            if (!(st & CUR_DONE) && !p2_first) {
+                const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, 1u);
+                if (c >= B1 - B0) st |= CUR_DONE;
+                else { s = B0 + c; kind = BV_FK_P1; x = bv_f_ref_scalar(a.ref_base, s); }
+            }
+            if (FUSE2 && kind == 0u) {
+                const uint32_t h = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]);
+                if (h != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) && bv_f_lds_cas_wave(qvhead_lds, h, h + 1u) == h) {
+                    const uint32_t *e = sh.qv[h & (BV_F_QVCAP - 1u)];
+                    while ((s = bv_f_lds_read_u(&e[0])) == BV_F_EMPTY) __builtin_amdgcn_s_sleep(1);
+                    x = bv_f_lds_read_u(&e[1]); y = bv_f_lds_read_u(&e[2]); z = bv_f_lds_read_u(&e[3]);
+                    if (lane == 0) *(bv_lds_vu32 *)&e[0] = BV_F_EMPTY;
+                    kind = BV_FK_P2;
+                }
+            }
+            if (kind == 0u) {
+                // no row right now.  None ever again: the cursor is exhausted, every streaming wave has published its last
+                // pass-1 row, no candidate waits, no solver job runs (each is counted before its entries leave their
+                // queue, until its variant sites are in theirs), and the variant queue is empty.
+                if ((st & CUR_DONE) &&
+                    (!FUSE2 || (bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS && bv_f_lds_read_u(&sh.ctl[BV_FC_BUSY]) == 0u &&
+                                bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) &&
+                                bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) &&
+                                bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD]) &&
+                                bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]))))
+                    st |= P_DONE;
+                return;
+            }
             const uint64_t off = (uint64_t)s * a.pitch;
-            pb = bv_uniform_ptr(a.bs + off); pq = bv_uniform_ptr(a.q + off);
-            p_left = n_slots;
-            if (!(st & C_HAVE)) { c_site = s; c_ref = r; st |= C_HAVE; }
-            else { n_site = s; n_ref = r; st |= N_HAVE; }
+            p0 = bv_uniform_ptr(a.bs + off);
+            if (kind == BV_FK_P1) { p1 = bv_uniform_ptr(a.q + off); p_left = n_slots1; }
+            else { p1 = bv_uniform_ptr(a.mapq + off); p2 = bv_uniform_ptr(reinterpret_cast<const uint8_t *>(a.rpr) + 2u * off); p_left = n_slots2; }
+            p_kind = kind;
+            if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; st |= C_HAVE; }
+            else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; st |= N_HAVE; }
         }
         const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
-        if (p_left > 1u) {
-            bv_f_glds_full(d0, pb, pq, va, vb);
-            pb += 2048; pq += 2048;
+        if (!FUSE2 || p_kind == BV_FK_P1) {
+            if (p_left > 1u) { bv_f_glds4(d0, p0, va, p0, vb, p1, va, p1, vb); p0 += 2048; p1 += 2048; }
+            else bv_f_glds4_masked(d0, p0, va, p0, vbl, p1, va, p1, vbl, mA1, mB1);
         } else {
-            bv_f_glds_last(d0, pb, pq, va, vbl, mA, mB);  // (the next row comes from a draw)
+            if (p_left > 1u) { bv_f_glds4(d0, p0, va, p1, va, p2, vr0, p2, vr1); p0 += 1024; p1 += 1024; p2 += 2048; }
+            else bv_f_glds4_masked(d0, p0, va, p1, va, p2, vr0, p2, vr1, mA2, mA2);
         }
         --p_left;
         ring_w = (ring_w + 1u == (uint32_t)BV_F_K) ? 0u : ring_w + 1u;
         ++inflight;
     };
-#pragma unroll 1
-    for (int k = 0; k < BV_F_K; ++k) issue();
 
-    // the previous row of this wave: published once its stores are known to be complete
+    // the previous pass-1 row of this wave: published once its stores are known to be complete
     uint32_t prev_site = 0, prev_kind = 0;  // kind 0: none; 1: not a candidate; 2 / 3: queue q2 / q3; 4: wave solver
     uint32_t wsel = 0;                      // stores of the previous row still to be allowed for in the slot waits: 0 none / unknown, 1, 3
+    BvFusedStash stash;
+    stash.site = 0; stash.n12 = 0; stash.tw_m = 0; stash.tw_r = 0; stash.n = 0;
+    // the end of this wave's pass-1 rows: its last one published, the wave counted in NDONE
+    auto finish_p1 = [&]() __attribute__((always_inline)) {
+        if (prev_kind != 0u) {
+            if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+            if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its cand_list entry; rare)
+            prev_kind = 0;
+        }
+        if (lane == 0) {
+            sh.pub[wave] = 0xFFFFFFFFu;
+#ifdef BV_TEAM_DEBUG  /* per workgroup: first / last streaming wave past its pass-1 rows, and what was left to solve then */
+            const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+            uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u;
+            if (atomicAdd(&sh.ctl[BV_FC_NDONE], 1u) == 0u) dbg_[1] = now;
+            else if (sh.ctl[BV_FC_NDONE] == (uint32_t)BV_F_NS) {
+                dbg_[2] = now;
+                dbg_[4] = sh.ctl[BV_FC_Q3_TAIL] - sh.ctl[BV_FC_Q3_HEAD];
+                dbg_[5] = sh.ctl[BV_FC_Q2_TAIL] - sh.ctl[BV_FC_Q2_HEAD];
+                dbg_[6] = FUSE2 ? sh.ctl[BV_FC_QV_TAIL] - sh.ctl[BV_FC_QV_HEAD] : ((B1 - B0 + 63u) >> 6) - sh.ctl[BV_FC_BLK_HEAD];
+            }
+#else
+            atomicAdd(&sh.ctl[BV_FC_NDONE], 1u);
+#endif
+        }
+        st |= P1_FIN;
+    };
+
+#pragma unroll 1
+    for (int k = 0; k < BV_F_K; ++k) issue();
 #pragma unroll 1
     while (st & C_HAVE) {
         const uint32_t site = c_site;
+        const bool is_p1 = !FUSE2 || c_kind == BV_FK_P1;
+        const uint32_t n_slots = is_p1 ? n_slots1 : n_slots2;
+        uint32_t hi_acc = 0;
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
             // The oldest slot in flight has landed once at most 8 younger loads are outstanding -- plus, for the three waits
-            // that follow a row's epilogue, that row's S stores, which are younger than the slot waited for (vmcnt counts in
-            // issue order).  Unknown S, or fewer than K slots in flight: the conservative wait.
+            // that follow a pass-1 row's epilogue, that row's S stores, which are younger than the slot waited for (vmcnt
+            // counts in issue order).  Unknown S, or fewer than K slots in flight: the conservative wait.
             if (inflight != (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (j >= 3u || wsel == 0u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (wsel == 1u) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
             const uint32_t *rs = ring + ring_r * BV_F_SLOT_WORDS + lane * 4;
-            bv_u32x4 vbA = *reinterpret_cast<const bv_u32x4 *>(rs);
-            bv_u32x4 vbB = *reinterpret_cast<const bv_u32x4 *>(rs + 256);
-            bv_u32x4 vqA = *reinterpret_cast<const bv_u32x4 *>(rs + 512);
-            bv_u32x4 vqB = *reinterpret_cast<const bv_u32x4 *>(rs + 768);
+            bv_u32x4 w0 = *reinterpret_cast<const bv_u32x4 *>(rs);
+            bv_u32x4 w1 = *reinterpret_cast<const bv_u32x4 *>(rs + 256);
+            bv_u32x4 w2 = *reinterpret_cast<const bv_u32x4 *>(rs + 512);
+            bv_u32x4 w3 = *reinterpret_cast<const bv_u32x4 *>(rs + 768);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers: the slot may be refilled
             ring_r = (ring_r + 1u == (uint32_t)BV_F_K) ? 0u : ring_r + 1u;
             --inflight;
             issue();
-            if (j + 1u == n_slots) {
-                const uint32_t N4 = 0x08080808u;
-                vbA.x = (vbA.x & keepA[0]) | (N4 & ~keepA[0]); vbA.y = (vbA.y & keepA[1]) | (N4 & ~keepA[1]);
-                vbA.z = (vbA.z & keepA[2]) | (N4 & ~keepA[2]); vbA.w = (vbA.w & keepA[3]) | (N4 & ~keepA[3]);
-                vbB.x = (vbB.x & keepB[0]) | (N4 & ~keepB[0]); vbB.y = (vbB.y & keepB[1]) | (N4 & ~keepB[1]);
-                vbB.z = (vbB.z & keepB[2]) | (N4 & ~keepB[2]); vbB.w = (vbB.w & keepB[3]) | (N4 & ~keepB[3]);
-                // (stale phred bytes of lanes that loaded nothing must not look like invalid input)
-                vqA.x &= keepA[0]; vqA.y &= keepA[1]; vqA.z &= keepA[2]; vqA.w &= keepA[3];
-                vqB.x &= keepB[0]; vqB.y &= keepB[1]; vqB.z &= keepB[2]; vqB.w &= keepB[3];
+            const uint32_t N4 = 0x08080808u;
+            if (is_p1) {
+                // w0 / w1: calls of the slot's first / second KiB; w2 / w3: their phreds
+                if (j + 1u == n_slots) {
+                    w0.x = (w0.x & keepA[0]) | (N4 & ~keepA[0]); w0.y = (w0.y & keepA[1]) | (N4 & ~keepA[1]);
+                    w0.z = (w0.z & keepA[2]) | (N4 & ~keepA[2]); w0.w = (w0.w & keepA[3]) | (N4 & ~keepA[3]);
+                    w1.x = (w1.x & keepB[0]) | (N4 & ~keepB[0]); w1.y = (w1.y & keepB[1]) | (N4 & ~keepB[1]);
+                    w1.z = (w1.z & keepB[2]) | (N4 & ~keepB[2]); w1.w = (w1.w & keepB[3]) | (N4 & ~keepB[3]);
+                    // (stale phred bytes of lanes that loaded nothing must not look like invalid input)
+                    w2.x &= keepA[0]; w2.y &= keepA[1]; w2.z &= keepA[2]; w2.w &= keepA[3];
+                    w3.x &= keepB[0]; w3.y &= keepB[1]; w3.z &= keepB[2]; w3.w &= keepB[3];
+                }
+                bv_f_tally2(w0, w2, w1, w3, hist, one);
+            } else {
+                // w0: calls; w1: mapq; w2 / w3: ranks 0-7 / 8-15 of the lane's 16 cells.  The tally of bv_pass2_dma_kernel
+                // (bv_pass2.hip): class bytes by one v_perm per dword, class << 8 | value by one v_perm per cell, "< 0x200"
+                // the whole predicate.
+                if (j + 1u == n_slots) {
+                    w0.x = (w0.x & keep2[0]) | (N4 & ~keep2[0]); w0.y = (w0.y & keep2[1]) | (N4 & ~keep2[1]);
+                    w0.z = (w0.z & keep2[2]) | (N4 & ~keep2[2]); w0.w = (w0.w & keep2[3]) | (N4 & ~keep2[3]);
+                    if ((uint32_t)lane >= last2) { w2 = bv_u32x4{0u, 0u, 0u, 0u}; w3 = w2; }  // (not loaded: stale bytes)
+                }
+                const uint32_t L = c_x;
+                const uint32_t c0 = __builtin_amdgcn_perm(L, L, w0.x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, w0.y) ^ 0x80808080u;
+                const uint32_t c2 = __builtin_amdgcn_perm(L, L, w0.z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, w0.w) ^ 0x80808080u;
+                // ranks that do not fit the 256-rank window: remembered, the row is then re-done by the window sweeps
+                hi_acc |= (w2.x | w2.y | w2.z | w2.w | w3.x | w3.y | w3.z | w3.w) & 0xFF00FF00u;
+                uint32_t x[16];
+                x[0] = bv_p2d_xm<0>(c0, w1.x); x[1] = bv_p2d_xm<1>(c0, w1.x); x[2] = bv_p2d_xm<2>(c0, w1.x); x[3] = bv_p2d_xm<3>(c0, w1.x);
+                x[4] = bv_p2d_xm<0>(c1, w1.y); x[5] = bv_p2d_xm<1>(c1, w1.y); x[6] = bv_p2d_xm<2>(c1, w1.y); x[7] = bv_p2d_xm<3>(c1, w1.y);
+                x[8] = bv_p2d_xm<0>(c2, w1.z); x[9] = bv_p2d_xm<1>(c2, w1.z); x[10] = bv_p2d_xm<2>(c2, w1.z); x[11] = bv_p2d_xm<3>(c2, w1.z);
+                x[12] = bv_p2d_xm<0>(c3, w1.w); x[13] = bv_p2d_xm<1>(c3, w1.w); x[14] = bv_p2d_xm<2>(c3, w1.w); x[15] = bv_p2d_xm<3>(c3, w1.w);
+                bv_lds_add16<2>(x, hist, one, 0x200u);
+                x[0] = bv_p2d_xr<0, 0>(c0, w2.x); x[1] = bv_p2d_xr<1, 1>(c0, w2.x); x[2] = bv_p2d_xr<2, 0>(c0, w2.y); x[3] = bv_p2d_xr<3, 1>(c0, w2.y);
+                x[4] = bv_p2d_xr<0, 0>(c1, w2.z); x[5] = bv_p2d_xr<1, 1>(c1, w2.z); x[6] = bv_p2d_xr<2, 0>(c1, w2.w); x[7] = bv_p2d_xr<3, 1>(c1, w2.w);
+                x[8] = bv_p2d_xr<0, 0>(c2, w3.x); x[9] = bv_p2d_xr<1, 1>(c2, w3.x); x[10] = bv_p2d_xr<2, 0>(c2, w3.y); x[11] = bv_p2d_xr<3, 1>(c2, w3.y);
+                x[12] = bv_p2d_xr<0, 0>(c3, w3.z); x[13] = bv_p2d_xr<1, 1>(c3, w3.z); x[14] = bv_p2d_xr<2, 0>(c3, w3.w); x[15] = bv_p2d_xr<3, 1>(c3, w3.w);
+                bv_lds_add16<2>(x, hist + 512, one, 0x200u);
             }
-            bv_f_tally2(vbA, vqA, vbB, vqB, hist, one);
         }
         bv_lrt_sync<0>();
 
-        // ---- the previous row's stores are older than the (at most) K slots in flight: wait for exactly them, publish it
+        // ---- the previous pass-1 row's stores are older than the (at most) K slots in flight: wait for exactly them, publish it
         if (prev_kind != 0u) {
             if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
-            if (lane == 0) sh.pub[wave] = site;  // every row of this wave below the current one is out
+            prev_kind = 0;
+            // every pass-1 row of this wave below its next one is out: the row of this epilogue, or the one already drawn, or
+            // -- none drawn -- whatever the cursor hands out next (the end of the pass-1 rows sets the mark to "all")
+            uint32_t mark = is_p1 ? site : (((st & N_HAVE) && n_kind == BV_FK_P1) ? n_site : B0 + bv_f_lds_read_u(&sh.ctl[BV_FC_CURSOR]));
+            if (lane == 0 && !(st & P1_FIN)) sh.pub[wave] = mark;
         }
 
+        if (is_p1) {
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
         bool bad = false;
@@ -548,7 +811,7 @@ __device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFused
             const bool act = (double)bv_sel4u(depth, bsel) / (int)total >= a.min_af;  // basetype.cpp:137, one base per lane
             const uint32_t act_mask = (uint32_t)(__ballot(act) & 0xFull);
             n_active = (uint32_t)__popc(act_mask);
-            int ref = (int)c_ref;
+            int ref = (int)c_x;
             if (ref > 4) ref = 4;
             const bool one_ref = act_mask != 0u && (act_mask & (act_mask - 1u)) == 0u && ref < 4 && act_mask == (1u << ref);
             is_cand = !one_ref || (q0_mask & act_mask) != 0u;
@@ -582,16 +845,19 @@ __device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFused
             kind = is_easy ? (n_active <= 2u ? 2u : 3u) : 4u;
             uint32_t *dst = a.bins + (size_t)site * BV_S_BIN_STRIDE;
             uint32_t pos0 = 0;
+            // (opaque to the optimiser: it would otherwise keep the eight bin codes of a lane as loop invariants -- in scratch
+            // memory, with a scratch load and an s_waitcnt vmcnt(0), a drained ring, per candidate row)
+            uint32_t lane16 = (uint32_t)lane << 16;
+            asm volatile("" : "+v"(lane16));
             if (is_easy) {
                 // through the LDS stage: two 64-lane stores whatever the number of bins (words past it are never read)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
 #pragma unroll
                     for (int qr = 0; qr < 2; ++qr) {
-                        const int q = (qr << 6) | lane;
                         const unsigned long long mm = m[b * 2 + qr];
                         const uint32_t pos = pos0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                        if (c[b][qr] != 0u) stage[pos] = ((((uint32_t)b << 7) | (uint32_t)q) << 16) | c[b][qr];
+                        if (c[b][qr] != 0u) stage[pos] = ((((uint32_t)b << 7) | ((uint32_t)qr << 6)) << 16) | lane16 | c[b][qr];
                         pos0 += (uint32_t)__popcll(mm);
                     }
                 }
@@ -605,10 +871,9 @@ __device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFused
                 for (int b = 0; b < 4; ++b) {
 #pragma unroll
                     for (int qr = 0; qr < 2; ++qr) {
-                        const int q = (qr << 6) | lane;
                         const unsigned long long mm = m[b * 2 + qr];
                         const uint32_t pos = pos0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
-                        if (c[b][qr] != 0u) dst[pos] = ((((uint32_t)b << 7) | (uint32_t)q) << 16) | c[b][qr];
+                        if (c[b][qr] != 0u) dst[pos] = ((((uint32_t)b << 7) | ((uint32_t)qr << 6)) << 16) | lane16 | c[b][qr];
                         pos0 += (uint32_t)__popcll(mm);
                     }
                 }
@@ -628,6 +893,33 @@ __device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFused
             w = (lane == 9) ? fl : w;
             if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
         }
+        prev_site = site;
+        prev_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+        wsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_stores);
+        } else {
+        // ---- a variant site's two rank sums (ref_vs_alt_ranksumtest on mapq and read-position rank, caller.cpp:1151-1154) from
+        // the [class][256] histograms, as exact integers; their phred values are formed for up to 64 rows at a time
+        wsel = 0u;
+        const unsigned long long n12 = (unsigned long long)(c_y & 0xFFFFu) + (unsigned long long)(c_y >> 16);
+        if (__ballot(hi_acc != 0u) != 0ull) {
+            // a rank >= 256 somewhere in the row (long reads): the row goes to the redo list, bv_pass2_dma_kernel's window sweeps
+            // take it after this kernel (a returning atomic: the ring drains -- rare)
+            if (lane == 0) a.easy_list[atomicAdd(&a.counters[BV_CTR_CANDS], 1u)] = site;
+        } else {
+            uint32_t *hm = hist, *hr = hist + 512;
+            unsigned long long below = 0, twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hm[w * 64 + lane], hm[256 + w * 64 + lane], n12, below, lane);
+            stash.tw_m = ((uint32_t)lane == stash.n) ? twoR : stash.tw_m;
+            below = 0; twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hr[w * 64 + lane], hr[256 + w * 64 + lane], n12, below, lane);
+            stash.tw_r = ((uint32_t)lane == stash.n) ? twoR : stash.tw_r;
+            stash.site = ((uint32_t)lane == stash.n) ? site : stash.site;
+            stash.n12 = ((uint32_t)lane == stash.n) ? c_y : stash.n12;
+            if (++stash.n == 64u) bv_f_stash_flush(a, stash, lane);
+        }
+        }
         // ---- hand the histogram back, zeroed
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
@@ -636,34 +928,27 @@ __device__ __forceinline__ void bv_f_stream_role(const BvP1ShortArgs &a, BvFused
             if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
         }
         bv_lrt_sync<0>();
-        prev_site = site;
-        prev_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
-        wsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_stores);
-        if (st & N_HAVE) { c_site = n_site; c_ref = n_ref; st &= ~N_HAVE; }
+        if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; st &= ~N_HAVE; }
         else st &= ~C_HAVE;
+        // the last pass-1 row of this wave is behind it: publish it, count the wave
+        if ((st & CUR_DONE) && !(st & P1_FIN) && !((st & C_HAVE) && c_kind == BV_FK_P1) && !((st & N_HAVE) && n_kind == BV_FK_P1)) finish_p1();
     }
-    // ---- this wave's last row, and the end of its streaming
+    // ---- no row in flight: the ring is idle
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (prev_kind != 0u) bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (a cand_list entry of the last row)
-    if (lane == 0) {
-        sh.pub[wave] = 0xFFFFFFFFu;
-#ifdef BV_TEAM_DEBUG  /* per workgroup: first / last streaming wave done, and what was left to solve then */
-        const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u;
-        if (atomicAdd(&sh.ctl[BV_FC_NDONE], 1u) == 0u) dbg_[1] = now;
-        else if (sh.ctl[BV_FC_NDONE] == (uint32_t)BV_F_NS) {
-            dbg_[2] = now;
-            dbg_[4] = sh.ctl[BV_FC_Q3_TAIL] - sh.ctl[BV_FC_Q3_HEAD];
-            dbg_[5] = sh.ctl[BV_FC_Q2_TAIL] - sh.ctl[BV_FC_Q2_HEAD];
-            dbg_[6] = ((B1 - B0 + 63u) >> 6) - sh.ctl[BV_FC_BLK_HEAD];
-        }
-#else
-        atomicAdd(&sh.ctl[BV_FC_NDONE], 1u);
-#endif
+    if (prev_kind != 0u) {  // (a pass-1 row whose successor was not drawn yet: the variant queue had priority and was emptied by another wave)
+        bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+        if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        prev_kind = 0;
+        if (lane == 0 && !(st & (P1_FIN | CUR_DONE))) sh.pub[wave] = B0 + bv_f_lds_read_u(&sh.ctl[BV_FC_CURSOR]);
     }
+    if ((st & CUR_DONE) && !(st & P1_FIN)) finish_p1();
+    if (FUSE2 && stash.n != 0u) bv_f_stash_flush(a, stash, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    (void)c_z;
+    return st & (P_DONE | CUR_DONE | P1_FIN);
 }
 
+template <bool FUSE2>
 __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1ShortArgs a) {
     __shared__ BvFusedShared sh;
 #ifdef BV_TL_DEBUG
@@ -680,6 +965,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
             if (i * BV_WAVE + lane < (BV_S_HWORDS + BV_S_OVF + 8) / 4) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
     }
     for (int i = tid; i < BV_F_QCAP; i += BV_WAVE * BV_F_NW) { sh.q3[i] = BV_F_EMPTY; sh.q2[i] = BV_F_EMPTY; }
+    for (int i = tid; i < BV_F_QVCAP; i += BV_WAVE * BV_F_NW) sh.qv[i][0] = BV_F_EMPTY;
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_F_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
@@ -696,16 +982,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #endif
     __syncthreads();
 
-    if (wave < BV_F_NS) {
-#ifdef BV_F_STREAM_PRIO
-        __builtin_amdgcn_s_setprio(BV_F_STREAM_PRIO);
-#endif
-        bv_f_stream_role(a, sh, wave, lane, B0, B1);
-#ifdef BV_F_STREAM_PRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    }
-
+    const bool is_stream = wave < BV_F_NS;
+    bool streaming = is_stream;
+    uint32_t sst = 0;
     BvFusedSolver v;
     v.sa.ref_base = a.ref_base; v.sa.out = a.out; v.sa.var_list = a.var_list; v.sa.counters = a.counters;
     v.sa.min_af = a.min_af; v.sa.flags = a.flags;
@@ -713,12 +992,41 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     v.sa.loghit = a.tables->loghit; v.sa.logmiss = a.tables->logmiss;
     v.sa.bs = a.bs; v.sa.q = a.q; v.sa.pitch = a.pitch; v.sa.n_samples = a.n_samples;
     v.n_vl = 0;
-    if (wave < BV_F_NS) {
+    v.fuse2 = FUSE2;
+    // this wave's solver scratch: a streaming wave's ring (while no row is in flight), a solver wave's own
+    if (is_stream) {
         v.grp = &sh.ring[wave].solve.ws.grp[0][0]; v.vl = sh.ring[wave].solve.vl; v.big = &sh.ring[wave].solve.ws;
     } else {
         v.grp = &sh.grp[wave - BV_F_NS][0][0]; v.vl = sh.vl[wave - BV_F_NS]; v.big = nullptr;
     }
-    bv_f_solver_loop(a, sh, v, B0, B1, lane);
+    const uint32_t sh_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) BvFusedShared *)&sh;
+    const uint64_t ka_ptr = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();  // the argument block `a`, as the streaming function reads it
+    // A streaming wave streams while it has rows; whenever none is in flight (waiting for a variant row, or finished) it does
+    // one unit of solver work with its ring as scratch.  ONE call site of the solver step for both kinds of waves (the solver
+    // is most of the kernel's code).
+#pragma unroll 1
+    for (;;) {
+        if (streaming) {
+#ifdef BV_F_STREAM_PRIO
+            __builtin_amdgcn_s_setprio(BV_F_STREAM_PRIO);
+#endif
+            sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
+#ifdef BV_F_STREAM_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+            if (sst & BV_FS_P_DONE) streaming = false;
+        }
+        __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
+        const int r = bv_f_solver_step(a, sh, v, B0, B1, lane);
+        __builtin_amdgcn_s_setprio(0);
+        if (streaming) {
+            if (r != 1) __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        if (r == 2) break;
+        if (r == 0) __builtin_amdgcn_s_sleep(8);
+    }
+    // (the solver step that reports "nothing left, ever" has flushed the wave's variant list)
 #ifdef BV_TEAM_DEBUG
     if (lane == 0) atomicMax(&a.counters[BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u + 3u], (uint32_t)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -741,5 +1049,7 @@ void bv_launch_p1s_fused(const BvP1ShortArgs &a, hipStream_t stream) {
     if (grid > need) grid = need > 0 ? need : 1;
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
     if (cap && grid > cap) grid = cap;
-    hipLaunchKernelGGL(bv_p1s_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_F_NW), 0, stream, a);
+    // with the rank planes (a.mapq, a.rpr): the variant sites' pass-2 rows are streamed by the same waves
+    if (a.mapq != nullptr && a.rpr != nullptr) hipLaunchKernelGGL(bv_p1s_fused_kernel<true>, dim3(grid), dim3(BV_WAVE * BV_F_NW), 0, stream, a);
+    else hipLaunchKernelGGL(bv_p1s_fused_kernel<false>, dim3(grid), dim3(BV_WAVE * BV_F_NW), 0, stream, a);
 }

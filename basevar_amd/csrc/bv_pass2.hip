@@ -134,19 +134,7 @@ __device__ __forceinline__ void bv_p2_sweep(BvP2Ctx &cx, const BvPass2Args &a, u
     }
 }
 
-// ---- the perm form of the rank-sum tally (see bv_pass2_dma_kernel for the derivation): class byte J << 8 | mapq byte J, and
-// rank_hi << 16 | class byte J << 8 | rank_lo (rank H of the dword r2); "< 0x200" is the whole predicate, the value the word
-// of a [class][256] histogram
-template <int J>
-__device__ __forceinline__ uint32_t bv_p2d_xm(uint32_t cls4, uint32_t mq4) {  // class byte J << 8 | mapq byte J
-    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
-    return __builtin_amdgcn_perm(cls4, mq4, SEL);
-}
-template <int J, int H>
-__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // rank_hi << 16 | class byte J << 8 | rank_lo (rank H of r2)
-    constexpr uint32_t SEL = 0x0C000000u | ((uint32_t)(2 * H + 1) << 16) | ((4u + J) << 8) | (uint32_t)(2 * H);
-    return __builtin_amdgcn_perm(cls4, r2, SEL);
-}
+// (bv_p2d_xm / bv_p2d_xr, the perm form of the rank-sum tally: bv_tally.h)
 
 // One sweep over the row in that form, by the whole workgroup into its shared mapq / rank histograms ([2][256] each; `hr` uses the
 // first 512 words of the 1024-rank window) and, with GROUPS, into the per-group (base, phred) histograms `hg`.  Returns this

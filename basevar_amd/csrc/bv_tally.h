@@ -135,3 +135,18 @@ __device__ __forceinline__ const uint8_t *bv_uniform_ptr(const uint8_t *p) {
     const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
+
+// ---- the perm form of the rank-sum tally (see bv_pass2_dma_kernel, bv_pass2.hip, for the derivation; also used by bv_pass1_fused.hip): class byte J << 8 | mapq byte J, and
+// rank_hi << 16 | class byte J << 8 | rank_lo (rank H of the dword r2); "< 0x200" is the whole predicate, the value the word
+// of a [class][256] histogram
+template <int J>
+__device__ __forceinline__ uint32_t bv_p2d_xm(uint32_t cls4, uint32_t mq4) {  // class byte J << 8 | mapq byte J
+    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)J;
+    return __builtin_amdgcn_perm(cls4, mq4, SEL);
+}
+template <int J, int H>
+__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // rank_hi << 16 | class byte J << 8 | rank_lo (rank H of r2)
+    constexpr uint32_t SEL = 0x0C000000u | ((uint32_t)(2 * H + 1) << 16) | ((4u + J) << 8) | (uint32_t)(2 * H);
+    return __builtin_amdgcn_perm(cls4, r2, SEL);
+}
+

@@ -8,7 +8,8 @@ for r in $(seq 1 $R); do
     unset BASEVAR_AMD_LIB; F=""
     case $v in
       base) ;;
-      old) F="--flags 36864" ;;
+      old) F="--flags 36864" ;;      # two-kernel pass 1, pass 2 a launch of its own (round 3)
+      p2sep) F="--flags 40960" ;;    # fused pass 1, pass 2 a launch of its own
       *) export BASEVAR_AMD_LIB=$PWD/basevar_amd/lib/libbasevar_amd_$v.so ;;
     esac
     timeout 120 python bench.py --no-cpu-baseline --samples 10000 --batch-sites 100000 $F $BENCH_EXTRA 2>> $O/err.log | python3 -c "
