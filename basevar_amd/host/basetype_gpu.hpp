@@ -56,7 +56,7 @@ public:
         rp_.resize(off + pitch_, 0);
         for (uint32_t i = 0; i < n_; ++i) {
             const std::string &tok = bi.align_bases[i];
-            const char fb = tok.empty() ? 'N' : tok[0];
+            const char fb = tok.empty() ? '\0' : tok[0];  // (an empty token fails the size() != 1 check below, as in the reference)
             uint8_t cell;
             if (fb == 'N') {
                 cell = BV_CELL_N;

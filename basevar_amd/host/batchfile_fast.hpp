@@ -1,11 +1,11 @@
 // batchfile_fast.hpp -- batchfile rows -> slab row, byte level.
 //
-// parse_site_rows (batchfile.hpp) restates the reference's text half of _basevar_caller literally: ngslib::split per column,
-// one std::istringstream extraction per token (src/utils.h:87-122), a BatchInfo of strings and vectors per site
-// (src/basetype_caller.cpp:688-736) -- 49 k rows/s at 100 samples per row on one core, and what bounds any real run of
-// bv_call by orders of magnitude.  The function below walks the same bytes once and writes the slab row directly: same
-// accepted inputs, same results, same errors (message and precedence), pinned against the literal form by
-// tests/cpp/host_formats_check.cpp (valid rows, ragged rows, malformed tokens).
+// The reference reads a position's rows with ngslib::split per column, one std::istringstream extraction per token
+// (src/utils.h:87-122) and a BatchInfo of strings and vectors per site (src/basetype_caller.cpp:688-736) -- 49 k rows/s at
+// 100 samples per row on one core, and what would bound any real run of bv_call by orders of magnitude.  The function below
+// walks the same bytes once and writes the slab row directly: same accepted inputs, same results, same errors (message and
+// precedence), pinned against a literal restatement of the reference's reader (tests/cpp/literal_reader.hpp: test
+// infrastructure) by tests/cpp/host_formats_check.cpp on valid rows, ragged rows and malformed tokens.
 //
 // Token semantics kept from the reference's readers:
 //   int columns (MappingQuality, ReadPositionRank)   `istringstream >> int` on the token: optional sign, digits, stops at the
@@ -40,7 +40,7 @@ inline int parse_int_token(const char *p, const char *e) {
 }
 
 // One row from every batchfile for the same position -> one slab row + its SiteText.  Returns false for the rows the reference
-// skips (total Depth == 0, caller.cpp:718): nothing is added then.  Throws what parse_site_rows + SlabBuilder::add_site throw.
+// skips (total Depth == 0, caller.cpp:718): nothing is added then.  Throws what the reference's reader and BaseType constructor throw (as restated in tests/cpp/literal_reader.hpp + SlabBuilder::add_site).
 inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_sample, SlabBuilder &sb, SiteText &st) {
     st = SiteText();
     SlabBuilder::Row r = sb.begin_row();
@@ -92,7 +92,7 @@ inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_
         walk(4, [&](const char *p, const char *e) { if (n_mq < n_sample) r.mapq[n_mq] = (uint8_t)parse_int_token(p, e); ++n_mq; });
         walk(5, [&](const char *p, const char *e) {
             if (n_base < n_sample) {
-                const char fb = p == e ? 'N' : *p;
+                const char fb = p == e ? '\0' : *p;  // (an EMPTY token: its [0] is the terminator, and size() != 1 below -- the reference's error)
                 uint8_t cell = BV_CELL_N;
                 if (fb == 'N') cell = BV_CELL_N;
                 else if (fb == '+' || fb == '-') {

@@ -13,7 +13,7 @@
 //
 //   bv_call --batchfiles a.bf.gz,b.bf.gz --output-vcf out.vcf --output-cvg out.cvg
 //           [--pop-group FILE] [--min-af 0.01] [--batch-sites N (default: 2^28 cells / samples, at most 65536)]
-//           [--parser fast|literal] [--timing FILE.json]
+//           [--timing FILE.json]
 //           [--gpus G] [--devices 0,1,... | --device 0]
 //           [--reference ref.fa --contig NAME:LENGTH ...]
 //   bv_call -I a.bam [-I b.bam ...] [-L bam.list] -R ref.fa[.gz] --regions CHR:BEG-END[,CHR:BEG-END...] [--mapq 10]
@@ -139,7 +139,7 @@ void parallel_ranges(size_t n, int threads, Fn fn) {
 
 int main(int argc, char **argv) {
     std::vector<std::string> batchfiles, bams;
-    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list, devices_arg, parser = "fast", timing_file;
+    std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list, devices_arg, timing_file;
     int mapq_thd = 10, threads = 1, n_gpus = 1;
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
@@ -148,13 +148,12 @@ int main(int argc, char **argv) {
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) die("missing value for " + a); return argv[++i]; };
-        if (a == "--batchfiles") bvamd::split(next(), batchfiles, ",");
+        if (a == "--batchfiles") batchfiles = bvamd::pieces(next(), ',');
         else if (a == "--output-vcf") out_vcf = next();
         else if (a == "--output-cvg") out_cvg = next();
         else if (a == "--pop-group") pop_group_file = next();
         else if (a == "--min-af") user_min_af = std::stof(next());
         else if (a == "--batch-sites") batch_sites = (uint32_t)std::stoul(next());
-        else if (a == "--parser") parser = next();
         else if (a == "--timing") timing_file = next();
         else if (a == "--device") device = std::stoi(next());
         else if (a == "--gpus") n_gpus = std::stoi(next());
@@ -166,7 +165,7 @@ int main(int argc, char **argv) {
         else if (a == "-q" || a == "--mapq") mapq_thd = std::stoi(next());
         else if (a == "-t" || a == "--thread") threads = std::stoi(next());
         else if (a == "--contig") {
-            std::vector<std::string> p; bvamd::split(next(), p, ":");
+            const std::vector<std::string> p = bvamd::pieces(next(), ':');
             if (p.size() != 2) die("--contig wants NAME:LENGTH");
             contigs.push_back({p[0], (uint32_t)std::stoul(p[1])});
         } else die("unknown argument " + a);
@@ -182,12 +181,11 @@ int main(int argc, char **argv) {
         }
     }
     if (!(user_min_af > 0.f)) die("[ERROR] --min-af must be > 0");  // the reference refuses it too (caller.cpp:73)
-    if (parser != "fast" && parser != "literal") die("[ERROR] --parser is fast or literal");
     if (n_gpus < 1) die("[ERROR] --gpus must be >= 1");
     // one engine per entry: --devices a,b,... (an ordinal may repeat: several engines on one GPU), else device, device+1, ...
     std::vector<int> devices;
     if (!devices_arg.empty()) {
-        std::vector<std::string> d; bvamd::split(devices_arg, d, ",");
+        const std::vector<std::string> d = bvamd::pieces(devices_arg, ',');
         for (const auto &x : d) devices.push_back(std::stoi(x));
         if (n_gpus != 1 && (size_t)n_gpus != devices.size()) die("[ERROR] --gpus and --devices disagree");
     } else {
@@ -357,7 +355,7 @@ int main(int argc, char **argv) {
             // ---- pileup windows -> slab rows, straight from the tile planes (no text round trip); a site is a position that
             // at least one sample covers (the reference skips rows of total depth 0, caller.cpp:718)
             std::vector<std::string> region_list;  // "-r chr:beg-end[,chr:beg-end ...]" (caller.cpp:311-356), in the order given
-            bvamd::split(regions, region_list, ",");
+            region_list = bvamd::pieces(regions, ',');
             std::string fa_seq, fa_of;
             for (const std::string &rg : region_list) {
                 const size_t colon = rg.rfind(':'), dash = rg.rfind('-');
@@ -390,9 +388,8 @@ int main(int argc, char **argv) {
             }
         } else {
             // ---- one row from every batchfile per position (caller.cpp:586-611)
-            const bool fast = parser == "fast";
             const size_t NB = batchfiles.size();
-            if (threads <= 1 || !fast) {
+            if (threads <= 1) {
                 std::vector<std::string> rows(NB);
                 for (; still_ok();) {
                     bool eof = false;
@@ -405,17 +402,10 @@ int main(int argc, char **argv) {
                     clk.read += t1 - t0;
                     if (eof) break;
                     if (!cur) fresh();
-                    if (fast) {
+                    {
                         // the rows' bytes straight into the slab row (batchfile_fast.hpp)
                         bvamd::SiteText st;
                         if (bvamd::parse_site_rows_fast(rows, n_sample, cur->slab, st)) cur->text.push_back(std::move(st));
-                    } else {
-                        // the reference's own steps: split -> BatchInfo -> slab row (batchfile.hpp)
-                        bvamd::BatchInfo bi;
-                        if (bvamd::parse_site_rows(rows, n_sample, bi)) {  // else total depth 0, caller.cpp:718
-                            cur->slab.add_site(bi);
-                            cur->text.push_back(bvamd::site_text_of(bi));
-                        }
                     }
                     clk.parse += StageClock::now() - t1;
                     if (cur->slab.n_sites() == batch_sites) ship();
@@ -509,13 +499,13 @@ int main(int argc, char **argv) {
     char line[512];
     std::snprintf(line, sizeof line,
                   "[INFO] -- %.3f s elapsed, %.1f sites/s: read %.3f s, parse+pack %.3f s (%s), engine %.3f s (%zu worker(s), batches of %u sites), emit %.3f s",
-                  total, total > 0 ? n_sites / total : 0.0, clk.read, clk.parse, from_bam ? "pileup" : parser.c_str(), clk.engine, G, batch_sites, clk.emit);
+                  total, total > 0 ? n_sites / total : 0.0, clk.read, clk.parse, from_bam ? "pileup" : "batchfile", clk.engine, G, batch_sites, clk.emit);
     std::cout << line << std::endl;
     if (!timing_file.empty()) {
         std::ofstream tf(timing_file);
         tf << "{\"sites\": " << n_sites << ", \"vcf_records\": " << n_variants << ", \"samples\": " << n_sample << ", \"engines\": " << G
            << ", \"batch_sites\": " << batch_sites << ", \"input\": \"" << (from_bam ? "bam" : "batchfile") << "\", \"parser\": \""
-           << (from_bam ? "pileup" : parser) << "\", \"total_s\": " << total << ", \"sites_per_s\": " << (total > 0 ? n_sites / total : 0.0)
+           << (from_bam ? "pileup" : "batchfile") << "\", \"total_s\": " << total << ", \"sites_per_s\": " << (total > 0 ? n_sites / total : 0.0)
            << ", \"read_s\": " << clk.read << ", \"parse_pack_s\": " << clk.parse << ", \"engine_s\": " << clk.engine
            << ", \"emit_s\": " << clk.emit << "}\n";
     }

@@ -8,10 +8,10 @@
 // (src/basetype_utils.cpp:32-88).  A host keeps, per pending site, a SiteText and nothing else.
 //
 // Number formatting is the reference's: std::to_string(double) ("%f", 6 decimals) for QUAL, QD,
-// FS, SOR, BP; ostringstream default (6 significant digits) through join() for CM_AF, CM_CAF and
+// FS, SOR, BP ("%f"); six significant digits ("%g", the reference's ostringstream formatting) for CM_AF, CM_CAF and
 // the group AFs; the three rank sums truncated to int (caller.cpp:1151-1157).
 //
-// PARITY STATUS: the numeric inputs are the pinned bv_site_result fields; join()/tostring() are
+// PARITY STATUS: the numeric inputs are the pinned bv_site_result fields; the two number formats are
 // pinned against the reference's own compiled ngslib functions (tests/test_host_formats.py); the field order
 // and literals are transcribed from the cited lines -- whole-line parity is not pinned by a run of
 // the reference binary (not buildable under this round's rules).
@@ -24,6 +24,9 @@
 #include <vector>
 
 #include "../../include/basevar_amd.h"
+#include <cstddef>
+#include <cstdio>
+
 #include "batchfile.hpp"
 
 namespace bvamd {
@@ -40,104 +43,143 @@ struct SiteText {
     std::vector<std::string> indel_tokens;
 };
 
-// __base_depth_and_indel, caller.cpp:1263-1289: "TOKEN|count" of the non-ACGT, non-N tokens,
-// ordered by std::map (lexicographic), "." if none.
+// The CVG row's indel column (what the reference's __base_depth_and_indel tallies, caller.cpp:1263-1289): "TOKEN|count" of the
+// '+' / '-' tokens in lexicographic order, comma-separated; "." if the site has none.
 inline std::string indel_string(const std::vector<std::string> &tokens) {
-    std::map<std::string, int> indel_depth;
-    for (const auto &bs : tokens) {
-        if (bs.empty() || bs[0] == 'N') continue;
-        if (bs[0] == 'A' || bs[0] == 'C' || bs[0] == 'G' || bs[0] == 'T') continue;
-        indel_depth[bs]++;
+    std::map<std::string, int> tally;
+    for (const auto &t : tokens)
+        if (!t.empty() && t[0] != 'N' && t[0] != 'A' && t[0] != 'C' && t[0] != 'G' && t[0] != 'T') ++tally[t];
+    if (tally.empty()) return ".";
+    std::string s;
+    for (const auto &kv : tally) {
+        if (!s.empty()) s += ',';
+        s += kv.first; s += '|'; s += std::to_string(kv.second);
     }
-    std::vector<std::string> indels;
-    for (const auto &kv : indel_depth) indels.push_back(kv.first + "|" + std::to_string(kv.second));
-    return indels.empty() ? "." : join(indels, ",");
+    return s;
 }
 
-// _out_cvg_line, caller.cpp:1246-1257.  Empty string when the reference writes nothing.
+// "%f" of a double (what std::to_string gives: QUAL, QD, FS, SOR, BP), appended
+inline void append_f6(std::string &s, double v) {
+    char buf[352];
+    std::snprintf(buf, sizeof buf, "%f", v);
+    s += buf;
+}
+
+// One CVG row (the columns of _out_cvg_line, caller.cpp:1246-1257).  Empty string when the reference writes nothing.
 inline std::string format_cvg_line(const SiteText &st, const bv_site_result &r) {
     if (r.total_depth == 0) return "";
-    std::vector<int> dd = {(int)r.depth[0], (int)r.depth[1], (int)r.depth[2], (int)r.depth[3]};
-    return st.ref_id + "\t" + std::to_string(st.ref_pos) + "\t" + st.ref_base + "\t" + std::to_string((int)r.total_depth) +
-           "\t" + join(dd, "\t") + "\t" + indel_string(st.indel_tokens) + "\t" + std::to_string(r.cvg_fs) + "\t" +
-           std::to_string(r.cvg_sor) + "\t" + std::to_string((int)r.cvg_sb[0]) + "," + std::to_string((int)r.cvg_sb[1]) +
-           "," + std::to_string((int)r.cvg_sb[2]) + "," + std::to_string((int)r.cvg_sb[3]) + "\n";
+    std::string s = st.ref_id;
+    s += '\t'; s += std::to_string(st.ref_pos);
+    s += '\t'; s += st.ref_base;
+    s += '\t'; s += std::to_string((int)r.total_depth);
+    for (int b = 0; b < 4; ++b) { s += '\t'; s += std::to_string((int)r.depth[b]); }
+    s += '\t'; s += indel_string(st.indel_tokens);
+    s += '\t'; append_f6(s, r.cvg_fs);
+    s += '\t'; append_f6(s, r.cvg_sor);
+    s += '\t';
+    for (int k = 0; k < 4; ++k) { if (k) s += ','; s += std::to_string((int)r.cvg_sb[k]); }
+    s += '\n';
+    return s;
 }
 
-// _out_vcf_line, caller.cpp:1103-1209, from the site's slab row: `cell` / `phred` are the n per-sample bytes of the
-// base_strand and qual planes (include/basevar_amd.h).  `groups`/`group_names`: the site's bv_group_result records
-// and the group names in the reference's iteration order (std::map: sorted by name); may be empty.
+// The INFO column as a table: key, and what of the record it prints.  Order and spelling are the file format's
+// (caller.cpp:1167-1180); the three rank sums are truncated to int as the reference's caller does (:1151-1157).
+enum InfoKind { INFO_TOTAL_DEPTH, INFO_ALT_DEPTHS, INFO_ALT_AF, INFO_ALT_CAF, INFO_INT_OF_DOUBLE, INFO_F6, INFO_INT_PAIR };
+struct InfoField {
+    const char *key;
+    InfoKind kind;
+    size_t offset;  // of the double / of the first of the two counts in bv_site_result (INFO_INT_OF_DOUBLE, INFO_F6, INFO_INT_PAIR)
+};
+static const InfoField EMIT_INFO[] = {
+    {"CM_DP", INFO_TOTAL_DEPTH, 0},
+    {"CM_AC", INFO_ALT_DEPTHS, 0},
+    {"CM_AF", INFO_ALT_AF, 0},
+    {"CM_CAF", INFO_ALT_CAF, 0},
+    {"MQRankSum", INFO_INT_OF_DOUBLE, offsetof(bv_site_result, mq_ranksum)},
+    {"ReadPosRankSum", INFO_INT_OF_DOUBLE, offsetof(bv_site_result, rpr_ranksum)},
+    {"BaseQRankSum", INFO_INT_OF_DOUBLE, offsetof(bv_site_result, bq_ranksum)},
+    {"QD", INFO_F6, offsetof(bv_site_result, qd)},
+    {"SOR", INFO_F6, offsetof(bv_site_result, var_sor)},
+    {"FS", INFO_F6, offsetof(bv_site_result, var_fs)},
+    {"SB_REF", INFO_INT_PAIR, offsetof(bv_site_result, var_sb)},
+    {"SB_ALT", INFO_INT_PAIR, offsetof(bv_site_result, var_sb) + 2 * sizeof(uint32_t)},
+};
+inline void append_info(std::string &s, const bv_site_result &r) {
+    const char *raw = reinterpret_cast<const char *>(&r);
+    bool first = true;
+    for (const InfoField &f : EMIT_INFO) {
+        if (!first) s += ';';
+        first = false;
+        s += f.key; s += '=';
+        switch (f.kind) {
+            case INFO_TOTAL_DEPTH: s += std::to_string((int)r.total_depth); break;
+            case INFO_ALT_DEPTHS:
+                for (int i = 0; i < r.n_alt; ++i) { if (i) s += ','; s += std::to_string((int)r.depth[r.alt[i] & 3]); }
+                break;
+            case INFO_ALT_AF:
+                for (int i = 0; i < r.n_alt; ++i) { if (i) s += ','; append_item(s, r.af[i]); }
+                break;
+            case INFO_ALT_CAF:
+                for (int i = 0; i < r.n_alt; ++i) { if (i) s += ','; append_item(s, r.caf[i]); }
+                break;
+            case INFO_INT_OF_DOUBLE: { double v; std::memcpy(&v, raw + f.offset, sizeof v); s += std::to_string((int)v); break; }
+            case INFO_F6: { double v; std::memcpy(&v, raw + f.offset, sizeof v); append_f6(s, v); break; }
+            case INFO_INT_PAIR: {
+                uint32_t c[2]; std::memcpy(c, raw + f.offset, sizeof c);
+                s += std::to_string((int)c[0]); s += ','; s += std::to_string((int)c[1]);
+                break;
+            }
+        }
+    }
+}
+
+// One VCF record (the columns of _out_vcf_line, caller.cpp:1103-1209) from the site's slab row: `cell` / `phred` are the n
+// per-sample bytes of the base_strand and qual planes (include/basevar_amd.h).  `groups`/`group_names`: the site's
+// bv_group_result records and the group names in the reference's iteration order (std::map: sorted by name); may be empty.
 inline std::string format_vcf_line(const SiteText &st, const uint8_t *cell, const uint8_t *phred, size_t n, const bv_site_result &r,
                                    const bv_group_result *groups, const std::vector<std::string> &group_names) {
     if (r.n_alt == 0) return "";  // caller.cpp:745
-    std::map<char, std::string> alt_gt;
-    std::vector<int> cm_ac;
-    std::vector<double> cm_af, cm_caf;
-    std::vector<char> alt_bases;
-    for (int i = 0; i < r.n_alt; ++i) {
-        const char b = EMIT_BASES[r.alt[i] & 3];
-        alt_bases.push_back(b);
-        alt_gt[b] = "./" + std::to_string(i + 1);
-        cm_ac.push_back((int)r.depth[r.alt[i] & 3]);  // (int)get_base_depth, :1120
-        cm_af.push_back(r.af[i]);
-        cm_caf.push_back(r.caf[i]);
-    }
-    // per-sample GT:AB:SO:BP, caller.cpp:1125-1145 -- the same text the reference builds with a vector of strings and
-    // ngslib::join (one ostringstream per sample), appended directly: a VCF line is n_samples fields, and at 10^4 samples the
-    // emitter, not the engine, sets the pace of a run (profiles/r3_host_pipeline.txt).  std::to_string(1 - eps(q)) depends on
-    // the phred byte only: 256 strings, formed once.
+    // FORMAT GT by base: "0/." for the reference base, "./k" for the k-th ALT, "./." for any other call (caller.cpp:1116, 1136-1143)
+    const char upper_ref = (char)std::toupper((unsigned char)st.ref_base[0]);
+    std::string gt_of[4];
+    for (int b = 0; b < 4; ++b) gt_of[b] = EMIT_BASES[b] == upper_ref ? "0/." : "./.";
+    for (int i = 0; i < r.n_alt; ++i)
+        if (EMIT_BASES[r.alt[i] & 3] != upper_ref) gt_of[r.alt[i] & 3] = "./" + std::to_string(i + 1);
+    // BP = std::to_string(1 - eps(q)) depends on the phred byte only: 256 strings, formed once (basetype.cpp:47-48)
     static const std::vector<std::string> bp_text = [] {
         std::vector<std::string> t(256);
-        for (int qv = 0; qv < 256; ++qv) t[(size_t)qv] = std::to_string(1.0 - std::exp(qv * EMIT_MLN10TO10));  // basetype.cpp:47-48
+        for (int qv = 0; qv < 256; ++qv) append_f6(t[(size_t)qv], 1.0 - std::exp(qv * EMIT_MLN10TO10));
         return t;
     }();
-    std::string gt_of[4];
-    for (int b = 0; b < 4; ++b) {
-        const auto it = alt_gt.find(EMIT_BASES[b]);
-        gt_of[b] = it == alt_gt.end() ? "./." : it->second;
-    }
-    const char upper_ref = (char)std::toupper((unsigned char)st.ref_base[0]);
-    std::string samples;
-    samples.reserve(n * 5);
-    for (size_t i = 0; i < n; ++i) {
-        if (i) samples += '\t';
-        if (!(cell[i] & BV_CELL_NOCALL)) {
-            const int bc = cell[i] & 3;
-            const char fb = EMIT_BASES[bc];
-            if (fb == upper_ref) samples += "0/."; else samples += gt_of[bc];
-            samples += ':'; samples += fb; samples += ':';
-            samples += (cell[i] & BV_CELL_REV) ? '-' : '+';
-            samples += ':';
-            samples += bp_text[phred[i]];
-        } else {
-            samples += "./.";
-        }
-    }
-    const int mq_rank_sum = (int)r.mq_ranksum, read_pos_rank_sum = (int)r.rpr_ranksum, base_q_rank_sum = (int)r.bq_ranksum;
-    std::vector<std::string> info = {
-        "CM_DP=" + std::to_string((int)r.total_depth),
-        "CM_AC=" + join(cm_ac, ","),
-        "CM_AF=" + join(cm_af, ","),
-        "CM_CAF=" + join(cm_caf, ","),
-        "MQRankSum=" + std::to_string(mq_rank_sum),
-        "ReadPosRankSum=" + std::to_string(read_pos_rank_sum),
-        "BaseQRankSum=" + std::to_string(base_q_rank_sum),
-        "QD=" + std::to_string(r.qd),
-        "SOR=" + std::to_string(r.var_sor),
-        "FS=" + std::to_string(r.var_fs),
-        "SB_REF=" + std::to_string((int)r.var_sb[0]) + "," + std::to_string((int)r.var_sb[1]),
-        "SB_ALT=" + std::to_string((int)r.var_sb[2]) + "," + std::to_string((int)r.var_sb[3]),
-    };
-    if (groups && !group_names.empty()) {  // caller.cpp:1182-1196
+    std::string s = st.ref_id;
+    s.reserve(128 + n * 18);
+    s += '\t'; s += std::to_string(st.ref_pos);
+    s += "\t.\t"; s += st.ref_base;
+    s += '\t';
+    for (int i = 0; i < r.n_alt; ++i) { if (i) s += ','; s += EMIT_BASES[r.alt[i] & 3]; }
+    s += '\t'; append_f6(s, r.qual);
+    s += (r.qual > EMIT_QUAL_THRESHOLD) ? "\t.\t" : "\tLowQual\t";
+    append_info(s, r);
+    if (groups && !group_names.empty()) {  // <group>_AF of the groups that have an ALT (caller.cpp:1182-1196)
         for (size_t g = 0; g < group_names.size(); ++g) {
-            std::vector<double> af;
-            for (int k = 0; k < groups[g].n_alt; ++k) af.push_back(groups[g].af[k]);
-            if (!af.empty()) info.push_back(group_names[g] + "_AF=" + join(af, ","));
+            if (groups[g].n_alt == 0) continue;
+            s += ';'; s += group_names[g]; s += "_AF=";
+            for (int k = 0; k < groups[g].n_alt; ++k) { if (k) s += ','; append_item(s, groups[g].af[k]); }
         }
     }
-    const std::string qs = (r.qual > EMIT_QUAL_THRESHOLD) ? "." : "LowQual";
-    return st.ref_id + "\t" + std::to_string(st.ref_pos) + "\t.\t" + st.ref_base + "\t" + join(alt_bases, ",") + "\t" +
-           std::to_string(r.qual) + "\t" + qs + "\t" + join(info, ";") + "\tGT:AB:SO:BP\t" + samples + "\n";
+    s += "\tGT:AB:SO:BP";
+    // per-sample GT:AB:SO:BP (caller.cpp:1125-1145), appended directly: a VCF line is n_samples fields, and at 10^4 samples the
+    // emitter, not the engine, sets the pace of a run (profiles/r3_host_pipeline.txt)
+    for (size_t i = 0; i < n; ++i) {
+        s += '\t';
+        if (cell[i] & BV_CELL_NOCALL) { s += "./."; continue; }
+        const int bc = cell[i] & 3;
+        s += gt_of[bc]; s += ':'; s += EMIT_BASES[bc]; s += ':';
+        s += (cell[i] & BV_CELL_REV) ? '-' : '+';
+        s += ':'; s += bp_text[phred[i]];
+    }
+    s += '\n';
+    return s;
 }
 
 // The same from a BatchInfo (the reference's per-site input): its tokens are packed into a slab row first.
@@ -165,11 +207,8 @@ inline std::string format_vcf_line(const BatchInfo &bi, const bv_site_result &r,
 
 // cvg_header_define, src/basetype_utils.cpp:72-88
 inline std::string cvg_header() {
-    std::vector<char> bases(EMIT_BASES, EMIT_BASES + 4);
-    const std::string h = "#CHROM\tPOS\tREF\tDepth\t" + join(bases, "\t") + "\t" +
-                          "Indels\tFS\tSOR\tStrand_Coverage(REF_FWD,REF_REV,ALT_FWD,ALT_REV)";
-    std::vector<std::string> header = {"##fileformat=CVGv1.0", "##Group information is the depth of A:C:G:T:Indel", h};
-    return join(header, "\n");
+    return "##fileformat=CVGv1.0\n##Group information is the depth of A:C:G:T:Indel\n"
+           "#CHROM\tPOS\tREF\tDepth\tA\tC\tG\tT\tIndels\tFS\tSOR\tStrand_Coverage(REF_FWD,REF_REV,ALT_FWD,ALT_REV)";
 }
 
 // vcf_header_define, src/basetype_utils.cpp:32-70.  The reference reads contig names/lengths from

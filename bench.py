@@ -394,7 +394,19 @@ def main():
         shape = (args.flags >> 8) & 0xF
         two_kernel = (shape == 0 and N <= 49152) or shape == 10
         kernel_name = "bv_p1s_stream_kernel" if two_kernel else ("bv_pass1_fused_kernel" if shape == 9 else "bv_pass1_kernel")
-        achieved = algo_bytes / st_avg_s / 1e9
+        # variant fraction of the last launch (a chained launch counts its whole queue)
+        fvar = nvar / max(1.0, Bl * args.steps / max(n_launch, 1))
+        # Short rows of at least three 4 KiB slots, not chained: ONE persistent kernel does all of pass 1 (streaming and solver
+        # waves side by side, csrc/bv_pass1_fused.hip) and, with rank planes and no pop-groups, streams the variant sites' pass-2
+        # rows too: its algorithmic bytes are then section 8d's S*N*(2 + 3 f_var) (its traffic 2 + 4 f_var: the call byte of a
+        # variant row is read twice).  Flag bits 12-15: 9 = the round-3 kernels, 10 = pass 2 a launch of its own.
+        tune = (args.flags >> 12) & 0xF
+        fused = two_kernel and K == 1 and tune in (0, 10) and ((args.flags >> 24) & 0xF) <= 1 and (((N + 15) // 16 + 127) // 128) >= 3
+        fused_p2 = fused and tune == 0 and ranks and args.groups == 0 and not (args.flags & 0x20)
+        kernel_bytes = algo_bytes * ((1.0 + 1.5 * fvar) if fused_p2 else 1.0)
+        if fused:
+            kernel_name = "bv_p1s_fused_kernel"
+        achieved = kernel_bytes / st_avg_s / 1e9
         # HBM bytes per launch of that kernel from the PMC counters: NOT measured in this run (counter collection needs
         # rocprofv3 around the process) but read from the committed record of the SAME kernel and configuration, if one
         # exists (tools/collect_profiles.sh + tools/summarize_profiles.py); `traffic_source` says which
@@ -410,8 +422,6 @@ def main():
                         break
             except Exception:
                 traffic = traffic_source = None
-        # variant fraction of the last launch (a chained launch counts its whole queue)
-        fvar = nvar / max(1.0, Bl * args.steps / max(n_launch, 1))
         line = {
             "metric": "genomic sites/sec through basetype caller at N samples",
             "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -445,8 +455,11 @@ def main():
                 # over the same bytes and whole_path_frac both passes over section 8d's bytes: compare those across row lengths
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "kernel": kernel_name, "frac_covers": "streaming kernel of pass 1" if two_kernel else "pass 1",
-                "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel": kernel_name,
+                "frac_covers": ("pass 1 and the variant sites' pass-2 rows (one persistent kernel)" if fused_p2 else
+                                "pass 1 (one persistent kernel: streaming and solver waves)" if fused else
+                                "streaming kernel of pass 1" if two_kernel else "pass 1"),
+                "algorithmic_bytes_per_launch": kernel_bytes,
                 "avg_launch_ms": st_avg_s * 1e3, "pass1_avg_ms": p1_avg_s * 1e3,
                 "pass1_frac": algo_bytes / p1_avg_s / 1e9 / HBM_PEAK_GBS,  # all of pass 1 (streaming + solve kernels) over the same bytes
                 "pass2_avg_launch_ms": p2_avg_s * 1e3, "launches": n_launch, "launches_timed": nsub,

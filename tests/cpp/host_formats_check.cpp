@@ -1,5 +1,5 @@
 // Test harness (tests/ only): checks basevar_amd/host/{batchfile,vcf_emit}.hpp
-//  (1) tokenisers / formatters against the reference's own ngslib functions (oracle/_ref), when
+//  (1) the literal reader's tokenisers (tests/cpp/literal_reader.hpp) and the product's formatters against the reference's own ngslib functions (oracle/_ref), when
 //      that library is given as argv[2];
 //  (2) batchfile writer -> reader round trip;
 //  (3) emits CVG/VCF lines for records computed by the oracle restatement (liboracle.so, argv[1])
@@ -13,6 +13,7 @@
 #include "../../basevar_amd/host/basetype_gpu.hpp"
 #include "../../basevar_amd/host/vcf_emit.hpp"
 #include "../../basevar_amd/host/batchfile_fast.hpp"
+#include "literal_reader.hpp"  // the literal restatement of the reference's reader: the checker (test infrastructure)
 
 using namespace bvamd;
 
@@ -54,14 +55,14 @@ int main(int argc, char **argv) {
         const char *delims[] = {"\t", " ", ","};
         for (const char *s : strs)
             for (const char *d : delims) {
-                std::vector<std::string> vs; split(std::string(s), vs, d);
+                std::vector<std::string> vs; bvlit::split(std::string(s), vs, d);
                 int n = rs(s, d, buf, sizeof buf);
                 CHECK(n == (int)vs.size() && pack(vs) == buf, "split<string> on [" << s << "] delim [" << d << "]");
-                std::vector<int> vi; split(std::string(s), vi, d);
+                std::vector<int> vi; bvlit::split(std::string(s), vi, d);
                 std::vector<std::string> vis; for (int x : vi) vis.push_back(std::to_string(x));
                 n = ri(s, d, buf, sizeof buf);
                 CHECK(n == (int)vi.size() && pack(vis) == buf, "split<int> on [" << s << "] delim [" << d << "]: " << pack(vis) << " vs " << buf);
-                std::vector<char> vc; split(std::string(s), vc, d);
+                std::vector<char> vc; bvlit::split(std::string(s), vc, d);
                 std::vector<std::string> vcs; for (char x : vc) vcs.push_back(std::to_string((int)x));
                 n = rc(s, d, buf, sizeof buf);
                 CHECK(n == (int)vc.size() && pack(vcs) == buf, "split<char> on [" << s << "] delim [" << d << "]");
@@ -69,7 +70,8 @@ int main(int argc, char **argv) {
         std::vector<double> dv = {0.0, 1.0, 0.5, 0.500057094119, 1e-7, 1.23456789e-5, 123456.789, 0.1, 1.0 / 3, 2.0 / 3, 1e10, 0.000999999,
                                   0.9999995, 0.99999949, 5e-324, 1e300, -0.0, 3.0e-3, 0.05, 12345678.0, NAN, INFINITY};
         jd(dv.data(), (int)dv.size(), ",", buf, sizeof buf);
-        CHECK(join(dv, ",") == buf, "join<double>: " << join(dv, ",") << " vs " << buf);
+        CHECK(join(dv, ",") == buf, "join<double>: " << join(dv, ",") << " vs " << buf);                 // the product's "%g"
+        CHECK(bvlit::join(dv, ",") == buf, "literal join<double>");
         std::vector<int> iv = {0, -1, 5, 2147483647, 60};
         ji(iv.data(), (int)iv.size(), " ", buf, sizeof buf);
         CHECK(join(iv, " ") == buf, "join<int>");
@@ -121,7 +123,7 @@ int main(int argc, char **argv) {
             rows.push_back(row);
         }
         BatchInfo back;
-        bool ok = parse_site_rows(rows, N, back);
+        bool ok = bvlit::parse_site_rows(rows, N, back);
         CHECK(ok == (bi.depth > 0), "depth-0 rows are skipped");
         if (ok) {
             CHECK(back.align_bases == bi.align_bases && back.align_base_quals == bi.align_base_quals && back.mapqs == bi.mapqs &&
@@ -131,10 +133,10 @@ int main(int argc, char **argv) {
     }
     {   // malformed rows raise the reference's errors
         bool threw = false;
-        try { BatchInfo b; parse_site_rows({"chr1\t5\tA\t1\t60"}, 1, b); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("invalid data") != std::string::npos; }
+        try { BatchInfo b; bvlit::parse_site_rows({"chr1\t5\tA\t1\t60"}, 1, b); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("invalid data") != std::string::npos; }
         CHECK(threw, "short row -> '[ERROR] batchfile has invalid data'");
         threw = false;
-        try { BatchInfo b; parse_site_rows({"chr1\t5\tA\t1\t60\tA\tI\t3\t+", "chr1\t6\tA\t1\t60\tA\tI\t3\t+"}, 2, b); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("same genome coordinate") != std::string::npos; }
+        try { BatchInfo b; bvlit::parse_site_rows({"chr1\t5\tA\t1\t60\tA\tI\t3\t+", "chr1\t6\tA\t1\t60\tA\tI\t3\t+"}, 2, b); } catch (const std::runtime_error &e) { threw = std::string(e.what()).find("same genome coordinate") != std::string::npos; }
         CHECK(threw, "coordinate mismatch -> error");
     }
 
@@ -163,7 +165,7 @@ int main(int argc, char **argv) {
             Outcome o;
             try {
                 BatchInfo bi;
-                if (!parse_site_rows(rows, n, bi)) { o.kind = 1; return o; }
+                if (!bvlit::parse_site_rows(rows, n, bi)) { o.kind = 1; return o; }
                 SlabBuilder sb((uint32_t)n);
                 sb.add_site(bi);
                 o = snapshot(sb, site_text_of(bi));
@@ -227,6 +229,14 @@ int main(int argc, char **argv) {
         compare({"chr1\t5\tA\t1\t60\tR\tI\t3\t+"}, 1, "base outside ACGT");
         compare({"chr1\t5\tA\t1\t60\tA\tI\t3\tx"}, 1, "strange strand");
         compare({"chr1\t5\tA\t2\t60 \tA N\t I\t3 +4\t+ ."}, 2, "empty tokens");
+        // an EMPTY Readbases token: the reference takes its [0] (the terminator), fails size() != 1 and throws (basetype.cpp:50-56)
+        compare({"chr1\t5\tA\t1\t60 60\tA \tI I\t3 3\t+ +"}, 2, "empty base token");
+        {
+            bool threw = false;
+            try { SlabBuilder sb(2); SiteText t; parse_site_rows_fast({"chr1\t5\tA\t1\t60 60\tA \tI I\t3 3\t+ +"}, 2, sb, t); }
+            catch (const std::runtime_error &e) { threw = std::string(e.what()).find("size of aligned base is not 1") != std::string::npos; }
+            CHECK(threw, "an empty base token raises the reference's error");
+        }
         compare({"chr1\t5\ta\t1\t-3\t+AT\t\t70000\t-"}, 1, "negative mapq, empty quality, rank past 16 bits");
         std::cout << "FAST_READER_CASES valid " << n_valid << " skipped " << n_skipped << " threw " << n_threw << std::endl;
         CHECK(n_valid > 100 && n_threw > 100, "the damaged rows exercise both outcomes");

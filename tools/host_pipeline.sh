@@ -3,7 +3,7 @@
 #   tools/host_pipeline.sh <tag>        -> gpurun_out/host_pipeline_<tag>.txt  (+ .json lines)
 # (a) the reference's 100-BAM test set (copied to tests/golden/_local/bam100 by `tools/host_pipeline.sh stage` in the build
 #     container; all-N surrogate FASTA as in tools/real_data_campaign.py), BAM -> pileup -> engine -> VCF/CVG;
-# (b) synthetic batchfiles, 10,000 samples in files of 200 (the reference's --batch-count), literal reader vs byte-level reader.
+# (b) synthetic batchfiles, 10,000 samples in files of 200 (the reference's --batch-count), the byte-level reader on 1 / 4 / 16 host threads.
 cd "$(dirname "$0")/.."; ROOT=$PWD
 if [ "$1" = "stage" ]; then
   mkdir -p tests/golden/_local/bam100
@@ -41,15 +41,12 @@ g++ -O2 -std=c++17 tools/gen_batchfiles.cpp -lz -o $W/gen || exit 1
 mkdir -p $W/bf; $W/gen $W/bf 10000 200 $SITES 0.08 7
 BF=$(ls $W/bf/*.gz | paste -sd,)
 say "== (b) synthetic batchfiles: 10000 samples in $(ls $W/bf | wc -l) files, $SITES sites, $(du -sh $W/bf | cut -f1) gzip"
-for p in literal fast; do
-  say "-- parser $p"
-  $CALL --batchfiles $BF --output-vcf $W/b_$p.vcf --output-cvg $W/b_$p.cvg --parser $p --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
-  cat $W/b.json >> $OUT
-done
-cmp $W/b_literal.vcf $W/b_fast.vcf && cmp $W/b_literal.cvg $W/b_fast.cvg && say "outputs of the two readers: byte-identical ($(wc -l < $W/b_fast.vcf) VCF lines, $(wc -l < $W/b_fast.cvg) CVG lines)"
+say "-- one host thread"
+$CALL --batchfiles $BF --output-vcf $W/b_fast.vcf --output-cvg $W/b_fast.cvg --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
+cat $W/b.json >> $OUT
 for t in 4 16; do
-  say "-- parser fast, --thread $t (files read and sites parsed in blocks by $t threads, lines formatted by $t threads)"
-  $CALL --batchfiles $BF --output-vcf $W/b_t.vcf --output-cvg $W/b_t.cvg --parser fast --thread $t --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
+  say "-- --thread $t (files read and sites parsed in blocks by $t threads, lines formatted by $t threads)"
+  $CALL --batchfiles $BF --output-vcf $W/b_t.vcf --output-cvg $W/b_t.cvg --thread $t --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
   cat $W/b.json >> $OUT
   cmp $W/b_t.vcf $W/b_fast.vcf && cmp $W/b_t.cvg $W/b_fast.cvg && say "outputs with --thread $t: byte-identical to one thread"
 done
