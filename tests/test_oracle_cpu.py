@@ -94,7 +94,7 @@ def test_known_answers(restatement):
     assert restatement.norm_dist(1.96) == pytest.approx(0.024997895148220445, rel=1e-15)
 
 
-def test_special_functions_against_scipy(restatement):
+def test_restated_kfunc_on_a_few_hand_picked_arguments(restatement):
     """Independent check that the restated kfunc algorithms compute what they claim."""
     from scipy import stats
     for x in (0.5, 3.84, 10.0, 24.0, 100.0, 700.0):
