@@ -98,8 +98,33 @@ def self_launch(args):
     sys.exit(rc if rc != 0 else 0)
 
 
+def host_cpu():
+    """(model name, physical cores this process may run on, logical CPUs it may run on) from /proc/cpuinfo + the affinity mask."""
+    allowed = sorted(os.sched_getaffinity(0))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" not in line:
+                if cur.get("processor") in allowed:
+                    cores.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+                cur = {}
+                continue
+            k, v = [t.strip() for t in line.split(":", 1)]
+            if k == "model name":
+                model = v
+            elif k in ("processor", "physical id", "core id"):
+                cur[k] = int(v)
+        if cur.get("processor") in allowed:
+            cores.add((cur.get("physical id", 0), cur.get("core id", cur.get("processor"))))
+    except OSError:
+        pass
+    return model, (len(cores) or len(allowed)), len(allowed)
+
+
 def cpu_baseline(torch, planes, n_samples, maf, want_sites):
-    """Times the reference's per-site path on the host cores over rows copied back from HBM."""
+    """Times the reference's per-site path on the host cores over rows copied back from HBM: an all-core leg (one thread per
+    physical core, static site-range partition as in _variants_discovery, src/basetype_caller.cpp:489-510) and a
+    single-thread leg, each at least ~2 s of wall per repeat, median of 3 repeats."""
     import numpy as np
     import oracle
     try:
@@ -110,8 +135,8 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
         chk, kind = oracle.Reference(), "reference"
     else:
         chk, kind = oracle.Restatement(), "port"
-    cores = len(os.sched_getaffinity(0))
-    threads = max(1, min(cores, 64))
+    model, physical, logical = host_cpu()
+    threads = max(1, physical)
     bs, q, mq, rp, ref = planes
     S = bs.shape[0]
 
@@ -123,39 +148,52 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
         if mq is not None:
             d["mapq"] = mq[ti].cpu().numpy()
             d["rpr"] = rp[ti].cpu().numpy().view(np.uint16)
-        return d
+        return d, idx
 
     last = {}
 
-    def timed(d, nthreads):
-        """(wall seconds of the path, per-thread path seconds or None)"""
+    def one_pass(d, nthreads):
+        """wall seconds of the path for one pass over the sample"""
         t0 = time.perf_counter()
         if kind == "reference":
             last["rec"], _, secs = chk.run_timed(d, maf, n_threads=nthreads)
             # the threads run concurrently: the path's wall time is the slowest thread's path time
             # (the driver's slab -> BatchInfo conversion is not part of the reference path)
-            return float(secs.max()), secs
+            return float(secs.max())
         last["rec"], _ = chk.run(d, maf, n_threads=nthreads)
-        return time.perf_counter() - t0, None
+        return time.perf_counter() - t0
 
-    # pilot to size the sample to ~15 s of CPU work
-    pilot = sub(threads * 2)
-    dt, secs = timed(pilot, threads)
-    per_site_cpu_s = max((float(secs.sum()) if secs is not None else dt * threads) / (threads * 2), 1e-6)
-    n = want_sites or int(max(threads * 2, min(S, 4096, 20.0 / per_site_cpu_s)))
-    n = max(threads, (n // threads) * threads)
-    wall, _ = timed(sub(n), threads)
-    cpu_records, cpu_idx = last["rec"], np.linspace(0, S - 1, num=n).astype(np.int64)
-    one = sub(max(8, min(64, n // threads)))
-    wall1, _ = timed(one, 1)
-    n1 = one["base_strand"].shape[0]
+    def leg(d, nthreads, min_wall=2.0, repeats=3):
+        """sites/s: median over `repeats` of (passes x sites) / (sum of the passes' path seconds), each repeat >= min_wall"""
+        n = d["base_strand"].shape[0]
+        first = one_pass(d, nthreads)  # also the calibration (and a warm-up of the page cache / thread pool)
+        passes = max(1, int(np.ceil(min_wall / max(first, 1e-6))))
+        rates, walls = [], []
+        for _ in range(repeats):
+            w = sum(one_pass(d, nthreads) for _ in range(passes))
+            rates.append(n * passes / w)
+            walls.append(w)
+        med = float(np.median(rates))
+        return med, (max(rates) - min(rates)) / med, passes, float(np.median(walls))
+
+    n_all = want_sites or 1024
+    n_all = max(threads, ((min(S, n_all) + threads - 1) // threads) * threads)
+    d_all, idx_all = sub(n_all)
+    rate_all, spread_all, passes_all, wall_all = leg(d_all, threads)
+    cpu_records, cpu_idx = last["rec"], idx_all
+    n_one = min(S, 512)
+    d_one, _ = sub(n_one)
+    rate_one, spread_one, passes_one, wall_one = leg(d_one, 1)
     return {
-        "value": n / wall, "unit": "sites/s", "cores": threads, "kind": kind,
-        "sample": "%d of the batch's %d sites (same synthetic rows, copied back from HBM), %d samples/site, "
-                  "%d host threads, static site-range partition, in-memory BatchInfo (no text parsing), timing "
-                  "BaseType ctor + lrt + strand_bias x2 + 3 rank sums; single-thread: %.1f sites/s" % (
-                      n, S, n_samples, threads, n1 / wall1),
-        "single_thread_value": n1 / wall1,
+        "value": rate_all, "unit": "sites/s", "cores": threads, "kind": kind,
+        "model": model, "physical_cores": physical, "logical_cpus": logical, "repeats": 3,
+        "spread": spread_all, "wall_s_per_repeat": wall_all, "passes_per_repeat": passes_all,
+        "sample": "%d of the batch's %d sites (same synthetic rows and class mix, copied back from HBM), %d samples/site, %d host threads "
+                  "(one per physical core), static site-range partition, in-memory BatchInfo (no text parsing), timing BaseType ctor "
+                  "+ lrt + strand_bias x2 + 3 rank sums; every repeat = %d passes over the sample (%.1f s of wall), median of 3 "
+                  "repeats; single thread: %d sites x %d passes per repeat (%.1f s), %.1f sites/s" % (
+                      n_all, S, n_samples, threads, passes_all, wall_all, n_one, passes_one, wall_one, rate_one),
+        "single_thread_value": rate_one, "single_thread_spread": spread_one, "single_thread_sites": n_one,
     }, cpu_records, cpu_idx
 
 

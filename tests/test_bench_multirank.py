@@ -100,3 +100,32 @@ def test_bench_chained_batches(samples):
     assert d["config"]["chain"] == 4 and d["config"]["batch_sites"] == 1024 and d["config"]["sites_per_launch"] == 4096
     assert d["roofline"]["launches"] == 3 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.0 * 4096 * samples
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()  # (counting devices does not initialise the GPU in this process)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rccl_two_devices(scaling):
+    """The driver's N = 2 run in small: `bench.py --gpus 2` with the RCCL backend, one rank per GPU, the ordered gather of
+    records over xGMI (reference analogue: the fan-out and file merge of src/basetype_caller.cpp:469-525).  Skipped on a
+    one-GPU box; the first multi-GPU lease produces evidence instead of a first run."""
+    if _n_devices() < 2:
+        pytest.skip("needs two GPUs (this box has %d)" % _n_devices())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BASEVAR_BENCH_BACKEND", "BASEVAR_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--samples", "20000",
+           "--batch-sites", "4096", "--no-cpu-baseline", "--scaling", scaling]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 2 and d["config"]["dist_world_size"] == 2
+    assert d["config"]["gathered_records_ok"] is True
+    assert d["config"]["job_batch_sites"] == (4096 if scaling == "strong" else 8192)

@@ -334,3 +334,12 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
     subprocess.check_call([call, "--batchfiles", bf, "--output-vcf", vcf5, "--output-cvg", cvg5, "--min-af", "0.05", "--batch-sites", "5",
                            "--devices", "0,0,0"])
     assert open(vcf5).read() == open(vcf).read() and open(cvg5).read() == open(cvg).read()
+    # ... and on two DIFFERENT devices where the box has them (one engine + host thread per GPU, ordered emit: the
+    # reference's fan-out and merge, caller.cpp:469-525)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        vcf6, cvg6 = str(tmp_path / "vz6.vcf"), str(tmp_path / "t6.cvg")
+        subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions", "CHROMOSOME_I:900-1200",
+                               "--mapq", "10", "--output-vcf", vcf6, "--output-cvg", cvg6, "--min-af", "0.05", "--batch-sites", "7",
+                               "--gpus", "2", "--devices", "0,1", "--thread", "2"])
+        assert open(vcf6).read() == open(vcf2).read() and open(cvg6).read() == open(cvg2).read()
