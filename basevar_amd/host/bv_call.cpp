@@ -31,6 +31,7 @@
 #include <iostream>
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -43,6 +44,7 @@
 #include "basetype_gpu.hpp"
 #include "batchfile_fast.hpp"
 #include "pileup.hpp"
+#include "bgzf_tabix.hpp"
 #include "vcf_emit.hpp"
 
 namespace {
@@ -120,14 +122,19 @@ struct StageClock {
 };
 
 // fn(i) for i in [0, n) on up to `threads` threads (contiguous ranges; the caller's thread takes the first)
+// An exception in any range (a malformed row, bad_alloc under large batches) is caught on its thread and the first one rethrown
+// on the caller's thread once all ranges are done -- the tool's "[ERROR] ..." exit path, not std::terminate.
 template <typename Fn>
 void parallel_ranges(size_t n, int threads, Fn fn) {
     const size_t nt = std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), n));
     if (nt <= 1) { fn(0, 0, n); return; }
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < nt; ++t) pool.emplace_back([&, t]() { fn(t, n * t / nt, n * (t + 1) / nt); });
-    fn(0, 0, n / nt);
+    std::vector<std::exception_ptr> errs(nt);
+    for (size_t t = 1; t < nt; ++t)
+        pool.emplace_back([&, t]() { try { fn(t, n * t / nt, n * (t + 1) / nt); } catch (...) { errs[t] = std::current_exception(); } });
+    try { fn(0, 0, n / nt); } catch (...) { errs[0] = std::current_exception(); }
     for (auto &th : pool) th.join();
+    for (auto &e : errs) if (e) std::rethrow_exception(e);
 }
 
 [[noreturn]] void die(const std::string &m) {
@@ -243,17 +250,17 @@ int main(int argc, char **argv) {
     }
 
     // ---- outputs
-    FILE *VCF = std::fopen(out_vcf.c_str(), "w"), *CVG = std::fopen(out_cvg.c_str(), "w");
-    if (!VCF) die("[ERROR] " + out_vcf + " open failure.");
-    if (!CVG) die("[ERROR] " + out_cvg + " open failure.");
+    // a name that ends in ".gz": BGZF blocks + a tabix index beside it (bgzf_tabix.hpp; caller.cpp:242-254), else plain text
+    bvamd::TextOut VCF, CVG;
+    try { VCF.open(out_vcf); CVG.open(out_cvg); } catch (const std::exception &ex) { die(ex.what()); }
     std::vector<std::string> add_group_info;
     for (const auto &g : group_names)  // caller.cpp:229-236
         add_group_info.push_back("##INFO=<ID=" + g + "_AF,Number=A,Type=Float,Description=\"Allele frequency in the " + g +
                                  " populations calculated base on LRT, in the range (0,1)\">");
     std::string hv = bvamd::vcf_header(reference, reference, contigs, add_group_info, sample_ids) + "\n";
     std::string hc = bvamd::cvg_header() + "\n";
-    std::fwrite(hv.data(), 1, hv.size(), VCF);
-    std::fwrite(hc.data(), 1, hc.size(), CVG);
+    VCF.write_header(hv);
+    CVG.write_header(hc);
 
     // ---- batches are bounded by cells (2^28 cells = 5 x 256 MiB of planes per batch in flight), not by a site count that
     // ignores the row length: a launch carries ~0.1 ms of fill and drain whatever its size, so small batches run the engine
@@ -322,11 +329,13 @@ int main(int argc, char **argv) {
                             }
                         }
                     });
-                    for (size_t t = 0; t < nt; ++t) {
-                        std::fwrite(cvg_txt[t].data(), 1, cvg_txt[t].size(), CVG);
-                        std::fwrite(vcf_txt[t].data(), 1, vcf_txt[t].size(), VCF);
-                        n_variants += nv[t];
-                    }
+                    try {
+                        for (size_t t = 0; t < nt; ++t) {
+                            CVG.write_lines(cvg_txt[t]);
+                            VCF.write_lines(vcf_txt[t]);
+                            n_variants += nv[t];
+                        }
+                    } catch (const std::exception &ex) { fail(ex.what()); }
                     n_sites += d.text.size();
                     clk.emit += StageClock::now() - t0;
                 }
@@ -488,8 +497,7 @@ int main(int argc, char **argv) {
     for (auto &w : workers) w.join();
     to_emit.close();
     emitter.join();
-    std::fclose(VCF);
-    std::fclose(CVG);
+    try { VCF.close(); CVG.close(); } catch (const std::exception &ex) { if (first_error.empty()) first_error = ex.what(); }
     if (!first_error.empty()) die(first_error);
     const double total = StageClock::now() - t_start;
     std::cout << "[INFO] bv_call: " << n_sites << " covered positions, " << n_variants << " VCF records, " << n_sample

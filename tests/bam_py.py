@@ -184,3 +184,78 @@ def batchfile_text(bam_paths, fasta, ref_id, reg_start, reg_end, mapq_thd, step=
                     [c[4] if c else "." for c in cells]]
             out.append("%s\t%d\t%s\t%d\t%s\n" % (ref_id, pos, fa[pos - 1], depth, "\t".join(" ".join(x) for x in cols)))
     return "".join(out)
+
+
+# ---------------------------------------------------------------- BGZF blocks and the tabix index, read independently
+def bgzf_blocks(path):
+    """-> [(file offset, compressed size, payload bytes)] of every BGZF block, checked field by field (SAM spec 4.1);
+    the last block must be the empty end-of-file marker."""
+    data = open(path, "rb").read()
+    out, o = [], 0
+    while o < len(data):
+        assert data[o:o + 4] == b"\x1f\x8b\x08\x04", "gzip member with FEXTRA at %d" % o
+        xlen, = struct.unpack_from("<H", data, o + 10)
+        assert xlen == 6 and data[o + 12:o + 14] == b"BC" and struct.unpack_from("<H", data, o + 14)[0] == 2
+        bsize, = struct.unpack_from("<H", data, o + 16)
+        total = bsize + 1
+        comp = data[o + 18:o + total - 8]
+        crc, isize = struct.unpack_from("<II", data, o + total - 8)
+        payload = zlib.decompress(comp, -15)
+        assert len(payload) == isize and (zlib.crc32(payload) & 0xffffffff) == crc and isize <= 65536
+        out.append((o, total, payload))
+        o += total
+    assert out and out[-1][2] == b"" and out[-1][1] == 28, "the file ends with the 28-byte EOF block"
+    return out
+
+
+def bgzf_lines(path):
+    """-> [(virtual offset of the line's first byte, virtual offset behind its newline, line bytes without the newline)]"""
+    blocks = bgzf_blocks(path)
+    lines, cur, start = [], b"", None
+    for bi, (off, _, payload) in enumerate(blocks):
+        for i in range(len(payload)):
+            if start is None:
+                start = (off << 16) | i
+            if payload[i] == 10:
+                # the offset behind the newline: inside this block -- or, when the newline filled the block to the writer's block
+                # size (0xff00: it was flushed at once), the start of the next block; both name the same byte
+                end = ((off << 16) | (i + 1)) if (i + 1 < len(payload) or len(payload) != 0xff00) else (blocks[bi + 1][0] << 16)
+                lines.append((start, end, cur))
+                cur, start = b"", None
+            else:
+                cur += payload[i:i + 1]
+    assert cur == b""
+    return lines
+
+
+def read_tbi(path):
+    """-> dict(conf, names, refs=[dict(bins={bin: [(beg, end)]}, linear=[...])])"""
+    data = b"".join(p for _, _, p in bgzf_blocks(path))
+    assert data[:4] == b"TBI\x01"
+    n_ref, preset, sc, bc, ec, meta, skip, l_nm = struct.unpack_from("<8i", data, 4)
+    o = 36
+    names = data[o:o + l_nm].split(b"\0")[:-1]
+    assert len(names) == n_ref
+    o += l_nm
+    refs = []
+    for _ in range(n_ref):
+        n_bin, = struct.unpack_from("<i", data, o); o += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", data, o); o += 8
+            bins[b] = [struct.unpack_from("<QQ", data, o + 16 * k) for k in range(n_chunk)]
+            o += 16 * n_chunk
+        n_intv, = struct.unpack_from("<i", data, o); o += 4
+        linear = list(struct.unpack_from("<%dQ" % n_intv, data, o)); o += 8 * n_intv
+        refs.append(dict(bins=bins, linear=linear))
+    assert o == len(data) or o + 8 == len(data)
+    return dict(conf=(preset, sc, bc, ec, meta, skip), names=[n.decode() for n in names], refs=refs)
+
+
+def reg2bins(beg, end):
+    """the bins that may hold records overlapping [beg, end) (the tabix / BAM binning scheme)"""
+    end -= 1
+    bins = [0]
+    for shift, first in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins.extend(range(first + (beg >> shift), first + (end >> shift) + 1))
+    return bins

@@ -272,6 +272,46 @@ def test_bv_call_end_to_end(tmp_path, restatement):
         assert open(c2, "rb").read() == open(cvg, "rb").read(), tag
 
 
+def test_bgzf_output_and_tabix_index_against_a_linear_scan(tmp_path):
+    """`x.gz` outputs (reference: bgzf_write + tbx_index_build, src/basetype_caller.cpp:242-254): the file is a
+    sequence of well-formed BGZF blocks ending in the EOF marker (every field, CRC and size checked by an independent reader),
+    and the .tbi beside it says, for every data line, where a linear scan finds it: the chunk of its bin covers the line's
+    virtual offsets, the linear index of its 16 kb window does not start behind it, the pseudo-bin counts the lines."""
+    import bam_py
+    exe = cxx(os.path.join(ROOT, "tests", "cpp", "bgzf_tabix_check.cpp"), str(tmp_path / "btc"), ["-lz"])
+    gz = str(tmp_path / "t.tsv.gz")
+    subprocess.check_call([exe, gz, "3"])
+    lines = bam_py.bgzf_lines(gz)
+    assert lines[0][2] == b"##fileformat=TESTv1" and lines[1][2].startswith(b"#CHROM")
+    recs = [(s, e, l.split(b"\t")) for s, e, l in lines if not l.startswith(b"#")]
+    assert len(recs) > 1000 and max(len(c[2]) for _, _, c in recs) == 150000
+    # gzip reads the concatenated members as one text
+    import gzip
+    assert gzip.open(gz, "rb").read() == b"".join(l + b"\n" for _, _, l in lines)
+    tbi = bam_py.read_tbi(gz + ".tbi")
+    assert tbi["conf"] == (1, 1, 2, 0, ord("#"), 0) and tbi["names"] == ["chr1", "chr2", "chr3"]
+    by_ref = {}
+    for s, e, c in recs:
+        by_ref.setdefault(c[0].decode(), []).append((int(c[1]), s, e))
+    for name, ref in zip(tbi["names"], tbi["refs"]):
+        mine = by_ref[name]
+        meta = ref["bins"].pop(37450)
+        assert meta[0] == (mine[0][1], mine[-1][2]) and meta[1] == (len(mine), 0)
+        chunks = sorted(c for cs in ref["bins"].values() for c in cs)
+        assert all(a[1] <= b[0] for a, b in zip(chunks, chunks[1:]))  # the chunks tile the data lines, in file order
+        assert chunks[0][0] == mine[0][1] and chunks[-1][1] == mine[-1][2]
+        for pos, s, e in mine:
+            beg = pos - 1
+            leaf = 4681 + (beg >> 14)
+            assert any(cb <= s and e <= ce for cb, ce in ref["bins"].get(leaf, [])), (name, pos)
+            assert leaf in bam_py.reg2bins(beg, beg + 1)
+            assert ref["linear"][beg >> 14] <= s
+        # a window's offset is the first line AT or AFTER the window (empty windows point forward): never behind a line in it
+        for w, off in enumerate(ref["linear"]):
+            later = [s for pos, s, _ in mine if (pos - 1) >> 14 >= w]
+            assert off == (later[0] if later else mine[-1][2])
+
+
 @pytest.mark.gpu
 def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement):
     """BASELINE configs[0] plumbing: the reference's own test command (tests/data/work.log.sh:1 -- 2 x range.bam,
@@ -315,6 +355,22 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
     assert [l for l in open(vcf2).read().split("\n") if l and not l.startswith("##")] == \
         [l for l in open(vcf).read().split("\n") if l and not l.startswith("##")]
     assert open(cvg2).read() == open(cvg).read()
+    # outputs named *.gz: BGZF + tabix index (caller.cpp:242-254) -- the same text inside, every CVG row where the index says
+    import gzip
+    import bam_py
+    vz, cz = str(tmp_path / "z.vcf.gz"), str(tmp_path / "z.cvg.gz")
+    subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions", "CHROMOSOME_I:900-1200",
+                           "--mapq", "10", "--output-vcf", vz, "--output-cvg", cz, "--min-af", "0.05", "--batch-sites", "64"])
+    assert gzip.open(vz, "rb").read() == open(vcf2, "rb").read() and gzip.open(cz, "rb").read() == open(cvg2, "rb").read()
+    for path, n_rec in ((vz, 5), (cz, 207)):
+        tbi = bam_py.read_tbi(path + ".tbi")
+        assert tbi["names"] == ["CHROMOSOME_I"] and tbi["conf"] == (1, 1, 2, 0, ord("#"), 0)
+        recs = [(s_, e_, l) for s_, e_, l in bam_py.bgzf_lines(path) if not l.startswith(b"#")]
+        assert len(recs) == n_rec and tbi["refs"][0]["bins"][37450][1] == (n_rec, 0)
+        for s_, e_, l in recs:
+            beg = int(l.split(b"\t")[1]) - 1
+            assert any(cb <= s_ and e_ <= ce for cb, ce in tbi["refs"][0]["bins"][4681 + (beg >> 14)])
+            assert tbi["refs"][0]["linear"][beg >> 14] <= s_
     # several regions in one call: the records of each, in the order given
     vcf3, cvg3 = str(tmp_path / "vz3.vcf"), str(tmp_path / "t3.cvg")
     subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions",
