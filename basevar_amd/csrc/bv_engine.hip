@@ -936,10 +936,14 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         bv_engine *l = e->lane[k];
         // (only if that stream holds unfinished work: recording an event on an idle stream and waiting for it on another cost
         // 0.5-2 ms per submit on this stack -- measured, round 3 -- against ~10 us when the marker follows real work)
-        if (stream_ && hipStreamQuery((hipStream_t)stream_) != hipSuccess) {
+        // NULL means the engine's own stream here too (include/basevar_amd.h): planes written on bv_engine_stream(e) just
+        // before a NULL-stream submit are ordered like those of any other stream.  (A stream that is being captured
+        // answers the query with an error: treated as "holds work", the marker is then part of the capture.)
+        hipStream_t src = stream_ ? (hipStream_t)stream_ : e->stream;
+        if (hipStreamQuery(src) != hipSuccess) {
             (void)hipGetLastError();  // hipErrorNotReady is the answer, not an error
             if (!e->ev_entry) BV_HIP(e, hipEventCreateWithFlags(&e->ev_entry, hipEventDisableTiming));
-            BV_HIP(e, hipEventRecord(e->ev_entry, (hipStream_t)stream_));
+            BV_HIP(e, hipEventRecord(e->ev_entry, src));
             BV_HIP(e, hipStreamWaitEvent(l->stream, e->ev_entry, 0));
         }
         const int rc = bv_engine_submit(l, slab, out, gout, nullptr);

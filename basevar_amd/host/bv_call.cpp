@@ -266,9 +266,14 @@ int main(int argc, char **argv) {
     // ignores the row length: a launch carries ~0.1 ms of fill and drain whatever its size, so small batches run the engine
     // in its worst regime (round 2's default was 671 sites at 100 k samples: 0.2 of the large-batch rate).  Per pending
     // site the host keeps the slab row and a SiteText, nothing else.
+    // The pipeline below holds up to (G + 1) + (2 G + 2) + G + 1 = 4 G + 4 batches at once (queued, on the engines, waiting for the
+    // emitter): the cell budget of a batch shrinks with the number of engines so that all of them together stay under 16 GiB of
+    // host planes (8 engines: 2^26.4 cells per batch instead of 2^28, 36 x 0.44 GB).
     if (batch_sites == 0) {
         const size_t pitch = (n_sample + 255) / 256 * 256;
-        const size_t by_cells = ((size_t)1 << 28) / std::max<size_t>(pitch, 1);
+        const size_t in_flight = 4 * devices.size() + 4;
+        const size_t budget = std::min<size_t>((size_t)1 << 28, (((size_t)16 << 30) / 5) / in_flight);
+        const size_t by_cells = budget / std::max<size_t>(pitch, 1);
         batch_sites = (uint32_t)std::min<size_t>(65536, std::max<size_t>(by_cells, 64));
     }
 

@@ -193,7 +193,11 @@ public:
         if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY) lim = (size_t)rl.rlim_cur;
         else if (getrlimit(RLIMIT_NOFILE, &rl) == 0) lim = 1u << 20;
         keep_ = lim > 96 ? std::min(paths.size(), lim - 96) : 0;
-        if (const char *k = std::getenv("BASEVAR_AMD_BAM_KEEP")) keep_ = std::min(paths.size(), (size_t)std::strtoul(k, nullptr, 10));  // measurements: 0 = reopen per window
+        // ... and at most 4,096 by default: a kept reader holds its loaded index and BGZF buffers (up to a few MB each), and
+        // where RLIMIT_NOFILE is 2^20 or unlimited a cohort of 10^5 samples would otherwise keep tens of GB of them.
+        // BASEVAR_AMD_BAM_KEEP=<n> sets the number explicitly (0 = reopen per window; measurements, or hosts with memory to spare).
+        keep_ = std::min(keep_, (size_t)4096);
+        if (const char *k = std::getenv("BASEVAR_AMD_BAM_KEEP")) keep_ = std::min(paths.size(), (size_t)std::strtoul(k, nullptr, 10));
     }
     struct Handle {
         BamFile *bf;
