@@ -875,12 +875,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
             if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * G * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * G); }
         }
-        if (pass2_fused) {
-            // what is left of pass 2: the rows whose ranks did not fit the fused kernel's 256-rank window (long reads), listed in
-            // easy_list / counted in the BV_CTR_CANDS line -- normally none, and the launch ends at once
-            ac.var_list = e->d_easy_list;
-            ac.counters = ac.counters + BV_CTR_CANDS;
-        }
+        if (pass2_fused) continue;  // pass 1's kernel has streamed the variant sites' rank-sum rows too
         bv_launch_pass2(ac, st);
         BV_HIP(e, hipGetLastError());
         bv_launch_p2g_solve16(ac, st);

@@ -158,7 +158,7 @@ struct BvP1ShortArgs {
     const BvChain *ch;     // device memory, or NULL: a chained launch -- the call / phred planes come per segment (biased), while
                            // ref_base / out are the engine's contiguous copies indexed with the global site number
     // bv_pass1_fused.hip only: the rank planes, when the kernel is to stream the variant sites' pass-2 rows too (both NULL: pass 2
-    // is launched after it as usual).  Rows whose ranks do not fit its 256-rank window go to easy_list (length: counters[BV_CTR_CANDS]).
+    // is launched after it as usual)
     const uint8_t *mapq;
     const uint16_t *rpr;
 };

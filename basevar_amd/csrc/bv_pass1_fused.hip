@@ -36,6 +36,7 @@
 #include "bv_tally.h"
 
 #include "bv_short.h"
+#include "bv_pass2_sweep.h"
 
 #include <type_traits>
 
@@ -49,7 +50,9 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_F_SLOT_WORDS 1024              /* pass-1 rows: 2 KiB of calls, 2 KiB of phreds; pass-2 rows: 1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks */
 #define BV_F_QCAP 256                     /* entries per candidate queue (ring buffers) */
 #define BV_F_QVCAP 128                    /* entries of the variant queue */
+#ifndef BV_F_QV_HIGH
 #define BV_F_QV_HIGH 64u                  /* from this many waiting variant rows on, a streaming wave takes one before its next pass-1 row */
+#endif
 #define BV_F_EMPTY 0xFFFFFFFFu
 // Issue priority of a wave while it solves (s_setprio; streaming: 0).  The solver's chains of dependent FP64 operations lose
 // 2-3 x beside two streaming waves per SIMD at equal priority (jobs of 35-65 us took 100-195 us, measured from the queue
@@ -210,8 +213,12 @@ __device__ __forceinline__ void bv_f_tally2(bv_u32x4 vbA, bv_u32x4 vqA, bv_u32x4
     // X = call << 8 | phred << 1 = twice the word index of the 8 x 128 histogram; call < 8 <=> X < 0x800
     vqA.x <<= 1; vqA.y <<= 1; vqA.z <<= 1; vqA.w <<= 1;
     vqB.x <<= 1; vqB.y <<= 1; vqB.z <<= 1; vqB.w <<= 1;
+#if defined(BV_ABL_F_NOTALLY)   /* attribution builds only: the stream without the tally (results are wrong) */
+    if ((vbA.x ^ vqA.y ^ vbB.z ^ vqB.w) == 0x12345678u && (vbA.z ^ vqA.w ^ vbB.x ^ vqB.y) == 0x9abcdef0u) hist[0] = one;
+#else
     bv_tally_chunk<1>(vbA, vqA, hist, one);
     bv_tally_chunk<1>(vbB, vqB, hist, one);
+#endif
 }
 
 // ------------------------------------------------------------------------------ the solver side
@@ -491,6 +498,61 @@ __device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShar
         bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, lane);
     }
 }
+// A variant row with a read-position rank beyond the 256-rank window of the fast tally (long reads): the exact window sweeps of
+// bv_pass2_sweep.h -- plain loads, as bv_pass2_dma_kernel falls back to them -- into the wave's histogram, the two rank sums
+// stored at once.  Rare, and not inlined: the streaming loop keeps its registers; the loads' waits drain the ring.
+__device__ __attribute__((noinline)) void bv_f_p2_redo(const uint8_t *bs_, const uint8_t *mapq_, const uint16_t *rpr_, bv_site_result *out_, uint64_t pitch,
+                                                       uint32_t n_samples, uint32_t site_, uint32_t lut_, uint32_t n12_, uint32_t hist_lds_) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)site_), lut = (uint32_t)__builtin_amdgcn_readfirstlane((int)lut_);
+    const uint32_t n12 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n12_);
+    uint32_t *h = (uint32_t *)(bv_lds_u32 *)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hist_lds_);
+    bv_site_result *out = (bv_site_result *)(__attribute__((address_space(1))) bv_site_result *)out_;
+    BvPass2Args as;
+    as.bs = (const uint8_t *)(__attribute__((address_space(1))) const uint8_t *)bs_;
+    as.mapq = (const uint8_t *)(__attribute__((address_space(1))) const uint8_t *)mapq_;
+    as.rpr = (const uint16_t *)(__attribute__((address_space(1))) const uint16_t *)rpr_;
+    as.q = nullptr; as.group_id = nullptr; as.pitch = pitch; as.n_samples = n_samples; as.n_groups = 0;
+    const unsigned long long n1 = n12 & 0xFFFFu, n2 = n12 >> 16;
+    uint32_t *hm = h, *hr = h + 512;
+    auto zero = [&](uint32_t *p, int words) {
+        uint4 *z = reinterpret_cast<uint4 *>(p);
+        for (int i = lane; i < words / 4; i += BV_WAVE) z[i] = make_uint4(0, 0, 0, 0);
+    };
+    zero(h, 4 * 256);
+    bv_lrt_sync<0>();
+    BvP2Ctx cx;
+    cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
+    bv_p2_sweep<BV_WAVE, true, true, false, 256>(cx, as, site, lane);
+    const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
+    bv_lrt_sync<0>();
+    {
+        unsigned long long below = 0, twoR = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hm[w * 64 + lane], hm[256 + w * 64 + lane], n1 + n2, below, lane);
+        const double ph = bv_ranksum_phred(twoR, n1, n2);
+        if (lane == 0) out[site].mq_ranksum = ph;
+    }
+    unsigned long long below = 0, twoR = 0;
+    for (uint32_t win_lo = 0;; win_lo += 256u) {
+        const int nblk = (maxr < win_lo + 256u) ? (int)((maxr - win_lo) >> 6) + 1 : 4;
+        for (int w = 0; w < nblk; ++w) twoR += bv_ranksum_window(hr[w * 64 + lane], hr[256 + w * 64 + lane], n1 + n2, below, lane);
+        if (maxr < win_lo + 256u) break;
+        bv_lrt_sync<0>();
+        zero(hr, 2 * 256);
+        bv_lrt_sync<0>();
+        cx.win_lo = win_lo + 256u;
+        bv_p2_sweep<BV_WAVE, true, false, false, 256>(cx, as, site, lane);
+        bv_lrt_sync<0>();
+    }
+    const double ph = bv_ranksum_phred(twoR, n1, n2);
+    if (lane == 0) {
+        out[site].rpr_ranksum = ph;
+        atomicOr(&out[site].status, BV_SITE_RANKSUM);
+    }
+    bv_lrt_sync<0>();
+}
+
 // pass-2 results of up to 64 rows of one wave, one row per lane: the two rank sums as exact integers, turned into phred values
 // (erfc, log10: scalar work per site) and stored for all of them at once
 struct BvFusedStash {
@@ -902,9 +964,8 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         wsel = 0u;
         const unsigned long long n12 = (unsigned long long)(c_y & 0xFFFFu) + (unsigned long long)(c_y >> 16);
         if (__ballot(hi_acc != 0u) != 0ull) {
-            // a rank >= 256 somewhere in the row (long reads): the row goes to the redo list, bv_pass2_dma_kernel's window sweeps
-            // take it after this kernel (a returning atomic: the ring drains -- rare)
-            if (lane == 0) a.easy_list[atomicAdd(&a.counters[BV_CTR_CANDS], 1u)] = site;
+            // a rank >= 256 somewhere in the row (long reads): re-done at once by the exact window sweeps (the ring drains -- rare)
+            bv_f_p2_redo(a.bs, a.mapq, a.rpr, a.out, a.pitch, a.n_samples, site, c_z, c_y, (uint32_t)(uintptr_t)(bv_lds_u32 *)hist);
         } else {
             uint32_t *hm = hist, *hr = hist + 512;
             unsigned long long below = 0, twoR = 0;

@@ -176,7 +176,7 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
         med = float(np.median(rates))
         return med, (max(rates) - min(rates)) / med, passes, float(np.median(walls))
 
-    n_all = want_sites or 1024
+    n_all = want_sites or max(1024, 32 * threads)  # >= 32 sites per thread: the static partition's slowest thread sets the pace
     n_all = max(threads, ((min(S, n_all) + threads - 1) // threads) * threads)
     d_all, idx_all = sub(n_all)
     rate_all, spread_all, passes_all, wall_all = leg(d_all, threads)

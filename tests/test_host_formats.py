@@ -356,7 +356,6 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
         [l for l in open(vcf).read().split("\n") if l and not l.startswith("##")]
     assert open(cvg2).read() == open(cvg).read()
     # outputs named *.gz: BGZF + tabix index (caller.cpp:242-254) -- the same text inside, every CVG row where the index says
-    import gzip
     import bam_py
     vz, cz = str(tmp_path / "z.vcf.gz"), str(tmp_path / "z.cvg.gz")
     subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions", "CHROMOSOME_I:900-1200",

@@ -63,7 +63,11 @@ def algorithmic_bytes(kernel, cfg, nvar):
     B, N = cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"]
     if cfg.get("tile_job"):
         return None, "-"  # the tile job's finish runs the pass kernels on other rows than the bench batch: nothing attributed
-    if kernel.startswith(("bv_pass1_kernel", "bv_pass1_fused_kernel", "bv_p1s_stream_kernel")):
+    if kernel.startswith("bv_p1s_fused_kernel<true>"):
+        # pass 1 and the variant sites' pass-2 rows in one kernel: SURVEY 8d's 2 B/cell + 3 B/cell of the variant rows
+        # (its traffic re-reads the call byte of a variant row: 4 B/cell there)
+        return (2.0 * B + 3.0 * nvar) * N, "2 B/cell x %d sites x %d samples + 3 B/cell x %d variant rows" % (B, N, nvar)
+    if kernel.startswith(("bv_pass1_kernel", "bv_pass1_fused_kernel", "bv_p1s_stream_kernel", "bv_p1s_fused_kernel")):
         return 2.0 * B * N, "2 B/cell x %d sites x %d samples" % (B, N)
     per = None
     if kernel.startswith(("bv_pass2_dma_kernel", "bv_pass2_short_kernel")):
@@ -87,7 +91,7 @@ def tkey(kernel, cfg):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
     src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
     names = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(src, "*.args")))
     out = {"tag": tag, "configs": {}}
@@ -172,7 +176,7 @@ def main():
                 k, v["calls"], v["avg_ns"] / 1e3, "%.0f" % f if f is not None else "-", "%.0f" % w if w is not None else "-",
                 "%.4g" % hbm if f is not None else "-", ("%.4g (%s)" % (algo, how)) if algo else "-",
                 "%.3f" % (hbm / algo) if (algo and f is not None) else "-", "%.3f" % frac if frac else "-"))
-            if algo and f is not None and k.startswith(("bv_pass1", "bv_p1s_stream")):
+            if algo and f is not None and k.startswith(("bv_pass1", "bv_p1s_stream", "bv_p1s_fused")):
                 # (several configurations run the same kernel on the same shape: the first one, in name order, is quoted)
                 traffic.setdefault(tkey(k, cfg), {}).update({} if traffic[tkey(k, cfg)] else {
                     "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
