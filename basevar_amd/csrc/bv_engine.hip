@@ -1500,29 +1500,30 @@ static void bv_fused_debug_report(const uint32_t *h) {
     for (int b = 0; b < 512; ++b)
         if (d[b * 8] && (!any || (int32_t)(d[b * 8] - t0) < 0)) { t0 = d[b * 8]; any = true; }
     if (!any) return;
-    const char *nm[4] = {"entry", "first streaming wave done", "last streaming wave done", "workgroup done"};
-    for (int j = 0; j < 4; ++j) {
+    const char *nm[5] = {"entry", "first streaming wave past its pass-1 rows", "last streaming wave past its pass-1 rows", "workgroup done", "last solver job done"};
+    const int col[5] = {0, 1, 2, 3, 5};
+    for (int j = 0; j < 5; ++j) {
         std::vector<double> v; double sum[8] = {}; uint32_t cnt[8] = {};
         for (int b = 0; b < 512; ++b) {
-            if (!d[b * 8] || !d[b * 8 + j]) continue;
-            const double t = (double)(int32_t)(d[b * 8 + j] - t0) * 0.01;
+            if (!d[b * 8] || !d[b * 8 + col[j]]) continue;
+            const double t = (double)(int32_t)(d[b * 8 + col[j]] - t0) * 0.01;
             v.push_back(t); sum[d[b * 8 + 7] & 7u] += t; cnt[d[b * 8 + 7] & 7u]++;
         }
         if (v.empty()) continue;
         std::sort(v.begin(), v.end());
         const size_t n = v.size();
-        fprintf(stderr, "[fused debug] %-26s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f us | mean per XCD:", nm[j], v[0], v[n / 10], v[n / 2],
+        fprintf(stderr, "[fused debug] %-42s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f max %6.1f us | mean per XCD:", nm[j], v[0], v[n / 10], v[n / 2],
                 v[n * 9 / 10], v[n - 1]);
         for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", cnt[x] ? sum[x] / cnt[x] : 0.);
         fprintf(stderr, "\n");
     }
-    const char *qn[3] = {"q3 entries", "q2 entries", "blocks of 64"};
+    const char *qn[3] = {"q3 entries", "q2 entries", "variant rows (or blocks of 64)"};
     for (int j = 0; j < 3; ++j) {
         std::vector<uint32_t> v;
-        for (int b = 0; b < 512; ++b) if (d[b * 8]) v.push_back(d[b * 8 + 4 + j]);
+        for (int b = 0; b < 512; ++b) if (d[b * 8]) v.push_back(j == 0 ? (d[b * 8 + 4] & 0xFFFFu) : j == 1 ? (d[b * 8 + 4] >> 16) : d[b * 8 + 6]);
         std::sort(v.begin(), v.end());
-        fprintf(stderr, "[fused debug] left when the last streaming wave was done, %-12s: min %u p50 %u p90 %u max %u\n", qn[j], v[0], v[v.size() / 2],
-                v[v.size() * 9 / 10], v.back());
+        fprintf(stderr, "[fused debug] waiting when the last streaming wave was past its pass-1 rows, %-30s: min %u p50 %u p90 %u max %u\n", qn[j], v[0],
+                v[v.size() / 2], v[v.size() * 9 / 10], v.back());
     }
 }
 #endif

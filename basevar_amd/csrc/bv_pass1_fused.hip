@@ -435,6 +435,9 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
             bv_f_job_hard(a, sh, v, site, lane);
         }
         if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
+#ifdef BV_TEAM_DEBUG  /* when the workgroup's last solver job ended */
+        if (n != 0u && lane == 0) atomicMax(&a.counters[BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u + 5u], (uint32_t)__builtin_amdgcn_s_memrealtime());
+#endif
         if (n != 0u) return 1;
     }
     {
@@ -733,8 +736,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             if (atomicAdd(&sh.ctl[BV_FC_NDONE], 1u) == 0u) dbg_[1] = now;
             else if (sh.ctl[BV_FC_NDONE] == (uint32_t)BV_F_NS) {
                 dbg_[2] = now;
-                dbg_[4] = sh.ctl[BV_FC_Q3_TAIL] - sh.ctl[BV_FC_Q3_HEAD];
-                dbg_[5] = sh.ctl[BV_FC_Q2_TAIL] - sh.ctl[BV_FC_Q2_HEAD];
+                dbg_[4] = (sh.ctl[BV_FC_Q3_TAIL] - sh.ctl[BV_FC_Q3_HEAD]) | ((sh.ctl[BV_FC_Q2_TAIL] - sh.ctl[BV_FC_Q2_HEAD]) << 16);
                 dbg_[6] = FUSE2 ? sh.ctl[BV_FC_QV_TAIL] - sh.ctl[BV_FC_QV_HEAD] : ((B1 - B0 + 63u) >> 6) - sh.ctl[BV_FC_BLK_HEAD];
             }
 #else
@@ -1036,7 +1038,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #ifdef BV_TEAM_DEBUG
     if (tid == 0) {
         uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u;
-        dbg_[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[3] = 0u;
+        dbg_[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[3] = 0u; dbg_[5] = 0u;
         dbg_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
         if (blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 4u;  // whose stamps these are
     }
