@@ -54,6 +54,9 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_F_QV_HIGH 64u                  /* from this many waiting variant rows on, a streaming wave takes one before its next pass-1 row */
 #endif
 #define BV_F_EMPTY 0xFFFFFFFFu
+// Every wait on another wave's LDS write is bounded (~1-2 s of s_sleep): a wave that gives up sets the sticky BV_CTR_TIMEOUT
+// counter -- the submit then fails loudly in bv_engine_wait -- instead of hanging the GPU on a protocol error.
+#define BV_F_SPIN_MAX (1u << 22)
 // Issue priority of a wave while it solves (s_setprio; streaming: 0).  The solver's chains of dependent FP64 operations lose
 // 2-3 x beside two streaming waves per SIMD at equal priority (jobs of 35-65 us took 100-195 us, measured from the queue
 // lengths at the end of the pass-1 rows: 28 candidates waiting); at priority 3 the solver waves keep up (1 waiting) and the
@@ -255,10 +258,10 @@ __device__ __forceinline__ uint32_t bv_f_claim(uint32_t *ctl, int tail_i, int he
 // the entry at `pos` (its producer reserved the position before writing it: wait for the site number), handed back empty
 __device__ __forceinline__ uint32_t bv_f_take(uint32_t *q, uint32_t pos) {
     volatile __attribute__((address_space(3))) uint32_t *e = (volatile __attribute__((address_space(3))) uint32_t *)q + (pos & (BV_F_QCAP - 1u));
-    uint32_t s = *e;
-    while (s == BV_F_EMPTY) { __builtin_amdgcn_s_sleep(1); s = *e; }
+    uint32_t s = *e, spins = 0;
+    while (s == BV_F_EMPTY && ++spins < BV_F_SPIN_MAX) { __builtin_amdgcn_s_sleep(4); s = *e; }
     *e = BV_F_EMPTY;
-    return s;
+    return s;  // (BV_F_EMPTY after a time-out: the caller flags it)
 }
 // What the rank sums of pass 2 need of a variant site (bv_pass2_dma_kernel forms the same from the record): the class of
 // every base -- byte b of L: 0x80 REF, 0x81 ALT, 0xFF neither (caller.cpp:1151-1157) --, the 2-bit form of it for the window
@@ -286,7 +289,7 @@ __device__ __forceinline__ void bv_f_push_variant(BvFusedShared &sh, uint32_t si
     volatile __attribute__((address_space(3))) uint32_t *e =
         (volatile __attribute__((address_space(3))) uint32_t *)&sh.qv[pos & (BV_F_QVCAP - 1u)][0];
     // (a slot still occupied: BV_F_QVCAP variant rows are waiting -- from BV_F_QV_HIGH on the streaming waves take them first)
-    while (e[0] != BV_F_EMPTY) __builtin_amdgcn_s_sleep(8);
+    for (uint32_t spins = 0; e[0] != BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(8);
     e[1] = L; e[2] = n12; e[3] = lut;
     e[0] = site;  // (LDS operations of one wave execute in order: the entry is whole when its site number appears)
 }
@@ -298,8 +301,10 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     uint32_t *scratch = v.grp + grp * BV_G16_GRP_WORDS;
     bool variant = false;
     uint32_t site = 0, pL = 0, pn12 = 0, plut = 0;
-    if ((uint32_t)grp < n) {
-        site = bv_f_take(q, first + (uint32_t)grp);
+    if ((uint32_t)grp < n) site = bv_f_take(q, first + (uint32_t)grp);
+    if ((uint32_t)grp < n && site == BV_F_EMPTY) {
+        if (gl == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], 1u);
+    } else if ((uint32_t)grp < n) {
         const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
         uint32_t nb, badq;
         BvG16Lrt pre;
@@ -482,7 +487,7 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
     const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)tail, 1u);
     bv_lds_vu32 *e = q + (pos & (BV_F_QCAP - 1u));
     // (a slot still occupied: the solvers are BV_F_QCAP candidates behind -- they never wait for a streaming wave, so this ends)
-    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*e) != BV_F_EMPTY) __builtin_amdgcn_s_sleep(8);
+    for (uint32_t spins = 0; (uint32_t)__builtin_amdgcn_readfirstlane((int)*e) != BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(8);
     if (lane == 0) *e = site;
 }
 // publish a pass-1 row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic,
@@ -670,14 +675,27 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
                 if (c >= B1 - B0) st |= CUR_DONE;
                 else { s = B0 + c; kind = BV_FK_P1; x = bv_f_ref_scalar(a.ref_base, s); }
             }
+            // (Measured and off: a wave past its pass-1 rows that SOLVES before it streams -- no row drawn while a job's worth of
+            // candidates waits.  The last solver job then ends 45 us earlier, but HBM idles while twelve waves solve: 168 against
+            // 175 M sites/s, interleaved.  The four solver waves keep the solving; the others stream what is there.)
+            bool solve_first = false;
+#ifdef BV_F_SOLVE_FIRST
+            if (FUSE2 && kind == 0u && (st & CUR_DONE)) {
+                const uint32_t need = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
+                solve_first = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= need ||
+                              bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= need;
+            }
+#endif
+            if (solve_first) return;
             if (FUSE2 && kind == 0u) {
                 const uint32_t h = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]);
                 if (h != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) && bv_f_lds_cas_wave(qvhead_lds, h, h + 1u) == h) {
                     const uint32_t *e = sh.qv[h & (BV_F_QVCAP - 1u)];
-                    while ((s = bv_f_lds_read_u(&e[0])) == BV_F_EMPTY) __builtin_amdgcn_s_sleep(1);
+                    for (uint32_t spins = 0; (s = bv_f_lds_read_u(&e[0])) == BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(4);
                     x = bv_f_lds_read_u(&e[1]); y = bv_f_lds_read_u(&e[2]); z = bv_f_lds_read_u(&e[3]);
                     if (lane == 0) *(bv_lds_vu32 *)&e[0] = BV_F_EMPTY;
-                    kind = BV_FK_P2;
+                    if (s == BV_F_EMPTY) { if (lane == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], 1u); }  // (timed out: no row, flagged)
+                    else kind = BV_FK_P2;
                 }
             }
             if (kind == 0u) {
