@@ -822,9 +822,11 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             const uint32_t tune = (e->cfg.flags >> 12) & 0xFu;
             if (H == 1u && (tune == 0u || tune == 10u) && bv_p1s_fused_takes(s1)) {
                 if (ev) e->ring_one_kernel[e->last_slot] = true;
-                // without pop-groups the same kernel streams the variant sites' rank-sum rows too (pass 2); bits 12-15 = 10 keep
-                // pass 2 a launch of its own (A/B)
-                if (tune == 0u && G == 0 && mq != nullptr && rp != nullptr && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP)) {
+                // the same kernel streams the variant sites' rank-sum rows too (pass 2); bits 12-15 = 10 keep pass 2 a launch
+                // of its own (A/B)
+                // (with pop-groups too where their tallies stream on their own -- short rows, <= 7 groups: the launch that follows
+                // then carries the group kernels only)
+                if (tune == 0u && (G == 0 || bv_p2g_streams(a2)) && mq != nullptr && rp != nullptr && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP)) {
                     s1.mapq = mq; s1.rpr = rp;
                     pass2_fused = true;
                 }
@@ -875,11 +877,15 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
             if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * G * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * G); }
         }
-        if (pass2_fused) continue;  // pass 1's kernel has streamed the variant sites' rank-sum rows too
+        if (pass2_fused) {  // pass 1's kernel has streamed the variant sites' rank-sum rows too: what is left is the pop-groups
+            if (G == 0) continue;
+            ac.mapq = nullptr; ac.rpr = nullptr;
+        }
         bv_launch_pass2(ac, st);
         BV_HIP(e, hipGetLastError());
         bv_launch_p2g_solve16(ac, st);
         BV_HIP(e, hipGetLastError());
+
     }
     if (ev) BV_HIP(e, hipEventRecord(ev[2], st));
 

@@ -679,8 +679,8 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             // candidates waits.  The last solver job then ends 45 us earlier, but HBM idles while twelve waves solve: 168 against
             // 175 M sites/s, interleaved.  The four solver waves keep the solving; the others stream what is there.)
             bool solve_first = false;
-#ifdef BV_F_SOLVE_FIRST
-            if (FUSE2 && kind == 0u && (st & CUR_DONE)) {
+#ifdef BV_F_SOLVE_FIRST  /* = m: the waves w with w % m == 0 */
+            if (FUSE2 && kind == 0u && (st & CUR_DONE) && (wave % BV_F_SOLVE_FIRST) == 0) {
                 const uint32_t need = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
                 solve_first = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= need ||
                               bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= need;
@@ -1088,6 +1088,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #pragma unroll 1
     for (;;) {
         if (streaming) {
+            // (the wave's variant sites since its last flush sit in its ring's LDS: out before rows stream through it again)
+            if (v.n_vl) bv_f_flush_vl(a, v, lane);
 #ifdef BV_F_STREAM_PRIO
             __builtin_amdgcn_s_setprio(BV_F_STREAM_PRIO);
 #endif

@@ -185,6 +185,24 @@ def test_short_row_group_kernels_with_many_sites_per_wave(bv, restatement):
         assert np.array_equal(got.groups["af"][shallow].view(np.uint64), gexp["af"][shallow].view(np.uint64))
 
 
+
+@pytest.mark.parametrize("grid_limit", [0, 2], ids=["full_grid", "two_workgroups"])
+def test_fused_short_row_kernel_feeds_the_group_kernels(bv, restatement, grid_limit):
+    """Rows of 4,097-49,152 samples with pop-groups: ONE persistent kernel does pass 1 and streams the variant sites' rank-sum rows
+    (csrc/bv_pass1_fused.hip), the group kernels that follow walk the variant list it leaves.  A streaming wave that solves
+    while it waits for a variant row keeps its variant sites in the LDS of its ring -- they must be out before rows stream
+    through that ring again (round 4: they were not; the list held garbage that only the group kernels read).  Few workgroups
+    make every wave go back and forth many times."""
+    n, S = 6000, 3000
+    slab = make_slab(S, n, seed=321, coverage=0.12, class_af=[(0.3, 0.0), (0.2, 0.1), (0.0, 0.0), (0.05, 0.0)], n_groups=2)
+    maf = bv.min_af(n)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=grid_limit << 16)
+    got = eng.lrt(slab)
+    eng.close()
+    check(got, exp, gexp, margins)
+    assert got.n_variant > 1000 and ((got.sites["status"] & 0x10) != 0).sum() == got.n_variant
+
 def test_short_row_group_tally_with_invalid_bytes(bv):
     """Call bytes above 15 and phred bytes above 127 leave the packed index of the streaming group tally: such slots are
     tallied cell by cell, with the result of the plain-load kernels (flag 0x20 | 0x10: every group solved by one wave)."""
