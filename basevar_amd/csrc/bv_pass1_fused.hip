@@ -844,6 +844,12 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             if (lane == 0 && !(st & P1_FIN)) sh.pub[wave] = mark;
         }
 
+#ifdef BV_ABL_F_NOEPI   /* attribution builds only: no totals, no candidate test (results are wrong) */
+        if (is_p1) {
+            if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = hist[lane * 37];
+            prev_site = site; prev_kind = 1u; wsel = 1u;
+        } else
+#endif
         if (is_p1) {
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
@@ -1002,12 +1008,14 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         }
         }
         // ---- hand the histogram back, zeroed
+#ifndef BV_ABL_F_NOZERO  /* attribution builds only */
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
             for (int i = 0; i < BV_S_HWORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
             if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
         }
+#endif
         bv_lrt_sync<0>();
         if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; st &= ~N_HAVE; }
         else st &= ~C_HAVE;
@@ -1099,7 +1107,11 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #endif
             if (sst & BV_FS_P_DONE) streaming = false;
         }
+#ifdef BV_F_EXSTREAM_PRIO0  /* measurement: streaming waves solve at priority 0, only the dedicated solver waves above it */
+        if (!is_stream) __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
+#else
         __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
+#endif
         const int r = bv_f_solver_step(a, sh, v, B0, B1, lane);
         __builtin_amdgcn_s_setprio(0);
         if (streaming) {
