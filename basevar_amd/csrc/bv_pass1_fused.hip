@@ -80,6 +80,18 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_FC_QV_TAIL 9                   /* variant sites whose rank-sum rows (pass 2) are to be streamed */
 #define BV_FC_QV_HEAD 10
 #define BV_FC_BUSY 11                     /* solver jobs in flight (each may still add to the variant queue) */
+#define BV_FC_XVALID 12                   /* chunks of the shared tail this workgroup has acquired */
+#define BV_FC_XBLK_HEAD 13                /* ... and how many of them the solvers have finished (their non-candidate sites) */
+// The shared tail (-DBV_F_SHARED_TAIL; measured and OFF by default).  A workgroup owns a contiguous range of sites; with the
+// switch the last eighth of a launch's sites is dealt in chunks of BV_F_XCH sites from a global counter as workgroups run out of
+// their own -- the XCDs stream at rates 7 % apart and workgroups of one XCD up to 8 %, and with static ranges the pass-1 rows end
+// 30 us apart.  Measured (100 k sites x 10 k samples, interleaved): the pass-1 rows then end within 21 us instead of 30, but the
+// median moves up by as much (a chunk's acquisition drains the acquiring wave's ring, the others wait for its first site
+// number), and the launch lasts as long as its last VARIANT rows, which stay with the workgroup that solved them: 166-174
+// against 175-176 M sites/s.  Records are the same either way (the GPU tests pass with it on).
+#define BV_F_XCH 16u                      /* sites per chunk of the shared tail */
+#define BV_F_XCAP 64u                     /* chunks a workgroup can take (1,024 sites) */
+#define BV_F_XDONE 0xFFFFFFFEu            /* the shared tail is exhausted */
 // a streaming wave's flags that outlive a call of bv_f_stream_until_idle
 #define BV_FS_P_DONE 1u                   /* no row will ever come again */
 #define BV_FS_CUR_DONE 8u                 /* the cursor is exhausted */
@@ -105,6 +117,7 @@ struct __attribute__((aligned(16))) BvFusedShared {
     uint32_t q3[BV_F_QCAP], q2[BV_F_QCAP];
     uint32_t qv[BV_F_QVCAP][4];                          // site, class table, n_ref | n_alt << 16, 2-bit lut
     uint32_t pub[BV_F_NS];                               // every pass-1 row of wave w below site pub[w] is published
+    uint32_t xbase[BV_F_XCAP], xdone[BV_F_XCAP];         // shared-tail chunks of this workgroup: first site; rows published
     uint32_t ctl[16];
 };
 static_assert(sizeof(BvFusedShared) <= 160 * 1024, "one workgroup per CU must fit the LDS");
@@ -181,6 +194,39 @@ __device__ __forceinline__ uint32_t bv_f_lds_cas_wave(uint32_t lds_addr, uint32_
         "s_mov_b64 exec, %[sv]"
         : [r] "=&s"(r), [tc] "=&v"(tc), [td] "=&v"(td), [sv] "=&s"(sv)
         : [adr] "v"(lds_addr), [cmp] "s"(expect), [val] "s"(desired)
+        : "memory");
+    return r;
+}
+// one LDS word written by lane 0 (no divergent branch for the compiler to see)
+__device__ __forceinline__ void bv_f_lds_write_wave(uint32_t lds_addr, uint32_t v) {
+    uint32_t t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %[t], %[val]\n\t"
+        "ds_write_b32 %[adr], %[t]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [t] "=&v"(t), [sv] "=&s"(sv)
+        : [adr] "v"(lds_addr), [val] "s"(v)
+        : "memory");
+}
+// One wave-level fetch-and-add on a word of device memory by lane 0, the old value in an SGPR (as the compiler emits a returning
+// agent-scope atomicAdd: `global_atomic_add ... sc0`), waited for inside the statement: the wave's LDS-DMA ring drains with it.
+__device__ __forceinline__ uint32_t bv_f_global_fetch_add_wave(const uint32_t *p, uint32_t v) {
+    uint32_t r, t, z;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "v_mov_b32 %[t], %[val]\n\t"
+        "v_mov_b32 %[z], 0\n\t"
+        "global_atomic_add %[t], %[z], %[t], %[base] sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[r], %[t]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [r] "=&s"(r), [t] "=&v"(t), [z] "=&v"(z), [sv] "=&s"(sv)
+        : [val] "s"(v), [base] "s"(p)
         : "memory");
     return r;
 }
@@ -410,6 +456,15 @@ __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedSha
     bv_lrt_sync<0>();
 }
 
+// the site number of the c-th site this workgroup handles: its own range first, then its chunks of the shared tail in the order
+// it acquired them (c must lie in a chunk that is acquired)
+__device__ __forceinline__ uint32_t bv_f_site_of(BvFusedShared &sh, uint32_t B0, uint32_t B1, uint32_t c) {
+    const uint32_t n_static = B1 - B0;
+    if (c < n_static) return B0 + c;
+    const uint32_t e = c - n_static;
+    return bv_f_lds_read_u(&sh.xbase[(e / BV_F_XCH) & (BV_F_XCAP - 1u)]) + (e % BV_F_XCH);
+}
+
 // One unit of solver work, in this order: a job of candidates with three or four active bases (the longest jobs), a job of
 // the others, (waves with the big scratch, once every streaming wave is past its last pass-1 row) a wave-solver candidate,
 // a block of 64 non-candidate sites that every streaming wave has passed.  Returns 1: did something; 0: nothing to do right
@@ -436,7 +491,7 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
         if (n == 0u && v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
             (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, 1u, first, lane)) != 0u) {
             // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
-            const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[B0 + first]));
+            const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[bv_f_site_of(sh, B0, B1, first)]));
             bv_f_job_hard(a, sh, v, site, lane);
         }
         if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
@@ -470,12 +525,28 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
             }
         }
     }
+    {
+        // a chunk of the shared tail whose rows are all published: its non-candidate sites, one lane each (chunks complete in
+        // the order they were acquired, near enough: they are finished in that order)
+        const uint32_t xh = bv_f_lds_read_u(&sh.ctl[BV_FC_XBLK_HEAD]);
+        if (xh < bv_f_lds_read_u(&sh.ctl[BV_FC_XVALID]) && bv_f_lds_read_u(&sh.xdone[xh]) == BV_F_XCH) {
+            uint32_t old = 0;
+            if (lane == 0) old = atomicCAS(&sh.ctl[BV_FC_XBLK_HEAD], xh, xh + 1u);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            if (old == xh) {
+                const uint32_t site = bv_f_lds_read_u(&sh.xbase[xh]) + (uint32_t)lane;
+                if ((uint32_t)lane < BV_F_XCH) bv_p1s_simple_site<true>(a, v.sa.lnfact, site);
+            }
+            return 1;
+        }
+    }
     if (n_done == (uint32_t)BV_F_NS) {
         // nothing was claimable a moment ago and no producer is left: done, unless a queue got its last entries in between
         const bool q_left = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) ||
                             bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) ||
                             (v.big != nullptr && bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD])) ||
-                            bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks;
+                            bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks ||
+                            bv_f_lds_read_u(&sh.ctl[BV_FC_XBLK_HEAD]) < bv_f_lds_read_u(&sh.ctl[BV_FC_XVALID]);
         if (!q_left && v.n_vl) bv_f_flush_vl(a, v, lane);
         return q_left ? 1 : 2;
     }
@@ -495,11 +566,14 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
 // the workgroup's slice of cand_list in HBM (unbounded: they are taken up only when every streaming wave is past its last
 // pass-1 row, see bv_f_solver_step, so no streaming wave ever waits on them); that store is one more in the vmcnt queue than
 // the slot waits allow for -- a conservative wait, never a wrong one.
-__device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, uint32_t site, uint32_t kind, int lane) {
+__device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, uint32_t B1, uint32_t site, uint32_t xk, uint32_t kind,
+                                             int lane) {
+    // a row of a shared-tail chunk: one more of the chunk's rows is out (the solvers finish its non-candidates when all are)
+    if (xk != 0xFFFFFFFFu && lane == 0) atomicAdd(&sh.xdone[xk], 1u);
     if (kind < 2u) return;
     if (kind == 4u) {
         const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QH_TAIL], 1u);
-        if (lane == 0) a.cand_list[B0 + pos] = site;
+        if (lane == 0) a.cand_list[bv_f_site_of(sh, B0, B1, pos)] = site;  // (a slot per site handled: the list cannot outgrow them)
     } else if (kind == 3u) {
         bv_f_push((bv_lds_vu32 *)sh.q3, (bv_lds_u32 *)&sh.ctl[BV_FC_Q3_TAIL], site, lane);
     } else {
@@ -592,10 +666,11 @@ __device__ __forceinline__ void bv_f_stash_flush(const BvP1ShortArgs &a, BvFused
 #define BV_F_GLOBAL(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
 template <bool FUSE2>
 __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
-                                                                     uint32_t B1_, uint32_t st_in_) {
+                                                                     uint32_t B1_, uint32_t tail0_, uint32_t st_in_) {
     const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
     const int wave = __builtin_amdgcn_readfirstlane((int)wave_);
     const uint32_t B0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B0_), B1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B1_);
+    const uint32_t tail0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail0_);  // first site of the shared tail (= n_sites: none)
     uint32_t st_io = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_in_);
     BvFusedShared &sh = *(BvFusedShared *)(__attribute__((address_space(3))) BvFusedShared *)(uintptr_t)sh_lds;
     BvP1ShortArgs a;
@@ -658,13 +733,14 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     uint32_t ring_w = 0, ring_r = 0, inflight = 0;
     // rows drawn: the one being tallied and the one after it (the prefetch runs at most one row ahead: every row has >= BV_F_K slots)
     // x / y: pass 1: reference base / -; pass 2: class table / n_ref | n_alt << 16; z: pass 2: the sweeps' 2-bit table
-    uint32_t c_site = 0, c_kind = 0, c_x = 0, c_y = 0, c_z = 0, n_site = 0, n_kind = 0, n_x = 0, n_y = 0, n_z = 0;
+    // k: pass 1: the row's chunk of the shared tail (its slot in xbase), or ~0 for a row of the workgroup's own range
+    uint32_t c_site = 0, c_kind = 0, c_x = 0, c_y = 0, c_z = 0, c_k = 0, n_site = 0, n_kind = 0, n_x = 0, n_y = 0, n_z = 0, n_k = 0;
     uint32_t st = st_io;
     constexpr uint32_t P_DONE = BV_FS_P_DONE, C_HAVE = 2u, N_HAVE = 4u, CUR_DONE = BV_FS_CUR_DONE, P1_FIN = BV_FS_P1_FIN;
     auto issue = [&]() __attribute__((always_inline)) {
         if (p_left == 0u) {
             if (st & P_DONE) return;
-            uint32_t s = 0, kind = 0, x = 0, y = 0, z = 0;
+            uint32_t s = 0, kind = 0, x = 0, y = 0, z = 0, xk = 0xFFFFFFFFu;
             // the next row: a pass-1 row while the cursor has any -- unless the variant queue is filling up (the solvers wait
             // on a full one) --, else a variant site's pass-2 row
             bool p2_first = false;
@@ -672,8 +748,30 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
                 p2_first = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) >= BV_F_QV_HIGH;
             if (!(st & CUR_DONE) && !p2_first) {
                 const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, 1u);
-                if (c >= B1 - B0) st |= CUR_DONE;
-                else { s = B0 + c; kind = BV_FK_P1; x = bv_f_ref_scalar(a.ref_base, s); }
+                if (c < B1 - B0) { s = B0 + c; kind = BV_FK_P1; }
+                else if (tail0 >= a.n_sites || (c - (B1 - B0)) / BV_F_XCH >= BV_F_XCAP) st |= CUR_DONE;
+                else {
+                    // past the workgroup's own range: the (c - n)-th site of its chunks of the shared tail.  The wave that draws
+                    // a chunk's first site acquires the chunk (one returning global atomic: its ring drains -- once per
+                    // BV_F_XCH rows of the tail); the others wait for the chunk's first site number to appear in LDS.
+                    const uint32_t e = c - (B1 - B0), k = e / BV_F_XCH, o = e % BV_F_XCH;
+                    uint32_t base;
+                    if (o == 0u) {
+                        const uint32_t g = bv_f_global_fetch_add_wave(&a.counters[BV_CTR_TICKET], 1u);
+                        base = ((uint64_t)tail0 + (uint64_t)g * BV_F_XCH < (uint64_t)a.n_sites) ? tail0 + g * BV_F_XCH : BV_F_XDONE;
+                        // (lane-0 side effects through statements that hide the branch: a divergent `if (lane == 0)` in this
+                        // lambda makes the compiler treat the ring's scalar state as per-lane)
+                        bv_f_lds_write_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.xbase[k], base);
+                        (void)bv_lds_fetch_add_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_XVALID], base != BV_F_XDONE ? 1u : 0u);
+                    } else {
+                        base = BV_F_EMPTY;
+                        for (uint32_t spins = 0; (base = bv_f_lds_read_u(&sh.xbase[k])) == BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(4);
+                        if (base == BV_F_EMPTY) { (void)bv_f_global_fetch_add_wave(&a.counters[BV_CTR_TIMEOUT], 1u); base = BV_F_XDONE; }
+                    }
+                    if (base == BV_F_XDONE) st |= CUR_DONE;
+                    else { s = base + o; kind = BV_FK_P1; xk = k; }
+                }
+                if (kind == BV_FK_P1) x = bv_f_ref_scalar(a.ref_base, s);
             }
             // (Measured and off: a wave past its pass-1 rows that SOLVES before it streams -- no row drawn while a job's worth of
             // candidates waits.  The last solver job then ends 45 us earlier, but HBM idles while twelve waves solve: 168 against
@@ -716,8 +814,8 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             if (kind == BV_FK_P1) { p1 = bv_uniform_ptr(a.q + off); p_left = n_slots1; }
             else { p1 = bv_uniform_ptr(a.mapq + off); p2 = bv_uniform_ptr(reinterpret_cast<const uint8_t *>(a.rpr) + 2u * off); p_left = n_slots2; }
             p_kind = kind;
-            if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; st |= C_HAVE; }
-            else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; st |= N_HAVE; }
+            if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; c_k = xk; st |= C_HAVE; }
+            else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; n_k = xk; st |= N_HAVE; }
         }
         const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
         if (!FUSE2 || p_kind == BV_FK_P1) {
@@ -733,7 +831,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     };
 
     // the previous pass-1 row of this wave: published once its stores are known to be complete
-    uint32_t prev_site = 0, prev_kind = 0;  // kind 0: none; 1: not a candidate; 2 / 3: queue q2 / q3; 4: wave solver
+    uint32_t prev_site = 0, prev_kind = 0, prev_x = 0xFFFFFFFFu;  // kind 0: none; 1: not a candidate; 2 / 3: queue q2 / q3; 4: wave solver
     uint32_t wsel = 0;                      // stores of the previous row still to be allowed for in the slot waits: 0 none / unknown, 1, 3
     BvFusedStash stash;
     stash.site = 0; stash.n12 = 0; stash.tw_m = 0; stash.tw_r = 0; stash.n = 0;
@@ -742,7 +840,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         if (prev_kind != 0u) {
             if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+            bv_f_publish(a, sh, B0, B1, prev_site, prev_x, prev_kind, lane);
             if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its cand_list entry; rare)
             prev_kind = 0;
         }
@@ -836,18 +934,20 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         if (prev_kind != 0u) {
             if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+            bv_f_publish(a, sh, B0, B1, prev_site, prev_x, prev_kind, lane);
             prev_kind = 0;
             // every pass-1 row of this wave below its next one is out: the row of this epilogue, or the one already drawn, or
             // -- none drawn -- whatever the cursor hands out next (the end of the pass-1 rows sets the mark to "all")
-            uint32_t mark = is_p1 ? site : (((st & N_HAVE) && n_kind == BV_FK_P1) ? n_site : B0 + bv_f_lds_read_u(&sh.ctl[BV_FC_CURSOR]));
+            // (a cursor past the workgroup's own range: everything of that range this wave had is out)
+            const uint32_t cur_now = bv_f_lds_read_u(&sh.ctl[BV_FC_CURSOR]);
+            uint32_t mark = is_p1 ? site : (((st & N_HAVE) && n_kind == BV_FK_P1) ? n_site : (cur_now < B1 - B0 ? B0 + cur_now : 0xFFFFFFF0u));
             if (lane == 0 && !(st & P1_FIN)) sh.pub[wave] = mark;
         }
 
 #ifdef BV_ABL_F_NOEPI   /* attribution builds only: no totals, no candidate test (results are wrong) */
         if (is_p1) {
             if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = hist[lane * 37];
-            prev_site = site; prev_kind = 1u; wsel = 1u;
+            prev_site = site; prev_x = c_k; prev_kind = 1u; wsel = 1u;
         } else
 #endif
         if (is_p1) {
@@ -981,7 +1081,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             w = (lane == 9) ? fl : w;
             if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
         }
-        prev_site = site;
+        prev_site = site; prev_x = c_k;
         prev_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
         wsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_stores);
         } else {
@@ -1017,7 +1117,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         }
 #endif
         bv_lrt_sync<0>();
-        if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; st &= ~N_HAVE; }
+        if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; c_k = n_k; st &= ~N_HAVE; }
         else st &= ~C_HAVE;
         // the last pass-1 row of this wave is behind it: publish it, count the wave
         if ((st & CUR_DONE) && !(st & P1_FIN) && !((st & C_HAVE) && c_kind == BV_FK_P1) && !((st & N_HAVE) && n_kind == BV_FK_P1)) finish_p1();
@@ -1025,10 +1125,13 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     // ---- no row in flight: the ring is idle
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (prev_kind != 0u) {  // (a pass-1 row whose successor was not drawn yet: the variant queue had priority and was emptied by another wave)
-        bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
+        bv_f_publish(a, sh, B0, B1, prev_site, prev_x, prev_kind, lane);
         if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         prev_kind = 0;
-        if (lane == 0 && !(st & (P1_FIN | CUR_DONE))) sh.pub[wave] = B0 + bv_f_lds_read_u(&sh.ctl[BV_FC_CURSOR]);
+        if (lane == 0 && !(st & (P1_FIN | CUR_DONE))) {
+            const uint32_t cur_now = bv_f_lds_read_u(&sh.ctl[BV_FC_CURSOR]);
+            sh.pub[wave] = cur_now < B1 - B0 ? B0 + cur_now : 0xFFFFFFF0u;
+        }
     }
     if ((st & CUR_DONE) && !(st & P1_FIN)) finish_p1();
     if (FUSE2 && stash.n != 0u) bv_f_stash_flush(a, stash, lane);
@@ -1045,7 +1148,19 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const uint32_t B0 = (uint32_t)((uint64_t)a.n_sites * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)a.n_sites * (blockIdx.x + 1) / gridDim.x);
+    // the workgroups' own contiguous ranges cover [0, tail0); the last eighth of the sites (in chunks of BV_F_XCH, at most half of
+    // what the workgroups' chunk tables hold) is the shared tail, dealt from a global counter to whoever is done with its own
+    uint32_t tail_sites = 0;
+#ifdef BV_F_SHARED_TAIL  /* measured, off: see BV_F_XCH */
+    if (a.n_sites >= gridDim.x * 128u) {
+        tail_sites = a.n_sites / 8u;
+        const uint32_t most = gridDim.x * (BV_F_XCAP * BV_F_XCH / 2u);
+        if (tail_sites > most) tail_sites = most;
+        tail_sites &= ~(BV_F_XCH - 1u);
+    }
+#endif
+    const uint32_t tail0 = a.n_sites - tail_sites;
+    const uint32_t B0 = (uint32_t)((uint64_t)tail0 * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)tail0 * (blockIdx.x + 1) / gridDim.x);
     // ---- set-up: histograms zeroed, queues empty, tables in LDS; nothing is in flight yet, so a plain barrier is fine
     if (wave < BV_F_NS) {
         uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[wave]);
@@ -1055,6 +1170,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     }
     for (int i = tid; i < BV_F_QCAP; i += BV_WAVE * BV_F_NW) { sh.q3[i] = BV_F_EMPTY; sh.q2[i] = BV_F_EMPTY; }
     for (int i = tid; i < BV_F_QVCAP; i += BV_WAVE * BV_F_NW) sh.qv[i][0] = BV_F_EMPTY;
+    for (int i = tid; i < (int)BV_F_XCAP; i += BV_WAVE * BV_F_NW) { sh.xbase[i] = BV_F_EMPTY; sh.xdone[i] = 0u; }
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_F_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
@@ -1101,7 +1217,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #ifdef BV_F_STREAM_PRIO
             __builtin_amdgcn_s_setprio(BV_F_STREAM_PRIO);
 #endif
-            sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
+            sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, tail0, sst));
 #ifdef BV_F_STREAM_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
