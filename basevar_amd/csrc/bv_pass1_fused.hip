@@ -434,6 +434,11 @@ __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedSha
     S.nb = nb;
     bv_lrt_sync<0>();
     BvHqMerged H{hq};
+    if (a.ch != nullptr) {  // chained launch: the ordered gather of a shallow site reads the segment's (biased) planes
+        const BvChainC ch = bv_chain_const(a.ch);
+        const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
+        v.sa.bs = ch->bs[sg]; v.sa.q = ch->q[sg];
+    }
     if (bv_site_solve<false, BvHqMerged, true>(v.sa, site, S, bin_code, bin_cnt, H, sv, sh.tab_hit, sh.tab_miss, lane)) {
         if (lane == 0) v.vl[v.n_vl] = site;
         ++v.n_vl;
@@ -684,7 +689,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         a.var_list = BV_F_GLOBAL(uint32_t, ka->var_list); a.counters = BV_F_GLOBAL(uint32_t, ka->counters);
         a.summ = BV_F_GLOBAL(BvSiteSummary, ka->summ); a.bins = BV_F_GLOBAL(uint32_t, ka->bins);
         a.cand_list = BV_F_GLOBAL(uint32_t, ka->cand_list); a.easy_list = BV_F_GLOBAL(uint32_t, ka->easy_list);
-        a.easy3_list = BV_F_GLOBAL(uint32_t, ka->easy3_list); a.ch = nullptr;
+        a.easy3_list = BV_F_GLOBAL(uint32_t, ka->easy3_list); a.ch = BV_F_GLOBAL(const BvChain, ka->ch);
         a.mapq = BV_F_GLOBAL(const uint8_t, ka->mapq); a.rpr = BV_F_GLOBAL(const uint16_t, ka->rpr);
 #ifdef BV_TL_DEBUG
         a.tl = nullptr;
@@ -810,9 +815,17 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
                 return;
             }
             const uint64_t off = (uint64_t)s * a.pitch;
-            p0 = bv_uniform_ptr(a.bs + off);
-            if (kind == BV_FK_P1) { p1 = bv_uniform_ptr(a.q + off); p_left = n_slots1; }
-            else { p1 = bv_uniform_ptr(a.mapq + off); p2 = bv_uniform_ptr(reinterpret_cast<const uint8_t *>(a.rpr) + 2u * off); p_left = n_slots2; }
+            // (a chained launch: the planes of the segment that holds the site, biased so that the global site number indexes
+            // them -- read through the constant address space: scalar loads, outside the counted vmcnt queue)
+            const uint8_t *r_bs = a.bs, *r_q = a.q, *r_mq = a.mapq, *r_rp = reinterpret_cast<const uint8_t *>(a.rpr);
+            if (a.ch != nullptr) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, s);
+                r_bs = ch->bs[sg]; r_q = ch->q[sg]; r_mq = ch->mapq[sg]; r_rp = reinterpret_cast<const uint8_t *>(ch->rpr[sg]);
+            }
+            p0 = bv_uniform_ptr(r_bs + off);
+            if (kind == BV_FK_P1) { p1 = bv_uniform_ptr(r_q + off); p_left = n_slots1; }
+            else { p1 = bv_uniform_ptr(r_mq + off); p2 = bv_uniform_ptr(r_rp + 2u * off); p_left = n_slots2; }
             p_kind = kind;
             if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; c_k = xk; st |= C_HAVE; }
             else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; n_k = xk; st |= N_HAVE; }
@@ -1091,7 +1104,14 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         const unsigned long long n12 = (unsigned long long)(c_y & 0xFFFFu) + (unsigned long long)(c_y >> 16);
         if (__ballot(hi_acc != 0u) != 0ull) {
             // a rank >= 256 somewhere in the row (long reads): re-done at once by the exact window sweeps (the ring drains -- rare)
-            bv_f_p2_redo(a.bs, a.mapq, a.rpr, a.out, a.pitch, a.n_samples, site, c_z, c_y, (uint32_t)(uintptr_t)(bv_lds_u32 *)hist);
+            const uint8_t *r_bs = a.bs, *r_mq = a.mapq;
+            const uint16_t *r_rp = a.rpr;
+            if (a.ch != nullptr) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, site);
+                r_bs = ch->bs[sg]; r_mq = ch->mapq[sg]; r_rp = ch->rpr[sg];
+            }
+            bv_f_p2_redo(r_bs, r_mq, r_rp, a.out, a.pitch, a.n_samples, site, c_z, c_y, (uint32_t)(uintptr_t)(bv_lds_u32 *)hist);
         } else {
             uint32_t *hm = hist, *hr = hist + 512;
             unsigned long long below = 0, twoR = 0;
@@ -1248,10 +1268,10 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 
 // ------------------------------------------------------------------------------ launcher
 bool bv_p1s_fused_takes(const BvP1ShortArgs &a) {
-    // rows of at least BV_F_K slots (the prefetch then never runs more than one row ahead); chained launches keep the
-    // two-kernel form (their planes come per segment)
+    // rows of at least BV_F_K slots (the prefetch then never runs more than one row ahead); chained launches too (the planes of
+    // a row are looked up per segment where its address is formed; ref_base / out are the engine's contiguous copies)
     const uint32_t n_chunks = (a.n_samples + 15u) >> 4, n_slots = (n_chunks + 127u) >> 7;
-    return a.ch == nullptr && n_slots >= (uint32_t)BV_F_K && a.n_samples <= BV_SHORT_ROW_MAX;
+    return n_slots >= (uint32_t)BV_F_K && a.n_samples <= BV_SHORT_ROW_MAX;
 }
 void bv_launch_p1s_fused(const BvP1ShortArgs &a, hipStream_t stream) {
     const uint32_t cu = a.n_cu ? a.n_cu : 256u;

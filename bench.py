@@ -439,7 +439,7 @@ def main():
         # rows too: its algorithmic bytes are then section 8d's S*N*(2 + 3 f_var) (its traffic 2 + 4 f_var: the call byte of a
         # variant row is read twice).  Flag bits 12-15: 9 = the round-3 kernels, 10 = pass 2 a launch of its own.
         tune = (args.flags >> 12) & 0xF
-        fused = two_kernel and K == 1 and tune in (0, 10) and ((args.flags >> 24) & 0xF) <= 1 and (((N + 15) // 16 + 127) // 128) >= 3
+        fused = two_kernel and tune in (0, 10) and ((args.flags >> 24) & 0xF) <= 1 and (((N + 15) // 16 + 127) // 128) >= 3
         fused_p2 = fused and tune == 0 and ranks and args.groups <= 7 and not (args.flags & 0x20)  # (groups: their tallies stream in pass 2's own launch)
         kernel_bytes = algo_bytes * ((1.0 + 1.5 * fvar) if fused_p2 else 1.0)
         if fused:

@@ -99,7 +99,14 @@ def test_bench_chained_batches(samples):
     d = json.loads(lines[0])
     assert d["config"]["chain"] == 4 and d["config"]["batch_sites"] == 1024 and d["config"]["sites_per_launch"] == 4096
     assert d["roofline"]["launches"] == 3 and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
-    assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.0 * 4096 * samples
+    if samples > 49152:
+        assert d["roofline"]["algorithmic_bytes_per_launch"] == 2.0 * 4096 * samples  # pass 1: 2 B per cell
+    else:
+        # short rows: ONE kernel streams pass 1 and the variant sites' rank-sum rows: 2 B per cell + 3 B per cell of variant rows
+        assert d["roofline"]["kernel"] == "bv_p1s_fused_kernel"
+        nvar = d["config"]["variant_sites_last_batch"]
+        assert 0 < nvar <= 4096
+        assert d["roofline"]["algorithmic_bytes_per_launch"] == pytest.approx((2.0 * 4096 + 3.0 * nvar) * samples, rel=1e-9)
 
 
 def _n_devices():

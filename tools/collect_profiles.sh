@@ -58,7 +58,7 @@ run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more th
 run_cfg n100k_chain16 --batch-sites 8192 --chain 16                    # small batches chained: bv_pass1_kernel<3,1,true>
 run_cfg n100k_8192 --batch-sites 8192 --steps 20                       # ... and one launch per small batch
 run_cfg n100k_8192_lanes2 --batch-sites 8192 --steps 20 --lanes 2      # ... through the engine's two lanes
-run_cfg n10k_chain16 --samples 10000 --batch-sites 8192 --chain 16     # short rows chained: bv_p1s_stream_kernel<4,3,2,true>, bv_chain_* kernels
+run_cfg n10k_chain16 --samples 10000 --batch-sites 8192 --chain 16     # short rows chained: bv_p1s_fused_kernel<true> over the queue, bv_chain_* kernels
 run_cfg n10k_8192 --samples 10000 --batch-sites 8192 --steps 30
 run_cfg tiles_joined_1M --samples 1000000 --batch-sites 8192 --tile-sites 8192 --with-tile-mode --steps 2 --warmup 1   # bv_tile_join_rows_kernel (bv_engine_tiles_add_many), bv_tile_scatter_kernel (tile by tile)
 run_cfg tiles_state_100k --samples 100000 --batch-sites 16384 --tile-sites 16384 --with-tile-mode --flags 8 --steps 2 --warmup 1   # bv_tile_tally_kernel, bv_tile_finish_kernel
