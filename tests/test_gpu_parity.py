@@ -186,6 +186,26 @@ def test_short_row_group_kernels_with_many_sites_per_wave(bv, restatement):
 
 
 
+@pytest.mark.parametrize("n", [4097, 6143, 6144, 6145, 8193, 10007, 12289, 20481, 32767, 49151])
+def test_fused_short_row_kernel_at_slot_boundaries(bv, restatement, n):
+    """Row lengths around the slot geometry of csrc/bv_pass1_fused.hip: pass-1 slots of 2,048 cells (a last slot that holds one
+    chunk, a full one, a second KiB that lies wholly past the row's end), pass-2 slots of 1,024 cells, rows that end inside a
+    16-byte chunk -- every record and both rank sums against the reference, with a grid of two workgroups too (streaming
+    waves that go back and forth between rows and solver jobs)."""
+    S = 192
+    slab = make_slab(S, n, seed=1000 + n, coverage=0.1, class_af=[(0.3, 0.0), (0.1, 0.1), (0.0, 0.0), (0.02, 0.0)], ref_n_frac=0.02)
+    rng = np.random.default_rng(n)
+    slab["rpr"][5, :] = np.where(slab["base_strand"][5] < 8, rng.integers(1, 900, size=slab["rpr"].shape[1]), 0)  # a row past the 256-rank window
+    maf = bv.min_af(n)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    for flags in (0, 2 << 16):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=flags)
+        got = eng.lrt(slab)
+        eng.close()
+        check(got, exp, gexp, margins)
+        assert got.n_variant > 60 and ((got.sites["status"] & 0x10) != 0).sum() == got.n_variant
+
+
 @pytest.mark.parametrize("grid_limit", [0, 2], ids=["full_grid", "two_workgroups"])
 def test_fused_short_row_kernel_feeds_the_group_kernels(bv, restatement, grid_limit):
     """Rows of 4,097-49,152 samples with pop-groups: ONE persistent kernel does pass 1 and streams the variant sites' rank-sum rows
