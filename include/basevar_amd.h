@@ -162,6 +162,11 @@ typedef struct bv_group_result {
                                      pipeline of n chunks of consecutive sites over two streams (solve kernels of chunk c under the
                                      streaming kernel of chunk c + 1); 0 = the engine's default (by batch size), 1 = no pipeline.
                                      Records do not depend on n. */
+#define BV_FLAG_SHORT_ROW_FORM(n) (((uint32_t)(n) & 0xFu) << 12) /* diagnostic / A-B runs: which kernels rows of 4,097 .. 49,152 samples take.
+                                     0 = the engine's default: ONE persistent kernel for pass 1 and the variant sites' rank-sum rows
+                                     (streaming and solver waves side by side; csrc/bv_pass1_fused.hip); 10 = that kernel for pass 1, pass 2 a
+                                     launch of its own; 9 = round 3's three launches (streaming kernel, solve kernel, pass-2 kernel).
+                                     Records do not depend on it. */
 #define BV_FLAG_HOST_ORDERED 0x80u /* BV_MEM_HOST planes: the engine's copy stream waits for everything queued on the caller's `stream`
                                      before it reads them (for callers that fill their pinned planes with asynchronous work on that
                                      stream).  Default (flag clear): host planes must be COMPLETE in host memory when bv_engine_submit /

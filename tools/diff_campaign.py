@@ -62,7 +62,9 @@ def main():
     tot_sites = tot_var = tot_amb = tot_bad = tot_exc_site = tot_exc_group = 0
     t0 = time.time()
     for it in range(rounds):
-        if os.environ.get("CAMPAIGN_SHALLOW") == "1":  # where order-dependent ties live: rows of a few covered samples
+        if os.environ.get("CAMPAIGN_FUSED") == "1":  # the row lengths of csrc/bv_pass1_fused.hip (4,097 .. 49,152 samples), ragged ones too
+            n = int(rng.choice([4097, 5000, 6145, 8191, 10000, 12289, 16400, 20003, 30000, 40000, 49151, 49152]))
+        elif os.environ.get("CAMPAIGN_SHALLOW") == "1":  # where order-dependent ties live: rows of a few covered samples
             n = int(rng.choice([8, 16, 37, 64, 120, 300, 1000]))
         else:
             n = int(rng.choice([37, 300, 2500, 10000, 40000, 49152, 49153, 60000, 120000, 300000, 1000000]))

@@ -1,8 +1,12 @@
 #!/bin/bash
 # the differential campaigns of a round against the real reference: tools/run_campaigns.sh <tag> [rounds per campaign]
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out
-TAG=${1:-r3}; R=${2:-30}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
+TAG=${1:-r4}; R=${2:-30}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
 run() { echo "### $1" >> $OUT; shift; env "$@" timeout 1500 python3 tools/diff_campaign.py $R 2>&1 | grep -E "TOTAL|tie-excused site [0-9]|MISMATCH|mismatching fields [1-9]" >> $OUT; }
+run "fused short-row kernel: rows of 4,097-49,152 samples, seed 61" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=61
+run "fused short-row kernel, seed 62" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=62
+run "fused short-row kernel, chained launches incl. pop-groups, seed 63" CAMPAIGN_FUSED=1 CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=63
+run "fused short-row kernel, two workgroups (BV_FLAG_GRID_LIMIT), seed 64" CAMPAIGN_FUSED=1 CAMPAIGN_FLAGS=$((2 << 16)) CAMPAIGN_SEED=64
 run "default shapes, seed 11" CAMPAIGN_SEED=11
 run "default shapes, seed 12" CAMPAIGN_SEED=12
 run "default shapes, seed 13" CAMPAIGN_SEED=13
