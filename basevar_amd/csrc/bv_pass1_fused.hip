@@ -40,7 +40,9 @@
 
 #include <type_traits>
 
+#ifndef BV_F_NS
 #define BV_F_NS 8                         /* streaming waves per workgroup */
+#endif
 #ifndef BV_F_NV
 #define BV_F_NV 4                         /* dedicated solver waves per workgroup */
 #endif
