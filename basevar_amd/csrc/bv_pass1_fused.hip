@@ -1,8 +1,10 @@
-// bv_pass1_fused.hip -- pass 1 for short rows (4,097 .. 49,152 samples per site) as ONE persistent kernel.
+// bv_pass1_fused.hip -- short rows (4,097 .. 49,152 samples per site): pass 1 and the variant sites' pass-2 rows as ONE
+// persistent kernel.
 //
-// bv_pass1_short.hip runs pass 1 as a streaming kernel followed by a solve kernel: while the first runs the chip's vector
-// units are ~40 % busy, while the second runs HBM is idle, and the second's 0.10 ms per 100 k sites (16 % of the step at
-// 10 k samples) is fully exposed.  Here both are roles of one workgroup of 12 waves (one per CU, three per SIMD):
+// bv_pass1_short.hip + bv_pass2.hip run these rows as three launches -- a streaming kernel, a solve kernel, the rank-sum
+// kernel of pass 2: while the first and third run the chip's vector units are ~40 % busy, while the second runs HBM is idle,
+// and its 0.10 ms per 100 k sites (16 % of the step at 10 k samples) is fully exposed.  Here all three are roles of one
+// workgroup of 12 waves (one per CU, three per SIMD):
 //
 //   waves 0-7  (stream)  draw sites from the workgroup's cursor and stream their rows through private LDS rings filled
 //                        by LDS-DMA, exactly one site per draw, three 4 KiB slots in flight per wave across row
@@ -15,19 +17,30 @@
 //                        so a candidate row no longer drains the ring.
 //   waves 8-11 (solve)   take the candidates from two queues in LDS (three or four active bases first), four sites per
 //                        wave on 16-lane groups (bv_solver16.h), and finish the non-candidate sites one lane per site in
-//                        blocks of 64 as soon as every streaming wave has passed them.
-//   at the end           a streaming wave that finds the cursor exhausted joins the solvers with its ring as scratch; only
-//                        these waves (12 KiB each) take the candidates that need the wave solver of bv_solver.h (shallow
-//                        sites, phred-0 calls, more than 128 bins).
+//                        blocks of 64 as soon as every streaming wave has passed them.  A variant site goes into a third
+//                        queue with what its rank sums need (class table, REF / ALT depths).
+//   pass-2 rows          (FUSE2: rank planes given) a streaming wave past its pass-1 rows takes variant sites from that queue
+//                        and streams calls + mapq + ranks through the same ring (again four 1 KiB pieces per slot: the
+//                        counted waits are unchanged), tallied as bv_pass2_dma_kernel tallies them; the solvers' last jobs
+//                        run UNDER these rows, and pass 2 has no launch, fill or drain of its own.
+//   no row to stream     a streaming wave whose ring is idle (waiting for a variant row, or done) solves with the ring as
+//                        scratch; only such waves (12 KiB each) take the candidates that need the wave solver of bv_solver.h
+//                        (shallow sites, phred-0 calls, more than 128 bins).
 //
 // Hand-off.  A row's summary and bins go to HBM scratch as before; they are PUBLISHED (queue entry / the wave's `pub` mark in
 // LDS) one row later, behind an s_waitcnt that covers exactly the stores of that row (vmcnt counts in issue order), and read
 // by the solvers through the L2 (sc1 loads; summaries of neighbouring sites share lines).  Producer and consumer are waves
-// of one CU: one L2, no cross-XCD visibility involved.  Streaming waves never wait for solver waves except on a full queue.
+// of one CU: one L2, no cross-XCD visibility involved.  Streaming waves never wait for solver waves except on a full queue,
+// and every such wait is bounded (BV_F_SPIN_MAX -> BV_CTR_TIMEOUT: a loud failure, not a hung GPU).
 //
-// Reference functions realised: those of bv_pass1_short.hip (src/basetype.cpp:22-295, src/algorithm.h:44-255,
-// htslib/kfunc.c:39-143,197-313); every record is byte-identical to the two-kernel form's (same bins, same order, same
-// solver code).  HBM-bound by design (2 B per cell, each byte read once); no MFMA (categorical tallies).
+// Two register allocations.  The streaming loop (bv_f_stream_until_idle) and the row re-do (bv_f_p2_redo) are functions of
+// their own, NOT inlined: see the comment at the first.  The solver step has one call site for both kinds of waves.
+//
+// Reference functions realised: those of bv_pass1_short.hip and bv_pass2_dma_kernel (src/basetype.cpp:22-295,
+// src/algorithm.h:44-255, htslib/kfunc.c:39-143,197-313; rank sums: src/basetype.cpp:201-242 via caller.cpp:1151-1154); every
+// record is byte-identical to the three-launch form's (same bins, same order, same solver code).  HBM-bound by design
+// (2 B per cell of every row + 4 B per cell of a variant row, the call byte of a variant row read twice); no MFMA
+// (categorical tallies).  Measurements, rejected variants: DESIGN.md section 4.3.
 #define BV_LNFACT_TABLE_ONLY 1  /* rows of at most 65,535 samples: see bv_lnfact */
 #include "bv_kernels.h"
 
