@@ -865,20 +865,30 @@ __device__ __noinline__ uint32_t bv_gather_ordered(const uint8_t *bs_row, const 
                                                   int lane, const uint8_t *gid = nullptr, uint32_t g = 0) {
     const uint32_t n_chunks = (n_samples + 15u) >> 4;
     uint32_t count = 0;
+    // a round is 64 chunks of 16 cells, one per lane: calls, phreds (and group ids) as 16-byte loads, the next round's issued
+    // before this round's cells are placed -- the walk is one wave's, its latency is the whole cost
+    bv_u32x4 nb_ = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u}, nq_ = bv_u32x4{0u, 0u, 0u, 0u}, ng_ = bv_u32x4{0u, 0u, 0u, 0u};
+    auto fetch = [&](uint32_t c0) {
+        const uint32_t chunk = c0 + (uint32_t)lane;
+        nb_ = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
+        if (chunk < n_chunks) {
+            nb_ = *reinterpret_cast<const bv_u32x4 *>(bs_row + (size_t)chunk * 16u);
+            nq_ = *reinterpret_cast<const bv_u32x4 *>(q_row + (size_t)chunk * 16u);
+            if (gid) ng_ = *reinterpret_cast<const bv_u32x4 *>(gid + (size_t)chunk * 16u);
+        }
+    };
+    fetch(0);
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += BV_WAVE) {
         const uint32_t chunk = c0 + (uint32_t)lane;
-        bv_u32x4 vb = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
-        bv_u32x4 vg = bv_u32x4{0u, 0u, 0u, 0u};
-        if (chunk < n_chunks) {
-            vb = *reinterpret_cast<const bv_u32x4 *>(bs_row + (size_t)chunk * 16u);
-            if (gid) vg = *reinterpret_cast<const bv_u32x4 *>(gid + (size_t)chunk * 16u);
-        }
-        const uint32_t wb[4] = {vb.x, vb.y, vb.z, vb.w}, wg[4] = {vg.x, vg.y, vg.z, vg.w};
+        const bv_u32x4 vb = nb_, vq = nq_, vg = ng_;
+        if (c0 + BV_WAVE < n_chunks) fetch(c0 + BV_WAVE);
         uint32_t mask = 0;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const uint32_t c = (wb[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-            const bool mine = !gid || ((wg[k >> 2] >> (8 * (k & 3))) & 0xFFu) == g;
+            const uint32_t wbk = (k >> 2) == 0 ? vb.x : (k >> 2) == 1 ? vb.y : (k >> 2) == 2 ? vb.z : vb.w;
+            const uint32_t wgk = (k >> 2) == 0 ? vg.x : (k >> 2) == 1 ? vg.y : (k >> 2) == 2 ? vg.z : vg.w;
+            const uint32_t c = (wbk >> (8 * (k & 3))) & 0xFFu;
+            const bool mine = !gid || ((wgk >> (8 * (k & 3))) & 0xFFu) == g;
             if (c < 8u && mine && chunk * 16u + (uint32_t)k < n_samples) mask |= 1u << k;
         }
         const uint32_t cnt = (uint32_t)__popc(mask);
@@ -888,8 +898,10 @@ __device__ __noinline__ uint32_t bv_gather_ordered(const uint8_t *bs_row, const 
             const int k = __builtin_ctz(mask);
             mask &= mask - 1u;
             if (pos < (uint32_t)BV_ORD_MAX) {
-                const uint32_t c = (wb[k >> 2] >> (8 * (k & 3))) & 0xFFu;
-                ord[pos] = (uint16_t)((c << 8) | q_row[(size_t)chunk * 16u + (uint32_t)k]);
+                const int wi = k >> 2, sh8 = 8 * (k & 3);
+                const uint32_t wbk = wi == 0 ? vb.x : wi == 1 ? vb.y : wi == 2 ? vb.z : vb.w;
+                const uint32_t wqk = wi == 0 ? vq.x : wi == 1 ? vq.y : wi == 2 ? vq.z : vq.w;
+                ord[pos] = (uint16_t)((((wbk >> sh8) & 0xFFu) << 8) | ((wqk >> sh8) & 0xFFu));
             }
             ++pos;
         }
@@ -998,6 +1010,7 @@ struct BvLrtOut {
     double chi2;     // last chi_sqrt_value
     int em_iters, n_em;
     bool zero_freq;
+    bool tie_risk;   // bv_lrt_g16<true> only: two subsets of one level scored within BV_TIE_TOL of each other (see there)
 };
 __device__ __forceinline__ int bv_alt_at(const BvLrtOut &o, int k) { return (o.alt_packed >> (2 * k)) & 3; }
 
@@ -1046,7 +1059,7 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
                               int nspec, int ref_code, double min_af, BvLrtShared *sh, int wave, int lane,
                               BvLrtOut &o, uint32_t q0_mask = 0xFu) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
-    o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false;
+    o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false; o.tie_risk = false;
     // active_bases as a packed ordered list: position k in bits [2k, 2k+1]
     int act = 0, m = 0;
     for (int k = 0; k < nspec; ++k) {

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     const int seen = (gd[0] != 0) + (gd[1] != 0) + (gd[2] != 0) + (gd[3] != 0);
                     const bool shal = gt <= (uint32_t)BV_ORD_MAX && seen >= 2;
                     const bool big = __ballot(cm > 0xFFFFu) != 0ull;
-                    const bool four = !shal && q0 == 0u && nbv <= (uint32_t)BV_G16_MAX_BINS && !big && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
+                    const bool four = q0 == 0u && nbv <= (uint32_t)BV_G16_MAX_BINS && !big && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
                     uint32_t *dst = a.gitems + ((size_t)v * a.n_groups + g) * BV_P2G_ITEM_WORDS;
                     if (gt != 0u) {
                         uint32_t pos0 = 0;
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                             pos0 += (uint32_t)__popcll(m);
                         }
                     }
-                    const uint32_t hdr = gt == 0u ? 0u : (nbv | (four ? BV_P2G_PENDING : BV_P2G_HARD | (shal ? BV_P2G_SHALLOW : 0u)));
+                    const uint32_t hdr = gt == 0u ? 0u : (nbv | (four ? BV_P2G_PENDING : BV_P2G_HARD) | (shal ? BV_P2G_SHALLOW : 0u));
                     uint32_t w = hdr;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) w = (lane == 1 + b) ? gd[b] : w;

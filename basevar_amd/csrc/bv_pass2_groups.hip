@@ -2,8 +2,9 @@
 // src/basetype_caller.cpp:756-759, 767-797) as kernels of their own:
 //   bv_p2g_stream_kernel   short rows: the per-group (base, phred) histograms of every variant row through an LDS-DMA ring
 //   bv_p2g_solve16_kernel  the group LRTs, four per wave (bv_solver16.h), for the items the tally kernels hand over
-//   bv_p2g_hard_kernel     the items that need the one-wave solver: shallow groups (the reference's per-sample order),
-//                          phred-0 calls, more than 128 bins, min_af <= 0
+//   bv_p2g_hard_kernel     the items that need the one-wave solver: phred-0 calls, more than 128 bins, min_af <= 0, and the
+//                          shallow groups (<= 64 covered samples) in which the four-per-wave solver met a tie: replayed in the
+//                          reference's per-sample order
 // The workgroup-per-row tally of long rows lives in bv_pass2.hip (bv_pass2_kernel<.., GROUPS>); it hands its groups over
 // in the same item format (BvPass2Args::gitems, bv_kernels.h).
 #include "bv_kernels.h"
@@ -183,7 +184,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GS_WAVES) void bv_p2g_stream_kernel(B
             }
             const int n_seen = (gdepth[0] != 0) + (gdepth[1] != 0) + (gdepth[2] != 0) + (gdepth[3] != 0);
             const bool shallow = gtotal <= (uint32_t)BV_ORD_MAX && n_seen >= 2;
-            const bool four = !shallow && q0_mask == 0u && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
+            // (a shallow group goes to the four-per-wave solver first; it comes back as a HARD item when that meets a tie)
+            const bool four = q0_mask == 0u && nb <= (uint32_t)BV_G16_MAX_BINS && a.min_af > 0.0 && !(a.flags & BV_FLAG_WAVE_SOLVER);
             if (gtotal != 0u) {
                 uint32_t pos0 = 0;
 #pragma unroll
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2GS_WAVES) void bv_p2g_stream_kernel(B
                     }
                 }
             }
-            const uint32_t hdr = gtotal == 0u ? 0u : (nb | (four ? BV_P2G_PENDING : BV_P2G_HARD | (shallow ? BV_P2G_SHALLOW : 0u)));
+            const uint32_t hdr = gtotal == 0u ? 0u : (nb | (four ? BV_P2G_PENDING : BV_P2G_HARD) | (shallow ? BV_P2G_SHALLOW : 0u));
             uint32_t w = hdr;
 #pragma unroll
             for (int b = 0; b < 4; ++b) w = (lane == 1 + b) ? gdepth[b] : w;
@@ -385,6 +387,18 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         }
         BvLrtOut L;
         bv_lrt_g16<true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        if ((hdr & BV_P2G_SHALLOW) && L.tie_risk) {
+            // a tie (or what rounding makes of one) in a group of at most BV_ORD_MAX covered samples: the reference's per-sample
+            // order decides it -- the item goes on to bv_p2g_hard_kernel, which runs behind this kernel, in that kernel's format
+            uint32_t *itw = a.gitems + (size_t)idx * BV_P2G_ITEM_WORDS;
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t i = (uint32_t)(s * 16 + gl);
+                if (i < nb) itw[8u + i] = ((B.w[s] >> 16) << 23) | (B.w[s] & 0xFFFFu);
+            }
+            if (gl == 0) itw[0] = nb | BV_P2G_HARD | BV_P2G_SHALLOW;
+            continue;
+        }
         if (gl == 0) {
             bv_group_result gr;
             gr.n_alt = (uint8_t)L.n_alt;

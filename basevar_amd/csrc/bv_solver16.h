@@ -271,11 +271,12 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
 // visited in Combinations order and the first minimum is kept as they come.  Requires q0_mask == 0.
 // SPEC: the candidate bases are `nspec` entries of `specific_packed` (3 bits each, reference order, 4 = not ACGT) as in
 // bv_lrt -- the pop-group calls of pass 2, lrt([REF] + alts); otherwise A, C, G, T.
+#define BV_TIE_TOL 1e-7  /* the sums' rounding is ~1e-13 relative; a true gap this small has never been seen */
 template <bool SPEC = false>
 __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], uint32_t total, int ref_code, double min_af,
                                   BvLrtOut &o, int specific_packed = 0, int nspec = 0) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
-    o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false;
+    o.m = 0; o.first = 0; o.chi2 = 0.; o.em_iters = 0; o.n_em = 0; o.zero_freq = false; o.tie_risk = false;
     int act = 0, m = 0;
     if (SPEC) {
         for (int k = 0; k < nspec; ++k) {
@@ -361,6 +362,10 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
             o.em_iters += it;
             o.n_em += 1;
             const double v = 2 * (lr_alt - lr);
+            // Which of two subsets that score (nearly) alike wins is decided by the rounding of the reference's per-sample
+            // sums, which sums over bins do not reproduce: the caller replays such an item in sample order if it can
+            // (pop-groups of at most BV_ORD_MAX covered samples, bv_p2g_solve16_kernel).  Conservative: any pair of the level.
+            if (SPEC && !top && c > 0 && fabs(v - best_v) <= BV_TIE_TOL * (1.0 + fabs(best_v))) o.tie_risk = true;
             if (top || c == 0 || v < best_v) {  // first minimum, algorithm.h:24-27
                 best_v = v; best_c = c; best_lr = lr;
                 bf0 = f[0]; bf1 = f[1]; bf2 = f[2]; bf3 = f[3];
