@@ -466,8 +466,10 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[2]: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
+                "workload": "%s: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
                             "HBM-resident batches of %d sites per GPU%s (%s; 1M-site job = %d such batches)" % (
+                                "BASELINE configs[2]" if N == 100000 else "BASELINE configs[1]" if N == 10000 else
+                                "BASELINE configs[4] shape" if N == 1000000 else "diagnostic shape",
                                 N, args.coverage, B, " per step" if K == 1 else ", %d batches per step chained into one launch per pass" % K,
                                 "strong scaling: the job's %d-site batch split over the ranks" % (world * B)
                                 if args.scaling == "strong" else "weak scaling: per-GPU batch fixed",

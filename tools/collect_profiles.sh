@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the MI355X box (through gpurun): rocprofv3 evidence for every shipped kernel.
-#   tools/collect_profiles.sh <tag>          e.g. r2
+#   tools/collect_profiles.sh <tag>          e.g. r2            (ONLY="name name ..." re-collects just those configurations)
 # For each configuration below: one un-profiled bench run (the JSON line), one `--kernel-trace --stats` run and two PMC
 # runs (FETCH_SIZE, WRITE_SIZE -- separate passes, no tracing beside them), all of the same bench command.
 # Back in the container:  python tools/summarize_profiles.py <tag>
@@ -11,6 +11,7 @@ O=$ROOT/gpurun_out/prof_$TAG
 rm -rf $O; mkdir -p $O
 run_cfg() {  # name, bench args
   local name=$1; shift
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name "; then return; fi
   echo "== $name: $*" >&2
   echo "$*" > $O/$name.args
   timeout 600 python3 bench.py --no-cpu-baseline "$@" > $O/$name.bench.json 2> $O/$name.err
@@ -36,6 +37,7 @@ PY
 }
 sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kernel, three passes
   local name=$1; shift
+  if [ -n "$ONLY" ] && ! echo " $ONLY " | grep -q " $name.sq "; then return; fi
   local i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
     timeout 600 rocprofv3 --pmc $set --output-format csv -d $O/$name.sq$i -- python3 bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > /dev/null 2>> $O/$name.err
@@ -55,6 +57,7 @@ run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short r
 run_cfg n10k_groups1 --samples 10000 --batch-sites 100000 --groups 1
 run_cfg n10k_noranks --samples 10000 --batch-sites 100000 --groups 2 --no-rank-planes   # groups without rank planes: bv_p2g_stream_kernel alone
 run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more than 7 groups: bv_pass2_kernel<256,true,true,false> + the group solve kernels
+run_cfg n10k_groups32 --samples 10000 --batch-sites 100000 --groups 32 # ... at BV_MAX_GROUPS: every group of the cohort is shallow (<= 64 covered samples)
 run_cfg n100k_chain16 --batch-sites 8192 --chain 16                    # small batches chained: bv_pass1_kernel<3,1,true>
 run_cfg n100k_8192 --batch-sites 8192 --steps 20                       # ... and one launch per small batch
 run_cfg n100k_8192_lanes2 --batch-sites 8192 --steps 20 --lanes 2      # ... through the engine's two lanes
