@@ -136,7 +136,9 @@ class BaseTypeEngine:
             raise RuntimeError("bv_engine_join: " + self._err())
 
     def stream_handle(self):
-        """hipStream_t of the engine's own stream as an int (e.g. for torch.cuda.ExternalStream)."""
+        """hipStream_t of the engine's own stream as an int (e.g. for torch.cuda.ExternalStream).  The stream dies with the
+        engine: free torch tensors that were used on it -- pinned host blocks above all, whose allocator records an event on
+        every stream a block has seen when the block is freed -- before close()."""
         return int(self._lib.bv_engine_stream(self._h) or 0)
 
     def wait(self):

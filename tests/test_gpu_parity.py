@@ -734,6 +734,43 @@ def test_two_lanes_give_the_records_of_one(bv, n):
     eng.close()
 
 
+def test_lane_submit_on_the_null_stream_waits_for_the_engines_own_stream(bv):
+    """BV_FLAG_LANES with stream = NULL ("the engine's own stream", include/basevar_amd.h): a lane must start behind whatever the
+    caller queued on bv_engine_stream(e) -- here ~250 MB of planes copied from pinned host memory immediately before each
+    submit (5 ms per slab at PCIe speed: a lane that did not wait would tally zeros)."""
+    import torch
+    from basevar_amd import _capi
+    dev = torch.device("cuda:0")
+    S, n = 700, 70000
+    maf = bv.min_af(n)
+    slabs = [make_slab(S, n, seed=900 + i, coverage=0.07, site_offset=7 * i) for i in range(3)]
+    want = [run_engine(bv, sl, maf) for sl in slabs]
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=_capi.BV_FLAG_LANES)
+    own = torch.cuda.ExternalStream(eng.stream_handle())
+    rec = bv.SITE_DTYPE.itemsize
+    keys = ("base_strand", "qual", "mapq", "rpr", "ref_base")
+    host = [{k: torch.from_numpy(np.ascontiguousarray(sl[k] if k != "rpr" else sl[k].view(np.int16))).pin_memory() for k in keys} for sl in slabs]
+    devt = [{k: torch.zeros_like(h[k], device=dev) for k in keys} for h in host]
+    outs = [torch.zeros(S * rec, dtype=torch.uint8, device=dev) for _ in slabs]
+    torch.cuda.synchronize()
+    for h, t, out in zip(host, devt, outs):
+        with torch.cuda.stream(own):
+            for k in keys:
+                t[k].copy_(h[k], non_blocking=True)
+        pitch = t["base_strand"].shape[1]
+        eng.submit_ptrs(S, n, pitch, t["base_strand"].data_ptr(), t["qual"].data_ptr(), t["ref_base"].data_ptr(), out.data_ptr(),
+                        t["mapq"].data_ptr(), t["rpr"].data_ptr())  # stream = 0
+    eng.wait()
+    got = [out.cpu().numpy().tobytes() for out in outs]
+    # (torch's pinned-memory allocator records an event on every stream a block was used on when the block is freed: the
+    # blocks go before the engine takes its stream with it)
+    del host, devt, outs, own, h, t, out
+    torch.cuda.synchronize()
+    eng.close()
+    for g, w in zip(got, want):
+        assert g == w.sites.tobytes()
+
+
 @pytest.mark.parametrize("n", [9000, 70000], ids=["short_rows", "long_rows"])
 def test_one_engine_on_alternating_streams(bv, n):
     """Submits of ONE engine on two caller streams in turn (no lanes): the engine shares its scratch between them, so a submit
