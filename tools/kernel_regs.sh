@@ -17,7 +17,22 @@ while True:
     pos+=4
 PY
 for f in $T/*.elf; do
-  /opt/rocm/lib/llvm/bin/llvm-readelf --notes $f | grep -E "\.name:|\.vgpr_count|\.sgpr_count|private_segment_fixed_size|group_segment_fixed_size|vgpr_spill_count" | sed 's/^ *//' | paste -sd' ' | sed 's/\.name:/\n.name:/g'
+  # one line per kernel; a kernel's block in the notes starts at "- .agpr_count" (its LDS size comes BEFORE its name)
+  /opt/rocm/lib/llvm/bin/llvm-readelf --notes $f | python3 -c '
+import sys
+cur = {}
+def flush():
+    if cur.get("name"):
+        print("%-72s vgpr %3s sgpr %3s spills %3s scratch %5s B  lds %6s B" % (cur["name"][:72], cur.get("vgpr_count", "?"), cur.get("sgpr_count", "?"),
+              cur.get("vgpr_spill_count", "?"), cur.get("private_segment_fixed_size", "?"), cur.get("group_segment_fixed_size", "?")))
+for line in sys.stdin:
+    t = line.strip()
+    if t.startswith("- .agpr_count"):
+        flush(); cur = {}
+        continue
+    for k in ("name", "vgpr_count", "sgpr_count", "vgpr_spill_count", "private_segment_fixed_size", "group_segment_fixed_size"):
+        if t.startswith("." + k + ":"):
+            cur[k] = t.split(":", 1)[1].strip()
+flush()'
 done
-echo
 rm -rf $T
