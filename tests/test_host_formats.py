@@ -272,6 +272,34 @@ def test_bv_call_end_to_end(tmp_path, restatement):
         assert open(c2, "rb").read() == open(cvg, "rb").read(), tag
 
 
+def test_tbi_reader_on_an_index_written_by_htslib():
+    """The reference's test data holds one real tabix index (tests/data/chr22.all.sites.vcf.gz.tbi, written by htslib; kept as
+    a fixture under tests/golden/).  The independent reader that checks this repo's .tbi writer must read THAT file the way the
+    format says: header, one name, bins whose chunks are ordered virtual offsets, the pseudo-bin 37450 (chunk 0 = the span of
+    the sequence's records, chunk 1 = record counts), a monotone linear index, and every leaf bin's first chunk at or behind
+    its 16 kb window's linear entry -- the invariants test_bgzf_output_and_tabix_index_against_a_linear_scan relies on."""
+    from bam_py import read_tbi
+    t = read_tbi(os.path.join(ROOT, "tests", "golden", "chr22.all.sites.vcf.gz.tbi"))
+    assert t["conf"] == (2, 1, 2, 0, ord("#"), 0)  # htslib's VCF preset: sequence in column 1, position in column 2
+    assert t["names"] == ["chr22"] and len(t["refs"]) == 1
+    r = t["refs"][0]
+    lin = r["linear"]
+    assert len(lin) > 1000 and all(a <= b for a, b in zip(lin, lin[1:]))
+    pseudo = r["bins"].pop(37450)
+    assert len(pseudo) == 2 and pseudo[0][0] < pseudo[0][1] and pseudo[1][0] > 0  # (span of the records), (mapped, unmapped)
+    lo, hi = pseudo[0]
+    n_leaf = 0
+    for b, chunks in r["bins"].items():
+        assert 0 <= b < 37449 and chunks
+        assert all(beg < end for beg, end in chunks) and all(c[1] <= d[0] for c, d in zip(chunks, chunks[1:]))
+        assert lo <= chunks[0][0] and chunks[-1][1] <= hi
+        if b >= 4681:  # a 16 kb leaf: window b - 4681 of the linear index starts no later than the bin's first record
+            w = b - 4681
+            assert w < len(lin) and lin[w] <= chunks[0][0]
+            n_leaf += 1
+    assert n_leaf > 1000
+
+
 def test_bgzf_output_and_tabix_index_against_a_linear_scan(tmp_path):
     """`x.gz` outputs (reference: bgzf_write + tbx_index_build, src/basetype_caller.cpp:242-254): the file is a
     sequence of well-formed BGZF blocks ending in the EOF marker (every field, CRC and size checked by an independent reader),
