@@ -1223,6 +1223,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     __syncthreads();
 
     const bool is_stream = wave < BV_F_NS;
+#ifdef BV_ABL_F_NOSOLVER  /* measurement: no dedicated solver waves -- the streaming waves solve everything once their rows are through */
+    if (!is_stream) return;
+#endif
     bool streaming = is_stream;
     uint32_t sst = 0;
     BvFusedSolver v;
