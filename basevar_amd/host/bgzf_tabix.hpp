@@ -102,7 +102,10 @@ private:
     uint64_t block_off_ = 0;
 };
 
-// the column configuration written into the index: the reference's {1, 1, 2, 0, '#', 0} (caller.cpp:242)
+// the column configuration written into the index: the reference's {1, 1, 2, 0, '#', 0} (caller.cpp:242).  Preset 1 is htslib's
+// SAM preset: with it tbx.c takes a record's END from column 6 read as a CIGAR string; the reference's column 6 is a number
+// (QUAL in the VCF, a depth in the CVG file), which that parser turns into a length of 1 -- every line covers the one base at
+// its position, which is what add_line() below indexes.
 struct TabixConf { int32_t preset = 1, seq_col = 1, beg_col = 2, end_col = 0, meta_char = '#', line_skip = 0; };
 
 class TabixIndex {
