@@ -48,7 +48,7 @@ extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_g
 // phred byte > 127) in the row, the caller re-does the row with the branchy window sweeps (bv_p2_sweep).  L: class table
 // (byte b = 0x80 REF / 0x81 ALT / 0xFF neither).  ~6 VALU + 2 predicated ds_add per cell for the rank sums, ~4 + 1 for the
 // groups; the branchy sweep takes ~18 VALU for the rank sums alone.
-template <int NT, bool RANKS, bool GROUPS>
+template <int NT, bool RANKS, bool GROUPS, bool HALF = false>
 __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr, uint32_t *hg) {
     const size_t row = (size_t)site * a.pitch;
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
@@ -119,15 +119,20 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
                 x[4] = bv_cell_index<0>(y1, q2.y); x[5] = bv_cell_index<1>(y1, q2.y); x[6] = bv_cell_index<2>(y1, q2.y); x[7] = bv_cell_index<3>(y1, q2.y);
                 x[8] = bv_cell_index<0>(y2, q2.z); x[9] = bv_cell_index<1>(y2, q2.z); x[10] = bv_cell_index<2>(y2, q2.z); x[11] = bv_cell_index<3>(y2, q2.z);
                 x[12] = bv_cell_index<0>(y3, q2.w); x[13] = bv_cell_index<1>(y3, q2.w); x[14] = bv_cell_index<2>(y3, q2.w); x[15] = bv_cell_index<3>(y3, q2.w);
-                bv_lds_add16<1>(x, hg, one, 0x8000u);
+                if (HALF) bv_lds_add16_half(x, hg, one, 0x8000u);  // X is the byte offset of a 16-bit counter of hg[group][base][128]
+                else bv_lds_add16<1>(x, hg, one, 0x8000u);
             }
         }
     }
     return hi_acc;
 }
 
-template <int NT, bool RANKS, bool GROUPS, bool INLINE = true>
+// HALF (with GROUPS, not INLINE; rows of at most 65,535 samples): the group histograms hold 16-bit counters, 1 KiB per group
+// instead of 2 -- with 16-32 groups that is what decides how many workgroups a CU holds (32 groups: 45 KiB instead of 77).
+template <int NT, bool RANKS, bool GROUPS, bool INLINE = true, bool HALF = false>
 __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
+    static_assert(!HALF || (GROUPS && !INLINE), "16-bit group counters: the item-exporting form only");
+    constexpr uint32_t GW = HALF ? 256u : 512u;  // words of one group's histogram
     constexpr int NW = NT / BV_WAVE;
     __shared__ BvPass2Shared<NW, INLINE> sh;
     uint32_t *hg = bv_dyn_lds;
@@ -184,18 +189,18 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
             for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
         }
         if (GROUPS)
-            for (uint32_t i = tid; i < a.n_groups * 512u; i += NT) hg[i] = 0u;
+            for (uint32_t i = tid; i < a.n_groups * GW; i += NT) hg[i] = 0u;
         __syncthreads();
 
         BvP2Ctx cx;
         cx.hm = sh.hm; cx.hr = sh.hr; cx.hg = hg;
-        cx.lut = lut; cx.win_lo = 0; cx.n_groups = a.n_groups; cx.maxr = 0;
+        cx.lut = lut; cx.win_lo = 0; cx.n_groups = a.n_groups; cx.maxr = 0; cx.half = HALF;
         // Rank sums without pop-groups: the perm form first (a third of the instructions; 256-rank window).  A row that holds a
         // rank >= 256 (long reads) is re-done by the window sweeps below.
         const bool FAST = !GROUPS || a.gidp != nullptr;
         bool fast_ok = false;
         if (FAST) {
-            const uint32_t hi = bv_p2_fast_sweep<NT, RANKS, GROUPS>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
+            const uint32_t hi = bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
             const bool any_hi = __ballot(hi != 0u) != 0ull;
             if (lane == 0) sh.maxr[wave] = any_hi ? 1u : 0u;
             __syncthreads();
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                 uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
                 for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
                 if (GROUPS)
-                    for (uint32_t i = tid; i < a.n_groups * 512u; i += NT) hg[i] = 0u;
+                    for (uint32_t i = tid; i < a.n_groups * GW; i += NT) hg[i] = 0u;
                 __syncthreads();
             }
         }
@@ -266,13 +271,14 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
 
         if (GROUPS) {
             for (uint32_t g = wave; g < a.n_groups; g += NW) {
-                const uint32_t *h = hg + g * 512u;
+                const uint32_t *h = hg + g * GW;
                 if (!INLINE) {
                     // every group leaves as an item (bv_p2g_solve16_kernel / bv_p2g_hard_kernel): bins straight from the histogram
                     uint32_t c[8], dpart[4], q0 = 0, cm = 0, nbv = 0;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
-                        c[r] = h[((r >> 1) << 7) | ((r & 1) << 6) | lane];
+                        if (HALF) c[r] = (h[(((r >> 1) << 7) | ((r & 1) << 6) | lane) >> 1] >> (16 * (lane & 1))) & 0xFFFFu;
+                        else c[r] = h[((r >> 1) << 7) | ((r & 1) << 6) | lane];
                         cm = max(cm, c[r]);
                         if (!(r & 1) && __builtin_amdgcn_readfirstlane((int)c[r]) != 0) q0 |= 1u << (r >> 1);
                         const bool valid = c[r] != 0u && (((r & 1) << 6) | lane) < BV_NQ_VALID;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2S_WAVES, 4) void bv_pass2_short_kerne
         bv_lrt_sync<0>();
         BvP2Ctx cx;
         cx.hm = hm; cx.hr = hr; cx.hg = nullptr;
-        cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
+        cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false;
         BvPass2Args as = a;  // the sweeps index the planes with the site number themselves
         if (a.ch != nullptr) {  // a chained launch (short rows: ref_base / out are contiguous): the segment's biased planes
             const BvChainC ch = bv_chain_const(a.ch);
@@ -673,7 +679,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
             }
             bv_lrt_sync<0>();
             BvP2Ctx cx;
-            cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
+            cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false;
             BvPass2Args as = a;  // the sweeps index the planes with the site number themselves
             if (a.ch != nullptr) {
                 const BvChainC ch = bv_chain_const(a.ch);
@@ -759,6 +765,15 @@ static void bv_launch_pass2_nt(const BvPass2Args &a, hipStream_t stream) {
     uint32_t grid = a.n_sites;
     size_t dyn = groups ? bv_pass2_lds_bytes(a.n_groups) : 0;
     const bool items = bv_p2g_all_items(a);
+    // many groups on rows whose counts fit 16 bits: half the histogram, more workgroups per CU -- from 14 groups on, where 32-bit
+    // counters leave room for three workgroups (13 KiB + 2 KiB per group of 160); below that the three extra VALU per cell cost
+    // more than the occupancy brings (100 k sites x 10 k samples: 8 groups -3 %, 12 +-0, 14 +4 %, 16 +4.5 %, 32 +9 %)
+    if (NT == 256 && groups && items && a.n_groups >= 14u && a.n_samples <= 65535u) {
+        dyn /= 2;
+        if (ranks) hipLaunchKernelGGL((bv_pass2_kernel<256, true, true, false, true>), dim3(grid), dim3(256), dyn, stream, a);
+        else hipLaunchKernelGGL((bv_pass2_kernel<256, false, true, false, true>), dim3(grid), dim3(256), dyn, stream, a);
+        return;
+    }
     if (ranks && groups && items)
         hipLaunchKernelGGL((bv_pass2_kernel<NT, true, true, false>), dim3(grid), dim3(NT), dyn, stream, a);
     else if (ranks && groups)

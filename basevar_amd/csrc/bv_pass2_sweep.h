@@ -17,6 +17,7 @@ struct BvP2Ctx {
     uint32_t win_lo;
     uint32_t n_groups;
     uint32_t maxr;     // per-lane running max of classified ranks
+    bool half;         // hg holds 16-bit counters, two per word (rows of at most 65,535 samples; bv_pass2_kernel<.., HALF>)
 };
 
 template <bool RANKS, bool MAPQ, bool GROUPS, int RW = BV_RPR_WIN>
@@ -39,7 +40,11 @@ __device__ __forceinline__ void bv_p2_dword(BvP2Ctx &cx, uint32_t w, uint32_t mq
             }
             if (GROUPS) {
                 uint32_t g = (gg >> (8 * j)) & 0xFFu;
-                if (g < cx.n_groups) atomicAdd(&cx.hg[((g * 4u + b) << 7) | min((qq >> (8 * j)) & 0xFFu, 127u)], 1u);  // phred >= 128: invalid bin 127 (in the depth, in no valid bin -- as in pass 1)
+                if (g < cx.n_groups) {
+                    const uint32_t gi = ((g * 4u + b) << 7) | min((qq >> (8 * j)) & 0xFFu, 127u);  // phred >= 128: invalid bin 127 (in the depth, in no valid bin -- as in pass 1)
+                    if (cx.half) atomicAdd(&cx.hg[gi >> 1], 1u << (16u * (gi & 1u)));
+                    else atomicAdd(&cx.hg[gi], 1u);
+                }
             }
         }
     }

@@ -73,6 +73,57 @@ __device__ __forceinline__ void bv_lds_add16(const uint32_t x[16], uint32_t *his
 }
 
 
+// The same into 16-bit counters (two per word): X = x[j] is the BYTE offset of the cell's half-word; the word X & ~3 gets
+// 1 << 16 * ((X >> 1) & 1).  For rows of at most 65,535 cells, where no count can carry into its neighbour.
+__device__ __forceinline__ void bv_lds_add16_half(const uint32_t x[16], uint32_t *hist, uint32_t one, uint32_t lim) {
+    const uint32_t hbase = (uint32_t)(uintptr_t)(bv_lds_u32 *)hist;
+    uint32_t ad[16], val[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        ad[j] = hbase + (x[j] & 0xFFFCu);
+        val[j] = one << ((x[j] << 3) & 31u);  // x is even: bit 1 = the index's low bit -> shift 0 or 16
+    }
+    unsigned long long m[16], sv;
+    asm volatile(
+        "v_cmp_gt_u32_e64 %[m0], %[lim], %[x0]\n\t"
+        "v_cmp_gt_u32_e64 %[m1], %[lim], %[x1]\n\t"
+        "v_cmp_gt_u32_e64 %[m2], %[lim], %[x2]\n\t"
+        "v_cmp_gt_u32_e64 %[m3], %[lim], %[x3]\n\t"
+        "v_cmp_gt_u32_e64 %[m4], %[lim], %[x4]\n\t"
+        "v_cmp_gt_u32_e64 %[m5], %[lim], %[x5]\n\t"
+        "v_cmp_gt_u32_e64 %[m6], %[lim], %[x6]\n\t"
+        "v_cmp_gt_u32_e64 %[m7], %[lim], %[x7]\n\t"
+        "v_cmp_gt_u32_e64 %[m8], %[lim], %[x8]\n\t"
+        "v_cmp_gt_u32_e64 %[m9], %[lim], %[x9]\n\t"
+        "v_cmp_gt_u32_e64 %[m10], %[lim], %[x10]\n\t"
+        "v_cmp_gt_u32_e64 %[m11], %[lim], %[x11]\n\t"
+        "v_cmp_gt_u32_e64 %[m12], %[lim], %[x12]\n\t"
+        "v_cmp_gt_u32_e64 %[m13], %[lim], %[x13]\n\t"
+        "v_cmp_gt_u32_e64 %[m14], %[lim], %[x14]\n\t"
+        "v_cmp_gt_u32_e64 %[m15], %[lim], %[x15]\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_and_b64 exec, %[sv], %[m0]\n\tds_add_u32 %[a0], %[v0]\n\t"
+        "s_and_b64 exec, %[sv], %[m1]\n\tds_add_u32 %[a1], %[v1]\n\t"
+        "s_and_b64 exec, %[sv], %[m2]\n\tds_add_u32 %[a2], %[v2]\n\t"
+        "s_and_b64 exec, %[sv], %[m3]\n\tds_add_u32 %[a3], %[v3]\n\t"
+        "s_and_b64 exec, %[sv], %[m4]\n\tds_add_u32 %[a4], %[v4]\n\t"
+        "s_and_b64 exec, %[sv], %[m5]\n\tds_add_u32 %[a5], %[v5]\n\t"
+        "s_and_b64 exec, %[sv], %[m6]\n\tds_add_u32 %[a6], %[v6]\n\t"
+        "s_and_b64 exec, %[sv], %[m7]\n\tds_add_u32 %[a7], %[v7]\n\t"
+        "s_and_b64 exec, %[sv], %[m8]\n\tds_add_u32 %[a8], %[v8]\n\t"
+        "s_and_b64 exec, %[sv], %[m9]\n\tds_add_u32 %[a9], %[v9]\n\t"
+        "s_and_b64 exec, %[sv], %[m10]\n\tds_add_u32 %[a10], %[v10]\n\t"
+        "s_and_b64 exec, %[sv], %[m11]\n\tds_add_u32 %[a11], %[v11]\n\t"
+        "s_and_b64 exec, %[sv], %[m12]\n\tds_add_u32 %[a12], %[v12]\n\t"
+        "s_and_b64 exec, %[sv], %[m13]\n\tds_add_u32 %[a13], %[v13]\n\t"
+        "s_and_b64 exec, %[sv], %[m14]\n\tds_add_u32 %[a14], %[v14]\n\t"
+        "s_and_b64 exec, %[sv], %[m15]\n\tds_add_u32 %[a15], %[v15]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [m2] "=&s"(m[2]), [m3] "=&s"(m[3]), [m4] "=&s"(m[4]), [m5] "=&s"(m[5]), [m6] "=&s"(m[6]), [m7] "=&s"(m[7]), [m8] "=&s"(m[8]), [m9] "=&s"(m[9]), [m10] "=&s"(m[10]), [m11] "=&s"(m[11]), [m12] "=&s"(m[12]), [m13] "=&s"(m[13]), [m14] "=&s"(m[14]), [m15] "=&s"(m[15]), [sv] "=&s"(sv)
+        : [x0] "v"(x[0]), [a0] "v"(ad[0]), [v0] "v"(val[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [v1] "v"(val[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [v2] "v"(val[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [v3] "v"(val[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [v4] "v"(val[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [v5] "v"(val[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [v6] "v"(val[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [v7] "v"(val[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [v8] "v"(val[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [v9] "v"(val[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [v10] "v"(val[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [v11] "v"(val[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [v12] "v"(val[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [v13] "v"(val[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [v14] "v"(val[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]), [v15] "v"(val[15]), [lim] "s"(lim)
+        : "memory", "scc");
+}
+
 // One 16-byte chunk = 16 cells of this lane: a per-cell perm -> cmp -> exec -> address -> ds_add chain cannot overlap with
 // its neighbours because every link goes through VCC / EXEC, hence the batched form of bv_lds_add16.
 // SH: log2 of the byte stride of index X (2: words indexed by X -- the 8 x 256 histogram; 1: X is twice the word index --

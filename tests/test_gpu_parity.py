@@ -289,6 +289,46 @@ def test_short_row_group_tally_with_invalid_bytes(bv):
         assert np.array_equal(a.sites[f], b.sites[f]), f
 
 
+@pytest.mark.parametrize("ranks", [True, False], ids=["rank_planes", "no_rank_planes"])
+def test_many_groups_with_16_bit_group_counters(bv, restatement, ranks):
+    """From 14 pop-groups on, rows of at most 65,535 samples tally their groups into 16-bit counters (bv_pass2_kernel<.., HALF>:
+    half the LDS, more workgroups per CU).  Against the reference -- also rows with a read-position rank past the 256-rank
+    window, which the branchy sweep re-does into the same half-word counters --, and rows with call bytes above 15 / phred bytes
+    above 127 (outside the packed index: cell by cell) against the engine's plain 32-bit path (BV_FLAG_GROUP_INLINE)."""
+    n, S, G = 5000, 160, 20
+    slab = make_slab(S, n, seed=1414, coverage=0.3, class_af=[(0.4, 0.0), (0.2, 0.2), (0.0, 0.0)], n_groups=G, ref_n_frac=0.02)
+    rng = np.random.default_rng(14)
+    for r in range(3, S, 11):  # long reads
+        cov = np.nonzero(slab["base_strand"][r, :n] < 8)[0]
+        slab["rpr"][r, cov[:5]] = [300, 999, 256, 4000, 65535]
+    if not ranks:
+        slab.pop("mapq"); slab.pop("rpr")
+    maf = bv.min_af(n)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    got = run_engine(bv, slab, maf)
+    check(got, exp, gexp, margins, check_ranks=ranks)
+    assert got.n_variant > 80
+    for r in range(0, S, 7):
+        cols = rng.choice(n, 6, replace=False)
+        slab["base_strand"][r, cols[:3]] = [0x23, 0x10, 0xF1]
+        slab["qual"][r, cols[3:]] = [128, 200, 255]
+    res = []
+    for flags in (0, 0x40):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=flags)
+        res.append(eng.lrt(slab))
+        eng.close()
+    a, b = res
+    assert a.n_variant == b.n_variant
+    for f in ("n_alt", "total_depth", "alt"):
+        assert np.array_equal(a.groups[f], b.groups[f]), f
+    # (groups of at most 64 covered samples aside: there the one-wave solver replays the reads, invalid phreds included,
+    # where the four-per-wave solver works on the bins, which hold valid phreds only -- undefined input, two answers)
+    deep = a.groups["total_depth"] > 64
+    assert deep.sum() > 100
+    assert np.allclose(a.groups["af"][deep], b.groups["af"][deep], rtol=1e-9, atol=0, equal_nan=True)
+    assert a.sites.tobytes() == b.sites.tobytes()
+
+
 def test_no_rank_planes_and_no_groups(bv, restatement):
     slab = make_slab(64, 5000, seed=41, coverage=0.2)
     slab.pop("mapq"); slab.pop("rpr")
