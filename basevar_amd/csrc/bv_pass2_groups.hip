@@ -386,7 +386,11 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
             B.w[s] = i < nb ? it[8u + i] : 0u;
         }
         BvLrtOut L;
-        bv_lrt_g16<true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        // (a job whose four groups all have at most 32 bins -- every job of a run with many groups -- runs the two-slot
+        // instance: a third of the eight-slot one's instructions are the tests of empty slots)
+        if (__ballot(nb > 32u) == 0ull) bv_lrt_g16<true, 2>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        else if (__ballot(nb > 48u) == 0ull) bv_lrt_g16<true, 3>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        else bv_lrt_g16<true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
         if ((hdr & BV_P2G_SHALLOW) && L.tie_risk) {
             // a tie (or what rounding makes of one) in a group of at most BV_ORD_MAX covered samples: the reference's per-sample
             // order decides it -- the item goes on to bv_p2g_hard_kernel, which runs behind this kernel, in that kernel's format

@@ -220,17 +220,19 @@ __device__ __forceinline__ bool bv_g16_bin(const BvG16Bins &B, int s, uint32_t &
 
 // EM, algorithm.h:210-255, on the bins (no phred-0 call among them, start frequencies not all zero -- the wave solver
 // takes the other sites).  `in_set`: bit b = base b; bases outside keep frequency +0.0 (their terms are exact zeros).
+// NS: slots in use (every group of the wave has at most 16 * NS bins): the loops over the slots stop there.
+template <int NS = BV_G16_SLOTS>
 __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsigned in_set, double n_cov, double *lr_out) {
     const double epsilon = (double)0.001f;
     const double inv_n = 1.0 / n_cov;
     double *pm = B.pm;
 #pragma unroll
-    for (int s = 0; s < BV_G16_SLOTS; ++s) pm[s * 16] = 1.0;
+    for (int s = 0; s < NS; ++s) pm[s * 16] = 1.0;
     int iters = 0;
     for (int k = 0; k <= 100; ++k) {
         double pf0 = 0., pf1 = 0., pf2 = 0., pf3 = 0., delta = 0.;
 #pragma unroll
-        for (int s = 0; s < BV_G16_SLOTS; ++s) {
+        for (int s = 0; s < NS; ++s) {
             uint32_t b, q;
             double c;
             if (bv_g16_bin(B, s, b, q, c)) {
@@ -257,7 +259,7 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
     }
     double lr = 0.;
 #pragma unroll
-    for (int s = 0; s < BV_G16_SLOTS; ++s) {
+    for (int s = 0; s < NS; ++s) {
         uint32_t b, q;
         double c;
         if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * 16]);
@@ -272,7 +274,7 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
 // SPEC: the candidate bases are `nspec` entries of `specific_packed` (3 bits each, reference order, 4 = not ACGT) as in
 // bv_lrt -- the pop-group calls of pass 2, lrt([REF] + alts); otherwise A, C, G, T.
 #define BV_TIE_TOL 1e-7  /* the sums' rounding is ~1e-13 relative; a true gap this small has never been seen */
-template <bool SPEC = false>
+template <bool SPEC = false, int NS = BV_G16_SLOTS>
 __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], uint32_t total, int ref_code, double min_af,
                                   BvLrtOut &o, int specific_packed = 0, int nspec = 0) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
@@ -315,7 +317,7 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
         if (!top && m == 2) {
             double a_ = 0., g0 = 0., g1 = 0., g2 = 0., g3 = 0.;
 #pragma unroll
-            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 uint32_t b, q;
                 double c;
                 if (bv_g16_bin(B, s, b, q, c)) {
@@ -357,7 +359,7 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
                 f[0] = (b1 == 0) ? 1.0 : 0.; f[1] = (b1 == 1) ? 1.0 : 0.;
                 f[2] = (b1 == 2) ? 1.0 : 0.; f[3] = (b1 == 3) ? 1.0 : 0.;
             } else {
-                it = bv_em_g16(B, f, in_set, n_cov, &lr);
+                it = bv_em_g16<NS>(B, f, in_set, n_cov, &lr);
             }
             o.em_iters += it;
             o.n_em += 1;
