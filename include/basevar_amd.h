@@ -313,7 +313,8 @@ int bv_engine_timing_get_ex(bv_engine *e, double *stream_total_ms, double *pass1
 
 /* ---- the host's log() on the device ---------------------------------------------
  * The reference's EM takes log() of per-sample marginals with the host libm (src/algorithm.h:243) and compares sums of
- * them; at tie-prone shallow sites (<= 64 covered samples) the engine replays that arithmetic in the reference's
+ * them; at tie-prone shallow sites (<= 64 covered samples; pop-groups of that size: where two allele subsets score
+ * within 1e-7 of each other) the engine replays that arithmetic in the reference's
  * order, with the host libm's own log algorithm restated on the device.  The libm data table is located in the
  * running process and accepted only after the restated algorithm matched log() bit for bit on ~10^6 probes.
  *   bv_host_log_probe  1 when that check passes (needs no GPU); copies the 274 doubles of the table when table != NULL
