@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BASEVAR_AMD_LIB") or os.path.join(HERE, "lib", "libbasevar_amd.so")  # override: A/B builds
 
 BV_MAX_ALT = 4
-BV_MAX_GROUPS = 32
+BV_MAX_GROUPS = 255
 BV_NO_GROUP = 0xFF
 BV_MEM_DEVICE, BV_MEM_HOST = 0, 1
 BV_FLAG_LANES = 0x10000000
@@ -65,7 +65,7 @@ EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "
            "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_add_many", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
            "bv_host_log_probe", "bv_host_log_eval", "bv_engine_host_log_exact", "bv_engine_host_log_eval",
-           "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill"]
+           "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill", "bv_device_numa_node", "bv_bind_thread_to_device_node"]
 
 _lib = None
 
@@ -143,5 +143,9 @@ def load():
     L.bv_synth_fill.restype = C.c_int
     L.bv_synth_fill.argtypes = [C.c_int, C.POINTER(SynthParams), C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bv_device_numa_node.restype = C.c_int
+    L.bv_device_numa_node.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+    L.bv_bind_thread_to_device_node.restype = C.c_int
+    L.bv_bind_thread_to_device_node.argtypes = [C.c_int]
     _lib = L
     return L

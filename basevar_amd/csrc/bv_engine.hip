@@ -6,8 +6,10 @@
 // usable, creation fails loudly with BV_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <link.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -215,6 +217,12 @@ struct bv_engine {
     uint32_t *d_gitems = nullptr;      // pop-group calls handed from the pass-2 tally kernels to bv_p2g_solve16_kernel
     uint32_t gitem_cap = 0;            // items (of BV_P2G_ITEM_WORDS words) d_gitems holds
     uint8_t *d_gidp = nullptr;         // group ids prepared for bv_p2g_stream_kernel (bv_launch_gid_prepare)
+    // more than BV_GROUPS_PER_ROUND pop-groups: pass 2 runs once per round of groups, on the round's own view of the group plane
+    // (groups of other rounds read as "no group") and into records of its own, which are then moved to their columns of `gout`
+    uint8_t *d_gid_round = nullptr;
+    size_t d_gid_round_bytes = 0;
+    bv_group_result *d_gout_round = nullptr;
+    size_t d_gout_round_bytes = 0;
     BvChain *d_chain = nullptr;        // segment tables of chained launches (bv_engine_submit_many)
     uint8_t *d_ref_cat = nullptr;      // chained short-row launches: reference bases / records of all segments, contiguous
     bv_site_result *d_out_cat = nullptr;
@@ -637,6 +645,8 @@ int bv_engine_destroy(bv_engine *e) {
         if (e->d_desc[i]) (void)hipFree(e->d_desc[i]);
         if (e->ev_desc[i]) (void)hipEventDestroy(e->ev_desc[i]);
     }
+    if (e->d_gid_round) (void)hipFree(e->d_gid_round);
+    if (e->d_gout_round) (void)hipFree(e->d_gout_round);
     if (e->tile_state) (void)hipFree(e->tile_state);
     if (e->tile_maxr) (void)hipFree(e->tile_maxr);
     if (e->j_buf) (void)hipFree(e->j_buf);
@@ -665,7 +675,28 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
                          bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */,
                          bool chain_cat = false /* chained short rows: refb / dout are contiguous copies */) {
     const size_t S = n_sites, G = n_groups;
+    // The group kernels hold one (base, phred) histogram per group in LDS and are built for at most BV_GROUPS_PER_ROUND of them;
+    // the reference takes any number of groups (a std::map, basetype_caller.cpp:372-410).  More groups run as ROUNDS of pass 2:
+    // round r sees groups [r x 32, r x 32 + 32) only (bv_launch_gid_round) and writes [S][32] records of its own, which one 2-D
+    // copy moves to their columns of the caller's [S][G] array.  Only round 0 forms the rank sums.
+    const size_t Gr = G < BV_GROUPS_PER_ROUND ? G : (size_t)BV_GROUPS_PER_ROUND, n_rounds = G ? (G + Gr - 1) / Gr : 1;
+    if (n_rounds > 1 && chain != nullptr) return fail(e, BV_ERR_INVALID_ARG, "launch_passes: more than 32 pop-groups do not chain");
     if (G && chain == nullptr) BV_HIP(e, hipMemsetAsync(dgout, 0, S * G * sizeof(bv_group_result), st));  // (chained: per segment, by the caller)
+    if (n_rounds > 1) {
+        const size_t gb = (((size_t)n_samples + 255) & ~(size_t)255) + 256, ob = S * Gr * sizeof(bv_group_result);
+        if (gb > e->d_gid_round_bytes) {
+            if (e->d_gid_round) BV_HIP(e, hipFree(e->d_gid_round));
+            e->d_gid_round = nullptr; e->d_gid_round_bytes = 0;
+            BV_HIP(e, hipMalloc(&e->d_gid_round, gb));
+            e->d_gid_round_bytes = gb;
+        }
+        if (ob > e->d_gout_round_bytes) {
+            if (e->d_gout_round) BV_HIP(e, hipFree(e->d_gout_round));
+            e->d_gout_round = nullptr; e->d_gout_round_bytes = 0;
+            BV_HIP(e, hipMalloc(&e->d_gout_round, ob));
+            e->d_gout_round_bytes = ob;
+        }
+    }
 
     // Per-pass timing: four event records per launch (start, end of the streaming kernel, end of pass 1, end of pass 2).  They are
     // not free -- each is a packet the next kernel queues behind: ~15 us per launch together (measured: 100 k sites x 10 k samples
@@ -712,7 +743,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
         // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel.  An allocation that
         // fails is retried at half the size (the inline path takes what the scratch cannot).
-        const uint64_t want64 = (uint64_t)S * G, most = (8192ull << 20) / (sizeof(uint32_t) * BV_P2G_ITEM_WORDS);
+        const uint64_t want64 = (uint64_t)S * Gr, most = (8192ull << 20) / (sizeof(uint32_t) * BV_P2G_ITEM_WORDS);
         uint32_t want = (uint32_t)(want64 < most ? want64 : most);
         if (want > e->gitem_cap) {
             if (e->d_gitems) BV_HIP(e, hipFree(e->d_gitems));
@@ -740,9 +771,13 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         }
         a2.gidp = e->d_gidp;
         // the group plane as the perm-form tallies read it (short rows: bv_p2g_stream_kernel; long rows: bv_p2_fast_sweep)
-        bv_launch_gid_prepare(gid, e->d_gidp, (uint32_t)n16, n_groups, st);
-        BV_HIP(e, hipGetLastError());
+        // (several rounds of groups: prepared per round, below)
+        if (n_rounds == 1) {
+            bv_launch_gid_prepare(gid, e->d_gidp, (uint32_t)n16, n_groups, st);
+            BV_HIP(e, hipGetLastError());
+        }
     }
+    if (n_rounds > 1) a2.n_groups = (uint32_t)Gr;  // (what the kernel-selection predicates below see)
 
     // ---- chunks of the pipeline (1: the plain sequence on `st`)
     uint32_t H = 1;
@@ -866,26 +901,40 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         if (ev) BV_HIP(e, hipEventRecord(ev[1], st));  // (one kernel: no separate event for "the streaming kernel")
     }
 
-    for (uint32_t c = 0; c < H; ++c) {
-        const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
-        BvPass2Args ac = a2;
-        if (H > 1u) {
-            BV_HIP(e, hipStreamWaitEvent(st, e->ev_v[c], 0));
-            ac.bs = bs + (size_t)c0 * P; ac.q = q + (size_t)c0 * P;
-            ac.mapq = mq ? mq + (size_t)c0 * P : nullptr; ac.rpr = rp ? rp + (size_t)c0 * P : nullptr;
-            ac.ref_base = refb + c0; ac.n_sites = nc; ac.out = dout + c0; ac.gout = dgout ? dgout + (size_t)c0 * G : nullptr;
-            ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
-            if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * G * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * G); }
+    for (size_t r = 0; r < n_rounds; ++r) {
+        const size_t g_lo = r * Gr, g_n = n_rounds > 1 ? std::min(Gr, G - g_lo) : G;  // this round's groups
+        if (n_rounds > 1) {
+            const size_t n16 = ((size_t)n_samples + 15) & ~(size_t)15;
+            bv_launch_gid_round(gid, e->d_gid_round, (uint32_t)n16, (uint32_t)g_lo, (uint32_t)g_n, st);
+            BV_HIP(e, hipGetLastError());
+            bv_launch_gid_prepare(e->d_gid_round, e->d_gidp, (uint32_t)n16, (uint32_t)g_n, st);
+            BV_HIP(e, hipGetLastError());
+            BV_HIP(e, hipMemsetAsync(e->d_gout_round, 0, S * g_n * sizeof(bv_group_result), st));
         }
-        if (pass2_fused) {  // pass 1's kernel has streamed the variant sites' rank-sum rows too: what is left is the pop-groups
-            if (G == 0) continue;
-            ac.mapq = nullptr; ac.rpr = nullptr;
+        for (uint32_t c = 0; c < H; ++c) {
+            const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
+            BvPass2Args ac = a2;
+            if (n_rounds > 1) { ac.group_id = e->d_gid_round; ac.n_groups = (uint32_t)g_n; ac.gout = e->d_gout_round; }
+            if (H > 1u) {
+                if (r == 0) BV_HIP(e, hipStreamWaitEvent(st, e->ev_v[c], 0));
+                ac.bs = bs + (size_t)c0 * P; ac.q = q + (size_t)c0 * P;
+                ac.mapq = mq ? mq + (size_t)c0 * P : nullptr; ac.rpr = rp ? rp + (size_t)c0 * P : nullptr;
+                ac.ref_base = refb + c0; ac.n_sites = nc; ac.out = dout + c0; ac.gout = ac.gout ? ac.gout + (size_t)c0 * g_n : nullptr;
+                ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
+                if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * g_n * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * g_n); }
+            }
+            if (pass2_fused || r > 0) {  // the rank sums are formed already (by pass 1's kernel / by round 0): what is left is the pop-groups
+                if (G == 0) continue;
+                ac.mapq = nullptr; ac.rpr = nullptr;
+            }
+            bv_launch_pass2(ac, st);
+            BV_HIP(e, hipGetLastError());
+            bv_launch_p2g_solve16(ac, st);
+            BV_HIP(e, hipGetLastError());
         }
-        bv_launch_pass2(ac, st);
-        BV_HIP(e, hipGetLastError());
-        bv_launch_p2g_solve16(ac, st);
-        BV_HIP(e, hipGetLastError());
-
+        if (n_rounds > 1)  // the round's records -> columns [g_lo, g_lo + g_n) of every site's groups
+            BV_HIP(e, hipMemcpy2DAsync(dgout + g_lo, G * sizeof(bv_group_result), e->d_gout_round, g_n * sizeof(bv_group_result),
+                                       g_n * sizeof(bv_group_result), S, hipMemcpyDeviceToDevice, st));
     }
     if (ev) BV_HIP(e, hipEventRecord(ev[2], st));
 
@@ -1038,6 +1087,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
     // pop-groups chain only when every (site, group) of a launch has an item in the scratch (no inline solves: their kernels
     // would need the segment look-up too) -- checked per launch below through the 8 GiB cap of launch_passes
     if (chainable && G && (uint64_t)std::min<uint64_t>(total, e->cfg.max_sites) * G * sizeof(uint32_t) * BV_P2G_ITEM_WORDS > (8192ull << 20)) chainable = false;
+    if (G > BV_GROUPS_PER_ROUND) chainable = false;  // several rounds of groups (launch_passes): slab by slab
     if (!chainable) {
         for (uint32_t k = 0; k < n_slabs; ++k) {
             int rc = bv_engine_submit(e, &slabs[k], outs[k], slabs[k].n_groups ? gouts[k] : nullptr, stream_);
@@ -1160,6 +1210,9 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
             return BV_OK;
         }
     }
+    if (n_groups > BV_GROUPS_PER_ROUND)
+        return fail(e, BV_ERR_TOO_LARGE, "bv_engine_tiles_begin: more than 32 pop-groups need the joined-rows realisation (2 KiB of "
+                                         "per-site state per group otherwise), and the joined planes of this job do not fit the device");
     // H1 2048 + Hm 1024 + Hr 4 x W + Hg 512/group (bv_tiles.hip); W = 1024 ranks, or what the caller announced
     const uint32_t rank_win = with_ranks > 1 ? (uint32_t)((with_ranks + 1023) / 1024 * 1024) : 1024u;
     const uint32_t hg_off = 3072u + 4u * rank_win, stride = hg_off + n_groups * 512u;
@@ -1792,6 +1845,57 @@ const char *bv_last_error(const bv_engine *e) {
         copy = g_err;
     }
     return copy.c_str();
+}
+
+// ---- NUMA placement of host buffers ---------------------------------------------------------------------------------
+// The node a GPU's PCIe function hangs off, from sysfs (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<bdf>/numa_node).
+int bv_device_numa_node(int device, char *pci_bdf, size_t pci_bdf_len) {
+    char bdf[32] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    for (char *c = bdf; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    if (pci_bdf && pci_bdf_len) std::snprintf(pci_bdf, pci_bdf_len, "%s", bdf);
+    char path[128];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE *f = std::fopen(path, "r")) {
+        if (std::fscanf(f, "%d", &node) != 1) node = -1;
+        std::fclose(f);
+    }
+    return node;
+}
+
+// The calling thread keeps those of its CPUs that belong to the GPU's node: memory it allocates and first touches from now on
+// (pinned tiles, staging vectors) is node-local under the default policy.  Returns the node, or -1 with the mask unchanged
+// (no node reported, no node CPU list, or none of the node's CPUs in the current mask).
+int bv_bind_thread_to_device_node(int device) {
+    const int node = bv_device_numa_node(device, nullptr, 0);
+    if (node < 0) return -1;
+    char path[128];
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = std::fopen(path, "r");
+    if (!f) return -1;
+    char buf[4096] = {0};
+    const size_t got = std::fread(buf, 1, sizeof buf - 1, f);
+    std::fclose(f);
+    buf[got] = 0;
+    cpu_set_t cur, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof cur, &cur) != 0) return -1;
+    int n_set = 0;
+    for (char *tok = std::strtok(buf, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {  // "0-63,128-191"
+        int lo = 0, hi = 0;
+        const int k = std::sscanf(tok, "%d-%d", &lo, &hi);
+        if (k < 1) continue;
+        if (k == 1) hi = lo;
+        for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &cur)) { CPU_SET(c, &want); ++n_set; }
+    }
+    if (n_set == 0) return -1;
+    if (sched_setaffinity(0, sizeof want, &want) != 0) return -1;
+    return node;
 }
 
 int bv_synth_fill(int device, const bv_synth_params *p, uint32_t n_sites, uint32_t n_samples, uint64_t pitch,

@@ -238,6 +238,9 @@ void bv_launch_p2g_stream(const BvPass2Args &a, hipStream_t stream);
 bool bv_p2g_all_items(const BvPass2Args &a);
 bool bv_p2g_streams(const BvPass2Args &a);  // whether bv_launch_pass2 takes the LDS-DMA group tally (needs a.gidp)
 void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, uint32_t n_groups, hipStream_t stream);
+// pop-groups [lo, lo + n) as 0 .. n - 1, every other sample BV_NO_GROUP: the group plane of one round of pass 2 (bv_engine.hip)
+#define BV_GROUPS_PER_ROUND 32u
+void bv_launch_gid_round(const uint8_t *gid, uint8_t *out, uint32_t n_bytes, uint32_t lo, uint32_t n, hipStream_t stream);
 size_t bv_pass2_lds_bytes(uint32_t n_groups);
 // short rows of at least three 4 KiB slots, not chained: pass 1 as ONE persistent kernel (bv_pass1_fused.hip)
 bool bv_p1s_fused_takes(const BvP1ShortArgs &a);

@@ -53,21 +53,15 @@
 
 #include <type_traits>
 
-#ifndef BV_F_NS
 #define BV_F_NS 8                         /* streaming waves per workgroup */
-#endif
-#ifndef BV_F_NV
-#define BV_F_NV 4                         /* dedicated solver waves per workgroup */
-#endif
+#define BV_F_NV 4                         /* dedicated solver waves per workgroup (7 + 5 measured -1.2 %) */
 static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody must be emptying it");
 #define BV_F_NW (BV_F_NS + BV_F_NV)
 #define BV_F_K 3                          /* ring slots per streaming wave */
 #define BV_F_SLOT_WORDS 1024              /* pass-1 rows: 2 KiB of calls, 2 KiB of phreds; pass-2 rows: 1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks */
 #define BV_F_QCAP 256                     /* entries per candidate queue (ring buffers) */
 #define BV_F_QVCAP 128                    /* entries of the variant queue */
-#ifndef BV_F_QV_HIGH
 #define BV_F_QV_HIGH 64u                  /* from this many waiting variant rows on, a streaming wave takes one before its next pass-1 row */
-#endif
 #define BV_F_EMPTY 0xFFFFFFFFu
 // Every wait on another wave's LDS write is bounded (~1-2 s of s_sleep): a wave that gives up sets the sticky BV_CTR_TIMEOUT
 // counter -- the submit then fails loudly in bv_engine_wait -- instead of hanging the GPU on a protocol error.
@@ -76,12 +70,8 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 // 2-3 x beside two streaming waves per SIMD at equal priority (jobs of 35-65 us took 100-195 us, measured from the queue
 // lengths at the end of the pass-1 rows: 28 candidates waiting); at priority 3 the solver waves keep up (1 waiting) and the
 // streaming waves, which wait on memory most of the time, lose ~4 %.
-#ifndef BV_F_SOLVER_PRIO
 #define BV_F_SOLVER_PRIO 3
-#endif
-#ifndef BV_F_MIN_JOB
 #define BV_F_MIN_JOB 4u                   /* sites per job of the 16-lane solver while rows are still streaming */
-#endif
 // control words in LDS
 #define BV_FC_CURSOR 0                    /* sites of the workgroup's range handed out so far */
 #define BV_FC_Q3_TAIL 1                   /* candidates with >= 3 active bases: reserved / claimed positions */
@@ -95,18 +85,10 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_FC_QV_TAIL 9                   /* variant sites whose rank-sum rows (pass 2) are to be streamed */
 #define BV_FC_QV_HEAD 10
 #define BV_FC_BUSY 11                     /* solver jobs in flight (each may still add to the variant queue) */
-#define BV_FC_XVALID 12                   /* chunks of the shared tail this workgroup has acquired */
-#define BV_FC_XBLK_HEAD 13                /* ... and how many of them the solvers have finished (their non-candidate sites) */
-// The shared tail (-DBV_F_SHARED_TAIL; measured and OFF by default).  A workgroup owns a contiguous range of sites; with the
-// switch the last eighth of a launch's sites is dealt in chunks of BV_F_XCH sites from a global counter as workgroups run out of
-// their own -- the XCDs stream at rates 7 % apart and workgroups of one XCD up to 8 %, and with static ranges the pass-1 rows end
-// 30 us apart.  Measured (100 k sites x 10 k samples, interleaved): the pass-1 rows then end within 21 us instead of 30, but the
-// median moves up by as much (a chunk's acquisition drains the acquiring wave's ring, the others wait for its first site
-// number), and the launch lasts as long as its last VARIANT rows, which stay with the workgroup that solved them: 166-174
-// against 175-176 M sites/s.  Records are the same either way (the GPU tests pass with it on).
-#define BV_F_XCH 16u                      /* sites per chunk of the shared tail */
-#define BV_F_XCAP 64u                     /* chunks a workgroup can take (1,024 sites) */
-#define BV_F_XDONE 0xFFFFFFFEu            /* the shared tail is exhausted */
+// (A workgroup owns a contiguous range of sites.  Dealing the launch's last eighth in 16-site chunks from a global counter --
+// the XCDs stream at rates 7 % apart -- was built and measured in round 4: the pass-1 rows end within 21 us instead of 30, but
+// the median moves up by as much and the launch ends with its last VARIANT rows, which stay local: 166-174 against 175-176 M
+// sites/s.  docs/history/DESIGN_round4.md.)
 // a streaming wave's flags that outlive a call of bv_f_stream_until_idle
 #define BV_FS_P_DONE 1u                   /* no row will ever come again */
 #define BV_FS_CUR_DONE 8u                 /* the cursor is exhausted */
@@ -132,7 +114,6 @@ struct __attribute__((aligned(16))) BvFusedShared {
     uint32_t q3[BV_F_QCAP], q2[BV_F_QCAP];
     uint32_t qv[BV_F_QVCAP][4];                          // site, class table, n_ref | n_alt << 16, 2-bit lut
     uint32_t pub[BV_F_NS];                               // every pass-1 row of wave w below site pub[w] is published
-    uint32_t xbase[BV_F_XCAP], xdone[BV_F_XCAP];         // shared-tail chunks of this workgroup: first site; rows published
     uint32_t ctl[16];
 };
 static_assert(sizeof(BvFusedShared) <= 160 * 1024, "one workgroup per CU must fit the LDS");
@@ -212,20 +193,6 @@ __device__ __forceinline__ uint32_t bv_f_lds_cas_wave(uint32_t lds_addr, uint32_
         : "memory");
     return r;
 }
-// one LDS word written by lane 0 (no divergent branch for the compiler to see)
-__device__ __forceinline__ void bv_f_lds_write_wave(uint32_t lds_addr, uint32_t v) {
-    uint32_t t;
-    unsigned long long sv;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b64 exec, 1\n\t"
-        "v_mov_b32 %[t], %[val]\n\t"
-        "ds_write_b32 %[adr], %[t]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [t] "=&v"(t), [sv] "=&s"(sv)
-        : [adr] "v"(lds_addr), [val] "s"(v)
-        : "memory");
-}
 // One wave-level fetch-and-add on a word of device memory by lane 0, the old value in an SGPR (as the compiler emits a returning
 // agent-scope atomicAdd: `global_atomic_add ... sc0`), waited for inside the statement: the wave's LDS-DMA ring drains with it.
 __device__ __forceinline__ uint32_t bv_f_global_fetch_add_wave(const uint32_t *p, uint32_t v) {
@@ -277,12 +244,8 @@ __device__ __forceinline__ void bv_f_tally2(bv_u32x4 vbA, bv_u32x4 vqA, bv_u32x4
     // X = call << 8 | phred << 1 = twice the word index of the 8 x 128 histogram; call < 8 <=> X < 0x800
     vqA.x <<= 1; vqA.y <<= 1; vqA.z <<= 1; vqA.w <<= 1;
     vqB.x <<= 1; vqB.y <<= 1; vqB.z <<= 1; vqB.w <<= 1;
-#if defined(BV_ABL_F_NOTALLY)   /* attribution builds only: the stream without the tally (results are wrong) */
-    if ((vbA.x ^ vqA.y ^ vbB.z ^ vqB.w) == 0x12345678u && (vbA.z ^ vqA.w ^ vbB.x ^ vqB.y) == 0x9abcdef0u) hist[0] = one;
-#else
     bv_tally_chunk<1>(vbA, vqA, hist, one);
     bv_tally_chunk<1>(vbB, vqB, hist, one);
-#endif
 }
 
 // ------------------------------------------------------------------------------ the solver side
@@ -345,12 +308,17 @@ __device__ __forceinline__ void bv_f_p2_facts(int ref, const uint32_t depth[4], 
     n12 = n1 | (n2 << 16);  // both at most the row length (<= 49,152)
 }
 // a variant site into the workgroup's variant queue (one lane; its record is complete in memory)
-__device__ __forceinline__ void bv_f_push_variant(BvFusedShared &sh, uint32_t site, uint32_t L, uint32_t n12, uint32_t lut) {
+__device__ __forceinline__ void bv_f_push_variant(BvFusedShared &sh, uint32_t site, uint32_t L, uint32_t n12, uint32_t lut, uint32_t *counters) {
     const uint32_t pos = atomicAdd(&sh.ctl[BV_FC_QV_TAIL], 1u);
     volatile __attribute__((address_space(3))) uint32_t *e =
         (volatile __attribute__((address_space(3))) uint32_t *)&sh.qv[pos & (BV_F_QVCAP - 1u)][0];
     // (a slot still occupied: BV_F_QVCAP variant rows are waiting -- from BV_F_QV_HIGH on the streaming waves take them first)
-    for (uint32_t spins = 0; e[0] != BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(8);
+    uint32_t spins = 0;
+    while (e[0] != BV_F_EMPTY && spins < BV_F_SPIN_MAX) { __builtin_amdgcn_s_sleep(8); ++spins; }
+    if (spins == BV_F_SPIN_MAX) {  // gave up: nothing is overwritten, the site's rank sums are not formed, the submit fails loudly
+        atomicAdd(&counters[BV_CTR_TIMEOUT], 1u);
+        return;
+    }
     e[1] = L; e[2] = n12; e[3] = lut;
     e[0] = site;  // (LDS operations of one wave execute in order: the entry is whole when its site number appears)
 }
@@ -407,7 +375,7 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     if (v.fuse2 && vm != 0ull) {
         // the records are complete (the rank sums' waves add to them: BV_SITE_RANKSUM is OR-ed into the status stored above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (variant && gl == 0) bv_f_push_variant(sh, site, pL, pn12, plut);
+        if (variant && gl == 0) bv_f_push_variant(sh, site, pL, pn12, plut, a.counters);
     }
     if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
 }
@@ -469,20 +437,11 @@ __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedSha
             if (ref > 4) ref = 4;
             uint32_t pL, pn12, plut;
             bv_f_p2_facts(ref, depth, aw0, aw1, pL, pn12, plut);
-            if (lane == 0) bv_f_push_variant(sh, site, pL, pn12, plut);
+            if (lane == 0) bv_f_push_variant(sh, site, pL, pn12, plut, a.counters);
         }
         if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
     }
     bv_lrt_sync<0>();
-}
-
-// the site number of the c-th site this workgroup handles: its own range first, then its chunks of the shared tail in the order
-// it acquired them (c must lie in a chunk that is acquired)
-__device__ __forceinline__ uint32_t bv_f_site_of(BvFusedShared &sh, uint32_t B0, uint32_t B1, uint32_t c) {
-    const uint32_t n_static = B1 - B0;
-    if (c < n_static) return B0 + c;
-    const uint32_t e = c - n_static;
-    return bv_f_lds_read_u(&sh.xbase[(e / BV_F_XCH) & (BV_F_XCAP - 1u)]) + (e % BV_F_XCH);
 }
 
 // One unit of solver work, in this order: a job of candidates with three or four active bases (the longest jobs), a job of
@@ -511,7 +470,7 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
         if (n == 0u && v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
             (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, 1u, first, lane)) != 0u) {
             // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
-            const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[bv_f_site_of(sh, B0, B1, first)]));
+            const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[B0 + first]));
             bv_f_job_hard(a, sh, v, site, lane);
         }
         if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
@@ -545,40 +504,46 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
             }
         }
     }
-    {
-        // a chunk of the shared tail whose rows are all published: its non-candidate sites, one lane each (chunks complete in
-        // the order they were acquired, near enough: they are finished in that order)
-        const uint32_t xh = bv_f_lds_read_u(&sh.ctl[BV_FC_XBLK_HEAD]);
-        if (xh < bv_f_lds_read_u(&sh.ctl[BV_FC_XVALID]) && bv_f_lds_read_u(&sh.xdone[xh]) == BV_F_XCH) {
-            uint32_t old = 0;
-            if (lane == 0) old = atomicCAS(&sh.ctl[BV_FC_XBLK_HEAD], xh, xh + 1u);
-            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
-            if (old == xh) {
-                const uint32_t site = bv_f_lds_read_u(&sh.xbase[xh]) + (uint32_t)lane;
-                if ((uint32_t)lane < BV_F_XCH) bv_p1s_simple_site<true>(a, v.sa.lnfact, site);
-            }
-            return 1;
-        }
-    }
     if (n_done == (uint32_t)BV_F_NS) {
         // nothing was claimable a moment ago and no producer is left: done, unless a queue got its last entries in between
         const bool q_left = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) ||
                             bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) ||
                             (v.big != nullptr && bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD])) ||
-                            bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks ||
-                            bv_f_lds_read_u(&sh.ctl[BV_FC_XBLK_HEAD]) < bv_f_lds_read_u(&sh.ctl[BV_FC_XVALID]);
+                            bv_f_lds_read_u(&sh.ctl[BV_FC_BLK_HEAD]) < n_blocks;
         if (!q_left && v.n_vl) bv_f_flush_vl(a, v, lane);
         return q_left ? 1 : 2;
     }
     return 0;
 }
 // ------------------------------------------------------------------------------ the streaming side
+// "No variant row will ever come again" (FUSE2), read in THIS order: (1) every streaming wave has published its last pass-1
+// row -- the candidate queues only shrink from here on; (2) the candidate queues are empty -- whoever took their last entries
+// had counted itself in BUSY before it claimed them (bv_f_solver_step); (3) no job is counted -- those jobs are over, and a job
+// pushes its variant sites before it leaves the count; (4) the variant queue is empty -- nothing can refill it.  (BUSY read
+// before the queues would leave a window: BUSY == 0, then a solver counts itself and claims the last entries, then the queues
+// and the variant queue are all seen empty while that job's variant rows are still to come.)
+__device__ __forceinline__ bool bv_f_no_row_ever(const uint32_t *ctl) {
+    if (bv_f_lds_read_u(&ctl[BV_FC_NDONE]) != (uint32_t)BV_F_NS) return false;
+    if (bv_f_lds_read_u(&ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&ctl[BV_FC_Q3_HEAD]) ||
+        bv_f_lds_read_u(&ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&ctl[BV_FC_Q2_HEAD]) ||
+        bv_f_lds_read_u(&ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&ctl[BV_FC_QH_HEAD]))
+        return false;
+    if (bv_f_lds_read_u(&ctl[BV_FC_BUSY]) != 0u) return false;
+    return bv_f_lds_read_u(&ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&ctl[BV_FC_QV_HEAD]);
+}
 typedef volatile __attribute__((address_space(3))) uint32_t bv_lds_vu32;
-__device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, int lane) {
+__device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, uint32_t *counters, int lane) {
     const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)tail, 1u);
     bv_lds_vu32 *e = q + (pos & (BV_F_QCAP - 1u));
     // (a slot still occupied: the solvers are BV_F_QCAP candidates behind -- they never wait for a streaming wave, so this ends)
-    for (uint32_t spins = 0; (uint32_t)__builtin_amdgcn_readfirstlane((int)*e) != BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(8);
+    uint32_t spins = 0;
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)*e) != BV_F_EMPTY && spins < BV_F_SPIN_MAX) { __builtin_amdgcn_s_sleep(8); ++spins; }
+    if (spins == BV_F_SPIN_MAX) {
+        // gave up: the entry that sits there is not overwritten (its consumer may still come), this site is not solved, and the
+        // submit fails loudly (the consumer of position `pos` times out in its turn)
+        (void)bv_f_global_fetch_add_wave(&counters[BV_CTR_TIMEOUT], 1u);
+        return;
+    }
     if (lane == 0) *e = site;
 }
 // publish a pass-1 row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic,
@@ -586,18 +551,15 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
 // the workgroup's slice of cand_list in HBM (unbounded: they are taken up only when every streaming wave is past its last
 // pass-1 row, see bv_f_solver_step, so no streaming wave ever waits on them); that store is one more in the vmcnt queue than
 // the slot waits allow for -- a conservative wait, never a wrong one.
-__device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, uint32_t B1, uint32_t site, uint32_t xk, uint32_t kind,
-                                             int lane) {
-    // a row of a shared-tail chunk: one more of the chunk's rows is out (the solvers finish its non-candidates when all are)
-    if (xk != 0xFFFFFFFFu && lane == 0) atomicAdd(&sh.xdone[xk], 1u);
+__device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, uint32_t site, uint32_t kind, int lane) {
     if (kind < 2u) return;
     if (kind == 4u) {
         const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QH_TAIL], 1u);
-        if (lane == 0) a.cand_list[bv_f_site_of(sh, B0, B1, pos)] = site;  // (a slot per site handled: the list cannot outgrow them)
+        if (lane == 0) a.cand_list[B0 + pos] = site;  // (a slot per site of the workgroup's range: the list cannot outgrow them)
     } else if (kind == 3u) {
-        bv_f_push((bv_lds_vu32 *)sh.q3, (bv_lds_u32 *)&sh.ctl[BV_FC_Q3_TAIL], site, lane);
+        bv_f_push((bv_lds_vu32 *)sh.q3, (bv_lds_u32 *)&sh.ctl[BV_FC_Q3_TAIL], site, a.counters, lane);
     } else {
-        bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, lane);
+        bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, a.counters, lane);
     }
 }
 // A variant row with a read-position rank beyond the 256-rank window of the fast tally (long reads): the exact window sweeps of
@@ -624,7 +586,7 @@ __device__ __attribute__((noinline)) void bv_f_p2_redo(const uint8_t *bs_, const
     zero(h, 4 * 256);
     bv_lrt_sync<0>();
     BvP2Ctx cx;
-    cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0;
+    cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false;
     bv_p2_sweep<BV_WAVE, true, true, false, 256>(cx, as, site, lane);
     const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
     bv_lrt_sync<0>();
@@ -686,11 +648,10 @@ __device__ __forceinline__ void bv_f_stash_flush(const BvP1ShortArgs &a, BvFused
 #define BV_F_GLOBAL(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
 template <bool FUSE2>
 __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
-                                                                     uint32_t B1_, uint32_t tail0_, uint32_t st_in_) {
+                                                                     uint32_t B1_, uint32_t st_in_) {
     const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
     const int wave = __builtin_amdgcn_readfirstlane((int)wave_);
     const uint32_t B0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B0_), B1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B1_);
-    const uint32_t tail0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tail0_);  // first site of the shared tail (= n_sites: none)
     uint32_t st_io = (uint32_t)__builtin_amdgcn_readfirstlane((int)st_in_);
     BvFusedShared &sh = *(BvFusedShared *)(__attribute__((address_space(3))) BvFusedShared *)(uintptr_t)sh_lds;
     BvP1ShortArgs a;
@@ -753,14 +714,13 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     uint32_t ring_w = 0, ring_r = 0, inflight = 0;
     // rows drawn: the one being tallied and the one after it (the prefetch runs at most one row ahead: every row has >= BV_F_K slots)
     // x / y: pass 1: reference base / -; pass 2: class table / n_ref | n_alt << 16; z: pass 2: the sweeps' 2-bit table
-    // k: pass 1: the row's chunk of the shared tail (its slot in xbase), or ~0 for a row of the workgroup's own range
-    uint32_t c_site = 0, c_kind = 0, c_x = 0, c_y = 0, c_z = 0, c_k = 0, n_site = 0, n_kind = 0, n_x = 0, n_y = 0, n_z = 0, n_k = 0;
+    uint32_t c_site = 0, c_kind = 0, c_x = 0, c_y = 0, c_z = 0, n_site = 0, n_kind = 0, n_x = 0, n_y = 0, n_z = 0;
     uint32_t st = st_io;
     constexpr uint32_t P_DONE = BV_FS_P_DONE, C_HAVE = 2u, N_HAVE = 4u, CUR_DONE = BV_FS_CUR_DONE, P1_FIN = BV_FS_P1_FIN;
     auto issue = [&]() __attribute__((always_inline)) {
         if (p_left == 0u) {
             if (st & P_DONE) return;
-            uint32_t s = 0, kind = 0, x = 0, y = 0, z = 0, xk = 0xFFFFFFFFu;
+            uint32_t s = 0, kind = 0, x = 0, y = 0, z = 0;
             // the next row: a pass-1 row while the cursor has any -- unless the variant queue is filling up (the solvers wait
             // on a full one) --, else a variant site's pass-2 row
             bool p2_first = false;
@@ -768,43 +728,11 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
                 p2_first = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) >= BV_F_QV_HIGH;
             if (!(st & CUR_DONE) && !p2_first) {
                 const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, 1u);
-                if (c < B1 - B0) { s = B0 + c; kind = BV_FK_P1; }
-                else if (tail0 >= a.n_sites || (c - (B1 - B0)) / BV_F_XCH >= BV_F_XCAP) st |= CUR_DONE;
-                else {
-                    // past the workgroup's own range: the (c - n)-th site of its chunks of the shared tail.  The wave that draws
-                    // a chunk's first site acquires the chunk (one returning global atomic: its ring drains -- once per
-                    // BV_F_XCH rows of the tail); the others wait for the chunk's first site number to appear in LDS.
-                    const uint32_t e = c - (B1 - B0), k = e / BV_F_XCH, o = e % BV_F_XCH;
-                    uint32_t base;
-                    if (o == 0u) {
-                        const uint32_t g = bv_f_global_fetch_add_wave(&a.counters[BV_CTR_TICKET], 1u);
-                        base = ((uint64_t)tail0 + (uint64_t)g * BV_F_XCH < (uint64_t)a.n_sites) ? tail0 + g * BV_F_XCH : BV_F_XDONE;
-                        // (lane-0 side effects through statements that hide the branch: a divergent `if (lane == 0)` in this
-                        // lambda makes the compiler treat the ring's scalar state as per-lane)
-                        bv_f_lds_write_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.xbase[k], base);
-                        (void)bv_lds_fetch_add_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_XVALID], base != BV_F_XDONE ? 1u : 0u);
-                    } else {
-                        base = BV_F_EMPTY;
-                        for (uint32_t spins = 0; (base = bv_f_lds_read_u(&sh.xbase[k])) == BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(4);
-                        if (base == BV_F_EMPTY) { (void)bv_f_global_fetch_add_wave(&a.counters[BV_CTR_TIMEOUT], 1u); base = BV_F_XDONE; }
-                    }
-                    if (base == BV_F_XDONE) st |= CUR_DONE;
-                    else { s = base + o; kind = BV_FK_P1; xk = k; }
-                }
-                if (kind == BV_FK_P1) x = bv_f_ref_scalar(a.ref_base, s);
+                if (c < B1 - B0) { s = B0 + c; kind = BV_FK_P1; x = bv_f_ref_scalar(a.ref_base, s); }
+                else st |= CUR_DONE;
             }
-            // (Measured and off: a wave past its pass-1 rows that SOLVES before it streams -- no row drawn while a job's worth of
-            // candidates waits.  The last solver job then ends 45 us earlier, but HBM idles while twelve waves solve: 168 against
-            // 175 M sites/s, interleaved.  The four solver waves keep the solving; the others stream what is there.)
-            bool solve_first = false;
-#ifdef BV_F_SOLVE_FIRST  /* = m: the waves w with w % m == 0 */
-            if (FUSE2 && kind == 0u && (st & CUR_DONE) && (wave % BV_F_SOLVE_FIRST) == 0) {
-                const uint32_t need = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
-                solve_first = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= need ||
-                              bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= need;
-            }
-#endif
-            if (solve_first) return;
+            // (a wave past its pass-1 rows streams what variant rows there are; one that solved first instead measured 168
+            // against 175 M sites/s: HBM idles while twelve waves solve)
             if (FUSE2 && kind == 0u) {
                 const uint32_t h = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]);
                 if (h != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) && bv_f_lds_cas_wave(qvhead_lds, h, h + 1u) == h) {
@@ -820,13 +748,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
                 // no row right now.  None ever again: the cursor is exhausted, every streaming wave has published its last
                 // pass-1 row, no candidate waits, no solver job runs (each is counted before its entries leave their
                 // queue, until its variant sites are in theirs), and the variant queue is empty.
-                if ((st & CUR_DONE) &&
-                    (!FUSE2 || (bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS && bv_f_lds_read_u(&sh.ctl[BV_FC_BUSY]) == 0u &&
-                                bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) &&
-                                bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) &&
-                                bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD]) &&
-                                bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]))))
-                    st |= P_DONE;
+                if ((st & CUR_DONE) && (!FUSE2 || bv_f_no_row_ever(sh.ctl))) st |= P_DONE;
                 return;
             }
             const uint64_t off = (uint64_t)s * a.pitch;
@@ -842,8 +764,8 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             if (kind == BV_FK_P1) { p1 = bv_uniform_ptr(r_q + off); p_left = n_slots1; }
             else { p1 = bv_uniform_ptr(r_mq + off); p2 = bv_uniform_ptr(r_rp + 2u * off); p_left = n_slots2; }
             p_kind = kind;
-            if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; c_k = xk; st |= C_HAVE; }
-            else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; n_k = xk; st |= N_HAVE; }
+            if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; st |= C_HAVE; }
+            else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; st |= N_HAVE; }
         }
         const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
         if (!FUSE2 || p_kind == BV_FK_P1) {
@@ -859,7 +781,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     };
 
     // the previous pass-1 row of this wave: published once its stores are known to be complete
-    uint32_t prev_site = 0, prev_kind = 0, prev_x = 0xFFFFFFFFu;  // kind 0: none; 1: not a candidate; 2 / 3: queue q2 / q3; 4: wave solver
+    uint32_t prev_site = 0, prev_kind = 0;  // kind 0: none; 1: not a candidate; 2 / 3: queue q2 / q3; 4: wave solver
     uint32_t wsel = 0;                      // stores of the previous row still to be allowed for in the slot waits: 0 none / unknown, 1, 3
     BvFusedStash stash;
     stash.site = 0; stash.n12 = 0; stash.tw_m = 0; stash.tw_r = 0; stash.n = 0;
@@ -868,7 +790,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         if (prev_kind != 0u) {
             if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bv_f_publish(a, sh, B0, B1, prev_site, prev_x, prev_kind, lane);
+            bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
             if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its cand_list entry; rare)
             prev_kind = 0;
         }
@@ -962,7 +884,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         if (prev_kind != 0u) {
             if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            bv_f_publish(a, sh, B0, B1, prev_site, prev_x, prev_kind, lane);
+            bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
             prev_kind = 0;
             // every pass-1 row of this wave below its next one is out: the row of this epilogue, or the one already drawn, or
             // -- none drawn -- whatever the cursor hands out next (the end of the pass-1 rows sets the mark to "all")
@@ -972,12 +894,6 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             if (lane == 0 && !(st & P1_FIN)) sh.pub[wave] = mark;
         }
 
-#ifdef BV_ABL_F_NOEPI   /* attribution builds only: no totals, no candidate test (results are wrong) */
-        if (is_p1) {
-            if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = hist[lane * 37];
-            prev_site = site; prev_x = c_k; prev_kind = 1u; wsel = 1u;
-        } else
-#endif
         if (is_p1) {
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
@@ -1109,7 +1025,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
             w = (lane == 9) ? fl : w;
             if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
         }
-        prev_site = site; prev_x = c_k;
+        prev_site = site;
         prev_kind = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
         wsel = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_stores);
         } else {
@@ -1143,16 +1059,14 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         }
         }
         // ---- hand the histogram back, zeroed
-#ifndef BV_ABL_F_NOZERO  /* attribution builds only */
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
             for (int i = 0; i < BV_S_HWORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
             if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
         }
-#endif
         bv_lrt_sync<0>();
-        if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; c_k = n_k; st &= ~N_HAVE; }
+        if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; st &= ~N_HAVE; }
         else st &= ~C_HAVE;
         // the last pass-1 row of this wave is behind it: publish it, count the wave
         if ((st & CUR_DONE) && !(st & P1_FIN) && !((st & C_HAVE) && c_kind == BV_FK_P1) && !((st & N_HAVE) && n_kind == BV_FK_P1)) finish_p1();
@@ -1160,7 +1074,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     // ---- no row in flight: the ring is idle
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (prev_kind != 0u) {  // (a pass-1 row whose successor was not drawn yet: the variant queue had priority and was emptied by another wave)
-        bv_f_publish(a, sh, B0, B1, prev_site, prev_x, prev_kind, lane);
+        bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
         if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         prev_kind = 0;
         if (lane == 0 && !(st & (P1_FIN | CUR_DONE))) {
@@ -1183,19 +1097,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    // the workgroups' own contiguous ranges cover [0, tail0); the last eighth of the sites (in chunks of BV_F_XCH, at most half of
-    // what the workgroups' chunk tables hold) is the shared tail, dealt from a global counter to whoever is done with its own
-    uint32_t tail_sites = 0;
-#ifdef BV_F_SHARED_TAIL  /* measured, off: see BV_F_XCH */
-    if (a.n_sites >= gridDim.x * 128u) {
-        tail_sites = a.n_sites / 8u;
-        const uint32_t most = gridDim.x * (BV_F_XCAP * BV_F_XCH / 2u);
-        if (tail_sites > most) tail_sites = most;
-        tail_sites &= ~(BV_F_XCH - 1u);
-    }
-#endif
-    const uint32_t tail0 = a.n_sites - tail_sites;
-    const uint32_t B0 = (uint32_t)((uint64_t)tail0 * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)tail0 * (blockIdx.x + 1) / gridDim.x);
+    // every workgroup owns a contiguous range of sites
+    const uint32_t B0 = (uint32_t)((uint64_t)a.n_sites * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)a.n_sites * (blockIdx.x + 1) / gridDim.x);
     // ---- set-up: histograms zeroed, queues empty, tables in LDS; nothing is in flight yet, so a plain barrier is fine
     if (wave < BV_F_NS) {
         uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[wave]);
@@ -1205,7 +1108,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     }
     for (int i = tid; i < BV_F_QCAP; i += BV_WAVE * BV_F_NW) { sh.q3[i] = BV_F_EMPTY; sh.q2[i] = BV_F_EMPTY; }
     for (int i = tid; i < BV_F_QVCAP; i += BV_WAVE * BV_F_NW) sh.qv[i][0] = BV_F_EMPTY;
-    for (int i = tid; i < (int)BV_F_XCAP; i += BV_WAVE * BV_F_NW) { sh.xbase[i] = BV_F_EMPTY; sh.xdone[i] = 0u; }
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_F_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
@@ -1223,9 +1125,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     __syncthreads();
 
     const bool is_stream = wave < BV_F_NS;
-#ifdef BV_ABL_F_NOSOLVER  /* measurement: no dedicated solver waves -- the streaming waves solve everything once their rows are through */
-    if (!is_stream) return;
-#endif
     bool streaming = is_stream;
     uint32_t sst = 0;
     BvFusedSolver v;
@@ -1249,23 +1148,26 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     // is most of the kernel's code).
 #pragma unroll 1
     for (;;) {
-        if (streaming) {
+        // A streaming wave past its pass-1 rows calls the streaming function only when a variant row waits: the call is not
+        // free -- the function's prologue saves the 60 callee-saved VGPRs it uses to scratch memory (15 KB per wave and call,
+        // as much again read back on return), and a wave that polled through it hammered the L2 while the launch's last rows
+        // and solver jobs were waiting on the same memory system (and the evicted scratch lines showed as HBM writes: 316 MB
+        // per launch of 8,192 sites, where the records and scratch of the launch are 4 MB).
+        bool go = streaming;
+        if (streaming && (sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)) {
+            if (!FUSE2) { go = false; streaming = false; }
+            else if (bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD])) {
+                go = false;
+                if (bv_f_no_row_ever(sh.ctl)) streaming = false;
+            }
+        }
+        if (go) {
             // (the wave's variant sites since its last flush sit in its ring's LDS: out before rows stream through it again)
             if (v.n_vl) bv_f_flush_vl(a, v, lane);
-#ifdef BV_F_STREAM_PRIO
-            __builtin_amdgcn_s_setprio(BV_F_STREAM_PRIO);
-#endif
-            sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, tail0, sst));
-#ifdef BV_F_STREAM_PRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
+            sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
             if (sst & BV_FS_P_DONE) streaming = false;
         }
-#ifdef BV_F_EXSTREAM_PRIO0  /* measurement: streaming waves solve at priority 0, only the dedicated solver waves above it */
-        if (!is_stream) __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
-#else
         __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
-#endif
         const int r = bv_f_solver_step(a, sh, v, B0, B1, lane);
         __builtin_amdgcn_s_setprio(0);
         if (streaming) {

@@ -316,6 +316,16 @@ __global__ void bv_gid_prepare_kernel(const uint8_t *gid, uint8_t *gidp, uint32_
         gidp[i] = g < n_groups ? (uint8_t)(g << 2) : (uint8_t)0x80u;
     }
 }
+__global__ void bv_gid_round_kernel(const uint8_t *gid, uint8_t *out, uint32_t n, uint32_t lo, uint32_t cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const uint32_t g = (uint32_t)gid[i] - lo;  // (wraps for groups below lo)
+        out[i] = g < cnt ? (uint8_t)g : (uint8_t)BV_NO_GROUP;
+    }
+}
+void bv_launch_gid_round(const uint8_t *gid, uint8_t *out, uint32_t n_bytes, uint32_t lo, uint32_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(bv_gid_round_kernel, dim3((n_bytes + 255u) / 256u), dim3(256), 0, stream, gid, out, n_bytes, lo, n);
+}
 void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, uint32_t n_groups, hipStream_t stream) {
     hipLaunchKernelGGL(bv_gid_prepare_kernel, dim3((n_bytes + 255u) / 256u), dim3(256), 0, stream, gid, gidp, n_bytes, n_groups);
 }

@@ -244,7 +244,7 @@ int main(int argc, char **argv) {
     std::vector<std::string> group_names;
     std::vector<uint8_t> group_id(n_sample, BV_NO_GROUP);
     for (const auto &kv : groups_idx) {
-        if (group_names.size() >= BV_MAX_GROUPS) die("[ERROR] more than 32 population groups");
+        if (group_names.size() >= BV_MAX_GROUPS) die("[ERROR] more than 255 population groups");
         for (size_t i : kv.second) group_id[i] = (uint8_t)group_names.size();
         group_names.push_back(kv.first);
     }
@@ -292,6 +292,8 @@ int main(int argc, char **argv) {
     for (size_t g = 0; g < G; ++g)
         workers.emplace_back([&, g]() {
             std::unique_ptr<bvamd::BaseTypeEngine> engine;
+            // this worker feeds one GPU: keep it (and the staging memory it touches first) on the CPUs of that GPU's NUMA node
+            (void)bv_bind_thread_to_device_node(devices[g]);
             try {
                 engine.reset(new bvamd::BaseTypeEngine(batch_sites, (uint32_t)n_sample, user_min_af, devices[g]));
             } catch (const std::exception &ex) { fail(ex.what()); }

@@ -37,9 +37,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; --tile-job: 6 jobs)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--samples", type=int, default=100000, help="samples per site (row length)")
+    ap.add_argument("--samples", type=int, default=0, help="samples per site (row length); default 100,000 (--tile-job: 1,000,000)")
     ap.add_argument("--batch-sites", type=int, default=131072, help="sites per step and per GPU")
     ap.add_argument("--coverage", type=float, default=0.08)
     ap.add_argument("--distinct-batches", type=int, default=2)
@@ -62,19 +62,37 @@ def parse():
                     help="BV_FLAG_SPARSE_TIMING: the engine records its per-pass timing events for one launch in eight (the four "
                          "events cost ~15 us per launch); the kernel averages of the line then rest on those launches")
     ap.add_argument("--groups", type=int, default=0,
-                    help="diagnostic: G pop-groups (random membership, ~15 % of the samples in none): adds the per-group calls of pass 2")
+                    help="diagnostic: G pop-groups (random membership, ~15 %% of the samples in none): adds the per-group calls of pass 2")
     ap.add_argument("--with-tile-mode", action="store_true",
                     help="also time BASELINE config #5's shape: sample-axis tiles (--tile-width samples each) accumulated in "
                          "HBM, from device-resident tiles and from pinned host memory over PCIe (never `value`)")
     ap.add_argument("--tile-width", type=int, default=200, help="samples per tile (the reference's --batch-count)")
     ap.add_argument("--tile-sites", type=int, default=16384, help="sites per tile job (at most --batch-sites)")
+    ap.add_argument("--tile-job", action="store_true",
+                    help="BASELINE configs[4]'s shape AS the timed workload: one STEP = one tile job per rank -- --tile-sites sites x "
+                         "--samples samples (default here: 1,000,000) delivered as --tile-width-sample tiles from pinned, NUMA-local "
+                         "host memory (bv_engine_tiles_add), joined in HBM, both passes, records gathered to rank 0; every rank owns "
+                         "its contiguous site range of the job")
+    ap.add_argument("--tile-distinct", type=int, default=64, help="distinct host tiles kept resident per rank (cycled over the job)")
+    ap.add_argument("--verify-sites", type=int, default=256,
+                    help="N > 1: rank 0 re-runs the first V sites of EVERY rank's last batch on its own device (the synthetic rows "
+                         "are stateless in the global site index) and compares them with the gathered records byte for byte "
+                         "(config.ranks_verified); 0 = skip")
     ap.add_argument("--with-host-path", action="store_true",
                     help="also time the PCIe-inclusive path: pinned host planes staged by the engine (never `value`)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch-sites per GPU per step (default); strong: --batch-sites is the WHOLE job's batch "
                          "per step and every rank takes its contiguous 1/N of it (the fixed 1 M-site job of BASELINE "
                          "configs[3] = 8 steps of 131072 sites whatever N)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.samples <= 0:
+        args.samples = 1000000 if args.tile_job else 100000
+    if args.tile_job:
+        if args.chain > 1 or args.lanes > 1 or args.streams > 1 or args.groups or args.scaling != "weak" or args.no_rank_planes:
+            ap.error("--tile-job runs plain tile jobs: no --chain / --lanes / --streams / --groups / --scaling strong / --no-rank-planes")
+    if args.steps is None:
+        args.steps = 6 if args.tile_job else 20  # (a 16,384-site x 1 M-sample tile job moves 85 GB over the host link: ~1.6 s)
+    return args
 
 
 def self_launch(args):
@@ -225,6 +243,92 @@ def parity_on_sample(gpu, cpu):
                 "cvg_fs", "var_fs", "cvg_sor", "var_sor", "mq_ranksum", "rpr_ranksum", "bq_ranksum"))}
 
 
+class TileRig:
+    """BASELINE configs[4]'s shape on one rank: the sample axis of `St` sites arrives as `n_tiles` tiles of `W` samples
+    (the reference's --batch-count batchfiles, src/basetype_caller.cpp:419-453, re-joined per site at :589-601), cut from a
+    synthetic source slab and cycled (`res` distinct tiles resident).  Host tiles are ONE pinned allocation each (the layout of
+    bv_tile_packed_layout: a tile crosses the link as one copy), allocated and first touched while the thread is bound to the
+    CPUs of the GPU's NUMA node (bv_bind_thread_to_device_node), so every rank streams from node-local DRAM."""
+
+    def __init__(self, torch, eng, dev, device_index, St, W, n_tiles, res, src, host=True):
+        import basevar_amd
+        from basevar_amd import _capi
+        self.torch, self.eng, self.lib, self.capi = torch, eng, eng._lib, _capi
+        self.St, self.W, self.Wp, self.n_tiles, self.res = St, W, (W + 15) // 16 * 16, n_tiles, res
+        self.n_samples = n_tiles * W
+        bs0, q0, mq0, rp0, ref0 = src
+        self.ref = ref0[:St].contiguous()
+
+        def cut(t, lo, dt):
+            o = torch.zeros((St, self.Wp), dtype=dt, device=dev)
+            o[:, :W] = t[:St, lo:lo + W]
+            return o
+        self.dtiles = [(cut(bs0, k * W, torch.uint8), cut(q0, k * W, torch.uint8), cut(mq0, k * W, torch.uint8),
+                        cut(rp0, k * W, torch.int16)) for k in range(res)]
+        self.numa_node = self.lib.bv_device_numa_node(device_index, None, 0)
+        self.bound_node = -1
+        self.htiles = []
+        if host:
+            _, offs, tot = basevar_amd.tile_packed_layout(St, W, True, False)
+            keep = os.sched_getaffinity(0)
+            self.bound_node = self.lib.bv_bind_thread_to_device_node(device_index)
+            try:
+                for tb, tq, tm_, tr in self.dtiles:
+                    buf = torch.zeros(tot, dtype=torch.uint8).pin_memory()
+                    views = []
+                    for o, t in zip(offs[:4], (tb, tq, tm_, tr)):
+                        nb_ = t.numel() * t.element_size()
+                        v = buf[o:o + nb_].view(t.dtype).view(t.shape)
+                        v.copy_(t)
+                        views.append(v)
+                    self.htiles.append(tuple(views) + (buf,))
+            finally:
+                os.sched_setaffinity(0, keep)  # (the CPU baseline and the launch threads want every core again)
+            torch.cuda.synchronize()
+        self._slabs = {}
+
+    def slabs(self, kind):
+        """the job's n_tiles bv_slab descriptors (ctypes), built once per kind"""
+        if kind not in self._slabs:
+            tiles = self.htiles if kind == self.capi.BV_MEM_HOST else self.dtiles
+            self._slabs[kind] = [self.capi.Slab(self.St, self.W, self.Wp, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
+                                                t[3].data_ptr(), None, None, 0, kind) for t in (tiles[k % self.res] for k in range(self.n_tiles))]
+        return self._slabs[kind]
+
+    def job(self, out_ptr, kind, many=False, stream=0):
+        """one tile job queued on `stream` (0: the engine's own): begin, every tile, finish -> records at device `out_ptr`"""
+        import ctypes as C
+        eng, lib = self.eng, self.lib
+        rc = lib.bv_engine_tiles_begin(eng._h, self.St, self.n_samples, 0, 1)
+        assert rc == 0, eng._err()
+        sl = self.slabs(kind)
+        st = C.c_void_p(stream) if stream else None
+        if many:  # device-resident tiles: one launch per 256 tiles (bv_engine_tiles_add_many)
+            eng.tiles_add_many(sl, stream=stream)
+        else:
+            for t in sl:
+                rc = lib.bv_engine_tiles_add(eng._h, C.byref(t), st)
+                assert rc == 0, eng._err()
+        rc = lib.bv_engine_tiles_finish(eng._h, self.ref.data_ptr(), out_ptr, None, self.capi.BV_MEM_DEVICE, st)
+        assert rc == 0, eng._err()
+
+    def host_bytes_per_job(self):
+        return 5 * self.St * self.n_tiles * self.Wp
+
+    def joined_rows(self, V, dtiles=None):
+        """the first V sites as ordinary rows [V][pitch] on the device (what the tiles of a job join to), for verification"""
+        torch = self.torch
+        tiles = dtiles if dtiles is not None else self.dtiles
+        pitch = (self.n_samples + 255) // 256 * 256
+        planes = []
+        for j, (dt, fill) in enumerate(((torch.uint8, 8), (torch.uint8, 0), (torch.uint8, 0), (torch.int16, 0))):
+            o = torch.full((V, pitch), fill, dtype=dt, device=tiles[0][j].device)
+            for k in range(self.n_tiles):
+                o[:, k * self.W:(k + 1) * self.W] = tiles[k % self.res][j][:V, :self.W]
+            planes.append(o)
+        return planes, pitch
+
+
 def main():
     args = parse()
     # dmabuf IPC: RCCL across processes needs it on this driver -- also when a launcher other than self_launch() started the
@@ -265,19 +369,32 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     import basevar_amd
+    from basevar_amd import _capi as _capi_mod
     from basevar_amd.shard import RecordGatherer
 
     N = args.samples
     B = args.batch_sites
+    tj = None  # --tile-job geometry
+    if args.tile_job:
+        W = args.tile_width
+        n_tiles = max(1, N // W)
+        res = max(1, min(n_tiles, args.tile_distinct))
+        tj = {"W": W, "n_tiles": n_tiles, "res": res, "N_job": n_tiles * W, "St": min(args.tile_sites, args.batch_sites)}
+        B = tj["St"]      # sites per step and rank = sites per tile job
+        N = tj["N_job"]   # samples per site as the engine sees them (whole tiles only)
     if args.scaling == "strong":
         if args.batch_sites % world:
             sys.exit("bench.py --scaling strong: --batch-sites must be a multiple of the number of ranks")
         B = args.batch_sites // world  # this rank's contiguous share of the job's batch
-    pitch = (N + 255) // 256 * 256
+    # (--tile-job: the synthetic SOURCE slab the tiles are cut from holds `res` distinct tiles' worth of samples, cycled over the job)
+    N_fill = tj["res"] * tj["W"] if tj else N
+    pitch = (N_fill + 255) // 256 * 256
     maf = basevar_amd.min_af(N)
     K = max(1, args.chain)          # batches per launch
     Bl = B * K                      # sites per launch (= per step)
     nb = max(1, min(args.distinct_batches, args.steps + args.warmup))
+    if tj:
+        nb = 1  # one source slab per rank; the job cycles its tiles
     if K > 1:
         # every batch of a chained launch is a different one (no re-reads that the 256 MB infinity cache could serve), as far
         # as 96 GB of HBM go
@@ -294,14 +411,14 @@ def main():
         mq = torch.empty((B, pitch), dtype=torch.uint8, device=dev) if ranks else None
         rp = torch.empty((B, pitch), dtype=torch.int16, device=dev) if ranks else None
         ref = torch.empty(B, dtype=torch.uint8, device=dev)
-        basevar_amd.synth_fill(local_rank, B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(),
+        basevar_amd.synth_fill(local_rank, B, N_fill, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(),
                                mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0, seed=args.seed,
                                site_offset=(b * world + rank) * B, coverage=args.coverage)
         batches.append((bs, q, mq, rp, ref))
     torch.cuda.synchronize()
 
     ns = max(1, args.streams)
-    engs = [basevar_amd.BaseTypeEngine(max_sites=Bl, min_af_value=maf, device=local_rank,
+    engs = [basevar_amd.BaseTypeEngine(max_sites=Bl, min_af_value=maf, device=local_rank, max_samples=(N if tj else 0),
                                        flags=(1 if args.tally_only else 0) | args.flags | (0x10000000 if args.lanes == 2 else 0) | (0x20000000 if args.sparse_timing else 0))
             for _ in range(ns)]
     eng = engs[0]
@@ -321,13 +438,18 @@ def main():
     gatherer = RecordGatherer(Bl * rec, torch.device("cpu") if gloo_host else dev, depth=depth) if dist_on else None
     last_slot = [0]
 
-    G = max(0, min(args.groups, 32))
+    G = max(0, min(args.groups, 255))
     gid = gouts = None
     if G:
         gen = torch.Generator(device="cpu").manual_seed(args.seed & 0xFFFF)
         g = torch.randint(0, G + 1, (pitch,), generator=gen, dtype=torch.int64)
         gid = torch.where(g == G, torch.full_like(g, 255), g).to(torch.uint8).to(dev)
         gouts = [torch.zeros(Bl * G * basevar_amd.GROUP_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(depth)]
+
+    rig = None
+    if tj:
+        # this rank's tiles: pinned host allocations on the GPU's NUMA node, cut from the rank's own source rows
+        rig = TileRig(torch, eng, dev, local_rank, B, tj["W"], tj["n_tiles"], tj["res"], batches[0], host=True)
 
     def step(i):
         bs, q, mq, rp, ref = batches[i % nb]
@@ -339,7 +461,11 @@ def main():
                 # the gather that last read this buffer must have completed; Work.wait() orders the
                 # CURRENT stream behind the collective, so it has to be called on the stream that writes
                 gatherer.before_reuse(slot)
-            if K > 1:
+            if rig is not None:
+                # one tile job: every tile from pinned host memory (the engine's copy streams run ahead of its kernels),
+                # joined in HBM, then both passes over the joined rows
+                rig.job(out.data_ptr(), _capi_mod.BV_MEM_HOST, stream=streams[k].cuda_stream)
+            elif K > 1:
                 # K batches, one launch per pass: segment j writes records [j * B, (j + 1) * B) of the step's buffer
                 segs = []
                 for j in range(K):
@@ -384,13 +510,6 @@ def main():
         last = step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
-    gathered_ok = None
-    if rank == 0 and dist_on:
-        # the gathered buffer holds world x B records in rank order: every record must be a covered site
-        recs = torch.cat([p.cpu() for p in gatherer.parts(last_slot[0])]).numpy().view(basevar_amd.SITE_DTYPE)
-        mine = outs[last_slot[0]].cpu().numpy().view(basevar_amd.SITE_DTYPE)
-        gathered_ok = bool(len(recs) == world * Bl and (recs["total_depth"] > 0).all() and
-                           recs[:Bl].tobytes() == mine.tobytes())
     p1_ms = p2_ms = st_ms = 0.0
     nsub = 0
     for e in engs:
@@ -398,6 +517,46 @@ def main():
         s_, a1, a2, n_ = e.timing_get_ex()
         st_ms += s_; p1_ms += a1; p2_ms += a2; nsub += n_
     nvar = eng.last_variant_count()
+    gathered_ok = None
+    ranks_verified = 0
+    if rank == 0 and dist_on:
+        # the gathered buffer holds world x B records in rank order: every record must be a covered site
+        recs = torch.cat([p.cpu() for p in gatherer.parts(last_slot[0])]).numpy().view(basevar_amd.SITE_DTYPE)
+        mine = outs[last_slot[0]].cpu().numpy().view(basevar_amd.SITE_DTYPE)
+        gathered_ok = bool(len(recs) == world * Bl and (recs["total_depth"] > 0).all() and
+                           recs[:Bl].tobytes() == mine.tobytes())
+        # ... and rank r's part must be what a ONE-rank run of rank r's site range writes: the synthetic rows are stateless in
+        # the global site index, so rank 0 regenerates the first V sites of every rank's last batch on its own device, runs them
+        # through its engine as ordinary rows and compares the records byte for byte (site ranges, rank order of the gather,
+        # and -- with --tile-job -- the tile realisation against the row realisation)
+        V = max(0, min(args.verify_sites, B))
+        if V:
+            i_last = args.warmup + args.steps - 1
+            b_last = 0 if tj else ((i_last * K) % nb)
+            vout = torch.zeros(V * rec, dtype=torch.uint8, device=dev)
+            for r in range(world):
+                vb = torch.empty((V, pitch), dtype=torch.uint8, device=dev); vq = torch.empty_like(vb)
+                vm = torch.empty_like(vb) if ranks else None
+                vr = torch.empty((V, pitch), dtype=torch.int16, device=dev) if ranks else None
+                vref = torch.empty(V, dtype=torch.uint8, device=dev)
+                basevar_amd.synth_fill(local_rank, V, N_fill, pitch, vb.data_ptr(), vq.data_ptr(), vref.data_ptr(),
+                                       vm.data_ptr() if ranks else 0, vr.data_ptr() if ranks else 0, seed=args.seed,
+                                       site_offset=(b_last * world + r) * B, coverage=args.coverage)
+                torch.cuda.synchronize()
+                if tj:
+                    vrig = TileRig(torch, eng, dev, local_rank, V, tj["W"], tj["n_tiles"], tj["res"], (vb, vq, vm, vr, vref), host=False)
+                    (jb, jq, jm, jr), jp = vrig.joined_rows(V)
+                    eng.submit_ptrs(V, N, jp, jb.data_ptr(), jq.data_ptr(), vref.data_ptr(), vout.data_ptr(), jm.data_ptr(), jr.data_ptr())
+                else:
+                    eng.submit_ptrs(V, N, pitch, vb.data_ptr(), vq.data_ptr(), vref.data_ptr(), vout.data_ptr(),
+                                    vm.data_ptr() if ranks else 0, vr.data_ptr() if ranks else 0,
+                                    group_id=gid.data_ptr() if G else 0, n_groups=G,
+                                    gout=gouts[0].data_ptr() if G else 0)
+                eng.wait()
+                want = vout.cpu().numpy().tobytes()
+                got = recs[r * Bl:r * Bl + V].tobytes()
+                ranks_verified += int(want == got)
+            gathered_ok = gathered_ok and ranks_verified == world
 
     # per-rank figures for rank 0's line: this rank's wall time of the timed region, its pass-1 fraction of the HBM peak, and
     # what of its step was NOT kernels (the gather's exposed time + launch gaps)
@@ -407,17 +566,58 @@ def main():
     n_launch = args.steps if args.sparse_timing else nsub
     my_p1_frac = (2.0 * Bl * N * args.steps / max(n_launch, 1)) / max(p1_ms / max(nsub, 1) / 1e3, 1e-12) / 1e9 / HBM_PEAK_GBS
     my_exposed_ms = max(0.0, elapsed / args.steps * 1e3 - (p1_ms + p2_ms) / max(nsub, 1) * n_launch / max(args.steps, 1))
-    mine = torch.tensor([elapsed, my_p1_frac, my_exposed_ms], dtype=torch.float64, device=dev)
-    per_rank = [mine.clone() for _ in range(world)] if dist_on else [mine]
-    if dist_on:
+    # --tile-job: bytes this rank pulled over its host link per second of the timed region; the NUMA node of its GPU and the
+    # node its pinned tiles were allocated on (-1: the platform does not say / nothing bound)
+    my_host_gbps = rig.host_bytes_per_job() * args.steps / elapsed / 1e9 if rig is not None else 0.0
+    my_nodes = (float(rig.numa_node), float(rig.bound_node)) if rig is not None else (-1.0, -1.0)
+
+    def all_ranks(vec):
+        """every rank's vector of float64 figures, in rank order (a list of lists)"""
+        mine_ = torch.tensor(vec, dtype=torch.float64, device=dev)
+        if not dist_on:
+            return [[float(x) for x in mine_.tolist()]]
         if backend == "nccl":
-            dist.all_gather(per_rank, mine)
+            lst = [mine_.clone() for _ in range(world)]
+            dist.all_gather(lst, mine_)
         else:
-            cpu_list = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
-            dist.all_gather(cpu_list, mine.cpu())
-            per_rank = cpu_list
-    per_rank = [[float(x) for x in t_.tolist()] for t_ in per_rank]
+            lst = [torch.zeros(len(vec), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(lst, mine_.cpu())
+        return [[float(x) for x in t_.tolist()] for t_ in lst]
+
+    per_rank = all_ranks([elapsed, my_p1_frac, my_exposed_ms, my_host_gbps, my_nodes[0], my_nodes[1]])
     elapsed = max(r[0] for r in per_rank)
+
+    tile_legs = None
+    if args.with_tile_mode and not tj:
+        # BASELINE configs[4]'s shape beside the row workload, on EVERY rank at once (the ranks share the host's memory
+        # channels and PCIe root complexes, so the per-rank link rates are only meaningful measured together): one tile =
+        # one batchfile's worth of samples for every site of the rank's site range; never `value`
+        St = min(B, args.tile_sites)
+        Wt = args.tile_width
+        n_tiles_t = max(1, N // Wt)
+        trig = TileRig(torch, eng, dev, local_rank, St, Wt, n_tiles_t, min(n_tiles_t, args.tile_distinct), batches[0], host=True)
+        tout = torch.zeros(St * rec, dtype=torch.uint8, device=dev)
+        tms = []
+        for kind, many in ((_capi_mod.BV_MEM_DEVICE, True), (_capi_mod.BV_MEM_DEVICE, False), (_capi_mod.BV_MEM_HOST, False)):
+            trig.job(tout.data_ptr(), kind, many); eng.wait()   # warm-up: scratch, staging ring
+            if dist_on:
+                dist.barrier()
+            t0 = time.perf_counter()
+            trig.job(tout.data_ptr(), kind, many); eng.wait()
+            tms.append(time.perf_counter() - t0)
+        legs = all_ranks(tms + [float(trig.numa_node), float(trig.bound_node)])
+        cells = float(St) * n_tiles_t * Wt
+        if rank == 0:
+            def leg(j, bytes_per_rank):
+                tmax = max(r[j] for r in legs)
+                return {"value": world * St / tmax, "unit": "sites/s", "GBps": world * bytes_per_rank / tmax / 1e9,
+                        "per_rank_GBps": [bytes_per_rank / r[j] / 1e9 for r in legs]}
+            tile_legs = {"sites_per_rank": St, "samples": n_tiles_t * Wt, "tile_width": Wt, "tiles": n_tiles_t, "ranks": world,
+                         "device_resident": dict(leg(0, 5 * cells), how="bv_engine_tiles_add_many, one launch per 256 tiles"),
+                         "device_resident_tile_by_tile": leg(1, 5 * cells),
+                         "host_pinned_pcie": dict(leg(2, float(trig.host_bytes_per_job())),
+                                                  numa_node_of_gpu=[int(r[3]) for r in legs], tiles_bound_to_node=[int(r[4]) for r in legs])}
+        del trig, tout
 
     if rank == 0:
         sites_per_s = world * Bl * args.steps / elapsed
@@ -452,11 +652,11 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
             try:
-                tj = json.load(open(tfile))
+                tjs = json.load(open(tfile))
                 for key in ("%s|%dx%d" % (kernel_name, Bl, N) + ("|chain%d" % K if K > 1 else ""),) + (("pass1_%dx%d" % (Bl, N),) if K == 1 else ()):
-                    if key in tj and (key.startswith(kernel_name) or kernel_name == "bv_pass1_kernel"):
-                        traffic = tj[key]["hbm_bytes_per_launch"]
-                        traffic_source = tj[key].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % key)
+                    if key in tjs and (key.startswith(kernel_name) or kernel_name == "bv_pass1_kernel"):
+                        traffic = tjs[key]["hbm_bytes_per_launch"]
+                        traffic_source = tjs[key].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % key)
                         break
             except Exception:
                 traffic = traffic_source = None
@@ -466,7 +666,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "%s: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
+                "workload": ("BASELINE configs[4] shape: synthetic NIPT pileup, %d samples/site delivered as %d tiles of %d samples "
+                             "(the reference's --batch-count batchfiles) from pinned host DRAM on the GPU's NUMA node, coverage %.2f, "
+                             "tile jobs of %d sites per GPU, joined in HBM, both passes; weak scaling: every rank owns its "
+                             "contiguous site range of the job (1M-site job = %d such jobs per GPU at %d GPUs)" % (
+                                 N, tj["n_tiles"], tj["W"], args.coverage, B, (1000000 + world * B - 1) // (world * B), world)) if tj else
+                            "%s: synthetic NIPT pileup, %d samples/site, coverage %.2f, "
                             "HBM-resident batches of %d sites per GPU%s (%s; 1M-site job = %d such batches)" % (
                                 "BASELINE configs[2]" if N == 100000 else "BASELINE configs[1]" if N == 10000 else
                                 "BASELINE configs[4] shape" if N == 1000000 else "diagnostic shape",
@@ -480,10 +685,20 @@ def main():
                 "rccl_ranks": (dist.get_world_size() if dist_on and backend == "nccl" else 0),
                 "dist_world_size": (dist.get_world_size() if dist_on else 1),
                 "variant_sites_last_batch": nvar, "gathered_records_ok": gathered_ok,
+                # N > 1: ranks whose first `verify_sites` gathered records equal rank 0's own re-run of that rank's site range
+                "ranks_verified": (ranks_verified if dist_on else None), "verify_sites": (max(0, min(args.verify_sites, B)) if dist_on else 0),
+                "tile_job": ({"tiles_per_job": tj["n_tiles"], "tile_width": tj["W"], "distinct_host_tiles": tj["res"],
+                              "host_bytes_per_job_per_rank": rig.host_bytes_per_job(),
+                              # what every rank pulled over ITS host link per second of the timed region, and all of them together
+                              "host_pinned_pcie_GBps_per_rank": [r[3] for r in per_rank],
+                              "host_pinned_pcie_GBps_total": sum(r[3] for r in per_rank),
+                              "numa_node_of_gpu": [int(r[4]) for r in per_rank], "tiles_bound_to_node": [int(r[5]) for r in per_rank]}
+                             if tj else None),
                 # 1: sites of <= 64 covered samples are replayed with the host libm's own log() (ties decided as the reference
                 # decides them); 0: the device library's log() (values within 1e-6, exact ties undecided, BV_SITE_LOG_APPROX)
                 "host_log_exact": int(eng.host_log_exact),
-                "per_rank": {"pass1_frac_min": min(r[1] for r in per_rank), "pass1_frac_max": max(r[1] for r in per_rank),
+                "per_rank": {"step_ms": [r[0] / args.steps * 1e3 for r in per_rank], "pass1_frac": [r[1] for r in per_rank],
+                             "pass1_frac_min": min(r[1] for r in per_rank), "pass1_frac_max": max(r[1] for r in per_rank),
                              "step_ms_min": min(r[0] for r in per_rank) / args.steps * 1e3,
                              "step_ms_max": max(r[0] for r in per_rank) / args.steps * 1e3,
                              # step time minus this rank's kernel time: launch gaps + what of the record gather is not hidden
@@ -542,71 +757,8 @@ def main():
             dt = (time.perf_counter() - t0) / 3
             line["pcie_inclusive"] = {"value": hb / dt, "unit": "sites/s", "batch_sites": hb,
                                       "host_GBps": hb * pitch * (5 if ranks else 2) / dt / 1e9}
-        if world == 1 and args.with_tile_mode:
-            # the reference's own on-disk shape: one tile = one batchfile's worth of samples for every site
-            import ctypes as C
-            from basevar_amd import _capi
-            St = min(B, args.tile_sites)
-            W = args.tile_width
-            Wp = (W + 15) // 16 * 16
-            n_tiles = N // W
-            res = min(n_tiles, 64)  # distinct tiles kept resident (cycled): 64 x St x Wp x 5 B
-            bs0, q0, mq0, rp0, ref0 = batches[0]
-
-            def cut(t, lo, dt):
-                o = torch.zeros((St, Wp), dtype=dt, device=dev)
-                o[:, :W] = t[:St, lo:lo + W]
-                return o
-            dtiles = [(cut(bs0, k * W, torch.uint8), cut(q0, k * W, torch.uint8), cut(mq0, k * W, torch.uint8),
-                       cut(rp0, k * W, torch.int16)) for k in range(res)]
-            # host tiles: ONE pinned allocation per tile, planes at the offsets of bv_tile_packed_layout, so that a tile
-            # crosses the link as one copy
-            _, offs, tot = basevar_amd.tile_packed_layout(St, W, True, False)
-            htiles = []
-            for tb, tq, tm_, tr in dtiles:
-                buf = torch.zeros(tot, dtype=torch.uint8).pin_memory()
-                views = []
-                for o, src in zip(offs[:4], (tb, tq, tm_, tr)):
-                    nb_ = src.numel() * src.element_size()
-                    v = buf[o:o + nb_].view(src.dtype).view(src.shape)
-                    v.copy_(src)
-                    views.append(v)
-                htiles.append(tuple(views) + (buf,))
-            tout = torch.zeros(St * rec, dtype=torch.uint8, device=dev)
-            lib = eng._lib
-
-            def tile_job(tiles, kind, many=False):
-                rc = lib.bv_engine_tiles_begin(eng._h, St, n_tiles * W, 0, 1)
-                assert rc == 0, eng._err()
-                slabs = []
-                for k in range(n_tiles):
-                    tb, tq, tm, tr = tiles[k % res][:4]
-                    t = _capi.Slab(St, W, Wp, tb.data_ptr(), tq.data_ptr(), tm.data_ptr(), tr.data_ptr(), None, None, 0, kind)
-                    if many:
-                        slabs.append(t)
-                        continue
-                    rc = lib.bv_engine_tiles_add(eng._h, C.byref(t), None)
-                    assert rc == 0, eng._err()
-                if many:  # device-resident tiles: one launch per 256 tiles (bv_engine_tiles_add_many)
-                    eng.tiles_add_many(slabs)
-                rc = lib.bv_engine_tiles_finish(eng._h, ref0.data_ptr(), tout.data_ptr(), None, _capi.BV_MEM_DEVICE, None)
-                assert rc == 0, eng._err()
-                eng.wait()
-            tm = {}
-            for name, tiles, kind, many in (("device", dtiles, _capi.BV_MEM_DEVICE, True), ("device_tile_by_tile", dtiles, _capi.BV_MEM_DEVICE, False),
-                                            ("host", htiles, _capi.BV_MEM_HOST, False)):
-                tile_job(tiles, kind, many)
-                t0 = time.perf_counter()
-                tile_job(tiles, kind, many)
-                tm[name] = time.perf_counter() - t0
-            cells = float(St) * n_tiles * W
-            line["tile_mode"] = {"sites": St, "samples": n_tiles * W, "tile_width": W, "tiles": n_tiles,
-                                 "device_resident": {"value": St / tm["device"], "unit": "sites/s", "GBps": 5 * cells / tm["device"] / 1e9,
-                                                     "how": "bv_engine_tiles_add_many, one launch per 256 tiles"},
-                                 "device_resident_tile_by_tile": {"value": St / tm["device_tile_by_tile"], "unit": "sites/s",
-                                                                  "GBps": 5 * cells / tm["device_tile_by_tile"] / 1e9},
-                                 "host_pinned_pcie": {"value": St / tm["host"], "unit": "sites/s", "GBps": 5 * St * n_tiles * Wp / tm["host"] / 1e9}}
-            del dtiles, htiles
+        if tile_legs is not None:
+            line["tile_mode"] = tile_legs
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, cpu_rec, cpu_idx = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)

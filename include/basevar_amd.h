@@ -60,7 +60,8 @@ extern "C" {
 #define BV_MAX_PHRED 93u
 #define BV_MAX_ALT 4 /* ref not in ACGT + four active bases (basetype.cpp:172-177) */
 #define BV_NO_GROUP 0xFFu
-#define BV_MAX_GROUPS 32u
+#define BV_MAX_GROUPS 255u /* group ids are bytes, 0xFF = none.  The reference takes any number (a std::map,
+                              src/basetype_caller.cpp:372-410); beyond 32 the engine runs pass 2 once per 32 groups */
 
 typedef enum bv_status {
     BV_OK = 0,
@@ -332,6 +333,17 @@ int bv_engine_last_variant_count(bv_engine *e, uint32_t *n_variant);
 
 /* Thread-safe: message of the last error on this engine (or global if e == NULL). */
 const char *bv_last_error(const bv_engine *e);
+
+/* ---- NUMA placement of host buffers (BASELINE config #5: tiles streamed from host DRAM on 8 GPUs) -----
+ * The reference reads its batchfiles wherever the OS puts them (src/basetype_caller.cpp:586-611); a host that streams
+ * pinned tiles to several GPUs should keep each GPU's tiles on the NUMA node its PCIe link hangs off.
+ *   bv_device_numa_node            the node of HIP device `device` (sysfs numa_node of its PCI function), -1 when the
+ *                                  platform does not say; pci_bdf (may be NULL) receives "dddd:bb:dd.f"
+ *   bv_bind_thread_to_device_node  restricts the CALLING thread to the CPUs of that node (within its current affinity
+ *                                  mask), so that buffers it allocates and first touches afterwards are node-local;
+ *                                  returns the node, or -1 and changes nothing */
+int bv_device_numa_node(int device, char *pci_bdf, size_t pci_bdf_len);
+int bv_bind_thread_to_device_node(int device);
 
 /* ---- measurement helper (bench only; not part of the reference surface) --------
  * Fill device planes with the synthetic pileup of SURVEY.md section 8(d) using a

@@ -51,6 +51,74 @@ def test_bench_self_launch_two_ranks(scaling):
     assert d["config"]["job_batch_sites"] == (2048 if scaling == "strong" else 4096)
 
 
+def _run_bench(extra, world, env_extra=None, timeout=900):
+    """`python bench.py --gpus <world> ...` self-launched, all ranks on cuda:0 over gloo; returns the parsed line"""
+    env = dict(os.environ, BASEVAR_BENCH_BACKEND="gloo", BASEVAR_BENCH_ONE_DEVICE="1")
+    env.update(env_extra or {})
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("samples", [6000, 60000], ids=["short_rows", "long_rows"])
+def test_bench_eight_ranks_one_device_every_rank_verified(samples):
+    """BASELINE configs[3] in small, at the driver's largest rank count: 8 ranks (one device, gloo), every rank its
+    contiguous site range of every batch; rank 0 re-runs the first sites of EVERY rank's last batch as a one-rank job
+    and the gathered records must equal them byte for byte, in rank order (reference analogue: the fan-out and ordered
+    merge of src/basetype_caller.cpp:469-525)."""
+    d = _run_bench(["--steps", "3", "--warmup", "1", "--samples", str(samples), "--batch-sites", "512", "--verify-sites", "128"], 8)
+    c = d["config"]
+    assert d["n_gpus"] == 8 and c["dist_world_size"] == 8 and c["job_batch_sites"] == 8 * 512
+    assert c["gathered_records_ok"] is True and c["ranks_verified"] == 8 and c["verify_sites"] == 128
+    assert len(c["per_rank"]["step_ms"]) == 8 and all(t > 0 for t in c["per_rank"]["step_ms"])
+    assert len(c["per_rank"]["pass1_frac"]) == 8
+    assert d["ms_per_step"] == pytest.approx(max(c["per_rank"]["step_ms"]), rel=1e-9)  # the slowest rank's time
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bench_tile_job_ranks_one_device(world):
+    """BASELINE configs[4] in small: `--tile-job` makes the tile job THE timed workload -- every rank streams its own
+    site range as tiles of --tile-width samples from pinned host memory (src/basetype_caller.cpp:419-453, 589-601), the
+    records are gathered, and rank 0 checks every rank's part against a ROW submit of the same cells (the tile
+    realisation against the row realisation, byte for byte)."""
+    extra = ["--tile-job", "--steps", "2", "--warmup", "1", "--samples", "5000", "--tile-width", "200", "--tile-sites", "192",
+             "--tile-distinct", "7", "--verify-sites", "64"]
+    env = {"BASEVAR_BENCH_FORCE_DIST": "1"} if world == 1 else None
+    d = _run_bench(extra, world, env)
+    c = d["config"]
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["unit"] == "sites/s" and d["value"] > 0
+    assert c["workload"].startswith("BASELINE configs[4] shape") and c["samples"] == 5000 and c["batch_sites"] == 192
+    tjob = c["tile_job"]
+    assert tjob["tiles_per_job"] == 25 and tjob["tile_width"] == 200 and tjob["distinct_host_tiles"] == 7
+    assert len(tjob["host_pinned_pcie_GBps_per_rank"]) == world and all(g > 0 for g in tjob["host_pinned_pcie_GBps_per_rank"])
+    assert tjob["host_pinned_pcie_GBps_total"] == pytest.approx(sum(tjob["host_pinned_pcie_GBps_per_rank"]))
+    assert len(tjob["numa_node_of_gpu"]) == world and len(tjob["tiles_bound_to_node"]) == world
+    for node, bound in zip(tjob["numa_node_of_gpu"], tjob["tiles_bound_to_node"]):
+        assert bound in (node, -1)  # bound to the GPU's node where the platform names it and the rank may run there
+    assert c["gathered_records_ok"] is True and c["ranks_verified"] == world
+    assert d["roofline"]["launches"] == 2 and 0 < d["roofline"]["frac"] < 1
+
+
+@pytest.mark.gpu
+def test_bench_with_tile_mode_on_two_ranks():
+    """`--with-tile-mode` beside the row workload on N ranks: the three tile legs run on every rank at once and the line
+    carries the per-rank link rates and their sum (never `value`)."""
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--samples", "20000", "--batch-sites", "1024", "--with-tile-mode",
+                    "--tile-sites", "256", "--tile-width", "200", "--tile-distinct", "8"], 2)
+    t = d["tile_mode"]
+    assert t["ranks"] == 2 and t["sites_per_rank"] == 256 and t["tiles"] == 100
+    for leg in ("device_resident", "device_resident_tile_by_tile", "host_pinned_pcie"):
+        assert len(t[leg]["per_rank_GBps"]) == 2 and t[leg]["value"] > 0 and t[leg]["GBps"] > 0
+    assert d["config"]["workload"].startswith("diagnostic shape") and d["config"]["ranks_verified"] == 2
+
+
 def test_bench_self_launch_fails_in_the_children_without_a_gpu():
     """On a GPU-less box `python bench.py --gpus 2` must get as far as starting its ranks: the failure is the
     ranks' "needs a GPU" check, relayed with a non-zero exit code -- not an argument check in the parent."""

@@ -611,6 +611,37 @@ def test_many_groups_and_engine_reuse(bv, restatement):
     eng.close()
 
 
+@pytest.mark.parametrize("n,ng,ranks", [(5000, 64, True), (5000, 33, False), (60000, 70, True), (300, 255, True), (20000, 255, True)],
+                         ids=["short_rows_64", "short_rows_33_no_ranks", "long_rows_70", "wave_per_row_255", "u8_limit_255"])
+def test_more_than_32_pop_groups(bv, restatement, n, ng, ranks):
+    """The reference takes any number of pop-groups (a std::map, src/basetype_caller.cpp:372-410; one __gb() per group,
+    :756-759); the engine runs pass 2 once per 32 of them.  Group g of round r must land in column 32 r + g of the site's
+    records, groups of other rounds must not leak into a round's tallies, and the rank sums are formed once."""
+    rng = np.random.default_rng(100 + ng)
+    S = 80
+    slab = make_slab(S, n, seed=int(rng.integers(1 << 20)), coverage=0.3, n_groups=0, site_offset=5)
+    gid = rng.integers(0, ng + 1, size=n).astype(np.uint8)   # every group has ~n / (ng + 1) samples, the rest none
+    gid[gid == ng] = 0xFF
+    gid[:ng] = np.arange(ng, dtype=np.uint8)                  # ... and no group is empty
+    slab["group_id"] = gid
+    slab["n_groups"] = ng
+    if not ranks:
+        slab.pop("mapq"); slab.pop("rpr")
+    eng = bv.BaseTypeEngine(max_sites=128, min_af_value=bv.min_af(n), device=0)
+    got = eng.lrt(slab)
+    exp, gexp, margins = restatement.run_with_margins(slab, eng.min_af, n_threads=8)
+    check(got, exp, gexp, margins, check_ranks=ranks)
+    var = (exp["status"] & 2) != 0
+    assert var.sum() > 10 and (gexp["total_depth"][var] > 0).any(axis=0).all()  # every group column carries data
+    # the same records through a tile job (joined rows) and again as rows: the round scratch is reused
+    if n <= 20000 and ranks:
+        t = eng.lrt_tiles(slab, 1000)
+        assert t.sites.tobytes() == got.sites.tobytes() and t.groups.tobytes() == got.groups.tobytes()
+    again = eng.lrt(slab)
+    assert again.sites.tobytes() == got.sites.tobytes() and again.groups.tobytes() == got.groups.tobytes()
+    eng.close()
+
+
 def test_device_log_is_the_hosts_log(bv):
     """bv_log_host on the device == the host libm's log(), bit for bit: the EM's marginals at shallow sites (mixtures of
     1 - eps_q and eps_q / 3), both branches of the algorithm, subnormals, specials."""

@@ -417,6 +417,12 @@ def test_bam_fixture_end_to_end_counts_of_the_real_binary(tmp_path, restatement)
     subprocess.check_call([call, "--batchfiles", bf, "--output-vcf", vcf5, "--output-cvg", cvg5, "--min-af", "0.05", "--batch-sites", "5",
                            "--devices", "0,0,0"])
     assert open(vcf5).read() == open(vcf).read() and open(cvg5).read() == open(cvg).read()
+    # eight engines (the driver's largest node shape, here all on the one GPU), batches of 3 sites: byte-identical to one engine
+    vcf8, cvg8 = str(tmp_path / "vz8.vcf"), str(tmp_path / "t8.cvg")
+    subprocess.check_call([call, "-I", bam, "-I", bam, "-R", os.path.join(data, "ce.fa.gz"), "--regions", "CHROMOSOME_I:900-1200",
+                           "--mapq", "10", "--output-vcf", vcf8, "--output-cvg", cvg8, "--min-af", "0.05", "--batch-sites", "3",
+                           "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0", "--thread", "2"])
+    assert open(vcf8).read() == open(vcf2).read() and open(cvg8).read() == open(cvg2).read()
     # ... and on two DIFFERENT devices where the box has them (one engine + host thread per GPU, ordered emit: the
     # reference's fan-out and merge, caller.cpp:469-525)
     import torch
