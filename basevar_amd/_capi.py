@@ -19,6 +19,7 @@ BV_NO_GROUP = 0xFF
 BV_MEM_DEVICE, BV_MEM_HOST = 0, 1
 BV_FLAG_LANES = 0x10000000
 BV_FLAG_SPARSE_TIMING = 0x20000000  # include/basevar_amd.h
+BV_FORM_SHORT_ROWS, BV_FORM_ONE_KERNEL, BV_FORM_PASS2_FUSED = 0x1, 0x2, 0x4  # include/basevar_amd_diag.h
 # bv_engine_config.flags (include/basevar_amd.h)
 BV_FLAG_TALLY_ONLY, BV_FLAG_SKIP_FISHER, BV_FLAG_SKIP_LRT, BV_FLAG_TILE_STATE, BV_FLAG_WAVE_SOLVER = 0x1, 0x2, 0x4, 0x8, 0x10
 BV_OK, BV_ERR_INVALID_ARG, BV_ERR_NO_DEVICE, BV_ERR_HIP, BV_ERR_TOO_LARGE, BV_ERR_SITE = 0, -1, -2, -3, -4, -5
@@ -65,7 +66,7 @@ EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "
            "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_add_many", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
            "bv_host_log_probe", "bv_host_log_eval", "bv_engine_host_log_exact", "bv_engine_host_log_eval",
-           "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill", "bv_device_numa_node", "bv_bind_thread_to_device_node"]
+           "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill", "bv_device_numa_node", "bv_bind_thread_to_device_node", "bv_engine_last_launch_form"]
 
 _lib = None
 
@@ -143,6 +144,8 @@ def load():
     L.bv_synth_fill.restype = C.c_int
     L.bv_synth_fill.argtypes = [C.c_int, C.POINTER(SynthParams), C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.bv_engine_last_launch_form.restype = C.c_int
+    L.bv_engine_last_launch_form.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
     L.bv_device_numa_node.restype = C.c_int
     L.bv_device_numa_node.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
     L.bv_bind_thread_to_device_node.restype = C.c_int

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/basevar_amd.h"
+#include "../../include/basevar_amd_diag.h"  // diagnostic / A-B flag bits the kernels honour
 
 #define BV_WAVE 64
 #define BV_QBINS 128                       /* phred axis of the LDS histogram          */
@@ -687,10 +688,6 @@ __device__ __forceinline__ double bv_int_abs_trunc(double d) {
 __device__ __forceinline__ int bv_em_wave_generic(const BvBins &B, double f[4], double n_cov, double *lr_out, int lane) {
     const double epsilon = (double)0.001f;  // `const float epsilon=0.001`, algorithm.h:213
     const int nslots = (B.nb + BV_WAVE - 1) / BV_WAVE;
-#ifdef BV_ABL_NO_EM  /* attribution builds only */
-    *lr_out = -f[0];
-    return 1;
-#endif
     // The reference takes log(marginal) of every sample in every pass, but uses the values only (a) in
     // the convergence term |int(llh_new - llh_old)| (algorithm.h:245, integer abs: zero unless the two logs
     // differ by >= 1) and (b) from the LAST pass, as the log-likelihood sum.  So the previous pass's
@@ -766,10 +763,6 @@ __device__ __forceinline__ int bv_em_wave(const BvBins &B, double f[4], unsigned
                                           int lane) {
     const double epsilon = (double)0.001f;
     const int nslots = (B.nb + BV_WAVE - 1) / BV_WAVE;
-#ifdef BV_ABL_NO_EM
-    *lr_out = -f[0];
-    return 1;
-#endif
     const double inv_n = 1.0 / n_cov;
     const bool s0 = in_set & 1u, s1 = in_set & 2u, s2 = in_set & 4u, s3 = in_set & 8u;
     const int nset = __popc(in_set);
@@ -1163,12 +1156,8 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
                 f[2] = (b1 == 2) ? 1.0 : 0.; f[3] = (b1 == 3) ? 1.0 : 0.;
             } else {
                 // phred-0 calls (1 - eps == 0) and all-zero starts make 0/0 in the reference: exact replay
-#ifdef BV_EXP_NO_GENERIC_EM  /* code-size experiment only: wrong for phred-0 sites */
-                it = bv_em_wave(B, f, in_set, n_cov, &lr, lane);
-#else
                 it = (q0_mask != 0u || s == 0.) ? bv_em_wave_generic(B, f, n_cov, &lr, lane)
                                                 : bv_em_wave(B, f, in_set, n_cov, &lr, lane);
-#endif
             }
             if (lane == 0) {
                 sh->f[par][c][0] = f[0]; sh->f[par][c][1] = f[1];

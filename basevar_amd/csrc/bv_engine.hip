@@ -184,10 +184,6 @@ struct bv_engine {
     // Counter blocks (BV_CTR_* words each, bv_kernels.h): a launch that is cut into chunks (short rows, launch_passes)
     // gives every chunk a block of its own; everything else uses block 0.
     static constexpr uint32_t kCtrBlocks = 8;
-#ifdef BV_TL_DEBUG
-    uint32_t *d_tl = nullptr;          // [512][8] kernel start / end stamps per submit
-    uint32_t tl_n = 0;
-#endif
     uint32_t *d_counters = nullptr;    // [kCtrBlocks][BV_CTR_WORDS]
     uint32_t *h_counters = nullptr;    // pinned host mirror
     uint32_t last_blocks = 1;          // blocks the last launch used (their VARIANTS words add up to its variant count)
@@ -198,17 +194,13 @@ struct bv_engine {
     // 100 k sites x 10 k samples 157.7 -> 160.4 M sites/s without it, 8,192-site batches 51.9 -> 55.7 M.)
     uint32_t ctr_rot = 0;
     bool ctr_mirror_stale = false;     // the device counters are ahead of h_counters
-    // Short rows: the solve kernels of pass 1 read no planes (issue-bound) while the streaming kernels leave the VALU idle, so
-    // a large batch runs as a software pipeline of chunks over two streams -- the caller's (streaming kernels, pass 2) and
-    // this one (solve kernels): solve(c) runs under stream(c + 1), pass2(c) under solve(c + 1).
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_s[kCtrBlocks] = {}, ev_v[kCtrBlocks] = {};  // per chunk: streaming kernel done / solve kernels done
     static constexpr int kRing = 256;
     hipEvent_t ring[kRing][4] = {};    // per-submit events: start, end of pass 1, end of pass 2, [3] end of the streaming kernel of pass 1
     bool ring_one_kernel[kRing] = {};  // pass 1 was ONE kernel (long rows): [3] was not recorded, its time is [0] -> [1]
     int ring_head = 0, ring_count = 0; // pending (not yet accumulated) triplets
     int last_slot = -1;
     uint32_t n_launches = 0;           // launches since creation (BV_FLAG_SPARSE_TIMING times every eighth)
+    uint32_t last_form = 0;            // BV_FORM_* bits of the last launch (bv_engine_last_launch_form)
     double acc1_ms = 0., acc2_ms = 0., acc_stream_ms = 0.;
     // short rows (bv_pass1_short.hip): HBM scratch between the streaming kernel and the solve kernel
     BvSiteSummary *d_summ = nullptr;
@@ -610,10 +602,6 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->ev_entry) (void)hipEventDestroy(e->ev_entry);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipStream_t st : e->used_streams) (void)hipStreamSynchronize(st);
-    if (e->aux) (void)hipStreamSynchronize(e->aux);
-    for (auto &ev : e->ev_s) if (ev) (void)hipEventDestroy(ev);
-    for (auto &ev : e->ev_v) if (ev) (void)hipEventDestroy(ev);
-    if (e->aux) (void)hipStreamDestroy(e->aux);
     for (auto &tri : e->ring)
         for (auto &ev : tri)
             if (ev) (void)hipEventDestroy(ev);
@@ -661,15 +649,9 @@ int bv_engine_destroy(bv_engine *e) {
 
 // The two passes over device-resident planes + the copies back (records to a host caller, counters).
 //
-// Short rows (bv_pass1_short.hip) run as a software pipeline.  Their pass 1 is a streaming kernel (HBM-bound, VALU half
-// idle) followed by solve kernels that read no planes (issue-bound, HBM idle), and pass 2 streams again: back to back on one
-// stream each of them leaves half the chip unused.  A batch is therefore cut into H chunks of consecutive sites, each with
-// its own slice of the scratch, of the variant list and its own counter block, and the chunks go through two streams:
-//     st :  stream(0) stream(1) ... stream(H-1)  pass2(0)      pass2(1) ...       pass2(H-1)
-//     aux:            solve(0)  ...              solve(H-2)    solve(H-1)
-// with events stream(c) -> solve(c) -> pass2(c).  Which chunk a site falls into has no influence on its record (every site is
-// solved from its own row), so the records are those of the unsplit launch byte for byte.  Reference analogue: none -- its
-// workers take one position at a time (basetype_caller.cpp:738-762).
+// (Round 3 also ran short-row batches as a software pipeline of chunks over two streams -- the solve kernels of chunk c under the
+// streaming kernel of chunk c + 1.  Measured a loss at every size (beside a streaming kernel the solve kernels get one
+// workgroup per CU and run 3 x longer, the streaming kernel slows by 50-70 %): removed; docs/history/DESIGN_round3.md 4.2b.)
 static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
                          bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */,
@@ -702,7 +684,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     // not free -- each is a packet the next kernel queues behind: ~15 us per launch together (measured: 100 k sites x 10 k samples
     // 158.4 -> 162.4 M sites/s without them, 8,192-site batches 56.7 -> 63.0 M) -- so BV_FLAG_SPARSE_TIMING records them for one
     // launch in eight; the averages of bv_engine_timing_get then rest on those launches.
-    const bool timed = !(e->cfg.flags & BV_FLAG_SPARSE_TIMING) || ((e->cfg.flags >> 24) & 0xFu) > 1u || (e->n_launches % 8u) == 0u;
+    const bool timed = !(e->cfg.flags & BV_FLAG_SPARSE_TIMING) || (e->n_launches % 8u) == 0u;
     e->n_launches += 1;
     hipEvent_t *ev = nullptr;
     if (timed) {
@@ -717,12 +699,8 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         ev = e->ring[slot];
         e->ring_one_kernel[slot] = false;
     }
-    // Short rows take the two-kernel form of pass 1 (bv_pass1_short.hip); bits 8-11 of the flags force a kernel for
-    // tuning runs (9: the one-kernel short-row form; 1, 2, 5: a long-row workgroup shape).
-    const uint32_t shape = (e->cfg.flags >> 8) & 0xFu;
-    const bool two_kernel = (shape == 0 && n_samples <= BV_SHORT_ROW_MAX) || shape == 10;
-    if (two_kernel && n_samples > 65535u)
-        return fail(e, BV_ERR_INVALID_ARG, "the two-kernel short-row pass 1 holds bin counts in 16 bits: n_samples <= 65535");
+    // Rows of at most BV_SHORT_ROW_MAX samples take the short-row forms of pass 1 (bv_pass1_fused.hip; bv_pass1_short.hip)
+    const bool two_kernel = n_samples <= BV_SHORT_ROW_MAX;
 
     // ---- pass-2 arguments common to every chunk; scratch of the pop-group calls
     BvPass2Args a2;
@@ -730,11 +708,6 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.n_sites = n_sites; a2.n_samples = n_samples; a2.n_groups = n_groups;
     a2.min_af = e->cfg.min_af; a2.tables = e->d_tables; a2.out = dout; a2.gout = dgout;
     a2.var_list = e->d_var_list; a2.counters = e->d_counters; a2.n_cu = e->n_cu; a2.flags = e->cfg.flags;
-#ifdef BV_TL_DEBUG
-    if (!e->d_tl) { BV_HIP(e, hipMalloc(&e->d_tl, 512 * 8 * sizeof(uint32_t))); BV_HIP(e, hipMemset(e->d_tl, 0, 512 * 8 * sizeof(uint32_t))); }
-    uint32_t *tl_rec = e->d_tl + 8 * (e->tl_n++ % 512u);
-    a2.tl = tl_rec;
-#endif
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
     a2.ch = chain;
     a2.ch_cat = chain_cat ? 1u : 0u;
@@ -779,29 +752,11 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     }
     if (n_rounds > 1) a2.n_groups = (uint32_t)Gr;  // (what the kernel-selection predicates below see)
 
-    // ---- chunks of the pipeline (1: the plain sequence on `st`)
-    uint32_t H = 1;
-    if (two_kernel && chain == nullptr && gitems_all) {
-        const uint32_t forced = (e->cfg.flags >> 24) & 0xFu;  // BV_FLAG_SPLIT(n)
-        // default: no pipeline.  Measured (round 3, 10 k samples): beside a streaming kernel the solve kernels get one
-        // workgroup per CU (LDS) and run 3 x longer, while the streaming kernel itself slows by 50-70 % -- both are bound by
-        // what a CU can issue, not by HBM, so the overlap loses (100 k sites: 0.66 ms unsplit, 0.76 with 2 chunks, 0.79 with 4)
-        H = forced ? forced : 1u;
-        if (H > bv_engine::kCtrBlocks) H = bv_engine::kCtrBlocks;
-        while (H > 1u && n_sites / H < 256u) --H;
-    }
-    if (H > 1u && !e->aux) {
-        // the second stream and its events exist only for engines that pipeline (a process has few hardware queues: every
-        // stream beyond them shares one)
-        BV_HIP(e, hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));
-        for (auto &ev : e->ev_s) BV_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        for (auto &ev : e->ev_v) BV_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    }
-    e->last_blocks = H;
-#if defined(BV_TEAM_DEBUG) || defined(BV_TL_DEBUG)
+    e->last_blocks = 1;
+#ifdef BV_TEAM_DEBUG
     const bool rotate = false;  // (the instrumented builds keep their stamps in the blocks behind the first)
 #else
-    const bool rotate = (H == 1u);
+    const bool rotate = true;
 #endif
     uint32_t cb = 0;  // this launch's first counter block
     if (rotate) {
@@ -812,16 +767,12 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         e->ctr_rot += 1;
     } else {
         e->ctr_rot = 0;  // (the next rotating launch starts a round of its own)
-        for (uint32_t c = 0; c < H; ++c)  // the per-launch lines of every block used
-            BV_HIP(e, hipMemsetAsync(e->d_counters + (size_t)c * BV_CTR_WORDS, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));
+        BV_HIP(e, hipMemsetAsync(e->d_counters, 0, sizeof(uint32_t) * BV_CTR_PER_LAUNCH * BV_CTR_STRIDE, st));
     }
     e->last_ctr_base = cb;
     a2.counters = e->d_counters + (size_t)cb * BV_CTR_WORDS;
-    auto chunk_lo = [&](uint32_t c) -> uint32_t {  // multiples of 64 sites
-        return c >= H ? n_sites : (uint32_t)(((uint64_t)n_sites * c / H) & ~(uint64_t)63);
-    };
-
     bool pass2_fused = false;  // pass 1's kernel has streamed the pass-2 rows too (bv_pass1_fused.hip)
+    e->last_form = two_kernel ? BV_FORM_SHORT_ROWS : 0u;
     if (ev) BV_HIP(e, hipEventRecord(ev[0], st));
     if (two_kernel) {
         if (n_sites > e->short_sites) {
@@ -839,56 +790,37 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             BV_HIP(e, hipMalloc(&e->d_easy3_list, sizeof(uint32_t) * (size_t)n_sites));
             e->short_sites = n_sites;
         }
-        for (uint32_t c = 0; c < H; ++c) {
-            const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
-            BvP1ShortArgs s1;
-            s1.bs = bs + (size_t)c0 * P; s1.q = q + (size_t)c0 * P; s1.ref_base = refb + c0; s1.pitch = P; s1.n_sites = nc; s1.n_samples = n_samples;
-#ifdef BV_TL_DEBUG
-            s1.tl = tl_rec;
-#endif
-            s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout + c0;
-            s1.var_list = e->d_var_list + c0; s1.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
-            s1.summ = e->d_summ + c0; s1.bins = e->d_bins + (size_t)c0 * BV_S_BIN_STRIDE;
-            s1.cand_list = e->d_cand_list + c0; s1.easy_list = e->d_easy_list + c0; s1.easy3_list = e->d_easy3_list + c0;
-            s1.ch = chain;
-            // rows of at least three 4 KiB slots: both halves of pass 1 as ONE persistent kernel (bv_pass1_fused.hip: solver
-            // waves beside the streaming waves of every workgroup); bits 12-15 of the flags = 9 keep the two-kernel form (A/B)
-            s1.mapq = nullptr; s1.rpr = nullptr;
-            const uint32_t tune = (e->cfg.flags >> 12) & 0xFu;
-            if (H == 1u && (tune == 0u || tune == 10u) && bv_p1s_fused_takes(s1)) {
-                if (ev) e->ring_one_kernel[e->last_slot] = true;
-                // the same kernel streams the variant sites' rank-sum rows too (pass 2); bits 12-15 = 10 keep pass 2 a launch
-                // of its own (A/B)
-                // (with pop-groups too where their tallies stream on their own -- short rows, <= 7 groups: the launch that follows
-                // then carries the group kernels only)
-                if (tune == 0u && (G == 0 || bv_p2g_streams(a2)) && mq != nullptr && rp != nullptr && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP)) {
-                    s1.mapq = mq; s1.rpr = rp;
-                    pass2_fused = true;
-                }
-                bv_launch_p1s_fused(s1, st);
-                BV_HIP(e, hipGetLastError());
-                continue;
+        BvP1ShortArgs s1;
+        s1.bs = bs; s1.q = q; s1.ref_base = refb; s1.pitch = P; s1.n_sites = n_sites; s1.n_samples = n_samples;
+        s1.flags = e->cfg.flags; s1.n_cu = e->n_cu; s1.min_af = e->cfg.min_af; s1.tables = e->d_tables; s1.out = dout;
+        s1.var_list = e->d_var_list; s1.counters = e->d_counters + (size_t)cb * BV_CTR_WORDS;
+        s1.summ = e->d_summ; s1.bins = e->d_bins;
+        s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list; s1.easy3_list = e->d_easy3_list;
+        s1.ch = chain;
+        s1.mapq = nullptr; s1.rpr = nullptr;
+        // Rows of at least three 4 KiB slots: pass 1 as ONE persistent kernel (bv_pass1_fused.hip: solver waves beside the
+        // streaming waves of every workgroup), which streams the variant sites' rank-sum rows (pass 2) too -- with pop-groups
+        // where their tallies stream on their own (<= 7 groups): the launch that follows then carries the group kernels only.
+        // Shorter rows, and BV_FLAG_SHORT_ROW_FORM(9) (tests: an independent realisation): a streaming kernel, a solve
+        // kernel, pass 2 a launch of its own (bv_pass1_short.hip); BV_FLAG_SHORT_ROW_FORM(10): the fused kernel for pass 1 only.
+        const uint32_t form = (e->cfg.flags >> 12) & 0xFu;
+        if (form != 9u && bv_p1s_fused_takes(s1)) {
+            if (ev) e->ring_one_kernel[e->last_slot] = true;
+            if (form != 10u && (G == 0 || bv_p2g_streams(a2)) && mq != nullptr && rp != nullptr && !(e->cfg.flags & BV_FLAG_PASS2_SWEEP)) {
+                s1.mapq = mq; s1.rpr = rp;
+                pass2_fused = true;
             }
+            bv_launch_p1s_fused(s1, st);
+            BV_HIP(e, hipGetLastError());
+            e->last_form |= BV_FORM_ONE_KERNEL | (pass2_fused ? BV_FORM_PASS2_FUSED : 0u);
+        } else {
             bv_launch_p1s_stream(s1, st);
             BV_HIP(e, hipGetLastError());
-            if (H > 1u) {
-                BV_HIP(e, hipEventRecord(e->ev_s[c], st));
-                BV_HIP(e, hipStreamWaitEvent(e->aux, e->ev_s[c], 0));
-                bv_launch_p1s_solve(s1, e->aux, true);
-                BV_HIP(e, hipGetLastError());
-                BV_HIP(e, hipEventRecord(e->ev_v[c], e->aux));
-            } else {
-                if (ev) BV_HIP(e, hipEventRecord(ev[3], st));
-                bv_launch_p1s_solve(s1, st);
-                BV_HIP(e, hipGetLastError());
-            }
+            if (ev) BV_HIP(e, hipEventRecord(ev[3], st));
+            bv_launch_p1s_solve(s1, st);
+            BV_HIP(e, hipGetLastError());
         }
-        if (H > 1u) {
-            BV_HIP(e, hipEventRecord(ev[3], st));      // the last streaming kernel
-            BV_HIP(e, hipEventRecord(ev[1], e->aux));  // the last solve kernel: end of pass 1
-        } else {
-            if (ev) BV_HIP(e, hipEventRecord(ev[1], st));
-        }
+        if (ev) BV_HIP(e, hipEventRecord(ev[1], st));
     } else {
         if (ev) e->ring_one_kernel[e->last_slot] = true;
         BvPass1Args a1;
@@ -898,6 +830,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         a1.ch = chain;
         bv_launch_pass1(a1, st);
         BV_HIP(e, hipGetLastError());
+        e->last_form |= BV_FORM_ONE_KERNEL;
         if (ev) BV_HIP(e, hipEventRecord(ev[1], st));  // (one kernel: no separate event for "the streaming kernel")
     }
 
@@ -911,27 +844,16 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             BV_HIP(e, hipGetLastError());
             BV_HIP(e, hipMemsetAsync(e->d_gout_round, 0, S * g_n * sizeof(bv_group_result), st));
         }
-        for (uint32_t c = 0; c < H; ++c) {
-            const uint32_t c0 = chunk_lo(c), nc = chunk_lo(c + 1) - c0;
-            BvPass2Args ac = a2;
-            if (n_rounds > 1) { ac.group_id = e->d_gid_round; ac.n_groups = (uint32_t)g_n; ac.gout = e->d_gout_round; }
-            if (H > 1u) {
-                if (r == 0) BV_HIP(e, hipStreamWaitEvent(st, e->ev_v[c], 0));
-                ac.bs = bs + (size_t)c0 * P; ac.q = q + (size_t)c0 * P;
-                ac.mapq = mq ? mq + (size_t)c0 * P : nullptr; ac.rpr = rp ? rp + (size_t)c0 * P : nullptr;
-                ac.ref_base = refb + c0; ac.n_sites = nc; ac.out = dout + c0; ac.gout = ac.gout ? ac.gout + (size_t)c0 * g_n : nullptr;
-                ac.var_list = e->d_var_list + c0; ac.counters = e->d_counters + (size_t)(cb + c) * BV_CTR_WORDS;
-                if (ac.gitems) { ac.gitems = a2.gitems + (size_t)c0 * g_n * BV_P2G_ITEM_WORDS; ac.gitem_cap = (uint32_t)((size_t)nc * g_n); }
-            }
-            if (pass2_fused || r > 0) {  // the rank sums are formed already (by pass 1's kernel / by round 0): what is left is the pop-groups
-                if (G == 0) continue;
-                ac.mapq = nullptr; ac.rpr = nullptr;
-            }
-            bv_launch_pass2(ac, st);
-            BV_HIP(e, hipGetLastError());
-            bv_launch_p2g_solve16(ac, st);
-            BV_HIP(e, hipGetLastError());
+        BvPass2Args ac = a2;
+        if (n_rounds > 1) { ac.group_id = e->d_gid_round; ac.n_groups = (uint32_t)g_n; ac.gout = e->d_gout_round; }
+        if (pass2_fused || r > 0) {  // the rank sums are formed already (by pass 1's kernel / by round 0): what is left is the pop-groups
+            if (G == 0) continue;
+            ac.mapq = nullptr; ac.rpr = nullptr;
         }
+        bv_launch_pass2(ac, st);
+        BV_HIP(e, hipGetLastError());
+        bv_launch_p2g_solve16(ac, st);
+        BV_HIP(e, hipGetLastError());
         if (n_rounds > 1)  // the round's records -> columns [g_lo, g_lo + g_n) of every site's groups
             BV_HIP(e, hipMemcpy2DAsync(dgout + g_lo, G * sizeof(bv_group_result), e->d_gout_round, g_n * sizeof(bv_group_result),
                                        g_n * sizeof(bv_group_result), S, hipMemcpyDeviceToDevice, st));
@@ -1062,7 +984,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
                             bv_group_result *const *gouts, void *stream_) {
     if (!e) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null engine");
     if (!slabs || !outs || n_slabs == 0) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null / empty argument");
-    bool chainable = n_slabs > 1 && ((e->cfg.flags >> 8) & 0xFu) == 0u;
+    bool chainable = n_slabs > 1;
     uint64_t total = 0;
     auto misaligned = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; };
     // every slab is checked before anything is launched (the checks of bv_engine_submit)
@@ -1587,31 +1509,6 @@ static void bv_fused_debug_report(const uint32_t *h) {
 }
 #endif
 #ifdef BV_TEAM_DEBUG
-// bv_p1s_solve16_kernel: wave 0 of every workgroup
-static void bv_solve16_debug_report(const uint32_t *h) {
-    const uint32_t *d = h + BV_CTR_WORDS;
-    uint32_t t0 = 0; bool any = false;
-    for (int b = 0; b < 768; ++b)
-        if (d[b * 6] && (!any || (int32_t)(d[b * 6] - t0) < 0)) { t0 = d[b * 6]; any = true; }
-    if (!any) return;
-    const char *nm[5] = {"entry", "set-up done", "first job done", "jobs done", "end (filler blocks done)"};
-    for (int j = 0; j < 5; ++j) {
-        std::vector<double> v;
-        for (int b = 0; b < 768; ++b) if (d[b * 6] && d[b * 6 + j]) v.push_back((double)(int32_t)(d[b * 6 + j] - t0) * 0.01);
-        if (v.empty()) continue;
-        std::sort(v.begin(), v.end());
-        const size_t n = v.size();
-        fprintf(stderr, "[solve16 debug] %-26s min %6.1f p10 %6.1f p50 %6.1f p90 %6.1f p99 %6.1f max %6.1f us (%zu workgroups)\n", nm[j], v[0], v[n / 10], v[n / 2],
-                v[n * 9 / 10], v[n * 99 / 100], v[n - 1], n);
-    }
-    std::vector<uint32_t> nj;
-    for (int b = 0; b < 768; ++b) if (d[b * 6]) nj.push_back(d[b * 6 + 5]);
-    std::sort(nj.begin(), nj.end());
-    fprintf(stderr, "[solve16 debug] jobs per wave: min %u p50 %u max %u; lists: easy %u, easy3 %u sites\n", nj[0], nj[nj.size() / 2], nj.back(), h[BV_CTR_EASY], h[BV_CTR_EASY3]);
-}
-#endif
-
-#ifdef BV_TEAM_DEBUG
 // the stamps of bv_pass1_kernel's team form (see BV_TEAM_STAMP in bv_pass1.hip): distribution over the workgroups, and per XCD
 static void bv_team_debug_report(const uint32_t *h) {
     fprintf(stderr, "[team debug] team jobs %u (mean %.0f cycles)  solo solves %u (mean %.0f cycles)\n", h[BV_CTR_CANDS],
@@ -1663,21 +1560,9 @@ int bv_engine_wait(bv_engine *e) {
     }
     uint32_t timed_out = 0, zero_freq = 0;
     for (uint32_t b = 0; b < bv_engine::kCtrBlocks; ++b) {
-#ifdef BV_TL_DEBUG
-        if (b == 0 && e->d_tl && e->tl_n) {
-            std::vector<uint32_t> tl(512 * 8);
-            (void)hipMemcpy(tl.data(), e->d_tl, tl.size() * sizeof(uint32_t), hipMemcpyDeviceToHost);
-            const uint32_t n = std::min(e->tl_n, 512u);
-            for (uint32_t i = (n > 24 ? n - 24 : 0); i < n; ++i) {
-                const uint32_t *r = &tl[8 * i];
-                fprintf(stderr, "[timeline] engine %p submit %u: stream %u %u  solve16 %u %u  pass2 %u %u  wave-solver %u %u\n", (void *)e, i, ~r[0], r[1], ~r[2], r[3], ~r[4], r[5], ~r[6], r[7]);
-            }
-        }
-#endif
 #ifdef BV_TEAM_DEBUG
         if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 1u) bv_stream_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 2u) bv_team_debug_report(e->h_counters);
-        else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 3u) bv_solve16_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 4u) bv_fused_debug_report(e->h_counters);
 #endif
         timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
@@ -1823,6 +1708,13 @@ int bv_engine_host_log_eval(bv_engine *e, const double *x, double *y, uint32_t n
     if (st == hipSuccess) st = hipMemcpy(y, d + n, sizeof(double) * n, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (st != hipSuccess) return fail(e, BV_ERR_HIP, std::string("bv_engine_host_log_eval: ") + hipGetErrorString(st));
+    return BV_OK;
+}
+
+int bv_engine_last_launch_form(bv_engine *e, uint32_t *form) {
+    if (!e || !form) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_last_launch_form: null argument");
+    if (e->last_lane >= 0) return bv_engine_last_launch_form(e->lane[e->last_lane], form);
+    *form = e->last_form;
     return BV_OK;
 }
 

@@ -26,17 +26,6 @@
 #define BV_CTR_TIMEOUT ((BV_CTR_PER_LAUNCH + 1u) * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag      */
 #define BV_CTR_WORDS ((BV_CTR_PER_LAUNCH + 2u) * BV_CTR_STRIDE)
 
-// -DBV_TL_DEBUG: every kernel of a short-row submit stamps s_memrealtime (100 MHz) of its first workgroup's start and its last
-// wave's end into the submit's record: tl[2k] = ~start (atomicMax of the complement = min), tl[2k + 1] = end; k = 0 stream,
-// 1 solve16, 2 pass-2 tally.  bv_engine_wait prints the records.
-#ifdef BV_TL_DEBUG
-#define BV_TL_START(TL, K) do { if ((TL) && threadIdx.x == 0) atomicMax(&(TL)[2 * (K)], ~(uint32_t)__builtin_amdgcn_s_memrealtime()); } while (0)
-#define BV_TL_END(TL, K) do { if ((TL) && (threadIdx.x & 63) == 0) atomicMax(&(TL)[2 * (K) + 1], (uint32_t)__builtin_amdgcn_s_memrealtime()); } while (0)
-#else
-#define BV_TL_START(TL, K) do { } while (0)
-#define BV_TL_END(TL, K) do { } while (0)
-#endif
-
 // A queue of slabs (same row length, no pop-groups) solved by ONE launch of each pass -- bv_engine_submit_many: the
 // persistent grid of pass 1 draws its site tickets across the whole queue, so the solve of the last deep sites of one
 // slab runs under the stream of the next.  Global site t of segment k is first[k] + its local index; every pointer is
@@ -105,9 +94,6 @@ struct BvPass2Args {
     uint32_t gitem_cap;       // (v = position in var_list) = BV_P2G_ITEM_WORDS words; items >= gitem_cap, or gitems == NULL:
                               // the tally kernel solves the group itself (one wave per group)
     const uint8_t *gidp;      // group_id prepared for bv_p2g_stream_kernel: g << 2, or 0x80 for "no group" (bv_launch_gid_prepare)
-#ifdef BV_TL_DEBUG
-    uint32_t *tl;
-#endif
     const BvChain *ch;        // device memory, or NULL: a chained launch -- planes (and gout) come per segment, biased
     uint32_t ch_cat;          // chained short rows: ref_base / out are the engine's CONTIGUOUS copies, indexed with the global site
                               // number as they are; else (long rows) they come per segment too
@@ -152,9 +138,6 @@ struct BvP1ShortArgs {
     uint32_t *easy_list;   // [n_sites]  candidates solved four per wave (bv_solver16.h), at most two active bases
     uint32_t *easy3_list;  // [n_sites]  the same with three or four active bases: several times the EM runs, so they are kept
                            //            apart -- the four sites of a wave run in lockstep and pay for the slowest
-#ifdef BV_TL_DEBUG
-    uint32_t *tl;          // this submit's 8-word record of kernel start / end stamps (tools/experiments/r3_lanes_timeline.sh)
-#endif
     const BvChain *ch;     // device memory, or NULL: a chained launch -- the call / phred planes come per segment (biased), while
                            // ref_base / out are the engine's contiguous copies indexed with the global site number
     // bv_pass1_fused.hip only: the rank planes, when the kernel is to stream the variant sites' pass-2 rows too (both NULL: pass 2
@@ -242,6 +225,7 @@ void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, 
 #define BV_GROUPS_PER_ROUND 32u
 void bv_launch_gid_round(const uint8_t *gid, uint8_t *out, uint32_t n_bytes, uint32_t lo, uint32_t n, hipStream_t stream);
 size_t bv_pass2_lds_bytes(uint32_t n_groups);
-// short rows of at least three 4 KiB slots, not chained: pass 1 as ONE persistent kernel (bv_pass1_fused.hip)
+// short rows of at least three 4 KiB slots (4,097 .. 49,152 samples), chained launches included: pass 1 -- and, with the rank
+// planes in a.mapq / a.rpr, the variant sites' pass-2 rows -- as ONE persistent kernel (bv_pass1_fused.hip)
 bool bv_p1s_fused_takes(const BvP1ShortArgs &a);
 void bv_launch_p1s_fused(const BvP1ShortArgs &a, hipStream_t stream);

@@ -34,9 +34,7 @@
 #include "bv_solver.h"
 #include "bv_tally.h"
 
-#ifndef BV_RING_EXTRA
 #define BV_RING_EXTRA 2
-#endif
 template <int NBUF, int NSOLVE>
 struct __attribute__((aligned(16))) BvPass1Shared {
     uint32_t hist[NBUF][BV_H2_WORDS];  // ring of histograms [(rev<<2)|base][phred byte]
@@ -50,9 +48,7 @@ struct __attribute__((aligned(16))) BvPass1Shared {
 
 // One wave streams one row, software-pipelined: two register sets of U chunks per plane, the
 // loads of the next set are in flight (16 KiB per wave) while the current set is tallied.
-#ifndef BV_TALLY_U
 #define BV_TALLY_U 4
-#endif
 struct BvChunkSet {
     bv_u32x4 vb[BV_TALLY_U], vq[BV_TALLY_U];
 };
@@ -140,14 +136,12 @@ __device__ __forceinline__ void bv_row_preload(BvChunkSet &A, const uint8_t *bs_
 // ------------------------------------------------------------------------------ kernel
 // Every spin is bounded (~1 s): a protocol bug must end the kernel with counters[3] set
 // (reported by bv_engine_wait) instead of hanging the GPU.
-#ifndef BV_SPIN_SLEEP
 #define BV_SPIN_SLEEP 16 /* x64 cycles between polls of a hand-off flag (4, 16, 64 measured: 4.09, 4.05, 4.04 ms) */
-#endif
 __device__ __forceinline__ void bv_wait_flag(const uint32_t *flag, uint32_t want, uint32_t *err) {
     uint32_t spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
         __builtin_amdgcn_s_sleep(BV_SPIN_SLEEP);
-        if (++spins > (1u << 23)) {
+        if (++spins > (1u << 22)) {  // ~2 s
             atomicOr(err, 1u);
             break;
         }
@@ -186,9 +180,7 @@ struct __attribute__((aligned(16))) BvTeam {
     double c_fs, c_sor, v_fs, v_sor;
 };
 #define BV_TEAM_NO_SITE 0xFFFFFFFEu
-#ifndef BV_TEAM_MAX_SITES
 #define BV_TEAM_MAX_SITES 65536
-#endif
 
 template <bool TEAM>
 __device__ __forceinline__ BvTeam *bv_team_lds() {
@@ -411,7 +403,10 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                 if (TEAM && lane == 0) atomicAdd(&a.counters[BV_CTR_EASY], (uint32_t)((__builtin_readcyclecounter() - tw_) >> 6));
 #endif
                 if (lane == 0) sh.site_of[buf] = site;
-                bv_set_flag(&sh.published[buf], gen + 1u);
+                // (BV_FLAG_FAULT_LOST_HANDOFF, tests: workgroup 0 never publishes its first slot -- the other tally waves must give
+                // up after their bounded wait)
+                if (!((a.flags & BV_FLAG_FAULT_LOST_HANDOFF) && blockIdx.x == 0u && k == 0u))
+                    bv_set_flag(&sh.published[buf], gen + 1u);
             } else {
                 bv_wait_flag(&sh.published[buf], gen + 1u, &a.counters[BV_CTR_TIMEOUT]);
                 site = sh.site_of[buf];
@@ -565,148 +560,30 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
     }
 }
 
-// ------------------------------------------------------------------------------ short rows
-// For short rows (N <~ 50 k samples: <= 100 KB of stream per site) the solve, not the stream,
-// dominates a site, so every wave should be a solver: one independent wave per workgroup tallies
-// its own site and solves it, persistent with the same ticket counter.  No hand-off, no flags.
-// (Measured and dropped: touching one byte per 128-byte line of the wave's NEXT row before the solve,
-// to turn the next row's first HBM latency into L2 hits -- 15 % slower: 64 uncoalesced line requests
-// per instruction cost more than the latency they hide.)
-#ifndef BV_FUSED_TICKET
-#define BV_FUSED_TICKET 4
-#endif
-#define BV_FUSED_WAVES 4
-#ifndef BV_FUSED_PRELOAD
-#define BV_FUSED_PRELOAD 1
-#endif
-#ifndef BV_FUSED_OCC
-#define BV_FUSED_OCC 3 /* waves per SIMD the register budget is set for (170 VGPRs) */
-#endif
-struct __attribute__((aligned(16))) BvPass1FusedShared {
-    uint32_t hist[BV_FUSED_WAVES][BV_H2_WORDS];  // one per wave; also holds that wave's bins (ALIAS mode)
-    double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
-    BvSolverScratch sc[BV_FUSED_WAVES];
-};
-
-// Four INDEPENDENT waves per workgroup (they share only the phred tables), 3 workgroups per CU.
-// (4 per CU at 128 VGPRs was measured too: +4 % without the preload below, 13 % slower with it -- spills.)
-__global__ __launch_bounds__(BV_WAVE *BV_FUSED_WAVES, BV_FUSED_OCC) void bv_pass1_fused_kernel(BvPass1Args a) {
-    __shared__ BvPass1FusedShared sh;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t *hist = sh.hist[wave];
-    {
-        uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-#pragma unroll
-        for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_FUSED_WAVES) {
-            sh.tab_hit[i] = a.tables->hit[i];
-            sh.tab_miss[i] = a.tables->miss[i];
-        }
-    }
-    __syncthreads();  // the only workgroup-wide barrier: tables ready; from here the waves never meet
-    BvSolveArgs sa;
-    sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
-    sa.min_af = a.min_af; sa.flags = a.flags;
-    sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
-    sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
-    sa.bs = a.bs; sa.q = a.q; sa.pitch = a.pitch; sa.n_samples = a.n_samples;
-    // Tickets are drawn BV_FUSED_TICKET sites at a time: at ~70 M short-row sites/s one ticket per
-    // site would run into the ~88 M/s ceiling of atomics on a single address (measured: throughput
-    // flat from 6 to 11 waves per CU until the draws were chunked).  (Drawing single sites over the last one or
-    // two rounds of the grid, to shorten the drain, was measured too: +-0 and -10 % -- the atomics pile up.)
-    uint32_t next = 0;
-    if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);
-#if BV_FUSED_PRELOAD
-    // The wave streams nothing while it solves, and its next row would start with a full HBM latency
-    // (PMC: 48 % of the wave time in s_waitcnt on row loads).  So the first 4 KiB set of the NEXT row is
-    // requested before the solve and kept in 32 VGPRs across it -- affordable at 3 waves per SIMD.
-    BvChunkSet P;
-    {
-        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-        if (s0 < a.n_sites) bv_row_preload(P, a.bs + (size_t)s0 * a.pitch, a.q + (size_t)s0 * a.pitch, a.n_samples, lane);
-    }
-#endif
-    for (;;) {
-        const uint32_t site0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-        if (site0 >= a.n_sites) break;
-        if (lane == 0) next = atomicAdd(&a.counters[BV_CTR_TICKET], (uint32_t)BV_FUSED_TICKET);  // in flight under this work
-        const uint32_t site1 = min(site0 + (uint32_t)BV_FUSED_TICKET, a.n_sites);
-        for (uint32_t site = site0; site < site1; ++site) {
-#if BV_FUSED_PRELOAD
-            bv_tally_row_wave<1, true>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, hist, 0,
-                                       lane, &P);
-            {
-                uint32_t nsite = site + 1;
-                if (nsite == site1) nsite = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
-                if (nsite < a.n_sites)
-                    bv_row_preload(P, a.bs + (size_t)nsite * a.pitch, a.q + (size_t)nsite * a.pitch, a.n_samples, lane);
-            }
-#else
-            bv_tally_row_wave<1>(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, hist, 0, lane);
-#endif
-            bv_lrt_sync<0>();
-            bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)hist, (BV_LDS uint32_t *)nullptr,
-                                     (BV_LDS uint32_t *)nullptr, (BV_LDS BvSolverScratch *)&sh.sc[wave],
-                                     (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
-            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-#pragma unroll
-            for (int i = 0; i < BV_H2_WORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
-            bv_lrt_sync<0>();
-        }
-    }
-}
-
-static void bv_launch_pass1_fused(const BvPass1Args &a, hipStream_t stream) {
-    uint32_t per_cu = (a.flags >> 12) & 0xFu;  // tuning knob: resident workgroups per CU (0 = default)
-    if (per_cu == 0) per_cu = (uint32_t)BV_FUSED_OCC;  // ~38 KiB of LDS and 4 x 168 VGPRs per workgroup -> 3 resident per CU
-    uint32_t grid = (a.n_cu ? a.n_cu : 256u) * per_cu;
-    const uint32_t need = (a.n_sites + BV_FUSED_TICKET * BV_FUSED_WAVES - 1) / (BV_FUSED_TICKET * BV_FUSED_WAVES);
-    if (grid > need) grid = need > 0 ? need : 1;
-    hipLaunchKernelGGL(bv_pass1_fused_kernel, dim3(grid), dim3(BV_WAVE * BV_FUSED_WAVES), 0, stream, a);
-}
-
-template <int NTALLY, int NSOLVE, int MODE = 0>
+// (Rows of at most 49,152 samples never come here: bv_pass1_short.hip / bv_pass1_fused.hip.  Round 1's form for them -- four
+// independent waves per workgroup that each tally and solve their own site -- is in docs/history/.)
+template <int NTALLY, int MODE>
 static void bv_launch_pass1_cfg(const BvPass1Args &a, hipStream_t stream) {
-    // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU),
-    // never more than there are sites.
+    // Persistent grid: as many workgroups as stay resident (VGPR-limited to 16 waves per CU), never more than there are sites.
+    constexpr int NSOLVE = 1;
     constexpr uint32_t by_vgpr = 16u / (NTALLY + NSOLVE);
     constexpr uint32_t by_lds = (uint32_t)((160u * 1024u) / sizeof(BvPass1Shared<NSOLVE + BV_RING_EXTRA, NSOLVE>));
     uint32_t grid = (a.n_cu ? a.n_cu : 256u) * (by_vgpr < by_lds ? by_vgpr : by_lds);
     if (grid > a.n_sites) grid = a.n_sites;
-    // (the chained and the team forms are instantiations of their own: the headline kernel keeps its register allocation)
+    // (the chained form is an instantiation of its own: the headline kernel keeps its register allocation)
     const dim3 block(64 * (NTALLY + NSOLVE));
-    if constexpr (MODE != 0) {
-        if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, true, MODE>), dim3(grid), block, 0, stream, a);
-        else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, 1, false, MODE>), dim3(grid), block, 0, stream, a);
-    } else {
-        if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, true>), dim3(grid), block, 0, stream, a);
-        else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, false>), dim3(grid), block, 0, stream, a);
-    }
+    if (a.ch != nullptr) hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, true, MODE>), dim3(grid), block, 0, stream, a);
+    else hipLaunchKernelGGL((bv_pass1_kernel<NTALLY, NSOLVE, false, MODE>), dim3(grid), block, 0, stream, a);
 }
 
 void bv_launch_pass1(const BvPass1Args &a, hipStream_t stream) {
-    // bits 8-11 of the flags select a workgroup shape for tuning runs (0 = default by row length)
-    const uint32_t shape = (a.flags >> 8) & 0xFu;
-    switch (shape) {
-        case 1: return bv_launch_pass1_cfg<3, 1>(a, stream);
-        case 2: return bv_launch_pass1_cfg<3, 2>(a, stream);  // measured: 15-30 % slower than <3,1>
-        case 5: return bv_launch_pass1_cfg<2, 1>(a, stream);  // measured:  4 % slower than <3,1>
-        // (<7,1> and <5,1>, i.e. fewer solver waves per CU, were measured too: 6 % slower than <3,1>)
-        // (solver-heavy shapes for short rows -- <1,3>, <1,2>, <2,2> at 10 k samples -- were measured as well:
-        //  24-90 % slower than the fused kernel, one tally wave cannot feed several solvers)
-        case 9: return bv_launch_pass1_fused(a, stream);
-        default: break;
-    }
-    if (a.n_samples > 49152u) {  // measured crossover of the two kernels: ~50 k samples per row
-        // long rows: several tally waves share a row (short per-site latency => short tail).  Up to BV_TEAM_MAX_SITES per
-        // launch the team form is used: the last solves of a workgroup are spread over its idle tally waves (8,192 sites:
-        // 0.351 -> 0.327 ms, 65,536: ~1 %; the 131,072-site launch measures the same either way and keeps the plain form).
-        // Larger launches take the team form's ticket rules and start-up without its helpers (MODE 2): 14 interleaved A/B runs at
-        // 131,072 sites x 100 k samples, pass 1 4.17 -> 4.12 ms (-1.1 %); with the helpers too (MODE 1) it measured 0.5 % slower there.
-        if (a.n_sites <= (uint32_t)BV_TEAM_MAX_SITES) bv_launch_pass1_cfg<3, 1, 1>(a, stream);
-        else bv_launch_pass1_cfg<3, 1, 2>(a, stream);
-    } else {
-        // short rows: solve-bound -> every wave tallies and solves its own site
-        bv_launch_pass1_fused(a, stream);
-    }
+    // Three tally waves + one solver wave per workgroup, four workgroups per CU.  (Measured and dropped, round 2: <3,2> 15-30 %
+    // slower, <2,1> 4 %, <7,1> and <5,1> 6 %.)  Several tally waves share a row: short per-site latency, short tail.  Up to
+    // BV_TEAM_MAX_SITES per launch the team form is used: the last solves of a workgroup are spread over its idle tally waves
+    // (8,192 sites: 0.351 -> 0.327 ms, 65,536: ~1 %).  Larger launches take the team form's ticket rules and start-up without
+    // its helpers (MODE 2): 14 interleaved A/B runs at 131,072 sites x 100 k samples, pass 1 4.17 -> 4.12 ms (-1.1 %); with the
+    // helpers too (MODE 1) it measured 0.5 % slower there.
+    // (BV_FLAG_LONG_ROW_FORM(2), tests: the form without helpers whatever the launch size -- an independent realisation of the tail)
+    if (a.n_sites <= (uint32_t)BV_TEAM_MAX_SITES && ((a.flags >> 8) & 0xFu) != 2u) bv_launch_pass1_cfg<3, 1>(a, stream);
+    else bv_launch_pass1_cfg<3, 2>(a, stream);
 }

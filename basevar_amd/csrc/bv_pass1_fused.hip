@@ -532,7 +532,7 @@ __device__ __forceinline__ bool bv_f_no_row_ever(const uint32_t *ctl) {
     return bv_f_lds_read_u(&ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&ctl[BV_FC_QV_HEAD]);
 }
 typedef volatile __attribute__((address_space(3))) uint32_t bv_lds_vu32;
-__device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, uint32_t *counters, int lane) {
+__device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, uint32_t *counters, bool lose_first, int lane) {
     const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)tail, 1u);
     bv_lds_vu32 *e = q + (pos & (BV_F_QCAP - 1u));
     // (a slot still occupied: the solvers are BV_F_QCAP candidates behind -- they never wait for a streaming wave, so this ends)
@@ -544,6 +544,9 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
         (void)bv_f_global_fetch_add_wave(&counters[BV_CTR_TIMEOUT], 1u);
         return;
     }
+    // (BV_FLAG_FAULT_LOST_HANDOFF, tests: the first entry of workgroup 0's queue is reserved and never written -- the solver wave
+    // that claims it must give up after its bounded wait)
+    if (lose_first && pos == 0u && blockIdx.x == 0u) return;
     if (lane == 0) *e = site;
 }
 // publish a pass-1 row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic,
@@ -557,9 +560,9 @@ __device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShar
         const uint32_t pos = bv_lds_fetch_add_wave((uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QH_TAIL], 1u);
         if (lane == 0) a.cand_list[B0 + pos] = site;  // (a slot per site of the workgroup's range: the list cannot outgrow them)
     } else if (kind == 3u) {
-        bv_f_push((bv_lds_vu32 *)sh.q3, (bv_lds_u32 *)&sh.ctl[BV_FC_Q3_TAIL], site, a.counters, lane);
+        bv_f_push((bv_lds_vu32 *)sh.q3, (bv_lds_u32 *)&sh.ctl[BV_FC_Q3_TAIL], site, a.counters, (a.flags & BV_FLAG_FAULT_LOST_HANDOFF) != 0u, lane);
     } else {
-        bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, a.counters, lane);
+        bv_f_push((bv_lds_vu32 *)sh.q2, (bv_lds_u32 *)&sh.ctl[BV_FC_Q2_TAIL], site, a.counters, (a.flags & BV_FLAG_FAULT_LOST_HANDOFF) != 0u, lane);
     }
 }
 // A variant row with a read-position rank beyond the 256-rank window of the fast tally (long reads): the exact window sweeps of
@@ -667,9 +670,6 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         a.cand_list = BV_F_GLOBAL(uint32_t, ka->cand_list); a.easy_list = BV_F_GLOBAL(uint32_t, ka->easy_list);
         a.easy3_list = BV_F_GLOBAL(uint32_t, ka->easy3_list); a.ch = BV_F_GLOBAL(const BvChain, ka->ch);
         a.mapq = BV_F_GLOBAL(const uint8_t, ka->mapq); a.rpr = BV_F_GLOBAL(const uint16_t, ka->rpr);
-#ifdef BV_TL_DEBUG
-        a.tl = nullptr;
-#endif
     }
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     uint32_t *hist = sh.hist[wave];
@@ -1092,9 +1092,6 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
 template <bool FUSE2>
 __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1ShortArgs a) {
     __shared__ BvFusedShared sh;
-#ifdef BV_TL_DEBUG
-    BV_TL_START(a.tl, 0);
-#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     // every workgroup owns a contiguous range of sites
@@ -1180,9 +1177,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     // (the solver step that reports "nothing left, ever" has flushed the wave's variant list)
 #ifdef BV_TEAM_DEBUG
     if (lane == 0) atomicMax(&a.counters[BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u + 3u], (uint32_t)__builtin_amdgcn_s_memrealtime());
-#endif
-#ifdef BV_TL_DEBUG
-    BV_TL_END(a.tl, 0);
 #endif
 }
 

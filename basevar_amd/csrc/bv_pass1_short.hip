@@ -74,25 +74,13 @@ __device__ __forceinline__ void bv_p1s_tally_slot(bv_u32x4 vb, bv_u32x4 vq, uint
     }
     // X = call << 8 | phred << 1 = twice the word index of the 8 x 128 histogram; call < 8 <=> X < 0x800
     vq.x <<= 1; vq.y <<= 1; vq.z <<= 1; vq.w <<= 1;
-#if defined(BV_ABL_P1S_NOTALLY)   /* attribution builds only: the stream without the tally (results are wrong) */
-    if ((vb.x ^ vq.y) == 0x12345678u && (vb.z ^ vq.w) == 0x9abcdef0u) hist[lane] = one;
-#else
     bv_tally_chunk<1>(vb, vq, hist, one);
-#endif
 }
 
-#ifndef BV_P1S_NW
 #define BV_P1S_NW 4
-#endif
 template <int NW, int K, int U, bool CHAIN = false>
 __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sStreamShared<NW, K, U> sh;
-#ifdef BV_STREAM_PRIO
-    __builtin_amdgcn_s_setprio(BV_STREAM_PRIO);  // beside the solve kernels of the previous chunk: the stream goes first
-#endif
-#ifdef BV_TL_DEBUG
-    BV_TL_START(a.tl, 0);
-#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *hist = sh.hist[wave];
@@ -219,7 +207,6 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
         }
         bv_lrt_sync<0>();
 
-#ifndef BV_ABL_P1S_NOROWEND  /* attribution builds only: the stream and the tally without the per-row epilogue (results are wrong) */
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
         bool bad = false;
@@ -321,9 +308,6 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
             w = (lane == 9) ? fl : w;
             if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = w;
         }
-#else
-        if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = hist[lane * 37];
-#endif
         // ---- hand the histogram back, zeroed
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
@@ -381,9 +365,6 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 #ifdef BV_TEAM_DEBUG
     if (gridDim.x * NW <= 2048u && lane == 0) dbg_[gw] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef BV_TL_DEBUG
-    BV_TL_END(a.tl, 0);
-#endif
 }
 
 
@@ -396,17 +377,13 @@ __global__ __launch_bounds__(BV_WAVE *NW) void bv_p1s_stream_kernel(BvP1ShortArg
 // workgroup w belong to slice j, w mod BV_TICKET_SLICES); a wave's first job is its rank in the slice, every further one is
 // drawn from the slice's ticket counter when the wave gets there -- no draw at the start of the kernel, where all waves
 // would queue on one address (~88 M atomics/s: 35 us for 3072 waves), and eight addresses instead of one after that.
-#ifndef BV_P1S_SOLVE16_NW
 #define BV_P1S_SOLVE16_NW 4
-#endif
 struct __attribute__((aligned(16))) BvP1sSolve16Shared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
     BvP1sWaveScratch ws[BV_P1S_SOLVE16_NW];
     uint32_t vl[BV_P1S_SOLVE16_NW][64];                    // the wave's variant sites since the last flush
 };
-#ifndef BV_P1S_SOLVE16_OCC
 #define BV_P1S_SOLVE16_OCC 3
-#endif
 struct BvP1sJob {
     const uint32_t *list;
     uint32_t idx;
@@ -446,15 +423,6 @@ __device__ __forceinline__ BvP1sJob bv_p1s_job(const BvP1ShortArgs &a, uint32_t 
 __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) void bv_p1s_solve16_kernel(BvP1ShortArgs a) {
     __shared__ BvP1sSolve16Shared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef BV_TL_DEBUG
-    BV_TL_START(a.tl, 1);
-#endif
-#ifdef BV_SOLVE16_DEBUG  /* wave 0 of every workgroup: entry, set-up done, first job done, jobs done, end; jobs taken */
-    uint32_t *dbg_ = a.counters + BV_CTR_WORDS + (blockIdx.x < 768u ? blockIdx.x : 767u) * 6u;
-    uint32_t njobs_ = 0;
-    if (tid == 0 && blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 3u;
-    if (tid == 0) dbg_[0] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
     const uint32_t n_easy = a.counters[BV_CTR_EASY], n_easy3 = a.counters[BV_CTR_EASY3];
     const uint32_t n_jobs = ((n_easy + 3u) >> 2) + ((n_easy3 + 3u) >> 2);
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P1S_SOLVE16_NW) {
@@ -462,9 +430,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         sh.tab_miss[i] = a.tables->miss[i];
     }
     __syncthreads();
-#ifdef BV_SOLVE16_DEBUG
-    if (tid == 0) dbg_[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
     BvSolveArgs sa;
     sa.ref_base = a.ref_base; sa.out = a.out; sa.var_list = a.var_list; sa.counters = a.counters;
     sa.min_af = a.min_af; sa.flags = a.flags;
@@ -587,15 +552,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         if (variant && gl == 0) vl[n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
         n_vl += (uint32_t)__popcll(vm);
         if (n_vl > 60u) flush_vl();
-#ifdef BV_SOLVE16_DEBUG
-        if (tid == 0 && njobs_ == 0) dbg_[2] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-        ++njobs_;
-#endif
     }
     if (n_vl) flush_vl();
-#ifdef BV_SOLVE16_DEBUG
-    if (tid == 0) { dbg_[3] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[5] = njobs_; }
-#endif
     // ---- the non-candidate sites, one lane per site, in blocks of 64 drawn like the jobs
     const uint32_t n_blocks = (a.n_sites + 63u) >> 6;
     BvP1sTickets tb;
@@ -604,12 +562,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_P1S_SOLVE16_NW, BV_P1S_SOLVE16_OCC) voi
         const uint32_t site = tb.job() * 64u + (uint32_t)lane;
         if (site < a.n_sites) bv_p1s_simple_site(a, sa.lnfact, site);
     }
-#ifdef BV_SOLVE16_DEBUG
-    if (tid == 0) dbg_[4] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
-#ifdef BV_TL_DEBUG
-    BV_TL_END(a.tl, 1);
-#endif
 }
 
 // ------------------------------------------------------------------------------ chained launches (bv_engine_submit_many)
@@ -648,20 +600,9 @@ static void bv_launch_p1s_stream_cfg(const BvP1ShortArgs &a, hipStream_t stream,
     else hipLaunchKernelGGL((bv_p1s_stream_kernel<NW, K, U, false>), dim3(grid), dim3(BV_WAVE * NW), 0, stream, a);
 }
 void bv_launch_p1s_stream(const BvP1ShortArgs &a, hipStream_t stream) {
-    // bits 12-15 of the flags select a ring depth / residency for tuning runs (0 = default)
-    switch ((a.flags >> 12) & 0xFu) {
-        case 1: return bv_launch_p1s_stream_cfg<4, 3>(a, stream, 4);   // 16 waves/CU, 2 slots in flight each
-        case 2: return bv_launch_p1s_stream_cfg<4, 6>(a, stream, 2);   //  8 waves/CU, 5 slots in flight each
-        case 3: return bv_launch_p1s_stream_cfg<4, 3, 2>(a, stream, 2);  // the default's slots, two workgroups of 4 waves per CU
-        // fewer waves per CU, to leave the other lane's solve (37.5 KB) / pass-2 (64 KB) workgroups room beside a streaming one --
-        // measured: 6 waves 0.449 ms per 100 k sites (8 waves: 0.363), 153 M sites/s with two lanes (8 waves: 177); 5 waves 0.511 ms, 140 M
-        case 4: return bv_launch_p1s_stream_cfg<6, 3, 2>(a, stream, 1);
-        case 5: return bv_launch_p1s_stream_cfg<5, 3, 2>(a, stream, 1);
-        case 6: return bv_launch_p1s_stream_cfg<4, 4, 1>(a, stream, 2);  // slots of 1 KiB per plane:  8 waves/CU, 6 KiB in flight each
-        case 8: return bv_launch_p1s_stream_cfg<4, 2, 2>(a, stream, 3);  //                          12 waves/CU, 4 KiB in flight each
-        default: break;
-    }
-    // default: slots of 2 KiB per plane, 3 slots per wave (8 KiB in flight), 8 waves per CU: measured best (+4-5 % over 1 KiB
+    // (Measured and dropped, rounds 2-3: 16 waves / CU with 2 slots in flight, 8 with 5, two workgroups of 4 waves, 6 or 5 waves
+    // per workgroup, slots of 1 KiB per plane at 8 or 12 waves / CU.)
+    // Slots of 2 KiB per plane, 3 slots per wave (8 KiB in flight), 8 waves per CU: measured best (+4-5 % over 1 KiB
     // slots; 4 slots of 2 KiB or 8 of 1 KiB need 82 KB of LDS per workgroup -- one workgroup per CU, 0.43 of peak)
     // One workgroup of 8 waves per CU (not two of 4): the waves of a workgroup share its sites through the LDS cursor, and the
     // two waves that share a SIMD -- the arbiter's favourite and the other -- must be in the same workgroup for that to even

@@ -15,12 +15,8 @@
 #include "bv_tally.h"
 #include "bv_pass2_sweep.h"  // BvP2Ctx, bv_p2_sweep, BV_RPR_WIN, BV_P2_U64
 
-#ifndef BV_P2_WIDE_GROUPS
 #define BV_P2_WIDE_GROUPS 2 /* from this many pop-groups on, short rows also take the four-wave kernel: one wave per group */
-#endif
-#ifndef BV_P2_BIG_GROUPS
 #define BV_P2_BIG_GROUPS 12 /* from this many pop-groups on, long rows take workgroups of eight waves */
-#endif
 
 // INLINE: the kernel solves pop-groups itself (one wave per group) and needs the solver's LDS; otherwise every group leaves
 // as an item for the group solve kernels and that LDS (and the solver's registers) are not taken.
@@ -509,12 +505,6 @@ struct __attribute__((aligned(16))) BvPass2DmaShared {
 
 __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvPass2Args a) {
     __shared__ BvPass2DmaShared sh;
-#ifdef BV_TL_DEBUG
-    BV_TL_START(a.tl, 2);
-#endif
-#ifdef BV_STREAM_PRIO
-    __builtin_amdgcn_s_setprio(BV_STREAM_PRIO);
-#endif
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *h = sh.h[wave];
@@ -750,9 +740,6 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
         }
         bv_lrt_sync<0>();
     }
-#ifdef BV_TL_DEBUG
-    BV_TL_END(a.tl, 2);
-#endif
 }
 
 size_t bv_pass2_lds_bytes(uint32_t n_groups) { return (size_t)n_groups * 512u * sizeof(uint32_t); }

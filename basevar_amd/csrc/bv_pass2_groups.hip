@@ -334,9 +334,7 @@ void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, 
 // __gb(): BaseType(subset) + lrt([REF] + alts), caller.cpp:756-759, 767-797, for the (variant site, group) items the tally
 // kernels handed over (BvPass2Args::gitems): one item per group of 16 lanes, bins in registers (bv_solver16.h).
 #define BV_P2G_NW 4
-#ifndef BV_P2G_OCC
 #define BV_P2G_OCC 3  /* 160 VGPRs, no spills; at 4 waves per SIMD (128 VGPRs) 28 registers spilled: equal at 1-2 groups, 19 % slower at 8 */
-#endif
 struct __attribute__((aligned(16))) BvP2gShared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
     uint32_t grp[BV_P2G_NW][4][BV_G16_GRP_WORDS];  // per group of 16 lanes: previous marginals, [slot][lane of the group]

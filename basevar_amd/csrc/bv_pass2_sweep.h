@@ -6,9 +6,7 @@
 
 #include "bv_kernels.h"
 
-#ifndef BV_P2_U64
 #define BV_P2_U64 4      /* 16-byte chunks per thread and iteration when one wave sweeps a row (latency-bound: more loads in flight) */
-#endif
 #define BV_RPR_WIN 1024  /* read-position ranks per LDS window; longer reads take extra sweeps */
 
 struct BvP2Ctx {

@@ -229,11 +229,7 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
                 double r = (double)bv_sel4u(depth, L.first) / (double)total;
                 double qual;
                 if (L.m == 1 && total > 10 && r > 0.5) qual = 5000.0;
-#ifdef BV_ABL_NO_QUAL  /* attribution builds only (tools/ablate.sh) */
-                else qual = L.chi2;
-#else
                 else qual = bv_qual_from_chi2(L.chi2);
-#endif
                 double ad_sum = 0;
 #pragma unroll
                 for (int k = 0; k < BV_MAX_ALT; ++k) {
@@ -267,7 +263,6 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
                 work.tables_known(vt, (v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar) ? 1 : 2, lane);
             }
             // base-quality rank sum from the (base, phred) counts this pass already holds (caller.cpp:1157)
-#ifndef BV_ABL_NO_BQ
             {
                 unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
                 unsigned long long below = 0, twoR = 0;
@@ -285,17 +280,12 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
                 }
                 bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
             }
-#endif
         }
         // ---- strand bias: FS / SOR of the CVG table, then of the VCF table unless it is the same 2x2 table (it is
         // whenever the chosen ALTs are all the non-ref bases seen)
         if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
             const bool same = have_var && v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar;
-#ifdef BV_ABL_NO_VARFS
-            const int ntab = 1;
-#else
             const int ntab = (have_var && !same) ? 2 : 1;
-#endif
             double c_fs = 0, c_sor = 0, v_fs = 0, v_sor = 0;
             {
                 const uint32_t ct[4] = {c_rf, c_rr, c_af, c_ar}, vt[4] = {v_rf, v_rr, v_af, v_ar};

@@ -539,11 +539,7 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
         {
             const double r = (double)bv_sel4u(depth, first) / (double)total;
             if (m == 1 && total > 10 && r > 0.5) qual = 5000.0;
-#ifdef BV_ABL16_NO_QUAL  /* attribution builds only */
-            else qual = chi2;
-#else
             else qual = bv_qual_from_chi2(chi2);
-#endif
             double ad_sum = 0;
 #pragma unroll
             for (int k = 0; k < BV_MAX_ALT; ++k) {
@@ -563,7 +559,6 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
             else if ((alt_mask >> b) & 1u) { v_af += S.fwd[b]; v_ar += S.rev[b]; }
         }
         // base-quality rank sum (caller.cpp:1157): REF / ALT counts per phred value, scattered from the bins
-#ifndef BV_ABL16_NO_BQ
         {
             for (int i = gl; i < 2 * 128; i += 16) cls[i] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -590,18 +585,13 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
             bq_ranksum = bv_ranksum_phred(twoR, n1, n2);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // before the next site's zeroing
         }
-#endif
     }
     // strand bias: FS / SOR of the CVG table, then of the VCF table unless it is the same 2 x 2 table.  ONE call site for the
     // test (its code is the bulk of this kernel)
     double c_fs = 0, c_sor = 0, v_fs = 0, v_sor = 0;
     if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
         const bool same = have_var && v_rf == c_rf && v_rr == c_rr && v_af == c_af && v_ar == c_ar;
-#ifdef BV_ABL16_NO_VARFS
-        const int ntab = 1;
-#else
         const int ntab = (have_var && !same) ? 2 : 1;
-#endif
 #pragma unroll 1
         for (int t = 0; t < ntab; ++t) {
             double fs, sor;

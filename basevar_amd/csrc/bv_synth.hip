@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../include/basevar_amd.h"
+#include "../../include/basevar_amd_diag.h"
 
 typedef uint32_t bvs_u32x4 __attribute__((ext_vector_type(4)));
 

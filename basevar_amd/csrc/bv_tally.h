@@ -45,10 +45,6 @@ __device__ __forceinline__ void bv_lds_add16(const uint32_t x[16], uint32_t *his
         "v_cmp_gt_u32_e64 %[m14], %[lim], %[x14]\n\t"
         "v_cmp_gt_u32_e64 %[m15], %[lim], %[x15]\n\t"
         "s_mov_b64 %[sv], exec\n\t"
-#ifdef BV_ABL_P1S_NOADD  /* attribution builds only: everything but the LDS adds (results are wrong) */
-        "s_and_b64 exec, %[sv], %[m0]\n\ts_and_b64 exec, %[sv], %[m15]\n\t"
-        "s_mov_b64 exec, %[sv]"
-#else
         "s_and_b64 exec, %[sv], %[m0]\n\tds_add_u32 %[a0], %[one]\n\t"
         "s_and_b64 exec, %[sv], %[m1]\n\tds_add_u32 %[a1], %[one]\n\t"
         "s_and_b64 exec, %[sv], %[m2]\n\tds_add_u32 %[a2], %[one]\n\t"
@@ -66,7 +62,6 @@ __device__ __forceinline__ void bv_lds_add16(const uint32_t x[16], uint32_t *his
         "s_and_b64 exec, %[sv], %[m14]\n\tds_add_u32 %[a14], %[one]\n\t"
         "s_and_b64 exec, %[sv], %[m15]\n\tds_add_u32 %[a15], %[one]\n\t"
         "s_mov_b64 exec, %[sv]"
-#endif
         : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [m2] "=&s"(m[2]), [m3] "=&s"(m[3]), [m4] "=&s"(m[4]), [m5] "=&s"(m[5]), [m6] "=&s"(m[6]), [m7] "=&s"(m[7]), [m8] "=&s"(m[8]), [m9] "=&s"(m[9]), [m10] "=&s"(m[10]), [m11] "=&s"(m[11]), [m12] "=&s"(m[12]), [m13] "=&s"(m[13]), [m14] "=&s"(m[14]), [m15] "=&s"(m[15]), [sv] "=&s"(sv)
         : [x0] "v"(x[0]), [a0] "v"(ad[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]), [one] "v"(one), [lim] "s"(lim)
         : "memory", "scc");

@@ -188,6 +188,13 @@ class BaseTypeEngine:
             raise RuntimeError("bv_engine_host_log_eval: " + self._err())
         return y
 
+    def last_launch_form(self):
+        """BV_FORM_* bits of the last launch's pass 1 (include/basevar_amd_diag.h)."""
+        f = C.c_uint32()
+        if self._lib.bv_engine_last_launch_form(self._h, C.byref(f)) != 0:
+            raise RuntimeError("bv_engine_last_launch_form: " + self._err())
+        return f.value
+
     def last_variant_count(self):
         n = C.c_uint32()
         self._lib.bv_engine_last_variant_count(self._h, C.byref(n))

@@ -13,7 +13,7 @@
 //
 // Header-only, plain C++17, no htslib.  ROWS ARE READ by batchfile_fast.hpp (a byte-level reader straight into the slab's planes);
 // this file holds the row record, the writer and the text helpers of the output side.  A literal restatement of the reference's
-// reader lives in tests/cpp/literal_reader.hpp as the checker for both (tests/cpp/host_formats_check.cpp).
+// reader lives in literal_reader.hpp outside the product tree (test infrastructure) as the checker for both (tests/cpp/host_formats_check.cpp).
 //
 // PARITY STATUS: number formatting is pinned against the reference's own compiled join() in
 // tests/test_host_formats.py; whole-file parity with a run of the reference binary is unpinned.

@@ -4,7 +4,7 @@
 // (src/utils.h:87-122) and a BatchInfo of strings and vectors per site (src/basetype_caller.cpp:688-736) -- 49 k rows/s at
 // 100 samples per row on one core, and what would bound any real run of bv_call by orders of magnitude.  The function below
 // walks the same bytes once and writes the slab row directly: same accepted inputs, same results, same errors (message and
-// precedence), pinned against a literal restatement of the reference's reader (tests/cpp/literal_reader.hpp: test
+// precedence), pinned against a literal restatement of the reference's reader (literal_reader.hpp, test infrastructure outside the product tree: test
 // infrastructure) by tests/cpp/host_formats_check.cpp on valid rows, ragged rows and malformed tokens.
 //
 // Token semantics kept from the reference's readers:
@@ -40,7 +40,7 @@ inline int parse_int_token(const char *p, const char *e) {
 }
 
 // One row from every batchfile for the same position -> one slab row + its SiteText.  Returns false for the rows the reference
-// skips (total Depth == 0, caller.cpp:718): nothing is added then.  Throws what the reference's reader and BaseType constructor throw (as restated in tests/cpp/literal_reader.hpp + SlabBuilder::add_site).
+// skips (total Depth == 0, caller.cpp:718): nothing is added then.  Throws what the reference's reader and BaseType constructor throw (as restated in literal_reader.hpp, test infrastructure outside the product tree + SlabBuilder::add_site).
 inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_sample, SlabBuilder &sb, SiteText &st) {
     st = SiteText();
     SlabBuilder::Row r = sb.begin_row();

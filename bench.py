@@ -517,6 +517,7 @@ def main():
         s_, a1, a2, n_ = e.timing_get_ex()
         st_ms += s_; p1_ms += a1; p2_ms += a2; nsub += n_
     nvar = eng.last_variant_count()
+    form = eng.last_launch_form()
     gathered_ok = None
     ranks_verified = 0
     if rank == 0 and dist_on:
@@ -629,21 +630,16 @@ def main():
         algo_bytes = 2.0 * Bl * N * args.steps / max(n_launch, 1)
         # the dominant (HBM-bound) kernel: on short rows pass 1 is a streaming kernel + a solve kernel that reads no
         # planes; on long rows it is one kernel (st_avg_s == p1_avg_s)
-        shape = (args.flags >> 8) & 0xF
-        two_kernel = (shape == 0 and N <= 49152) or shape == 10
-        kernel_name = "bv_p1s_stream_kernel" if two_kernel else ("bv_pass1_fused_kernel" if shape == 9 else "bv_pass1_kernel")
+        # which kernels the launches took: asked of the engine (bv_engine_last_launch_form), not re-derived here
+        two_kernel = bool(form & _capi_mod.BV_FORM_SHORT_ROWS)
+        fused = two_kernel and bool(form & _capi_mod.BV_FORM_ONE_KERNEL)
+        fused_p2 = bool(form & _capi_mod.BV_FORM_PASS2_FUSED)
+        kernel_name = "bv_p1s_fused_kernel" if fused else "bv_p1s_stream_kernel" if two_kernel else "bv_pass1_kernel"
         # variant fraction of the last launch (a chained launch counts its whole queue)
         fvar = nvar / max(1.0, Bl * args.steps / max(n_launch, 1))
-        # Short rows of at least three 4 KiB slots, not chained: ONE persistent kernel does all of pass 1 (streaming and solver
-        # waves side by side, csrc/bv_pass1_fused.hip) and, with rank planes and no pop-groups, streams the variant sites' pass-2
-        # rows too: its algorithmic bytes are then section 8d's S*N*(2 + 3 f_var) (its traffic 2 + 4 f_var: the call byte of a
-        # variant row is read twice).  Flag bits 12-15: 9 = the round-3 kernels, 10 = pass 2 a launch of its own.
-        tune = (args.flags >> 12) & 0xF
-        fused = two_kernel and tune in (0, 10) and ((args.flags >> 24) & 0xF) <= 1 and (((N + 15) // 16 + 127) // 128) >= 3
-        fused_p2 = fused and tune == 0 and ranks and args.groups <= 7 and not (args.flags & 0x20)  # (groups: their tallies stream in pass 2's own launch)
+        # The fused short-row kernel that also streams the variant sites' pass-2 rows: its algorithmic bytes are section 8d's
+        # S*N*(2 + 3 f_var) (its traffic 2 + 4 f_var: the call byte of a variant row is read twice).
         kernel_bytes = algo_bytes * ((1.0 + 1.5 * fvar) if fused_p2 else 1.0)
-        if fused:
-            kernel_name = "bv_p1s_fused_kernel"
         achieved = kernel_bytes / st_avg_s / 1e9
         # HBM bytes per launch of that kernel from the PMC counters: NOT measured in this run (counter collection needs
         # rocprofv3 around the process) but read from the committed record of the SAME kernel and configuration, if one

@@ -1,4 +1,4 @@
-// literal_reader.hpp -- TEST INFRASTRUCTURE (tests/ only; nothing under basevar_amd/ includes it).
+// literal_reader.hpp -- TEST INFRASTRUCTURE, part of the oracle (tests/ only; nothing under basevar_amd/ includes it).
 //
 // A literal restatement of the reference's text layer on the input side of the path, kept as the CHECKER for the product's own
 // byte-level reader (basevar_amd/host/batchfile_fast.hpp) and formatters (basevar_amd/host/batchfile.hpp, vcf_emit.hpp):

@@ -1,5 +1,5 @@
 // Test harness (tests/ only): checks basevar_amd/host/{batchfile,vcf_emit}.hpp
-//  (1) the literal reader's tokenisers (tests/cpp/literal_reader.hpp) and the product's formatters against the reference's own ngslib functions (oracle/_ref), when
+//  (1) the literal reader's tokenisers (oracle/literal_reader.hpp) and the product's formatters against the reference's own ngslib functions (oracle/_ref), when
 //      that library is given as argv[2];
 //  (2) batchfile writer -> reader round trip;
 //  (3) emits CVG/VCF lines for records computed by the oracle restatement (liboracle.so, argv[1])
@@ -13,7 +13,7 @@
 #include "../../basevar_amd/host/basetype_gpu.hpp"
 #include "../../basevar_amd/host/vcf_emit.hpp"
 #include "../../basevar_amd/host/batchfile_fast.hpp"
-#include "literal_reader.hpp"  // the literal restatement of the reference's reader: the checker (test infrastructure)
+#include "../../oracle/literal_reader.hpp"  // the literal restatement of the reference's reader: the checker (test infrastructure)
 
 using namespace bvamd;
 

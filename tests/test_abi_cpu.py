@@ -21,9 +21,12 @@ def lib():
 
 
 def declared_functions():
-    hdr = open(os.path.join(ROOT, "include", "basevar_amd.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    return sorted(set(re.findall(r"\b(bv_[a-z0-9_]+)\s*\(", hdr)))
+    names = set()
+    for h in ("basevar_amd.h", "basevar_amd_diag.h"):  # the reference-facing surface + diagnostics / measurement helpers
+        hdr = open(os.path.join(ROOT, "include", h)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        names.update(re.findall(r"\b(bv_[a-z0-9_]+)\s*\(", hdr))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -34,6 +37,14 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), n
 
 
+def test_public_header_is_the_product_surface_only():
+    """include/basevar_amd.h is what a maintainer of the reference reads: no diagnostic / A-B switch in it, and short."""
+    hdr = open(os.path.join(ROOT, "include", "basevar_amd.h")).read()
+    assert len(hdr.splitlines()) <= 250
+    for lab in ("TALLY_ONLY", "SKIP_", "GRID_LIMIT", "GROUP_INLINE", "PASS2_SWEEP", "WAVE_SOLVER", "BV_FLAG_SPLIT", "SHORT_ROW_FORM", "FAULT"):
+        assert lab not in hdr, lab
+
+
 def test_record_layout_matches_header(tmp_path):
     from basevar_amd import _capi
     src = tmp_path / "layout.c"
@@ -41,7 +52,7 @@ def test_record_layout_matches_header(tmp_path):
     gfields = [f for f in _capi.GROUP_DTYPE.names]
     body = "".join('printf("s %s %%zu\\n", offsetof(bv_site_result, %s));\n' % (f, f) for f in fields)
     body += "".join('printf("g %s %%zu\\n", offsetof(bv_group_result, %s));\n' % (f, f) for f in gfields)
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "basevar_amd.h"\nint main(void){\n'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "basevar_amd_diag.h"\nint main(void){\n'
                    'printf("S %zu\\nG %zu\\nslab %zu\\ncfg %zu\\nsynth %zu\\n", sizeof(bv_site_result), sizeof(bv_group_result),'
                    ' sizeof(bv_slab), sizeof(bv_engine_config), sizeof(bv_synth_params));\n' + body + "return 0;}\n")
     exe = tmp_path / "layout"

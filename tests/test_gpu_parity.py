@@ -105,11 +105,12 @@ def test_vs_real_reference_when_present(bv):
     check(got, exp, gexp, check_chi2=False)
 
 
-@pytest.mark.parametrize("flags", [0x10, 0x900, 0x1000, 0x8000], ids=["wave_solver_only", "one_kernel_form", "1KiB_slots_16_waves", "2KiB_slots_12_waves"])
+@pytest.mark.parametrize("flags", [0x10, 0x9000, 0xA000, 0x9010], ids=["wave_solver_only", "three_launches", "fused_pass1_only", "three_launches_wave_solver"])
 def test_short_row_kernel_variants_agree(bv, restatement, flags):
-    """The short-row pass 1 has several realisations behind diagnostic flags (all candidates on the one-site-per-wave solver;
-    round 1's one-kernel form; other ring shapes of the streaming kernel): every one must meet the oracle, and the integer
-    fields must equal those of the default path bit for bit."""
+    """The short-row path has several realisations behind diagnostic flags (include/basevar_amd_diag.h): all candidates on the
+    one-site-per-wave solver; the three launches that rows of <= 4,096 samples take (BV_FLAG_SHORT_ROW_FORM(9)); the fused
+    kernel for pass 1 with pass 2 a launch of its own (10).  Every one must meet the oracle, and the integer fields must equal
+    those of the default path bit for bit."""
     n = 12000
     slab = make_slab(700, n, seed=77, coverage=0.1, n_groups=2, ref_n_frac=0.03, site_offset=3)
     maf = bv.min_af(n)
@@ -642,6 +643,29 @@ def test_more_than_32_pop_groups(bv, restatement, n, ng, ranks):
     eng.close()
 
 
+@pytest.mark.parametrize("n", [9000, 70000], ids=["fused_short_row_kernel", "long_row_kernel"])
+def test_lost_handoff_ends_in_a_loud_timeout_not_a_hung_gpu(bv, restatement, n):
+    """Every wait of the persistent kernels on another wave's LDS write is bounded; this is the test that makes one fire.
+    BV_FLAG_FAULT_LOST_HANDOFF (include/basevar_amd_diag.h) loses ONE hand-off of workgroup 0 -- a candidate-queue entry that
+    is reserved and never written (bv_p1s_fused_kernel), a ring slot that is never published (bv_pass1_kernel).  The launch
+    must END within seconds, bv_engine_wait must fail naming the time-out, the engine must be destroyable, and a fresh engine
+    on the same device must give the reference's records."""
+    import time
+    slab = make_slab(600, n, seed=31, coverage=0.1, site_offset=2)
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=600, min_af_value=maf, device=0, flags=0x40000000)
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="timed out"):
+        eng.lrt(slab)
+    dt = time.perf_counter() - t0
+    assert dt < 8.0, "the bounded wait took %.1f s" % dt
+    assert dt > 0.2   # (it really waited: the fault was injected)
+    eng.close()
+    got = run_engine(bv, slab, maf)   # a fresh engine, same device: the GPU is alive and sane
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins)
+
+
 def test_device_log_is_the_hosts_log(bv):
     """bv_log_host on the device == the host libm's log(), bit for bit: the EM's marginals at shallow sites (mixtures of
     1 - eps_q and eps_q / 3), both branches of the algorithm, subnormals, specials."""
@@ -698,30 +722,12 @@ def test_exact_tie_site_follows_the_reference_rounding(bv, restatement):
     assert got.sites["n_alt"][0] == 0
 
 
-@pytest.mark.parametrize("groups", [0, 3], ids=["no_groups", "groups"])
-def test_chunk_pipeline_gives_the_records_of_the_plain_launch(bv, groups):
-    """BV_FLAG_SPLIT(n): a short-row batch cut into n chunks that go through the engine's two streams (measured slower than the
-    plain sequence and off by default) must still give every record of the plain launch byte for byte -- per-chunk
-    scratch slices, variant lists and counter blocks, pop-group items included."""
-    n, S = 9000, 3000
-    slab = make_slab(S, n, seed=808, coverage=0.08, n_groups=groups, site_offset=5)
-    maf = bv.min_af(n)
-    want = run_engine(bv, slab, maf)
-    for split in (2, 3, 5):
-        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=split << 24)
-        got = eng.lrt(slab)
-        eng.close()
-        assert got.sites.tobytes() == want.sites.tobytes(), split
-        assert got.n_variant == want.n_variant
-        if groups:
-            assert got.groups.tobytes() == want.groups.tobytes(), split
-
-
 @pytest.mark.parametrize("S", [640, 3000, 9000], ids=["one_row_per_workgroup", "three_rows", "nine_rows"])
 def test_team_tail_gives_the_records_of_the_plain_kernel(bv, restatement, S):
     """Long rows, launches of up to 65,536 sites: the last solves of a workgroup are spread over its idle tally waves (EM runs
     of an LRT level on three waves, the Fisher tests on a fourth -- bv_pass1.hip, team form).  Whoever runs them, the records
-    are those of the plain kernel (shape 1: <3 tally, 1 solver>, no team) byte for byte, and those of the reference.
+    are those of the kernel without helpers (BV_FLAG_LONG_ROW_FORM(2): the solver wave solves alone) byte for byte, and those of
+    the reference.
     640 sites = one row per workgroup: every deep site is a team job.  Shallow sites (<= 64 covered samples, replayed in
     sample order by one wave) and empty ones stay with the solver wave."""
     n = 52000
@@ -732,7 +738,7 @@ def test_team_tail_gives_the_records_of_the_plain_kernel(bv, restatement, S):
     slab["qual"][9, :200] = 0
     maf = bv.min_af(n)
     got = run_engine(bv, slab, maf)
-    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=1 << 8)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=2 << 8)
     plain = eng.lrt(slab)
     eng.close()
     assert got.sites.tobytes() == plain.sites.tobytes()

@@ -15,6 +15,6 @@ run "shallow rows (ties), seed 22" CAMPAIGN_SHALLOW=1 CAMPAIGN_SEED=22
 run "chained launches incl. pop-groups, seed 31" CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=31
 run "chained launches incl. pop-groups, seed 32" CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=32
 run "chained + shallow, seed 33" CAMPAIGN_CHAIN=1 CAMPAIGN_SHALLOW=1 CAMPAIGN_SEED=33
-run "chunk pipeline BV_FLAG_SPLIT(3), seed 41" CAMPAIGN_FLAGS=$((3 << 24)) CAMPAIGN_SEED=41
+run "three-launch short-row form BV_FLAG_SHORT_ROW_FORM(9), seed 41" CAMPAIGN_FLAGS=$((9 << 12)) CAMPAIGN_SEED=41
 run "wave solver only (BV_FLAG_WAVE_SOLVER), seed 51" CAMPAIGN_FLAGS=16 CAMPAIGN_SEED=51
 cat $OUT
