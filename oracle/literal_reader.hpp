@@ -18,7 +18,7 @@
 #include <string>
 #include <vector>
 
-#include "../../basevar_amd/host/batchfile.hpp"
+#include "../basevar_amd/host/batchfile.hpp"
 
 namespace bvlit {
 
