@@ -245,7 +245,9 @@ struct bv_engine {
     uint32_t *tile_maxr = nullptr;
     size_t tile_state_bytes = 0, tile_maxr_bytes = 0;
     uint32_t tile_sites = 0, tile_groups = 0, tile_stride = 0, tile_samples_total = 0, tile_samples_seen = 0;
-    uint32_t tile_rank_win = 1024, tile_hg_off = 0;
+    uint32_t tile_rank_win = 1024, tile_hg_off = 0, tile_ord_off = 0;
+    uint32_t *tile_ovf = nullptr;      // pool of read-position ranks beyond the window (bv_tiles.hip), kOvfCap entries
+    static constexpr uint32_t kOvfCap = 1u << 22;
     bool tile_ranks = false, tile_open = false;
     hipStream_t copy_stream[2] = {nullptr, nullptr};  // alternate: the set-up of one copy hides under the transfer of the other
     // joined-rows realisation of the tile mode: resident planes [tile_sites][j_pitch]
@@ -637,6 +639,7 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_gout_round) (void)hipFree(e->d_gout_round);
     if (e->tile_state) (void)hipFree(e->tile_state);
     if (e->tile_maxr) (void)hipFree(e->tile_maxr);
+    if (e->tile_ovf) (void)hipFree(e->tile_ovf);
     if (e->j_buf) (void)hipFree(e->j_buf);
     for (hipStream_t cs : e->copy_stream)
         if (cs) (void)hipStreamSynchronize(cs);
@@ -1137,8 +1140,10 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
                                          "per-site state per group otherwise), and the joined planes of this job do not fit the device");
     // H1 2048 + Hm 1024 + Hr 4 x W + Hg 512/group (bv_tiles.hip); W = 1024 ranks, or what the caller announced
     const uint32_t rank_win = with_ranks > 1 ? (uint32_t)((with_ranks + 1023) / 1024 * 1024) : 1024u;
-    const uint32_t hg_off = 3072u + 4u * rank_win, stride = hg_off + n_groups * 512u;
-    e->tile_rank_win = rank_win; e->tile_hg_off = hg_off;
+    const uint32_t hg_off = 3072u + 4u * rank_win, ord_off = hg_off + n_groups * 512u, stride = ord_off + BV_TS_ORD_WORDS;
+    e->tile_rank_win = rank_win; e->tile_hg_off = hg_off; e->tile_ord_off = ord_off;
+    if (!e->tile_ovf) BV_HIP(e, hipMalloc(&e->tile_ovf, sizeof(uint32_t) * (2u + 2u * (size_t)bv_engine::kOvfCap)));
+    BV_HIP(e, hipMemset(e->tile_ovf, 0, 2 * sizeof(uint32_t)));
     const size_t bytes = (size_t)n_sites * stride * sizeof(uint32_t), mbytes = (size_t)n_sites * sizeof(uint32_t);
     if (bytes > e->tile_state_bytes) {
         if (e->tile_state) BV_HIP(e, hipFree(e->tile_state));
@@ -1241,6 +1246,7 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     a.width = t->n_samples; a.n_groups = e->tile_groups; a.stride = e->tile_stride; a.state = e->tile_state;
     a.rank_win = e->tile_rank_win; a.hg_off = e->tile_hg_off;
     a.maxr = e->tile_maxr;
+    a.ord_off = e->tile_ord_off; a.col0 = e->tile_samples_seen; a.ovf = e->tile_ovf; a.ovf_cap = bv_engine::kOvfCap;
     bv_launch_tile_tally(a, st);
     BV_HIP(e, hipGetLastError());
     if (slot) {
@@ -1416,6 +1422,7 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     f.state = e->tile_state; f.maxr = e->tile_maxr; f.ref_base = dref; f.n_sites = e->tile_sites; f.n_groups = e->tile_groups;
     f.stride = e->tile_stride; f.have_ranks = e->tile_ranks ? 1u : 0u; f.min_af = e->cfg.min_af; f.tables = e->d_tables;
     f.rank_win = e->tile_rank_win; f.hg_off = e->tile_hg_off;
+    f.ord_off = e->tile_ord_off; f.ovf = e->tile_ovf; f.ovf_cap = bv_engine::kOvfCap;
     f.out = dout; f.gout = dgout; f.var_list = e->d_var_list; f.counters = e->d_counters;
     bv_launch_tile_finish(f, st);
     BV_HIP(e, hipGetLastError());

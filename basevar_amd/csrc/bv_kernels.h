@@ -167,7 +167,16 @@ struct BvTileArgs {
     uint32_t hg_off;          // word offset of the pop-group tallies in a site's state
     uint32_t *state;          // [n_sites][stride]
     uint32_t *maxr;           // [n_sites] largest read-position rank seen
+    uint32_t ord_off;         // word offset of the site's covered-cell list (BV_TS_ORD_WORDS words) in its state
+    uint32_t col0;            // index of the tile's first sample in the job (the list is put in sample order by it)
+    uint32_t *ovf;            // pool of read-position ranks >= rank_win: [0] entries appended, then (site, base << 16 | rank) pairs
+    uint32_t ovf_cap;         // entries the pool holds
 };
+// Per-site list of covered cells (per-site-tally realisation): word 0 = cells appended, then BV_ORD_MAX x (sample index,
+// call << 8 | phred | group << 16).  Complete -- and used, sorted by sample index, for the reference's per-sample replay --
+// exactly when the site has at most BV_ORD_MAX covered cells.
+#define BV_TS_ORD_WORDS (4u + 2u * 64u)
+#define BV_TS_OVF_LIST 2048u /* ranks beyond the window a SITE can have and still get an exact ReadPosRankSum */
 struct BvTileFinishArgs {
     const uint32_t *state;
     const uint32_t *maxr;
@@ -177,6 +186,9 @@ struct BvTileFinishArgs {
     uint32_t stride;
     uint32_t have_ranks;
     uint32_t rank_win, hg_off;
+    uint32_t ord_off;         // see BvTileArgs
+    const uint32_t *ovf;
+    uint32_t ovf_cap;
     double min_af;
     const BvTables *tables;
     bv_site_result *out;

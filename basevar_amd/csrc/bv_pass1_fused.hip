@@ -544,9 +544,9 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
         (void)bv_f_global_fetch_add_wave(&counters[BV_CTR_TIMEOUT], 1u);
         return;
     }
-    // (BV_FLAG_FAULT_LOST_HANDOFF, tests: the first entry of workgroup 0's queue is reserved and never written -- the solver wave
-    // that claims it must give up after its bounded wait)
-    if (lose_first && pos == 0u && blockIdx.x == 0u) return;
+    // (BV_FLAG_FAULT_LOST_HANDOFF, tests: the first entry of every workgroup's queue is reserved and never written -- the solver
+    // wave that claims it must give up after its bounded wait)
+    if (lose_first && pos == 0u) return;
     if (lane == 0) *e = site;
 }
 // publish a pass-1 row whose stores are complete.  Candidates of the 16-lane solver: a place in their queue -- one LDS atomic,

@@ -2,6 +2,7 @@
 // from its (strand, base, phred) histogram in LDS.  Shared by the streaming kernels
 // (bv_pass1.hip) and the sample-axis tile mode (bv_tiles.hip).
 #pragma once
+#include <type_traits>
 
 #include "bv_kernels.h"
 
@@ -141,6 +142,13 @@ struct BvSoloWork {
     }
 };
 
+// A WORK policy may bring its own source of a shallow site's covered cells in sample order (`uint32_t ordered(site, ord, lane)`:
+// bv_tiles.hip, which has no rows left when it solves); every other policy takes them from the site's row (bv_gather_ordered).
+template <class W, class = void>
+struct bv_work_has_ordered : std::false_type {};
+template <class W>
+struct bv_work_has_ordered<W, std::void_t<decltype(&W::ordered)>> : std::true_type {};
+
 // Everything the reference computes for one site, on one wave, from the site's totals, its compacted bins
 // (bin_code / bin_cnt, layout given by ALIAS) and the merged (base, phred) counts `hq`.
 // Register-pressure note: this body sits inside the persistent loop of the kernel.  With
@@ -197,10 +205,13 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
         B.loghit = a.loghit; B.logmiss = a.logmiss;
         B.nb = (int)nb;
         B.ord = nullptr; B.n_ord = 0;
-        if (a.bs != nullptr && total >= 2u && total <= (uint32_t)BV_ORD_MAX && !(a.flags & BV_FLAG_SKIP_LRT)) {
+        bool have_src = a.bs != nullptr;
+        if constexpr (bv_work_has_ordered<WORK>::value) have_src = true;
+        if (have_src && total >= 2u && total <= (uint32_t)BV_ORD_MAX && !(a.flags & BV_FLAG_SKIP_LRT)) {
             // shallow site: the reference's per-sample order decides ties -- replay it (bv_em_ordered)
-            const uint32_t got = bv_gather_ordered(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples,
-                                                   sv->ord, lane);
+            uint32_t got;
+            if constexpr (bv_work_has_ordered<WORK>::value) got = work.ordered(site, sv->ord, lane);
+            else got = bv_gather_ordered(a.bs + (size_t)site * a.pitch, a.q + (size_t)site * a.pitch, a.n_samples, sv->ord, lane);
             bv_lrt_sync<0>();
             if (got == total) { B.ord = sv->ord; B.n_ord = (int)total; }
             if (B.ord != nullptr && bv_hostlog_of(a.logmiss) == nullptr) flags |= BV_SITE_LOG_APPROX;  // loud: see basevar_amd.h
@@ -328,11 +339,11 @@ __device__ __forceinline__ bool bv_site_solve(const BvSolveArgs &a, uint32_t sit
 }
 
 // Tally histogram -> record: the prologue (totals + bins) and the solve, on one wave.
-template <bool ALIAS>
+template <bool ALIAS, class WORK = BvSoloWork>
 __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site, BV_LDS uint32_t *hist_l,
                                                   BV_LDS uint32_t *bin_code_l, BV_LDS uint32_t *bin_cnt_l,
                                                   BV_LDS BvSolverScratch *sv_l, BV_LDS const double *tab_hit_l,
-                                                  BV_LDS const double *tab_miss_l, int lane) {
+                                                  BV_LDS const double *tab_miss_l, int lane, const WORK &work = WORK()) {
     uint32_t *hist = (uint32_t *)hist_l;
     uint32_t *bin_code = ALIAS ? hist + BV_ALIAS_CODE_OFF : (uint32_t *)bin_code_l;
     uint32_t *bin_cnt = ALIAS ? hist + BV_ALIAS_CNT_OFF : (uint32_t *)bin_cnt_l;
@@ -351,5 +362,5 @@ __device__ __forceinline__ void bv_solve_site_wave(BvSolveArgs a, uint32_t site,
     bv_prologue_wave<ALIAS>(hist, bin_code, bin_cnt, lane, S.fwd, S.rev, &S.nb, &S.badq);
     bv_lrt_sync<0>();  // bin_code / bin_cnt / res zeroing visible to every lane
     BvHqFromHist hq{hist};
-    bv_site_solve<ALIAS>(a, site, S, bin_code, bin_cnt, hq, sv, (const double *)tab_hit_l, (const double *)tab_miss_l, lane);
+    bv_site_solve<ALIAS, BvHqFromHist, false, WORK>(a, site, S, bin_code, bin_cnt, hq, sv, (const double *)tab_hit_l, (const double *)tab_miss_l, lane, work);
 }

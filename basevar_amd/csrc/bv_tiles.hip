@@ -11,10 +11,15 @@
 //     Hr [ base * W + rank ]                   4 x W  read-position ranks 0..W-1 per called base; W = 1024 unless the job
 //                                                     announced longer reads (bv_engine_tiles_begin, with_ranks > 1)
 //     Hg [ (group*4 + base) << 7 | phred ]     512 per pop-group
+//     Ord                                      BV_TS_ORD_WORDS: the site's first covered cells as (sample index, call, phred, group)
 // Keeping Hm/Hr per BASE (not per REF/ALT class) is what makes a single sweep enough: the alt set
 // is only known after the last tile, and any (ref, alts) partition can be read off per-base tallies.
-// A rank at or beyond W cannot be tallied: such a site gets BV_SITE_RPR_RANGE and a NaN ReadPosRankSum (announce
-// the read length at bv_engine_tiles_begin, or use the joined-rows realisation, whose pass 2 sweeps rank windows).
+// A site of at most 64 covered samples has ALL its cells in Ord: at finish they are put in sample order and the site (and its
+// pop-groups) replay the reference's per-sample EM literally, as the row kernels do from the row (sum / argmin order,
+// src/algorithm.h:24-41): exact ties fall as the reference's do.
+// A rank at or beyond W does not fit Hr: the cell goes to a pool of (site, base, rank) entries, and a site that has such cells
+// forms its ReadPosRankSum from Hr plus its pool entries -- exact (src/basetype.cpp:201-242), slower.  Only a site with more
+// than BV_TS_OVF_LIST such cells, or a pool that overflowed, still gets BV_SITE_RPR_RANGE and a NaN (announce the read length).
 //
 // Tally: one thread per 16-byte chunk of the tile (coalesced loads), covered cells go to the site's state with
 // global atomics.  This per-site-state realisation is the FALLBACK of the tile mode (for jobs whose joined planes do
@@ -60,10 +65,23 @@ __global__ __launch_bounds__(256) void bv_tile_tally_kernel(BvTileArgs a) {
             atomicAdd(&S[BV_TS_HM + ((b << 8) | mq)], 1u);
             maxr = max(maxr, r);
             if (r < a.rank_win) atomicAdd(&S[BV_TS_HR + b * a.rank_win + r], 1u);
+            else {  // beyond the window: into the pool (exact path at finish)
+                const uint32_t k = atomicAdd(&a.ovf[0], 1u);
+                if (k < a.ovf_cap) { a.ovf[2u + 2u * k] = site; a.ovf[3u + 2u * k] = (b << 16) | r; }
+            }
         }
+        uint32_t gi = BV_NO_GROUP;
         if (a.n_groups) {
-            const uint32_t gi = a.group_id[smp];
+            gi = a.group_id[smp];
             if (gi < a.n_groups) atomicAdd(&S[a.hg_off + (((gi * 4u + b) << 7) | min(q, 127u))], 1u);
+        }
+        // the site's covered cells while they are few (a plain look first: a deep site stops paying for the atomic)
+        if (__builtin_nontemporal_load(&S[a.ord_off]) < (uint32_t)BV_ORD_MAX) {
+            const uint32_t k = atomicAdd(&S[a.ord_off], 1u);
+            if (k < (uint32_t)BV_ORD_MAX) {
+                S[a.ord_off + 4u + 2u * k] = a.col0 + smp;
+                S[a.ord_off + 5u + 2u * k] = (c << 8) | q | (gi << 16);
+            }
         }
     }
     if (a.mapq && maxr) atomicMax(&a.maxr[site], maxr);
@@ -75,6 +93,32 @@ struct __attribute__((aligned(16))) BvTileFinishShared {
     BvSolverScratch sc;
     uint32_t bin_code[BV_SLOTS * BV_WAVE];  // group calls
     uint32_t bin_cnt[BV_SLOTS * BV_WAVE];
+    uint32_t cells[BV_ORD_MAX];             // a shallow site's covered cells in sample order: call << 8 | phred | group << 16
+    uint32_t n_cells;                       // ... how many (0: the site is not shallow / its list is incomplete)
+    uint32_t ovf[BV_TS_OVF_LIST];           // the site's read-position ranks beyond the window: class << 16 | rank
+};
+
+// The site's covered cells in sample order, from its list in the state: every lane takes one entry, its place is the number of
+// entries with a smaller sample index (indices are distinct).  Returns how many cells the list holds (> BV_ORD_MAX: incomplete).
+__device__ __forceinline__ uint32_t bv_tile_sorted_cells(const uint32_t *L, uint32_t *cells, int lane) {
+    const uint32_t n = L[0];
+    if (n == 0u || n > (uint32_t)BV_ORD_MAX) return n;
+    const bool have = (uint32_t)lane < n;
+    const uint32_t idx = have ? L[4 + 2 * lane] : 0xFFFFFFFFu, cell = have ? L[5 + 2 * lane] : 0u;
+    uint32_t place = 0;
+    for (uint32_t j = 0; j < n; ++j) place += ((uint32_t)__shfl((int)idx, (int)j) < idx) ? 1u : 0u;
+    if (have) cells[place] = cell;
+    bv_lrt_sync<0>();
+    return n;
+}
+// WHO supplies a shallow site's ordered cells here: the list above (bv_site_solve asks through `ordered`)
+struct BvTileWork : BvSoloWork {
+    const uint32_t *cells;
+    uint32_t n_cells;
+    __device__ __forceinline__ uint32_t ordered(uint32_t, uint16_t *ord, int lane) const {
+        if ((uint32_t)lane < n_cells) ord[lane] = (uint16_t)(cells[lane] & 0xFFFFu);
+        return n_cells;
+    }
 };
 
 // One wave per site: the record from the accumulated state.
@@ -99,10 +143,16 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
     sa.min_af = a.min_af; sa.flags = 0;
     sa.lnfact.t = a.tables->lnfact; sa.lnfact.n = (int)a.tables->lnfact_n;
     sa.loghit = a.tables->loghit; sa.logmiss = a.tables->logmiss;
-    sa.bs = nullptr; sa.q = nullptr; sa.pitch = 0; sa.n_samples = 0;  // no rows here: ties of shallow sites stay order-blind
-    bv_solve_site_wave<true>(sa, site, (BV_LDS uint32_t *)sh.hist, (BV_LDS uint32_t *)nullptr, (BV_LDS uint32_t *)nullptr,
-                             (BV_LDS BvSolverScratch *)&sh.sc, (BV_LDS const double *)sh.tab_hit,
-                             (BV_LDS const double *)sh.tab_miss, lane);
+    sa.bs = nullptr; sa.q = nullptr; sa.pitch = 0; sa.n_samples = 0;  // no rows here: a shallow site's cells come from its list
+    BvTileWork work;
+    {
+        const uint32_t n_list = bv_tile_sorted_cells(S + a.ord_off, sh.cells, lane);
+        work.cells = sh.cells;
+        work.n_cells = n_list <= (uint32_t)BV_ORD_MAX ? n_list : 0u;
+    }
+    bv_solve_site_wave<true, BvTileWork>(sa, site, (BV_LDS uint32_t *)sh.hist, (BV_LDS uint32_t *)nullptr, (BV_LDS uint32_t *)nullptr,
+                                         (BV_LDS BvSolverScratch *)&sh.sc, (BV_LDS const double *)sh.tab_hit,
+                                         (BV_LDS const double *)sh.tab_miss, lane, work);
     // what the solver decided (its staged record is still in LDS)
     const int n_alt = sh.sc.res.n_alt;
     if (n_alt == 0) return;
@@ -141,10 +191,34 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
         const double mq_ph = bv_ranksum_phred(twoR, n1, n2);
         double rp_ph = __builtin_nan("");
         const uint32_t maxr = a.maxr[site];
-        const bool in_range = maxr < a.rank_win;
+        bool in_range = maxr < a.rank_win;
+        uint32_t n_ovf = 0;
+        if (!in_range) {
+            // the site's cells beyond the window, from the pool: class (0 REF, 1 ALT; others dropped) << 16 | rank
+            const uint32_t n_pool = a.ovf[0];
+            in_range = n_pool <= a.ovf_cap;  // (a pool that overflowed lost cells: no exact answer)
+            for (uint32_t i0 = 0; in_range && i0 < n_pool; i0 += BV_WAVE) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                uint32_t w = 0;
+                bool mine = false;
+                if (i < n_pool && a.ovf[2u + 2u * i] == site) {
+                    w = a.ovf[3u + 2u * i];
+                    const int b = (int)(w >> 16);
+                    mine = b == ref || ((alt_mask >> b) & 1u);
+                    w = ((b == ref) ? 0u : 1u) << 16 | (w & 0xFFFFu);
+                }
+                const unsigned long long m = __ballot(mine);
+                const uint32_t pos = n_ovf + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (mine && pos < BV_TS_OVF_LIST) sh.ovf[pos] = w;
+                n_ovf += (uint32_t)__popcll(m);
+                if (n_ovf > BV_TS_OVF_LIST) in_range = false;
+            }
+            bv_lrt_sync<0>();
+        }
         if (in_range) {
             below = 0; twoR = 0;
-            for (uint32_t w = 0; w * 64u <= maxr; ++w) {  // ranks beyond the site's largest hold nothing
+            const uint32_t top = maxr < a.rank_win ? maxr : a.rank_win - 1u;
+            for (uint32_t w = 0; w * 64u <= top; ++w) {  // ranks beyond the site's largest hold nothing
                 const uint32_t v = w * 64u + (uint32_t)lane;
                 uint32_t rv = 0, av = 0;
 #pragma unroll
@@ -154,6 +228,21 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
                     else if ((alt_mask >> b) & 1u) av += c;
                 }
                 twoR += bv_ranksum_window(rv, av, n1 + n2, below, lane);
+            }
+            // ... then the values beyond the window, every one larger than all of the window's: for an entry of value v,
+            // below_v = the window's cells + the entries with a smaller value, t_v = the entries of the same value (both classes)
+            for (uint32_t i0 = 0; i0 < n_ovf; i0 += BV_WAVE) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const bool have = i < n_ovf;
+                const uint32_t me = have ? sh.ovf[i] : 0u, v = me & 0xFFFFu;
+                uint32_t less = 0, same = 0;
+                for (uint32_t j = 0; j < n_ovf; ++j) {
+                    const uint32_t o = sh.ovf[j] & 0xFFFFu;  // (wave-uniform address: an LDS broadcast)
+                    less += o < v ? 1u : 0u;
+                    same += o == v ? 1u : 0u;
+                }
+                const unsigned long long term = (have && (me >> 16) == 0u) ? (2ull * (n1 + n2) - 2ull * (below + less) - same + 1ull) : 0ull;
+                twoR += bv_wave_sum_u64(term);
             }
             rp_ph = bv_ranksum_phred(twoR, n1, n2);
         }
@@ -193,6 +282,14 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
             BvBins B;
             B.code = sh.bin_code; B.cnt = sh.bin_cnt; B.skip_mask = 0u; B.hit = sh.tab_hit; B.miss = sh.tab_miss;
             B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss; B.ord = nullptr; B.n_ord = 0;
+            if (work.n_cells != 0u && gtotal >= 2u) {
+                // a shallow site: the group's cells in sample order (the site's list, filtered), for the literal replay
+                const bool mine = (uint32_t)lane < work.n_cells && (sh.cells[lane] >> 16) == g;
+                const unsigned long long m = __ballot(mine);
+                if (mine) sh.sc.ord[__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(sh.cells[lane] & 0xFFFFu);
+                bv_lrt_sync<0>();
+                if ((uint32_t)__popcll(m) == gtotal) { B.ord = sh.sc.ord; B.n_ord = (int)gtotal; }
+            }
             B.nb = (int)nb;
             bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.sc.lrt, 0, lane, L);
         }

@@ -137,14 +137,18 @@ public:
         rp_.insert(rp_.end(), o.rp_.begin(), o.rp_.end());
         ref_.insert(ref_.end(), o.ref_.begin(), o.ref_.end());
     }
-    // the first `k` rows of `o` only
-    void append_first(const SlabBuilder &o, size_t k) {
+    // rows [first, first + k) of `o` only
+    void append_rows(const SlabBuilder &o, size_t first, size_t k) {
         if (o.n_ != n_) throw std::runtime_error("[ERROR] SlabBuilder::append: different sample counts");
-        bs_.insert(bs_.end(), o.bs_.begin(), o.bs_.begin() + k * pitch_);
-        q_.insert(q_.end(), o.q_.begin(), o.q_.begin() + k * pitch_);
-        mq_.insert(mq_.end(), o.mq_.begin(), o.mq_.begin() + k * pitch_);
-        rp_.insert(rp_.end(), o.rp_.begin(), o.rp_.begin() + k * pitch_);
-        ref_.insert(ref_.end(), o.ref_.begin(), o.ref_.begin() + k);
+        const size_t a = first * pitch_, b = (first + k) * pitch_;
+        bs_.insert(bs_.end(), o.bs_.begin() + a, o.bs_.begin() + b);
+        q_.insert(q_.end(), o.q_.begin() + a, o.q_.begin() + b);
+        mq_.insert(mq_.end(), o.mq_.begin() + a, o.mq_.begin() + b);
+        rp_.insert(rp_.end(), o.rp_.begin() + a, o.rp_.begin() + b);
+        ref_.insert(ref_.end(), o.ref_.begin() + first, o.ref_.begin() + first + k);
+    }
+    void reserve_rows(size_t rows) {
+        bs_.reserve(rows * pitch_); q_.reserve(rows * pitch_); mq_.reserve(rows * pitch_); rp_.reserve(rows * pitch_); ref_.reserve(rows);
     }
     const uint8_t *cell_row(size_t site) const { return &bs_[site * pitch_]; }
     const uint8_t *phred_row(size_t site) const { return &q_[site * pitch_]; }

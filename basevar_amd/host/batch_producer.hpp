@@ -1,0 +1,298 @@
+// batch_producer.hpp -- reference-format batchfiles -> slab rows, on T host threads.
+//
+// The reference joins one row from each of its NB batchfiles per position on ONE thread per region
+// (src/basetype_caller.cpp:586-611); at 10,000 samples per position that thread parses ~1,000 positions a second, six orders
+// of magnitude below the engine.  Here the same rows go through a pipeline of BLOCKS of R consecutive positions:
+//
+//   read   (task per file and block)   inflate + split R lines of one file -- a gzip stream is sequential, so a file's blocks
+//                                      are read one after the other, but the NB files of a block, and blocks k + 1, k + 2 of
+//                                      other files, are read at the same time
+//   parse  (task per chunk of a block) the byte-level reader (batchfile_fast.hpp) on a run of consecutive positions, one row
+//                                      from every file each, into a slab builder of its own
+//   join   (the caller's thread)       the chunks of a block in position order -> sink(part, texts); the block's line storage
+//                                      goes back to the readers
+//
+// with K block buffers in flight, so that reading block k + 2, parsing block k + 1 and joining block k overlap (round 3 ran
+// the three as phases with a barrier between them and started its threads anew in each: 3.6 x on 16 threads).  Same rows, and
+// the error of the first offending position in position order, as the position-by-position loop: what precedes the
+// offending position is delivered, then the error is thrown on the caller's thread.
+#pragma once
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "batchfile_fast.hpp"
+
+namespace bvamd {
+
+// Lines of a gzip / BGZF / plain file (zlib reads all three): gzread into a large buffer, lines cut with memchr.
+class GzLineReader {
+public:
+    GzLineReader() = default;
+    GzLineReader(const GzLineReader &) = delete;
+    GzLineReader &operator=(const GzLineReader &) = delete;
+    ~GzLineReader() { if (f_) gzclose(f_); }
+    bool open(const std::string &path) {
+        f_ = gzopen(path.c_str(), "rb");
+        if (f_) gzbuffer(f_, 1 << 20);
+        buf_.resize(kBuf);
+        return f_ != nullptr;
+    }
+    // the next line without its '\n' (a last line without one counts); false at the end of the file
+    bool getline(std::string &line) {
+        line.clear();
+        for (;;) {
+            if (pos_ < end_) {
+                const char *b = buf_.data() + pos_;
+                const char *nl = (const char *)std::memchr(b, '\n', end_ - pos_);
+                if (nl) {
+                    line.append(b, (size_t)(nl - b));
+                    pos_ = (size_t)(nl - buf_.data()) + 1;
+                    return true;
+                }
+                line.append(b, end_ - pos_);
+                pos_ = end_;
+            }
+            if (eof_) return !line.empty();
+            const int n = gzread(f_, &buf_[0], (unsigned)kBuf);
+            if (n <= 0) { eof_ = true; pos_ = end_ = 0; continue; }
+            pos_ = 0; end_ = (size_t)n;
+        }
+    }
+private:
+    static constexpr size_t kBuf = (size_t)4 << 20;
+    gzFile f_ = nullptr;
+    std::string buf_;
+    size_t pos_ = 0, end_ = 0;
+    bool eof_ = false;
+};
+
+// A fixed set of worker threads that run queued tasks (no task waits for another task: the bookkeeping below queues a task
+// only when it can run to its end).
+class TaskPool {
+public:
+    explicit TaskPool(int threads) {
+        const int n = std::max(1, threads);
+        for (int i = 0; i < n; ++i) workers_.emplace_back([this]() { loop(); });
+    }
+    ~TaskPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void submit(std::function<void()> fn) {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(fn)); }
+        cv_.notify_one();
+    }
+private:
+    void loop() {
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                fn = std::move(q_.front());
+                q_.pop_front();
+            }
+            fn();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::deque<std::function<void()>> q_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+struct ProducerClock {  // seconds summed over the pool's threads (read, parse) and of the caller's thread (join + sink)
+    double read = 0, parse = 0, join = 0;
+};
+
+class BatchfileProducer {
+public:
+    // `readers`: one open reader per batchfile, positioned behind the header; `first_row[f]` (have_row[f]): a data row that the
+    // header scan has already taken from file f
+    BatchfileProducer(std::vector<GzLineReader> &readers, std::vector<std::string> first_row, const std::vector<bool> &have_row, size_t n_sample,
+                      int threads)
+        : rd_(readers), first_row_(std::move(first_row)), have_row_(have_row.begin(), have_row.end()), n_sample_(n_sample), threads_(std::max(1, threads)) {}
+
+    // sink(std::unique_ptr<SlabBuilder> part, std::vector<SiteText> &texts): consecutive positions, in position order, on the
+    // calling thread; returns false to stop early.  Throws the first error in position order after delivering what precedes it.
+    template <class Sink>
+    void run(Sink &&sink) {
+        const size_t NB = rd_.size();
+        if (NB == 0) return;
+        // positions per block: ~32 MB of row text, at least a few chunks per thread
+        R_ = std::max<size_t>(std::max<size_t>(64, 4 * (size_t)threads_), std::min<size_t>(4096, ((size_t)1 << 25) / std::max<size_t>(n_sample_ * 12, 1)));
+        chunk_ = std::max<size_t>(1, R_ / (4 * (size_t)threads_));
+        blocks_.resize(kBlocks);
+        for (auto &b : blocks_) {
+            b.lines.assign(NB, std::vector<std::string>(R_));
+            b.got.assign(NB, 0);
+        }
+        file_next_.assign(NB, 0);
+        file_busy_.assign(NB, false);
+        TaskPool pool(threads_);
+        pool_ = &pool;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t f = 0; f < NB; ++f) try_read(f);
+        }
+        bool go_on = true;
+        std::exception_ptr err;
+        for (size_t b = 0;; ++b) {
+            Block &B = blocks_[b % kBlocks];
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return B.index == b && B.parsed; });
+            }
+            const double t0 = now();
+            const bool last = B.n_blk < R_;
+            // the chunks in position order; the first error in position order ends the run
+            for (Part &p : B.parts) {
+                if (go_on && !err && p.slab && p.slab->n_sites()) go_on = sink(std::move(p.slab), p.text);
+                if (p.error && !err) err = p.error;
+                p.slab.reset(); p.text.clear(); p.error = nullptr;
+            }
+            clock.join += now() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                B.parsed = false;
+                B.index = (size_t)-1;
+                freed_ = b + 1;
+                if (last || err || !go_on) stop_at_ = std::min(stop_at_, b);  // nothing beyond this block is wanted
+                else for (size_t f = 0; f < NB; ++f) try_read(f);
+            }
+            if (last || err || !go_on) break;
+        }
+        {
+            // tasks still in flight (reads of later blocks) touch this object: let them finish
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return in_flight_ == 0; });
+        }
+        pool_ = nullptr;
+        if (err) std::rethrow_exception(err);
+    }
+
+    ProducerClock clock;
+    size_t block_sites() const { return R_; }
+
+private:
+    struct Part {
+        std::unique_ptr<SlabBuilder> slab;
+        std::vector<SiteText> text;
+        std::exception_ptr error;
+    };
+    struct Block {
+        size_t index = (size_t)-1;                    // which block of the job this buffer holds
+        std::vector<std::vector<std::string>> lines;  // [file][R]
+        std::vector<size_t> got;                      // lines file f delivered
+        size_t reads_done = 0, parts_done = 0, n_blk = 0;
+        std::vector<Part> parts;
+        bool parsed = false;
+    };
+    static constexpr size_t kBlocks = 3;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    // (mu_ held) queue the read of file f's next block if its buffer is free and nobody is reading the file
+    void try_read(size_t f) {
+        const size_t b = file_next_[f];
+        if (file_busy_[f] || b >= freed_ + kBlocks || b > stop_at_) return;
+        Block &B = blocks_[b % kBlocks];
+        if (B.index == (size_t)-1) { B.index = b; B.reads_done = 0; B.parts_done = 0; B.parsed = false; B.parts.clear(); }
+        if (B.index != b) return;
+        file_busy_[f] = true;
+        ++in_flight_;
+        pool_->submit([this, f, b]() { read_task(f, b); });
+    }
+    void read_task(size_t f, size_t b) {
+        const double t0 = now();
+        Block &B = blocks_[b % kBlocks];
+        size_t k = 0;
+        std::exception_ptr ex;
+        try {
+            if (have_row_[f]) { B.lines[f][k++] = first_row_[f]; have_row_[f] = 0; }
+            while (k < R_ && rd_[f].getline(B.lines[f][k])) ++k;
+        } catch (...) { ex = std::current_exception(); }
+        const double dt = now() - t0;
+        std::lock_guard<std::mutex> lk(mu_);
+        clock.read += dt;
+        B.got[f] = k;
+        if (ex && !read_error_) read_error_ = ex;
+        file_busy_[f] = false;
+        file_next_[f] = b + 1;
+        if (k < R_) stop_at_ = std::min(stop_at_, b);  // this file ends in block b: no position beyond it has a row from every file
+        if (++B.reads_done == rd_.size()) start_parse(B);
+        try_read(f);
+        --in_flight_;
+        cv_.notify_all();
+    }
+    // (mu_ held) every file has delivered its lines of block B: the positions every file still has, cut into chunks
+    void start_parse(Block &B) {
+        size_t n = R_;
+        for (size_t g : B.got) n = std::min(n, g);
+        B.n_blk = n;
+        const size_t n_parts = n ? (n + chunk_ - 1) / chunk_ : 0;
+        B.parts.clear();
+        B.parts.resize(std::max<size_t>(n_parts, 1));
+        if (read_error_) { B.parts[0].error = read_error_; B.parsed = true; return; }
+        if (n_parts == 0) { B.parsed = true; return; }
+        for (size_t p = 0; p < n_parts; ++p) {
+            ++in_flight_;
+            pool_->submit([this, &B, p]() { parse_task(B, p); });
+        }
+    }
+    void parse_task(Block &B, size_t p) {
+        const double t0 = now();
+        Part &P = B.parts[p];
+        const size_t lo = p * chunk_, hi = std::min(B.n_blk, lo + chunk_), NB = rd_.size();
+        P.slab.reset(new SlabBuilder((uint32_t)n_sample_));
+        P.slab->reserve_rows(hi - lo);
+        P.text.reserve(hi - lo);
+        std::vector<std::string> rows(NB);
+        try {
+            for (size_t r = lo; r < hi; ++r) {
+                for (size_t f = 0; f < NB; ++f) rows[f].swap(B.lines[f][r]);
+                SiteText st;
+                if (parse_site_rows_fast(rows, n_sample_, *P.slab, st)) P.text.push_back(std::move(st));
+                for (size_t f = 0; f < NB; ++f) rows[f].swap(B.lines[f][r]);  // (the strings keep their capacity for the next block)
+            }
+        } catch (...) { P.error = std::current_exception(); }  // the positions before the offending one are in P
+        const double dt = now() - t0;
+        std::lock_guard<std::mutex> lk(mu_);
+        clock.parse += dt;
+        if (++B.parts_done == B.parts.size()) B.parsed = true;
+        --in_flight_;
+        cv_.notify_all();
+    }
+
+    std::vector<GzLineReader> &rd_;
+    std::vector<std::string> first_row_;
+    std::vector<char> have_row_;   // (one byte per file: the files' read tasks touch their own entry concurrently)
+    size_t n_sample_;
+    int threads_;
+    size_t R_ = 0, chunk_ = 1;
+    std::vector<Block> blocks_;
+    std::vector<size_t> file_next_;
+    std::vector<bool> file_busy_;
+    size_t freed_ = 0, stop_at_ = (size_t)-1, in_flight_ = 0;
+    std::exception_ptr read_error_;
+    TaskPool *pool_ = nullptr;
+    std::mutex mu_;
+    std::condition_variable cv_;
+};
+
+}  // namespace bvamd

@@ -42,35 +42,13 @@
 #include <chrono>
 
 #include "basetype_gpu.hpp"
+#include "batch_producer.hpp"
 #include "batchfile_fast.hpp"
 #include "pileup.hpp"
 #include "bgzf_tabix.hpp"
 #include "vcf_emit.hpp"
 
 namespace {
-
-struct GzReader {
-    gzFile f = nullptr;
-    std::string buf;
-    bool open(const std::string &path) {
-        f = gzopen(path.c_str(), "rb");
-        if (f) gzbuffer(f, 1 << 20);
-        return f != nullptr;
-    }
-    bool getline(std::string &line) {
-        line.clear();
-        char tmp[1 << 16];
-        for (;;) {
-            if (!gzgets(f, tmp, sizeof tmp)) return !line.empty();
-            line += tmp;
-            if (!line.empty() && line.back() == '\n') {
-                line.pop_back();
-                return true;
-            }
-        }
-    }
-    ~GzReader() { if (f) gzclose(f); }
-};
 
 // One batch of consecutive sites on its way through the pipeline.
 struct Batch {
@@ -204,7 +182,7 @@ int main(int argc, char **argv) {
             "--output-cvg FILE [--pop-group FILE] [--min-af F] [--gpus G]");
 
     // ---- headers: sample ids in batchfile order (caller.cpp:637-665)
-    std::vector<GzReader> readers(batchfiles.size());
+    std::vector<bvamd::GzLineReader> readers(batchfiles.size());
     std::vector<std::string> sample_ids;
     std::vector<std::string> first_row(batchfiles.size());
     std::vector<bool> have_row(batchfiles.size(), false);
@@ -403,100 +381,29 @@ int main(int argc, char **argv) {
                 clk.parse += StageClock::now() - tp0;
             }
         } else {
-            // ---- one row from every batchfile per position (caller.cpp:586-611)
-            const size_t NB = batchfiles.size();
-            if (threads <= 1) {
-                std::vector<std::string> rows(NB);
-                for (; still_ok();) {
-                    bool eof = false;
-                    double t0 = StageClock::now();
-                    for (size_t b = 0; b < NB; ++b) {
-                        if (have_row[b]) { rows[b] = first_row[b]; have_row[b] = false; }
-                        else if (!readers[b].getline(rows[b])) { eof = true; break; }
+            // ---- one row from every batchfile per position (caller.cpp:586-611), on `--thread` host threads: files read and
+            // positions parsed in blocks by a pipeline of tasks (batch_producer.hpp), joined here in position order
+            bvamd::BatchfileProducer producer(readers, first_row, have_row, n_sample, threads);
+            try {
+                producer.run([&](std::unique_ptr<bvamd::SlabBuilder> part, std::vector<bvamd::SiteText> &text) {
+                    size_t done = 0;
+                    const size_t have = part->n_sites();
+                    while (done < have) {
+                        if (!cur) fresh();
+                        const size_t room = batch_sites - cur->slab.n_sites(), take = std::min(room, have - done);
+                        if (done == 0 && take == have) cur->slab.append(*part);
+                        else cur->slab.append_rows(*part, done, take);  // (a part that straddles a batch boundary)
+                        for (size_t i = done; i < done + take; ++i) cur->text.push_back(std::move(text[i]));
+                        done += take;
+                        if (cur->slab.n_sites() == batch_sites) ship();
                     }
-                    double t1 = StageClock::now();
-                    clk.read += t1 - t0;
-                    if (eof) break;
-                    if (!cur) fresh();
-                    {
-                        // the rows' bytes straight into the slab row (batchfile_fast.hpp)
-                        bvamd::SiteText st;
-                        if (bvamd::parse_site_rows_fast(rows, n_sample, cur->slab, st)) cur->text.push_back(std::move(st));
-                    }
-                    clk.parse += StageClock::now() - t1;
-                    if (cur->slab.n_sites() == batch_sites) ship();
-                }
-            } else {
-                // ---- `--thread T`: blocks of sites.  The files are read by T threads (every thread its files, a block of lines
-                // each), then the block's sites are parsed by T threads (every thread a range of consecutive sites into a slab
-                // builder of its own, with the byte-level reader unchanged) and joined in site order: same rows, and the error
-                // of the first offending site in site order, as the site-by-site loop.
-                const size_t R = std::max<size_t>(64, std::min<size_t>(1024, ((size_t)1 << 24) / std::max<size_t>(n_sample, 1)));
-                std::vector<std::vector<std::string>> lines(NB, std::vector<std::string>(R));
-                std::vector<size_t> got(NB, 0);
-                struct Part {
-                    std::unique_ptr<bvamd::SlabBuilder> slab;
-                    std::vector<bvamd::SiteText> text;
-                    std::string error;
-                    size_t error_site = (size_t)-1;
-                };
-                bool at_eof = false;
-                while (still_ok() && !at_eof) {
-                    double t0 = StageClock::now();
-                    parallel_ranges(NB, threads, [&](size_t, size_t lo, size_t hi) {
-                        for (size_t b = lo; b < hi; ++b) {
-                            size_t k = 0;
-                            if (have_row[b]) { lines[b][k++] = first_row[b]; have_row[b] = false; }
-                            while (k < R && readers[b].getline(lines[b][k])) ++k;
-                            got[b] = k;
-                        }
-                    });
-                    size_t n_blk = R;
-                    for (size_t b = 0; b < NB; ++b) n_blk = std::min(n_blk, got[b]);
-                    if (n_blk < R) at_eof = true;  // a file ran out: the sites every file still has, then stop (caller.cpp:589-601)
-                    double t1 = StageClock::now();
-                    clk.read += t1 - t0;
-                    if (n_blk == 0) break;
-                    std::vector<Part> parts((size_t)std::max(1, threads));
-                    parallel_ranges(n_blk, threads, [&](size_t t, size_t lo, size_t hi) {
-                        Part &p = parts[t];
-                        p.slab.reset(new bvamd::SlabBuilder((uint32_t)n_sample));
-                        std::vector<std::string> rows(NB);
-                        for (size_t r = lo; r < hi; ++r) {
-                            for (size_t b = 0; b < NB; ++b) rows[b].swap(lines[b][r]);
-                            try {
-                                bvamd::SiteText st;
-                                if (bvamd::parse_site_rows_fast(rows, n_sample, *p.slab, st)) p.text.push_back(std::move(st));
-                            } catch (const std::exception &ex) {
-                                p.error = ex.what(); p.error_site = r;
-                                return;  // the sites before r of this range are in p; nothing after r counts
-                            }
-                        }
-                    });
-                    // join in site order; the first error in site order ends the run (what precedes it in the block is kept)
-                    for (Part &p : parts) {
-                        if (!p.slab) continue;
-                        size_t done = 0;
-                        const size_t have = p.slab->n_sites();
-                        while (done < have) {
-                            if (!cur) fresh();
-                            const size_t room = batch_sites - cur->slab.n_sites(), take = std::min(room, have - done);
-                            if (done == 0 && take == have) cur->slab.append(*p.slab);
-                            else {
-                                bvamd::SlabBuilder piece((uint32_t)n_sample);
-                                // (rare: a part straddles a batch boundary -- copy it row range by row range)
-                                for (size_t i = done; i < done + take; ++i) piece.add_row(p.slab->cell_row(i), p.slab->phred_row(i), p.slab->mapq_row(i), p.slab->rank_row(i), p.slab->ref_code(i));
-                                cur->slab.append(piece);
-                            }
-                            for (size_t i = done; i < done + take; ++i) cur->text.push_back(std::move(p.text[i]));
-                            done += take;
-                            if (cur->slab.n_sites() == batch_sites) ship();
-                        }
-                        if (!p.error.empty()) throw std::runtime_error(p.error);
-                    }
-                    clk.parse += StageClock::now() - t1;
-                }
+                    return still_ok();
+                });
+            } catch (...) {
+                clk.read += producer.clock.read; clk.parse += producer.clock.parse;
+                throw;
             }
+            clk.read += producer.clock.read; clk.parse += producer.clock.parse;
         }
         ship();
     } catch (const std::exception &ex) { fail(ex.what()); }

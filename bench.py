@@ -547,6 +547,7 @@ def main():
                 if tj:
                     vrig = TileRig(torch, eng, dev, local_rank, V, tj["W"], tj["n_tiles"], tj["res"], (vb, vq, vm, vr, vref), host=False)
                     (jb, jq, jm, jr), jp = vrig.joined_rows(V)
+                    torch.cuda.synchronize()  # (torch built the rows on ITS stream; the engine's own stream does not wait for it)
                     eng.submit_ptrs(V, N, jp, jb.data_ptr(), jq.data_ptr(), vref.data_ptr(), vout.data_ptr(), jm.data_ptr(), jr.data_ptr())
                 else:
                     eng.submit_ptrs(V, N, pitch, vb.data_ptr(), vq.data_ptr(), vref.data_ptr(), vout.data_ptr(),
@@ -554,9 +555,16 @@ def main():
                                     group_id=gid.data_ptr() if G else 0, n_groups=G,
                                     gout=gouts[0].data_ptr() if G else 0)
                 eng.wait()
-                want = vout.cpu().numpy().tobytes()
-                got = recs[r * Bl:r * Bl + V].tobytes()
-                ranks_verified += int(want == got)
+                want = vout.cpu().numpy().view(basevar_amd.SITE_DTYPE)
+                got = recs[r * Bl:r * Bl + V]
+                same = want.tobytes() == got.tobytes()
+                ranks_verified += int(same)
+                if not same:  # say what differs: a wrong site range, a wrong rank order and a numerical difference look different
+                    for f in want.dtype.names:
+                        bad = np.nonzero(~np.all(np.atleast_2d((want[f] == got[f]) | ((want[f] != want[f]) & (got[f] != got[f]))).reshape(V, -1), axis=1))[0]
+                        if bad.size:
+                            print("[bench] rank %d: %d of its first %d gathered records differ from the one-rank re-run in `%s`, first at site %d: "
+                                  "gathered %r, re-run %r" % (r, bad.size, V, f, int(bad[0]), got[f][bad[0]].tolist(), want[f][bad[0]].tolist()), file=sys.stderr)
             gathered_ok = gathered_ok and ranks_verified == world
 
     # per-rank figures for rank 0's line: this rank's wall time of the timed region, its pass-1 fraction of the HBM peak, and

@@ -33,8 +33,8 @@ extern "C" {
                                      (csrc/bv_pass1_fused.hip); 10 = that kernel for pass 1, pass 2 a launch of its own; 9 = the kernels
                                      shorter rows take: a streaming kernel, a solve kernel, a pass-2 kernel (csrc/bv_pass1_short.hip).
                                      Records do not depend on it. */
-/* test only: ONE hand-off of the first launch's first workgroup is reserved but never written -- the fused short-row kernel's
- * first candidate-queue entry, the long-row kernel's first ring slot --, so that its consumer runs into its bounded wait:
+/* test only: a hand-off is reserved but never written -- the first candidate-queue entry of every workgroup of the fused
+ * short-row kernel, the first ring slot of the long-row kernel's workgroup 0 --, so that its consumer runs into its bounded wait:
  * the launch must end (no hung GPU), bv_engine_wait must return BV_ERR_HIP naming the time-out, and the records are invalid */
 #define BV_FLAG_FAULT_LOST_HANDOFF 0x40000000u
 

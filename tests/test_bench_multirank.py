@@ -62,7 +62,9 @@ def _run_bench(extra, world, env_extra=None, timeout=900):
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    d = json.loads(lines[0])
+    d["_stderr"] = "\n".join(l for l in p.stderr.splitlines() if l.startswith("[bench]"))  # what a failed verification says
+    return d
 
 
 @pytest.mark.gpu
@@ -75,7 +77,7 @@ def test_bench_eight_ranks_one_device_every_rank_verified(samples):
     d = _run_bench(["--steps", "3", "--warmup", "1", "--samples", str(samples), "--batch-sites", "512", "--verify-sites", "128"], 8)
     c = d["config"]
     assert d["n_gpus"] == 8 and c["dist_world_size"] == 8 and c["job_batch_sites"] == 8 * 512
-    assert c["gathered_records_ok"] is True and c["ranks_verified"] == 8 and c["verify_sites"] == 128
+    assert c["gathered_records_ok"] is True and c["ranks_verified"] == 8 and c["verify_sites"] == 128, d["_stderr"]
     assert len(c["per_rank"]["step_ms"]) == 8 and all(t > 0 for t in c["per_rank"]["step_ms"])
     assert len(c["per_rank"]["pass1_frac"]) == 8
     assert d["ms_per_step"] == pytest.approx(max(c["per_rank"]["step_ms"]), rel=1e-9)  # the slowest rank's time
@@ -102,7 +104,7 @@ def test_bench_tile_job_ranks_one_device(world):
     assert len(tjob["numa_node_of_gpu"]) == world and len(tjob["tiles_bound_to_node"]) == world
     for node, bound in zip(tjob["numa_node_of_gpu"], tjob["tiles_bound_to_node"]):
         assert bound in (node, -1)  # bound to the GPU's node where the platform names it and the rank may run there
-    assert c["gathered_records_ok"] is True and c["ranks_verified"] == world
+    assert c["gathered_records_ok"] is True and c["ranks_verified"] == world, d["_stderr"]
     assert d["roofline"]["launches"] == 2 and 0 < d["roofline"]["frac"] < 1
 
 

@@ -1016,8 +1016,8 @@ def test_tile_job_with_fewer_samples_than_announced(bv):
 
 
 def test_sample_axis_tiles_long_read_ranks(bv, restatement):
-    """Ranks >= 1024: exact in the default (joined-rows) realisation of the tile mode, flagged in the per-site-tally
-    fallback (BV_FLAG_TILE_STATE), whose layout cannot hold them."""
+    """Ranks >= 1024: exact in the default (joined-rows) realisation of the tile mode (the per-site-tally realisation:
+    test_per_site_tallies_ranks_beyond_the_window_take_the_exact_path)."""
     slab = make_slab(16, 400, seed=950, coverage=0.6, class_af=[(0.4, 0.0)])
     cov = slab["base_strand"] < 8
     slab["rpr"][3, np.nonzero(cov[3])[0][:2]] = 2000
@@ -1031,9 +1031,8 @@ def test_sample_axis_tiles_long_read_ranks(bv, restatement):
     eng = bv.BaseTypeEngine(max_sites=16, min_af_value=maf, device=0, flags=0x8)
     t = eng.lrt_tiles(slab, 100)
     eng.close()
-    flagged = (t.sites["status"] & 0x40) != 0
-    assert flagged[3] and flagged.sum() == 1 and np.isnan(t.sites["rpr_ranksum"][3])
-    assert not np.isnan(t.sites["mq_ranksum"][3])
+    check(t, exp, gexp, margins)   # the per-site-tally realisation: through its overflow pool, exact too
+    assert ((t.sites["status"] & 0x40) == 0).all()
 
 
 @pytest.mark.parametrize("flags", [0, 0x8], ids=["joined_rows", "per_site_tallies"])
@@ -1092,11 +1091,64 @@ def test_per_site_tallies_with_an_announced_read_length(bv, restatement):
     t = eng.lrt_tiles(slab, 100, max_rank=6000)
     eng.close()
     exp, gexp, margins = restatement.run_with_margins(slab, maf)
-    flagged = (t.sites["status"] & 0x40) != 0
-    assert flagged[7] and flagged.sum() == 1 and np.isnan(t.sites["rpr_ranksum"][7])  # 9000 >= the announced 6000 (-> 6144)
-    keep = ~flagged
-    sub = type(t)(t.sites[keep], None, int(((t.sites["status"][keep] & 2) != 0).sum()), 0.0, 0.0)
-    check(sub, exp[keep], None, margins[keep])
+    # site 7 holds a rank (9000) beyond the announced 6000 (-> 6144): its cell comes through the overflow pool, exactly
+    assert ((t.sites["status"] & 0x40) == 0).all() and not np.isnan(t.sites["rpr_ranksum"][(exp["status"] & 2) != 0]).any()
+    check(t, exp, gexp, margins)
+
+
+@pytest.mark.parametrize("n_beyond", [1, 7, 300], ids=["one_cell", "seven_cells_with_ties", "three_hundred_cells"])
+def test_per_site_tallies_ranks_beyond_the_window_take_the_exact_path(bv, restatement, n_beyond):
+    """The per-site-tally realisation tallies read-position ranks below its window (1024 unannounced); cells beyond it go to a
+    pool and a site that has such cells forms its ReadPosRankSum from the window AND its pool entries: the reference's value
+    (ref_vs_alt_ranksumtest, src/basetype.cpp:201-242), no BV_SITE_RPR_RANGE, no NaN -- also with ties among the cells
+    beyond the window, with cells of a base that is neither REF nor ALT among them, and from several tiles."""
+    rng = np.random.default_rng(77 + n_beyond)
+    slab = make_slab(24, 1200, seed=960 + n_beyond, coverage=0.7, class_af=[(0.35, 0.05)])
+    cov = slab["base_strand"] < 8
+    for site in (2, 5, 11, 17):
+        idx = rng.permutation(np.nonzero(cov[site])[0])[:n_beyond]
+        slab["rpr"][site, idx] = rng.choice([1024, 1500, 2000, 2000, 3777, 65535], size=len(idx))
+    maf = bv.min_af(1200)
+    eng = bv.BaseTypeEngine(max_sites=24, min_af_value=maf, device=0, flags=0x8)
+    t = eng.lrt_tiles(slab, 200)
+    again = eng.lrt_tiles(slab, 1200)   # one tile: the pool is reset per job
+    eng.close()
+    exp, gexp, margins = restatement.run_with_margins(slab, maf)
+    assert ((t.sites["status"] & 0x40) == 0).all()
+    check(t, exp, gexp, margins)
+    assert np.array_equal(again.sites["rpr_ranksum"], t.sites["rpr_ranksum"], equal_nan=True)
+
+
+def test_per_site_tallies_replay_shallow_sites_in_sample_order(bv, restatement):
+    """Sites (and pop-groups) of <= 64 covered samples keep their cells in the per-site state and are replayed in the
+    reference's per-sample order at finish(), as the row kernels replay them from the row: deliberate exact ties (one read of
+    each of two bases at one phred; src/algorithm.h:24-41 decides by the rounding of per-sample sums) must fall as the
+    reference's do, whatever the order in which the tiles' cells reached the state."""
+    n, S = 900, 48
+    slab = make_slab(S, n, seed=4100, coverage=0.01, n_groups=3, site_offset=1)   # ~9 covered samples per site
+    rng = np.random.default_rng(4)
+    for site in range(0, S, 3):   # exact two- and three-way ties
+        slab["base_strand"][site, :] = 8
+        cols = rng.permutation(n)[:3]
+        k = 2 + (site // 3) % 2
+        slab["base_strand"][site, cols[:k]] = [(slab["ref_base"][site] + 1 + j) % 4 for j in range(k)]
+        slab["qual"][site, :] = 0
+        slab["qual"][site, cols[:k]] = 30
+        slab["mapq"][site, cols[:k]] = 60
+        slab["rpr"][site, cols[:k]] = 10
+    maf = bv.min_af(n)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=0x8)
+    rows = eng.lrt(slab)
+    for width in (900, 64, 7):
+        t = eng.lrt_tiles(slab, width)
+        # the same calls as the row kernels, to the bit where the replay decides (alt sets, AF of shallow sites)
+        for f in ("n_alt", "alt", "depth", "total_depth", "af", "chi2"):
+            assert np.array_equal(rows.sites[f], t.sites[f], equal_nan=True), (width, f)
+        assert np.array_equal(rows.groups["alt"], t.groups["alt"]) and np.array_equal(rows.groups["n_alt"], t.groups["n_alt"])
+        assert np.allclose(rows.groups["af"], t.groups["af"], rtol=1e-12, atol=0, equal_nan=True)
+    eng.close()
+    exp, gexp, margins = restatement.run_with_margins(slab, maf)
+    assert check(t, exp, gexp, margins) == 0   # no site needs the tie excuse
 
 
 def _strand_table_slab(tables, n_samples):
