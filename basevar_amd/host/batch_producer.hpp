@@ -137,7 +137,7 @@ public:
         if (NB == 0) return;
         // positions per block: ~32 MB of row text, at least a few chunks per thread
         R_ = std::max<size_t>(std::max<size_t>(64, 4 * (size_t)threads_), std::min<size_t>(4096, ((size_t)1 << 25) / std::max<size_t>(n_sample_ * 12, 1)));
-        chunk_ = std::max<size_t>(1, R_ / (4 * (size_t)threads_));
+        chunk_ = std::max<size_t>(1, std::min<size_t>(64, R_ / (4 * (size_t)threads_)));
         blocks_.resize(kBlocks);
         for (auto &b : blocks_) {
             b.lines.assign(NB, std::vector<std::string>(R_));

@@ -80,13 +80,15 @@ inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_
         }
         depth += (uint32_t)std::stoi(field(3));
         // the five per-sample columns: one token per delimiter, empty tokens included (ngslib::split)
+        // (tokens are one to three characters: a byte loop finds their ends several times faster than a memchr call per token)
         auto walk = [&](int k, auto &&fn) {
             const char *p = col[k], *e = col[k + 1] - 1;
             for (;;) {
-                const char *sp = (const char *)std::memchr(p, ' ', (size_t)(e - p));
-                fn(p, sp ? sp : e);
-                if (!sp) break;
-                p = sp + 1;
+                const char *t = p;
+                while (t != e && *t != ' ') ++t;
+                fn(p, t);
+                if (t == e) break;
+                p = t + 1;
             }
         };
         walk(4, [&](const char *p, const char *e) { if (n_mq < n_sample) r.mapq[n_mq] = (uint8_t)parse_int_token(p, e); ++n_mq; });

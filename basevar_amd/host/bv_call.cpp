@@ -416,11 +416,12 @@ int main(int argc, char **argv) {
     const double total = StageClock::now() - t_start;
     std::cout << "[INFO] bv_call: " << n_sites << " covered positions, " << n_variants << " VCF records, " << n_sample
               << " samples, " << group_names.size() << " groups, " << G << " engine(s)" << std::endl;
-    // stage seconds: read / parse+pack on the producer thread (BAM input: pileup + pack, all under "parse"), engine summed over
-    // the workers (staging copies + kernels + records back), emit on the emitter thread; the stages overlap, total is wall time
+    // stage seconds: read / parse+pack summed over the producer's threads (BAM input: pileup + pack on the producer thread, all under
+    // "parse"), engine summed over the workers (staging copies + kernels + records back), emit on the emitter thread; the
+    // stages overlap, total is wall time
     char line[512];
     std::snprintf(line, sizeof line,
-                  "[INFO] -- %.3f s elapsed, %.1f sites/s: read %.3f s, parse+pack %.3f s (%s), engine %.3f s (%zu worker(s), batches of %u sites), emit %.3f s",
+                  "[INFO] -- %.3f s elapsed, %.1f sites/s: read %.3f s, parse+pack %.3f s (%s; thread-seconds), engine %.3f s (%zu worker(s), batches of %u sites), emit %.3f s",
                   total, total > 0 ? n_sites / total : 0.0, clk.read, clk.parse, from_bam ? "pileup" : "batchfile", clk.engine, G, batch_sites, clk.emit);
     std::cout << line << std::endl;
     if (!timing_file.empty()) {

@@ -86,6 +86,70 @@ def expected_vcf(site, r, groups, gnames):
                       "GT:AB:SO:BP"] + samples)
 
 
+def _write_batchfiles(dirpath, n_files, per, sites, seed, plain_last=False):
+    """small reference-format batchfiles (gzip; optionally the last one plain text): `sites` = list of row counts per file, or int"""
+    import gzip
+    rng = np.random.default_rng(seed)
+    paths = []
+    rows_of = sites if isinstance(sites, (list, tuple)) else [sites] * n_files
+    refs = rng.integers(0, 4, size=max(rows_of))
+    for f in range(n_files):
+        lines = ["##fileformat=BaseVarBatchFile_v1.0", "##SampleIDs=" + ",".join("S%d" % (f * per + i) for i in range(per)),
+                 "#CHROM\tPOS\tREF\tDepth(CoveredSample)\tMappingQuality\tReadbases\tReadbasesQuality\tReadPositionRank\tStrand"]
+        for s in range(rows_of[f]):
+            cov = rng.random(per) < (0.0 if s % 17 == 5 else 0.3)   # every 17th position is covered by nobody (dropped rows)
+            toks = [[], [], [], [], []]
+            for i in range(per):
+                if cov[i]:
+                    b = "ACGT"[int(rng.integers(0, 4))]
+                    if rng.random() < 0.05:
+                        b = ("+" if rng.random() < 0.5 else "-") + b + "TT"
+                    toks[0].append(str(int(rng.integers(0, 61)))); toks[1].append(b); toks[2].append(chr(33 + int(rng.integers(2, 42))))
+                    toks[3].append(str(int(rng.integers(1, 151)))); toks[4].append("+-"[int(rng.integers(0, 2))])
+                else:
+                    toks[0].append("0"); toks[1].append("N"); toks[2].append("!"); toks[3].append("0"); toks[4].append(".")
+            lines.append("\t".join(["chr1", str(100 + s), "ACGT"[refs[s]], str(int(cov.sum()))] + [" ".join(t) for t in toks]))
+        path = os.path.join(dirpath, "bf_%02d.%s" % (f, "txt" if (plain_last and f == n_files - 1) else "gz"))
+        data = ("\n".join(lines) + "\n").encode()
+        if path.endswith(".gz"):
+            with gzip.open(path, "wb", compresslevel=1) as fh:
+                fh.write(data)
+        else:
+            open(path, "wb").write(data)
+        paths.append(path)
+    return paths
+
+
+def test_pipelined_batchfile_producer_equals_the_plain_loop(tmp_path):
+    """basevar_amd/host/batch_producer.hpp (files read and positions parsed as a pipeline of tasks on T threads) delivers
+    what the position-by-position loop of the reference delivers (src/basetype_caller.cpp:586-611): the same positions in
+    order, byte-identical planes and texts on 1 / 2 / 3 / 8 threads; positions nobody covers dropped; the run ends at the
+    shortest file; a malformed row ends it with the reference's error AFTER the positions before it."""
+    exe = cxx(os.path.join(ROOT, "tests", "cpp", "producer_check.cpp"), str(tmp_path / "pc"), ["-lz"])
+    d = tmp_path / "a"; d.mkdir()
+    files = _write_batchfiles(str(d), 5, 37, 700, seed=1, plain_last=True)           # several blocks, a plain-text file among them
+    out = subprocess.run([exe, ",".join(files)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout + out.stderr
+    n_pos = int(out.stdout.split()[1])
+    assert 600 < n_pos < 700 and "185 samples" in out.stdout                         # the uncovered positions are gone
+    d = tmp_path / "b"; d.mkdir()
+    files = _write_batchfiles(str(d), 4, 50, [300, 300, 171, 300], seed=2)           # one file ends early, inside a block
+    out = subprocess.run([exe, ",".join(files)], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout + out.stderr
+    assert int(out.stdout.split()[1]) <= 171
+    d = tmp_path / "c"; d.mkdir()
+    files = _write_batchfiles(str(d), 3, 40, 400, seed=3)
+    import gzip
+    lines = gzip.open(files[1], "rb").read().decode().split("\n")
+    cols = lines[3 + 250].split("\t")                                               # position 251 of file 1: a two-letter base token
+    toks = cols[5].split(" "); toks[7] = "AC"; cols[5] = " ".join(toks); cols[3] = str(int(cols[3]) + 1)
+    lines[3 + 250] = "\t".join(cols)
+    gzip.open(files[1], "wb").write("\n".join(lines).encode())
+    out = subprocess.run([exe, ",".join(files), "Why dose the size of aligned base is not 1? Check: AC"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("OK "), out.stdout + out.stderr
+    assert 200 < int(out.stdout.split()[1]) <= 250                                   # the positions before the malformed one
+
+
 def test_host_formats_harness(tmp_path, restatement):
     exe = cxx(os.path.join(ROOT, "tests", "cpp", "host_formats_check.cpp"), str(tmp_path / "hfc"), ["-ldl"])
     args = [exe, os.path.join(ROOT, "oracle", "liboracle.so")]

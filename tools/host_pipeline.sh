@@ -3,7 +3,8 @@
 #   tools/host_pipeline.sh <tag>        -> gpurun_out/host_pipeline_<tag>.txt  (+ .json lines)
 # (a) the reference's 100-BAM test set (copied to tests/golden/_local/bam100 by `tools/host_pipeline.sh stage` in the build
 #     container; all-N surrogate FASTA as in tools/real_data_campaign.py), BAM -> pileup -> engine -> VCF/CVG;
-# (b) synthetic batchfiles, 10,000 samples in files of 200 (the reference's --batch-count), the byte-level reader on 1 / 4 / 16 host threads.
+# (b) synthetic batchfiles, 10,000 samples in files of 200 (the reference's --batch-count): the producer alone on 1 .. 96 host
+#     threads (parallel efficiency), then bv_call end to end on 1 .. 64.
 cd "$(dirname "$0")/.."; ROOT=$PWD
 if [ "$1" = "stage" ]; then
   mkdir -p tests/golden/_local/bam100
@@ -12,7 +13,7 @@ if [ "$1" = "stage" ]; then
   ls tests/golden/_local/bam100 | wc -l
   exit 0
 fi
-TAG=${1:-r3}; SITES=${2:-1500}; shift; shift
+TAG=${1:-r5}; SITES=${2:-12000}; shift; shift
 mkdir -p gpurun_out; OUT=gpurun_out/host_pipeline_$TAG.txt; : > $OUT
 W=$(mktemp -d)
 CALL=basevar_amd/lib/bv_call
@@ -38,16 +39,23 @@ else
 fi
 # ---- (b) synthetic batchfiles
 g++ -O2 -std=c++17 tools/gen_batchfiles.cpp -lz -o $W/gen || exit 1
+g++ -O2 -std=c++17 -pthread -I include tools/producer_bench.cpp -lz -o $W/pbench || exit 1
 mkdir -p $W/bf; $W/gen $W/bf 10000 200 $SITES 0.08 7
 BF=$(ls $W/bf/*.gz | paste -sd,)
-say "== (b) synthetic batchfiles: 10000 samples in $(ls $W/bf | wc -l) files, $SITES sites, $(du -sh $W/bf | cut -f1) gzip"
-say "-- one host thread"
-$CALL --batchfiles $BF --output-vcf $W/b_fast.vcf --output-cvg $W/b_fast.cvg --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
-cat $W/b.json >> $OUT
-for t in 4 16; do
-  say "-- --thread $t (files read and sites parsed in blocks by $t threads, lines formatted by $t threads)"
-  $CALL --batchfiles $BF --output-vcf $W/b_t.vcf --output-cvg $W/b_t.cvg --thread $t --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
+say "== (b) synthetic batchfiles: 10000 samples in $(ls $W/bf | wc -l) files, $SITES sites, $(du -sh $W/bf | cut -f1) gzip; host: $(nproc) logical CPUs"
+say "-- the producer alone (tools/producer_bench.cpp: files -> slab rows, rows discarded; no GPU): sites/s by host threads"
+P1=""
+for t in 1 2 4 8 16 32 64 96; do
+  L=$($W/pbench $t $BF); echo "$L" >> $OUT
+  R=$(echo "$L" | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['sites_per_s'])")
+  [ -z "$P1" ] && P1=$R
+  say "$(python3 -c "print('   --thread %3d: %9.0f sites/s   speed-up %5.1f   parallel efficiency %.2f' % ($t, $R, $R / $P1, $R / $P1 / $t))")"
+done
+say "-- bv_call end to end (producer -> engine -> emitter), one engine; engine idle = 1 - engine seconds / elapsed"
+for t in 1 4 16 32 64; do
+  $CALL --batchfiles $BF --output-vcf $W/b_t$t.vcf --output-cvg $W/b_t$t.cvg --thread $t --timing $W/b.json 2>&1 | tail -2 | tee -a $OUT
   cat $W/b.json >> $OUT
-  cmp $W/b_t.vcf $W/b_fast.vcf && cmp $W/b_t.cvg $W/b_fast.cvg && say "outputs with --thread $t: byte-identical to one thread"
+  say "$(python3 -c "import json; d = json.load(open('$W/b.json')); print('   --thread %3d: %9.0f sites/s end to end, engine idle %.2f' % ($t, d['sites_per_s'], 1 - d['engine_s'] / d['total_s']))")"
+  [ $t != 1 ] && cmp $W/b_t$t.vcf $W/b_t1.vcf && cmp $W/b_t$t.cvg $W/b_t1.cvg && say "   outputs with --thread $t: byte-identical to one thread"
 done
 rm -rf $W
