@@ -714,7 +714,6 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
     a2.ch = chain;
     a2.ch_cat = chain_cat ? 1u : 0u;
-    bool gitems_all = true;  // the item scratch holds every (site, group) of this launch
     if (G && gid && dgout && !(e->cfg.flags & BV_FLAG_GROUP_INLINE)) {
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
         // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel.  An allocation that
@@ -735,7 +734,6 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
                 want /= 2u;
             }
         }
-        gitems_all = (uint64_t)e->gitem_cap >= want64;
         a2.gitems = e->d_gitems; a2.gitem_cap = e->gitem_cap;
         // short rows: the group plane as the streaming group tally wants it
         const size_t n16 = ((size_t)n_samples + 15) & ~(size_t)15;

@@ -366,7 +366,9 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
             const double v = 2 * (lr_alt - lr);
             // Which of two subsets that score (nearly) alike wins is decided by the rounding of the reference's per-sample
             // sums, which sums over bins do not reproduce: the caller replays such an item in sample order if it can
-            // (pop-groups of at most BV_ORD_MAX covered samples, bv_p2g_solve16_kernel).  Conservative: any pair of the level.
+            // (pop-groups of at most BV_ORD_MAX covered samples, bv_p2g_solve16_kernel).  Comparing with the RUNNING minimum is
+            // enough to catch every score within the tolerance of the level's final minimum: if the minimum comes later it is
+            // compared with a running value that lies between the two; if it came earlier it is the running value.
             if (SPEC && !top && c > 0 && fabs(v - best_v) <= BV_TIE_TOL * (1.0 + fabs(best_v))) o.tie_risk = true;
             if (top || c == 0 || v < best_v) {  // first minimum, algorithm.h:24-27
                 best_v = v; best_c = c; best_lr = lr;
@@ -378,6 +380,8 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
         if (!top) {
             chi = best_v;
             accept = chi < 24;  // LRT_THRESHOLD, basetype.h:21
+            // (a chi-square within rounding of the threshold: whether the allele is kept hangs on the reference's sums too)
+            if (SPEC && fabs(chi - 24.0) <= BV_TIE_TOL * 25.0) o.tie_risk = true;
             if (accept) {
                 const int drop = m - 1 - best_c;
                 const int low = act & ((1 << (2 * drop)) - 1), high = act >> (2 * drop + 2);

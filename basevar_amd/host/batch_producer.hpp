@@ -6,7 +6,13 @@
 //
 //   read   (task per file and block)   inflate + split R lines of one file -- a gzip stream is sequential, so a file's blocks
 //                                      are read one after the other, but the NB files of a block, and blocks k + 1, k + 2 of
-//                                      other files, are read at the same time
+//                                      other files, are read at the same time.  A BGZF file (what the reference writes and
+//                                      requires, src/basetype_caller.cpp:428) is not one stream but a chain of independent
+//                                      <= 64 KiB gzip members: there the file is FETCHED in segments of 16 members (raw
+//                                      bytes, sequential, cheap), the segments are INFLATED by tasks of their own, several of
+//                                      one file at a time, and only the cutting of lines is sequential per file -- one plain
+//                                      gzip stream inflates ~40,000 rows of 200 samples a second, which capped every thread
+//                                      count above 16 (round 5, profiles/r5_host_pipeline.txt)
 //   parse  (task per chunk of a block) the byte-level reader (batchfile_fast.hpp) on a run of consecutive positions, one row
 //                                      from every file each, into a slab builder of its own
 //   join   (the caller's thread)       the chunks of a block in position order -> sink(part, texts); the block's line storage
@@ -23,6 +29,8 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstring>
 #include <deque>
 #include <exception>
 #include <functional>
@@ -119,7 +127,30 @@ private:
 
 struct ProducerClock {  // seconds summed over the pool's threads (read, parse) and of the caller's thread (join + sink)
     double read = 0, parse = 0, join = 0;
+    double fetch = 0, inflate = 0, split = 0;  // BGZF files: the three parts of `read`
+    size_t n_fetch = 0, n_inflate = 0, n_split = 0;
 };
+
+// One BGZF file read as segments of members: fetch (sequential) -> inflate (a task per segment) -> lines (sequential).
+struct BgzfSegment {
+    std::vector<unsigned char> raw;          // the members, back to back
+    std::vector<uint32_t> off, clen, isize;  // per member: where its deflate data starts in raw, its length, the inflated size
+    std::string text;
+    size_t pos = 0;                          // bytes of text already cut into lines
+    bool inflated = false;
+};
+struct BgzfFile {
+    std::FILE *fp = nullptr;
+    bool raw_eof = false, fetching = false;
+    std::deque<std::unique_ptr<BgzfSegment>> segs;  // in file order
+    size_t skip_lines = 0;                   // header lines still to drop
+    std::string carry;                       // the beginning of a line that continues in the next segment
+    size_t k = 0;                            // lines of the file's current block delivered so far
+    ~BgzfFile() { if (fp) std::fclose(fp); }
+};
+inline bool bgzf_member_header(const unsigned char *h) {  // SAM spec 4.1: gzip member with the 'BC' extra subfield first
+    return h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4) && h[12] == 'B' && h[13] == 'C' && h[14] == 2 && h[15] == 0;
+}
 
 class BatchfileProducer {
 public:
@@ -129,6 +160,28 @@ public:
                       int threads)
         : rd_(readers), first_row_(std::move(first_row)), have_row_(have_row.begin(), have_row.end()), n_sample_(n_sample), threads_(std::max(1, threads)) {}
 
+    // Tell the producer where the files are and how many header lines each has: a file that turns out to be BGZF is then read
+    // from its start through the segment pipeline (its reader in `readers` and its first_row are not used); anything else --
+    // plain gzip, plain text -- keeps its sequential reader.  Without this call every file is read sequentially.
+    void set_paths(const std::vector<std::string> &paths, const std::vector<size_t> &header_lines) {
+        bg_.clear();
+        bg_.resize(paths.size());
+        for (size_t f = 0; f < paths.size() && f < rd_.size(); ++f) {
+            std::FILE *fp = std::fopen(paths[f].c_str(), "rb");
+            if (!fp) continue;
+            unsigned char h[18];
+            const bool is_bgzf = std::fread(h, 1, 18, fp) == 18 && bgzf_member_header(h);
+            if (is_bgzf && std::fseek(fp, 0, SEEK_SET) == 0) {
+                bg_[f].reset(new BgzfFile);
+                bg_[f]->fp = fp;
+                bg_[f]->skip_lines = f < header_lines.size() ? header_lines[f] : 0;
+            } else {
+                std::fclose(fp);
+            }
+        }
+    }
+    size_t bgzf_files() const { size_t n = 0; for (const auto &b : bg_) n += b ? 1 : 0; return n; }
+
     // sink(std::unique_ptr<SlabBuilder> part, std::vector<SiteText> &texts): consecutive positions, in position order, on the
     // calling thread; returns false to stop early.  Throws the first error in position order after delivering what precedes it.
     template <class Sink>
@@ -137,7 +190,8 @@ public:
         if (NB == 0) return;
         // positions per block: ~32 MB of row text, at least a few chunks per thread
         R_ = std::max<size_t>(std::max<size_t>(64, 4 * (size_t)threads_), std::min<size_t>(4096, ((size_t)1 << 25) / std::max<size_t>(n_sample_ * 12, 1)));
-        chunk_ = std::max<size_t>(1, std::min<size_t>(64, R_ / (4 * (size_t)threads_)));
+        chunk_ = std::max<size_t>(1, std::min<size_t>(16, R_ / (4 * (size_t)threads_)));
+        bg_.resize(NB);
         blocks_.resize(kBlocks);
         for (auto &b : blocks_) {
             b.lines.assign(NB, std::vector<std::string>(R_));
@@ -209,6 +263,17 @@ private:
 
     // (mu_ held) queue the read of file f's next block if its buffer is free and nobody is reading the file
     void try_read(size_t f) {
+        if (bg_[f]) {
+            // a BGZF file: keep its window of segments full, and cut lines whenever the next segment is inflated (or the file is through)
+            BgzfFile &F = *bg_[f];
+            if (!F.fetching && !F.raw_eof && F.segs.size() < kWindow) {
+                F.fetching = true;
+                ++in_flight_;
+                pool_->submit([this, f]() { fetch_task(f); });
+            }
+            const bool data = !F.segs.empty() && F.segs.front()->inflated, at_end = F.raw_eof && F.segs.empty() && !F.fetching;
+            if (!data && !at_end) return;
+        }
         const size_t b = file_next_[f];
         if (file_busy_[f] || b >= freed_ + kBlocks || b > stop_at_) return;
         Block &B = blocks_[b % kBlocks];
@@ -216,7 +281,139 @@ private:
         if (B.index != b) return;
         file_busy_[f] = true;
         ++in_flight_;
-        pool_->submit([this, f, b]() { read_task(f, b); });
+        if (bg_[f]) pool_->submit([this, f, b]() { split_task(f, b); });
+        else pool_->submit([this, f, b]() { read_task(f, b); });
+    }
+    // ---- BGZF files
+    static constexpr size_t kWindow = 6;      // segments of one file in flight (fetched, being inflated, waiting to be cut)
+    static constexpr size_t kSegMembers = 16; // BGZF members per segment: <= 1 MiB of text, ~1 ms of inflate
+    void fetch_task(size_t f) {
+        const double t0 = now();
+        BgzfFile &F = *bg_[f];
+        std::unique_ptr<BgzfSegment> seg(new BgzfSegment);
+        bool eof = false;
+        std::exception_ptr ex;
+        try {
+            for (size_t m = 0; m < kSegMembers; ++m) {
+                unsigned char h[18];
+                const size_t n = std::fread(h, 1, 18, F.fp);
+                if (n == 0) { eof = true; break; }
+                if (n != 18 || !bgzf_member_header(h)) throw std::runtime_error("[ERROR] not a BGZF member where one was expected (truncated or damaged batchfile)");
+                const size_t total = ((size_t)h[16] | ((size_t)h[17] << 8)) + 1, xlen = (size_t)h[10] | ((size_t)h[11] << 8);
+                if (total < 12 + xlen + 8) throw std::runtime_error("[ERROR] damaged BGZF member");
+                const size_t at = seg->raw.size();
+                seg->raw.resize(at + total);
+                std::memcpy(&seg->raw[at], h, 18);
+                if (std::fread(&seg->raw[at + 18], 1, total - 18, F.fp) != total - 18) throw std::runtime_error("[ERROR] truncated BGZF member");
+                const unsigned char *t = &seg->raw[at + total - 4];
+                seg->off.push_back((uint32_t)(at + 12 + xlen));
+                seg->clen.push_back((uint32_t)(total - 12 - xlen - 8));
+                seg->isize.push_back((uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24));
+            }
+        } catch (...) { ex = std::current_exception(); eof = true; }
+        const double dt = now() - t0;
+        std::lock_guard<std::mutex> lk(mu_);
+        clock.read += dt; clock.fetch += dt; ++clock.n_fetch;
+        if (ex && !read_error_) read_error_ = ex;
+        if (ex) seg->off.clear();
+        if (eof) F.raw_eof = true;
+        F.fetching = false;
+        if (!seg->off.empty()) {
+            BgzfSegment *sp = seg.get();
+            F.segs.push_back(std::move(seg));
+            ++in_flight_;
+            pool_->submit([this, f, sp]() { inflate_task(f, sp); });
+        }
+        try_read(f);
+        --in_flight_;
+        cv_.notify_all();
+    }
+    void inflate_task(size_t f, BgzfSegment *seg) {
+        const double t0 = now();
+        std::exception_ptr ex;
+        try {
+            size_t total = 0;
+            for (uint32_t n : seg->isize) total += n;
+            seg->text.resize(total);
+            z_stream zs;
+            std::memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) throw std::runtime_error("[ERROR] inflateInit2 failed");
+            size_t at = 0;
+            for (size_t m = 0; m < seg->off.size(); ++m) {
+                if (seg->isize[m] == 0) continue;  // (the end-of-file marker, or an empty member)
+                inflateReset(&zs);
+                zs.next_in = &seg->raw[seg->off[m]];
+                zs.avail_in = seg->clen[m];
+                zs.next_out = reinterpret_cast<Bytef *>(&seg->text[at]);
+                zs.avail_out = seg->isize[m];
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) { inflateEnd(&zs); throw std::runtime_error("[ERROR] a BGZF member does not inflate to its recorded size"); }
+                at += seg->isize[m];
+            }
+            inflateEnd(&zs);
+            std::vector<unsigned char>().swap(seg->raw);
+        } catch (...) { ex = std::current_exception(); seg->text.clear(); }
+        const double dt = now() - t0;
+        std::lock_guard<std::mutex> lk(mu_);
+        clock.read += dt; clock.inflate += dt; ++clock.n_inflate;
+        if (ex && !read_error_) read_error_ = ex;
+        seg->inflated = true;
+        try_read(f);
+        --in_flight_;
+        cv_.notify_all();
+    }
+    // the lines of file f's block b from its inflated segments, as far as they reach: the block is complete at R lines or at the
+    // end of the file; else the task ends and is queued again when the next segment is inflated
+    void split_task(size_t f, size_t b) {
+        const double t0 = now();
+        BgzfFile &F = *bg_[f];
+        Block &B = blocks_[b % kBlocks];
+        auto deliver = [&](const char *p, size_t n) {
+            if (F.skip_lines) { --F.skip_lines; F.carry.clear(); return; }
+            std::string &dst = B.lines[f][F.k++];
+            if (F.carry.empty()) dst.assign(p, n);
+            else { F.carry.append(p, n); dst.swap(F.carry); F.carry.clear(); }
+        };
+        bool at_end = false;
+        for (;;) {
+            BgzfSegment *s = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!F.segs.empty() && F.segs.front()->inflated) s = F.segs.front().get();
+                else at_end = F.raw_eof && F.segs.empty() && !F.fetching;
+            }
+            if (!s) break;
+            const char *base = s->text.data();
+            const size_t end = s->text.size();
+            while (F.k < R_ && s->pos < end) {
+                const char *nl = (const char *)std::memchr(base + s->pos, '\n', end - s->pos);
+                if (!nl) { F.carry.append(base + s->pos, end - s->pos); s->pos = end; break; }
+                deliver(base + s->pos, (size_t)(nl - (base + s->pos)));
+                s->pos = (size_t)(nl - base) + 1;
+            }
+            if (s->pos == end) {
+                std::lock_guard<std::mutex> lk(mu_);
+                F.segs.pop_front();
+                try_read(f);  // (room in the window: the next fetch; the split itself is busy -- this task)
+            }
+            if (F.k == R_) break;
+        }
+        if (at_end && F.k < R_ && !F.carry.empty()) deliver("", 0);  // a last line without its newline
+        const double dt = now() - t0;
+        std::lock_guard<std::mutex> lk(mu_);
+        clock.read += dt; clock.split += dt; ++clock.n_split;
+        file_busy_[f] = false;
+        if (F.k == R_ || at_end || read_error_) {
+            const size_t k = F.k;
+            F.k = 0;
+            B.got[f] = k;
+            file_next_[f] = b + 1;
+            if (k < R_) stop_at_ = std::min(stop_at_, b);
+            if (++B.reads_done == rd_.size()) start_parse(B);
+        }
+        try_read(f);
+        --in_flight_;
+        cv_.notify_all();
     }
     void read_task(size_t f, size_t b) {
         const double t0 = now();
@@ -280,6 +477,7 @@ private:
     }
 
     std::vector<GzLineReader> &rd_;
+    std::vector<std::unique_ptr<BgzfFile>> bg_;   // per file: the BGZF segment pipeline, or null (sequential reader)
     std::vector<std::string> first_row_;
     std::vector<char> have_row_;   // (one byte per file: the files' read tasks touch their own entry concurrently)
     size_t n_sample_;

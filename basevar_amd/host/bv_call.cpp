@@ -189,12 +189,14 @@ int main(int argc, char **argv) {
     try {
         for (const auto &b : bams) sample_ids.push_back(bvamd::BamFile(b, false).sample_name());
     } catch (const std::exception &ex) { die(ex.what()); }
+    std::vector<size_t> header_lines(batchfiles.size(), 0);  // lines in front of the first data row
     for (size_t b = 0; b < batchfiles.size() && !from_bam; ++b) {
         if (!readers[b].open(batchfiles[b])) die("[ERROR] " + batchfiles[b] + " open failure.");
         std::string line;
         while (readers[b].getline(line)) {
-            if (line.empty() || line[0] != '#') { first_row[b] = line; have_row[b] = !line.empty(); break; }
+            if (line.empty() || line[0] != '#') { first_row[b] = line; have_row[b] = !line.empty(); header_lines[b] += line.empty() ? 1 : 0; break; }
             bvamd::parse_sample_ids(line, sample_ids);
+            ++header_lines[b];
         }
     }
     const size_t n_sample = sample_ids.size();
@@ -384,6 +386,7 @@ int main(int argc, char **argv) {
             // ---- one row from every batchfile per position (caller.cpp:586-611), on `--thread` host threads: files read and
             // positions parsed in blocks by a pipeline of tasks (batch_producer.hpp), joined here in position order
             bvamd::BatchfileProducer producer(readers, first_row, have_row, n_sample, threads);
+            producer.set_paths(batchfiles, header_lines);  // BGZF files (what the reference writes): members inflated in parallel
             try {
                 producer.run([&](std::unique_ptr<bvamd::SlabBuilder> part, std::vector<bvamd::SiteText> &text) {
                     size_t done = 0;

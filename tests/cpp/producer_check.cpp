@@ -33,15 +33,17 @@ struct Opened {
     std::vector<bvamd::GzLineReader> readers;
     std::vector<std::string> first_row;
     std::vector<bool> have_row;
+    std::vector<size_t> header_lines;
     size_t n_sample = 0;
-    explicit Opened(const std::vector<std::string> &files) : readers(files.size()), first_row(files.size()), have_row(files.size(), false) {
+    explicit Opened(const std::vector<std::string> &files) : readers(files.size()), first_row(files.size()), have_row(files.size(), false), header_lines(files.size(), 0) {
         std::vector<std::string> ids;
         for (size_t b = 0; b < files.size(); ++b) {
             if (!readers[b].open(files[b])) throw std::runtime_error("cannot open " + files[b]);
             std::string line;
             while (readers[b].getline(line)) {
-                if (line.empty() || line[0] != '#') { first_row[b] = line; have_row[b] = !line.empty(); break; }
+                if (line.empty() || line[0] != '#') { first_row[b] = line; have_row[b] = !line.empty(); header_lines[b] += line.empty() ? 1 : 0; break; }
                 bvamd::parse_sample_ids(line, ids);
+                ++header_lines[b];
             }
         }
         n_sample = ids.size();
@@ -85,6 +87,7 @@ int main(int argc, char **argv) {
         Out got;
         Opened in(files);
         bvamd::BatchfileProducer producer(in.readers, in.first_row, in.have_row, in.n_sample, threads);
+        producer.set_paths(files, in.header_lines);  // (BGZF files then go through the segment pipeline; the others stay sequential)
         try {
             producer.run([&](std::unique_ptr<bvamd::SlabBuilder> part, std::vector<bvamd::SiteText> &text) {
                 take(got, *part, text, n);

@@ -86,7 +86,7 @@ def expected_vcf(site, r, groups, gnames):
                       "GT:AB:SO:BP"] + samples)
 
 
-def _write_batchfiles(dirpath, n_files, per, sites, seed, plain_last=False):
+def _write_batchfiles(dirpath, n_files, per, sites, seed, plain_last=False, bgzf=True):
     """small reference-format batchfiles (gzip; optionally the last one plain text): `sites` = list of row counts per file, or int"""
     import gzip
     rng = np.random.default_rng(seed)
@@ -111,7 +111,9 @@ def _write_batchfiles(dirpath, n_files, per, sites, seed, plain_last=False):
             lines.append("\t".join(["chr1", str(100 + s), "ACGT"[refs[s]], str(int(cov.sum()))] + [" ".join(t) for t in toks]))
         path = os.path.join(dirpath, "bf_%02d.%s" % (f, "txt" if (plain_last and f == n_files - 1) else "gz"))
         data = ("\n".join(lines) + "\n").encode()
-        if path.endswith(".gz"):
+        if path.endswith(".gz") and bgzf and f % 2 == 0:
+            open(path, "wb").write(_bgzf_bytes(data, member=int(rng.integers(300, 4000))))   # small members: lines straddle them
+        elif path.endswith(".gz"):
             with gzip.open(path, "wb", compresslevel=1) as fh:
                 fh.write(data)
         else:
@@ -120,11 +122,27 @@ def _write_batchfiles(dirpath, n_files, per, sites, seed, plain_last=False):
     return paths
 
 
+def _bgzf_bytes(data, member=0xff00):
+    """`data` as a BGZF file (SAM spec 4.1): gzip members with the BC extra field, raw deflate inside, the empty end marker"""
+    import struct
+    import zlib
+    out = bytearray()
+    for at in list(range(0, len(data), member)) + [None]:
+        chunk = b"" if at is None else data[at:at + member]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        total = 18 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", total - 1) + body
+        out += struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
 def test_pipelined_batchfile_producer_equals_the_plain_loop(tmp_path):
-    """basevar_amd/host/batch_producer.hpp (files read and positions parsed as a pipeline of tasks on T threads) delivers
-    what the position-by-position loop of the reference delivers (src/basetype_caller.cpp:586-611): the same positions in
-    order, byte-identical planes and texts on 1 / 2 / 3 / 8 threads; positions nobody covers dropped; the run ends at the
-    shortest file; a malformed row ends it with the reference's error AFTER the positions before it."""
+    """basevar_amd/host/batch_producer.hpp (files read and positions parsed as a pipeline of tasks on T threads; BGZF files --
+    every other file here, with members so small that lines straddle them -- fetched in segments and inflated by tasks of
+    their own) delivers what the position-by-position loop of the reference delivers (src/basetype_caller.cpp:586-611): the
+    same positions in order, byte-identical planes and texts on 1 / 2 / 3 / 8 threads; positions nobody covers dropped; the
+    run ends at the shortest file; a malformed row ends it with the reference's error AFTER the positions before it."""
     exe = cxx(os.path.join(ROOT, "tests", "cpp", "producer_check.cpp"), str(tmp_path / "pc"), ["-lz"])
     d = tmp_path / "a"; d.mkdir()
     files = _write_batchfiles(str(d), 5, 37, 700, seed=1, plain_last=True)           # several blocks, a plain-text file among them

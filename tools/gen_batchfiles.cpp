@@ -1,9 +1,11 @@
 // gen_batchfiles.cpp -- synthetic batchfiles in the reference's format (BaseVarBatchFile_v1.0) for host-pipeline measurements:
 //   gen_batchfiles OUT_DIR N_SAMPLES SAMPLES_PER_FILE N_SITES [COVERAGE=0.08] [SEED=1]
-// writes OUT_DIR/bf_000.gz ... (gzip level 1), each holding SAMPLES_PER_FILE samples of every site (the reference's
+// writes OUT_DIR/bf_000.gz ... (BGZF, deflate level 1), each holding SAMPLES_PER_FILE samples of every site (the reference's
 // --batch-count), with the cell statistics of SURVEY.md section 8d (coverage, phred ~ N(32, 6), 10 % of the sites carry an ALT).
 // g++ -O2 -std=c++17 tools/gen_batchfiles.cpp -lz -o gen_batchfiles
 #include <zlib.h>
+
+#include "../basevar_amd/host/bgzf_tabix.hpp"
 
 #include <cmath>
 #include <cstdint>
@@ -21,16 +23,15 @@ int main(int argc, char **argv) {
     auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
     auto uni = [&]() { return (double)(rnd() >> 11) * 0x1p-53; };
     const uint32_t nf = (n + per - 1) / per;
-    std::vector<gzFile> out(nf);
+    std::vector<bvamd::BgzfWriter> out(nf);  // BGZF, as the reference writes its batchfiles (src/basetype_caller.cpp:428)
     for (uint32_t f = 0; f < nf; ++f) {
         char name[64];
         std::snprintf(name, sizeof name, "/bf_%03u.gz", f);
-        out[f] = gzopen((dir + name).c_str(), "wb1");
-        if (!out[f]) { std::fprintf(stderr, "cannot write %s\n", (dir + name).c_str()); return 1; }
+        out[f].open(dir + name, 1);
         std::string h = "##fileformat=BaseVarBatchFile_v1.0\n##SampleIDs=";
         for (uint32_t i = f * per; i < std::min(n, (f + 1) * per); ++i) { if (i != f * per) h += ','; h += "S" + std::to_string(i); }
         h += "\n#CHROM\tPOS\tREF\tDepth(CoveredSample)\tMappingQuality\tReadbases\tReadbasesQuality\tReadPositionRank\tStrand\n";
-        gzwrite(out[f], h.data(), (unsigned)h.size());
+        out[f].write(h);
     }
     std::string mq, bs, qs, rk, sd, row;
     for (uint32_t s = 0; s < sites; ++s) {
@@ -56,9 +57,9 @@ int main(int argc, char **argv) {
                 } else { mq += '0'; bs += 'N'; qs += '!'; rk += '0'; sd += '.'; }
             }
             row = "chr1\t" + std::to_string(1000 + s) + "\t" + ref + "\t" + std::to_string(covered) + "\t" + mq + "\t" + bs + "\t" + qs + "\t" + rk + "\t" + sd + "\n";
-            gzwrite(out[f], row.data(), (unsigned)row.size());
+            out[f].write(row);
         }
     }
-    for (gzFile f : out) gzclose(f);
+    for (auto &f : out) f.close();
     return 0;
 }
