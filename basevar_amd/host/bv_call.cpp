@@ -336,6 +336,7 @@ int main(int argc, char **argv) {
     BatchPtr cur;
     auto fresh = [&]() {
         cur.reset(new Batch((uint32_t)n_sample));
+        if (!from_bam) cur->slab.reserve_rows(batch_sites);  // (address space; the pages come as the rows do -- no regrowth copies)
         if (!group_names.empty()) cur->slab.set_groups(group_id, (uint32_t)group_names.size());
         cur->seq = seq++;
     };
@@ -388,7 +389,8 @@ int main(int argc, char **argv) {
             bvamd::BatchfileProducer producer(readers, first_row, have_row, n_sample, threads);
             producer.set_paths(batchfiles, header_lines);  // BGZF files (what the reference writes): members inflated in parallel
             try {
-                producer.run([&](std::unique_ptr<bvamd::SlabBuilder> part, std::vector<bvamd::SiteText> &text) {
+                producer.run([&](bvamd::SlabBuilder &part_, std::vector<bvamd::SiteText> &text) {
+                    bvamd::SlabBuilder *part = &part_;
                     size_t done = 0;
                     const size_t have = part->n_sites();
                     while (done < have) {

@@ -89,7 +89,8 @@ int main(int argc, char **argv) {
         bvamd::BatchfileProducer producer(in.readers, in.first_row, in.have_row, in.n_sample, threads);
         producer.set_paths(files, in.header_lines);  // (BGZF files then go through the segment pipeline; the others stay sequential)
         try {
-            producer.run([&](std::unique_ptr<bvamd::SlabBuilder> part, std::vector<bvamd::SiteText> &text) {
+            producer.run([&](bvamd::SlabBuilder &part_, std::vector<bvamd::SiteText> &text) {
+        bvamd::SlabBuilder *part = &part_;
                 take(got, *part, text, n);
                 return true;
             });

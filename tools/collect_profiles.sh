@@ -4,7 +4,7 @@
 # For each configuration below: one un-profiled bench run (the JSON line), one `--kernel-trace --stats` run and two PMC
 # runs (FETCH_SIZE, WRITE_SIZE -- separate passes, no tracing beside them), all of the same bench command.
 # Back in the container:  python tools/summarize_profiles.py <tag>
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd "$(dirname "$0")/.."; ROOT=$PWD
 export TMPDIR=/tmp
 O=$ROOT/gpurun_out/prof_$TAG
@@ -45,28 +45,31 @@ sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kern
     i=$((i+1))
   done
 }
-run_cfg n100k                                               # headline: bv_pass1_kernel<3,1>, bv_pass2_kernel<256,true,false>
+run_cfg n100k                                               # headline: bv_pass1_kernel<3,1,false,2>, bv_pass2_kernel<256,true,false>
 run_cfg n100k_groups2 --groups 2 --batch-sites 65536        # bv_pass2_kernel<256,true,true,false> + bv_p2g_solve16_kernel on long rows
 run_cfg n1M --samples 1000000 --batch-sites 16384 --steps 8 # the same kernels at 1 M samples
 run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_fused_kernel<true> (pass 1 + the variant sites' pass-2 rows in one persistent kernel)
-run_cfg n10k_p2sep --samples 10000 --batch-sites 100000 --flags 40960   # ... pass 2 a launch of its own: bv_p1s_fused_kernel<false> + bv_pass2_dma_kernel
-run_cfg n10k_round3 --samples 10000 --batch-sites 100000 --flags 36864  # ... the round-3 kernels: bv_p1s_stream_kernel, bv_p1s_solve16_kernel, bv_pass2_dma_kernel
+run_cfg n10k_p2sep --samples 10000 --batch-sites 100000 --flags 40960   # BV_FLAG_SHORT_ROW_FORM(10): pass 2 a launch of its own: bv_p1s_fused_kernel<false> + bv_pass2_dma_kernel
+run_cfg n10k_three_launches --samples 10000 --batch-sites 100000 --flags 36864  # BV_FLAG_SHORT_ROW_FORM(9): the kernels rows of <= 4,096 samples take: bv_p1s_stream_kernel, bv_p1s_solve16_kernel, bv_pass2_dma_kernel
 run_cfg n10k_lanes2 --samples 10000 --batch-sites 100000 --lanes 2   # the same through the engine's two lanes (BV_FLAG_LANES)
 run_cfg n10k_524k --samples 10000 --batch-sites 524288
-run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_pass2_dma_kernel + bv_p2g_stream_kernel + bv_p2g_solve16/hard
+# the fused kernel's HBM writes by launch size: scratch memory of the persistent grid is the fixed part
+run_cfg n10k_2048 --samples 10000 --batch-sites 2048 --steps 40
+run_cfg n10k_8192 --samples 10000 --batch-sites 8192 --steps 30
+run_cfg n10k_32768 --samples 10000 --batch-sites 32768 --steps 20
+run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_p2g_stream_kernel + bv_p2g_solve16/hard behind the fused kernel
 run_cfg n10k_groups1 --samples 10000 --batch-sites 100000 --groups 1
 run_cfg n10k_noranks --samples 10000 --batch-sites 100000 --groups 2 --no-rank-planes   # groups without rank planes: bv_p2g_stream_kernel alone
 run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more than 7 groups: bv_pass2_kernel<256,true,true,false> + the group solve kernels
-run_cfg n10k_groups32 --samples 10000 --batch-sites 100000 --groups 32 # ... at BV_MAX_GROUPS: every group of the cohort is shallow (<= 64 covered samples)
+run_cfg n10k_groups32 --samples 10000 --batch-sites 100000 --groups 32 # one round of groups: every group of the cohort is shallow (<= 64 covered samples)
+run_cfg n10k_groups64 --samples 10000 --batch-sites 100000 --groups 64 # two rounds of 32 groups (BV_GROUPS_PER_ROUND): pass 2 runs twice, the rank sums once
 run_cfg n100k_chain16 --batch-sites 8192 --chain 16                    # small batches chained: bv_pass1_kernel<3,1,true>
 run_cfg n100k_8192 --batch-sites 8192 --steps 20                       # ... and one launch per small batch
-run_cfg n100k_8192_lanes2 --batch-sites 8192 --steps 20 --lanes 2      # ... through the engine's two lanes
 run_cfg n10k_chain16 --samples 10000 --batch-sites 8192 --chain 16     # short rows chained: bv_p1s_fused_kernel<true> over the queue, bv_chain_* kernels
-run_cfg n10k_8192 --samples 10000 --batch-sites 8192 --steps 30
 run_cfg tiles_joined_1M --samples 1000000 --batch-sites 8192 --tile-sites 8192 --with-tile-mode --steps 2 --warmup 1   # bv_tile_join_rows_kernel (bv_engine_tiles_add_many), bv_tile_scatter_kernel (tile by tile)
 run_cfg tiles_state_100k --samples 100000 --batch-sites 16384 --tile-sites 16384 --with-tile-mode --flags 8 --steps 2 --warmup 1   # bv_tile_tally_kernel, bv_tile_finish_kernel
+run_cfg tile_job_1M --tile-job --tile-sites 8192 --steps 2 --warmup 1  # BASELINE configs[4] shape as the timed workload: host tiles -> bv_tile_scatter_kernel -> both passes
 sq_cfg n10k --samples 10000 --batch-sites 100000
-sq_cfg n10k_round3 --samples 10000 --batch-sites 100000 --flags 36864
 sq_cfg n100k
 ls $O | head -80 >&2
 du -sh $O >&2

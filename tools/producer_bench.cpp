@@ -32,7 +32,8 @@ int main(int argc, char **argv) {
     size_t sites = 0;
     unsigned long long checksum = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    producer.run([&](std::unique_ptr<bvamd::SlabBuilder> part, std::vector<bvamd::SiteText> &text) {
+    producer.run([&](bvamd::SlabBuilder &part_, std::vector<bvamd::SiteText> &text) {
+        bvamd::SlabBuilder *part = &part_;
         for (size_t i = 0; i < part->n_sites(); ++i) checksum += part->cell_row(i)[(sites + i) % n_sample] * 131u + part->rank_row(i)[(sites + i) * 7 % n_sample] + text[i].ref_pos;
         sites += part->n_sites();
         return true;

@@ -91,7 +91,7 @@ def tkey(kernel, cfg):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
     src = os.path.join(ROOT, "gpurun_out", "prof_%s" % tag)
     names = sorted(os.path.basename(p)[:-5] for p in glob.glob(os.path.join(src, "*.args")))
     out = {"tag": tag, "configs": {}}
@@ -112,7 +112,7 @@ def main():
             if t == "--groups": cfg["groups"] = int(toks[i + 1])
             if t == "--chain": cfg["chain"] = int(toks[i + 1])
             if t == "--no-rank-planes": cfg["ranks"] = False
-            if t == "--with-tile-mode": cfg["tile_job"] = True
+            if t in ("--with-tile-mode", "--tile-job"): cfg["tile_job"] = True
         nvar = 0
         bj = os.path.join(src, name + ".bench.json")
         bench = None
