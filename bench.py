@@ -139,6 +139,22 @@ def host_cpu():
     return model, (len(cores) or len(allowed)), len(allowed)
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use per period (cgroup v2 cpu.max, v1 cfs quota), or None if unlimited: the
+    GPU boxes of this pool show 256 logical CPUs and `1600000 100000` -- 16 CPUs; threads beyond that only take turns."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(torch, planes, n_samples, maf, want_sites):
     """Times the reference's per-site path on the host cores over rows copied back from HBM: an all-core leg (one thread per
     physical core, static site-range partition as in _variants_discovery, src/basetype_caller.cpp:489-510) and a
@@ -154,7 +170,10 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
     else:
         chk, kind = oracle.Restatement(), "port"
     model, physical, logical = host_cpu()
-    threads = max(1, physical)
+    quota = cpu_quota()
+    # one thread per physical core the process can actually RUN on: a CPU quota below the core count (cgroup cpu.max) means
+    # more threads only take turns (measured on this pool: 128 cores shown, quota 16 -> the all-core leg scaled 9.4 x)
+    threads = max(1, physical if quota is None else min(physical, int(quota + 0.5)))
     bs, q, mq, rp, ref = planes
     S = bs.shape[0]
 
@@ -204,10 +223,10 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
     rate_one, spread_one, passes_one, wall_one = leg(d_one, 1)
     return {
         "value": rate_all, "unit": "sites/s", "cores": threads, "kind": kind,
-        "model": model, "physical_cores": physical, "logical_cpus": logical, "repeats": 3,
+        "model": model, "physical_cores": physical, "logical_cpus": logical, "cpu_quota": quota, "repeats": 3,
         "spread": spread_all, "wall_s_per_repeat": wall_all, "passes_per_repeat": passes_all,
         "sample": "%d of the batch's %d sites (same synthetic rows and class mix, copied back from HBM), %d samples/site, %d host threads "
-                  "(one per physical core), static site-range partition, in-memory BatchInfo (no text parsing), timing BaseType ctor "
+                  "(one per physical core the container's CPU quota lets run), static site-range partition, in-memory BatchInfo (no text parsing), timing BaseType ctor "
                   "+ lrt + strand_bias x2 + 3 rank sums; every repeat = %d passes over the sample (%.1f s of wall), median of 3 "
                   "repeats; single thread: %d sites x %d passes per repeat (%.1f s), %.1f sites/s" % (
                       n_all, S, n_samples, threads, passes_all, wall_all, n_one, passes_one, wall_one, rate_one),

@@ -42,14 +42,24 @@ g++ -O2 -std=c++17 tools/gen_batchfiles.cpp -lz -o $W/gen || exit 1
 g++ -O2 -std=c++17 -pthread -I include tools/producer_bench.cpp -lz -o $W/pbench || exit 1
 mkdir -p $W/bf; $W/gen $W/bf 10000 200 $SITES 0.08 7
 BF=$(ls $W/bf/*.gz | paste -sd,)
-say "== (b) synthetic batchfiles: 10000 samples in $(ls $W/bf | wc -l) files, $SITES sites, $(du -sh $W/bf | cut -f1) gzip; host: $(nproc) logical CPUs"
+QUOTA=$(python3 -c "
+try:
+    q, p = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+    print(0 if q == 'max' else float(q) / float(p))
+except Exception:
+    print(0)")
+say "== (b) synthetic batchfiles: 10000 samples in $(ls $W/bf | wc -l) files, $SITES sites, $(du -sh $W/bf | cut -f1) BGZF; host: $(nproc) logical CPUs, container CPU quota (cgroup cpu.max): $QUOTA CPUs (0 = none)"
+say "   (parallel efficiency is quoted against min(threads, quota): threads beyond the quota only take turns on the same CPU time)"
 say "-- the producer alone (tools/producer_bench.cpp: files -> slab rows, rows discarded; no GPU): sites/s by host threads"
 P1=""
 for t in 1 2 4 8 16 32 64 96; do
   L=$($W/pbench $t $BF); echo "$L" >> $OUT
   R=$(echo "$L" | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['sites_per_s'])")
   [ -z "$P1" ] && P1=$R
-  say "$(python3 -c "print('   --thread %3d: %9.0f sites/s   speed-up %5.1f   parallel efficiency %.2f' % ($t, $R, $R / $P1, $R / $P1 / $t))")"
+  say "$(python3 -c "
+q = $QUOTA
+cpus = min($t, q) if q > 0 else $t
+print('   --thread %3d: %9.0f sites/s   speed-up %5.1f   parallel efficiency %.2f (of %g CPUs)' % ($t, $R, $R / $P1, $R / $P1 / cpus, cpus))")"
 done
 say "-- bv_call end to end (producer -> engine -> emitter), one engine; engine idle = 1 - engine seconds / elapsed"
 for t in 1 4 16 32 64; do
