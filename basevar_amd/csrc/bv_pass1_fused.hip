@@ -452,14 +452,22 @@ __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedSha
 __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t B1,
                                                      int lane) {
     const uint32_t n_blocks = (B1 - B0 + 63u) >> 6;
-    uint32_t first, n;
+    uint32_t first, n = 0;
     // (read before everything else: once every streaming wave is done, every block is ready and no candidate queue grows any more)
     const uint32_t n_done = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]);
     // While rows are still streaming only FULL jobs are taken (four sites): a wave that runs off with the one candidate
     // that has just arrived spends a whole job on it, and the queue behind it grows -- the solver waves have ~60 % of the
     // streaming time's worth of work when every job is full.
     const uint32_t least = n_done == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
-    {
+    // Is there anything to claim at all?  Only then is the wave counted in BUSY: a wave that merely polls must not hold the
+    // count up -- the streaming waves wait for BUSY == 0 to know that no variant row is still to come (bv_f_no_row_ever), and
+    // twelve waves polling through an unconditional count left it non-zero nearly all the time: a launch whose workgroups
+    // all ran dry together (8 sites each) ended after SECONDS, whenever all counts happened to be down at once (round 5).
+    const bool claimable = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= least ||
+                           bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= least ||
+                           (v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
+                            bv_f_lds_read_u(&sh.ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QH_HEAD]));
+    if (claimable) {
         // a job in flight is counted BEFORE its entries leave the queue (a wave that finds the queues empty and no job
         // counted knows that no variant site is still to come)
         if (lane == 0) atomicAdd(&sh.ctl[BV_FC_BUSY], 1u);

@@ -643,6 +643,33 @@ def test_more_than_32_pop_groups(bv, restatement, n, ng, ranks):
     eng.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1, 2, 4], ids=["default", "tally_only", "skip_fisher", "skip_lrt"])
+def test_workgroups_that_run_dry_together_end_promptly(bv, flags):
+    """2,048 sites of 10,000 samples = exactly one row per streaming wave of the fused short-row kernel: every workgroup runs
+    dry at the same moment and twelve waves poll for work.  The "no variant row will ever come" test waits for the count of
+    solver jobs in flight to be zero; while every POLL was counted too, such a launch ended after seconds -- whenever all
+    counts happened to be down at once (found in round 5 by the profile sweep; no record was ever wrong).  Twenty launches,
+    each must take milliseconds."""
+    import torch
+    S, n = 2048, 10000
+    pitch = 10240
+    dev = torch.device("cuda", 0)
+    bs = torch.empty((S, pitch), dtype=torch.uint8, device=dev); q = torch.empty_like(bs); mq = torch.empty_like(bs)
+    rp = torch.empty((S, pitch), dtype=torch.int16, device=dev); ref = torch.empty(S, dtype=torch.uint8, device=dev)
+    bv.synth_fill(0, S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), mq.data_ptr(), rp.data_ptr(), seed=99)
+    out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=bv.min_af(n), device=0, flags=flags)
+    worst = 0.0
+    for _ in range(20):
+        eng.submit_ptrs(S, n, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(), mq.data_ptr(), rp.data_ptr())
+        eng.wait()
+        p1, p2 = eng.kernel_ms()
+        worst = max(worst, p1 + p2)
+    eng.close()
+    assert worst < 20.0, "a 2,048-site launch took %.1f ms" % worst
+
+
 @pytest.mark.parametrize("n", [9000, 70000], ids=["fused_short_row_kernel", "long_row_kernel"])
 def test_lost_handoff_ends_in_a_loud_timeout_not_a_hung_gpu(bv, restatement, n):
     """Every wait of the persistent kernels on another wave's LDS write is bounded; this is the test that makes one fire.
