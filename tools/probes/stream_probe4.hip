@@ -5,8 +5,21 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/probes/stream_probe4.hip -o tools/probes/bin/stream_probe4
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include "../../basevar_amd/csrc/bv_tally.h"   // the kernel's own per-cell tally (MODE bit 1)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+// a row's last slot: lanes past the row's end load nothing (the kernel's bv_f_glds4_masked)
+__device__ __forceinline__ void glds4_masked(uint32_t d0, const uint8_t *p0, uint32_t v0, uint32_t v1, const uint8_t *p1, unsigned long long mA, unsigned long long mB) {
+    uint32_t keep, t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\ts_mov_b64 %[sv], exec\n\ts_mov_b64 exec, %[mA]\n\ts_mov_b32 m0, %[d0]\n\ts_add_u32 %[t], %[d0], 0x800\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\ts_mov_b32 m0, %[t]\n\ts_add_u32 %[t], %[d0], 0x400\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p1] nt\n\ts_mov_b64 exec, %[mB]\n\ts_mov_b32 m0, %[t]\n\ts_add_u32 %[t], %[d0], 0xc00\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p0] nt\n\ts_mov_b32 m0, %[t]\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\ts_mov_b64 exec, %[sv]\n\ts_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv) : [d0] "s"(d0), [p0] "s"(p0), [p1] "s"(p1), [v0] "v"(v0), [v1] "v"(v1), [mA] "s"(mA), [mB] "s"(mB) : "memory", "scc");
+}
 __device__ __forceinline__ void glds4(uint32_t d0, const uint8_t *p0, uint32_t v0, const uint8_t *p1, uint32_t v1) {
     uint32_t keep, t;
     asm volatile(
@@ -22,9 +35,11 @@ __device__ __forceinline__ const uint8_t *uni(const uint8_t *p) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
-template <int NS, int K, int NIDLE>
+// MODE bit 0: rows end where they end (masked last slot, no read past the row); bit 1: the kernel's per-cell tally into an 8 x 128
+// histogram; bit 2: a per-row epilogue (16 LDS reads, wave reductions, a 48-byte store); bit 3: 4 KiB of LDS zeroed per row
+template <int NS, int K, int NIDLE, int MODE = 0>
 __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, const uint8_t *q, uint32_t n_sites, uint32_t n_samples, uint64_t pitch, uint32_t *sink) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [NS][K][1024] ring, then the cursor
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [NS][K][1024] ring, the cursor (16 words), [NS][1040] histograms
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *cursor = lds + NS * K * 1024;
     if (threadIdx.x == 0) { cursor[0] = 0; cursor[1] = 0; }
@@ -38,6 +53,14 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)(lds + wave * K * 1024));
     const uint32_t *ring = lds + wave * K * 1024;
     const uint32_t va = lane * 16u, vb = va + 1024u;
+    uint32_t *hist = lds + NS * K * 1024 + 16 + wave * 1040;
+    if (MODE & 6) { for (int i = lane; i < 1040; i += 64) hist[i] = 0; }
+    const uint32_t last1 = n_chunks - (n_slots - 1u) * 128u;
+    const uint32_t vbl = last1 > 64u ? vb : va;
+    const unsigned long long mA1 = last1 >= 64u ? ~0ull : ((1ull << last1) - 1ull);
+    const unsigned long long mB1 = last1 > 64u ? (last1 >= 128u ? ~0ull : ((1ull << (last1 - 64u)) - 1ull)) : 1ull;
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
     const uint8_t *p0 = bs, *p1 = q;
     uint32_t p_left = 0, ring_w = 0, ring_r = 0, inflight = 0, rows = 0;
     bool done = false;
@@ -51,7 +74,8 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
             const uint64_t off = (uint64_t)(B0 + c) * pitch;
             p0 = uni(bs + off); p1 = uni(q + off); p_left = n_slots; ++rows;
         }
-        glds4(ring_lds + ring_w * 4096u, p0, va, p1, vb);   // (the last slot of a row reads a little past it: the planes are padded)
+        if (!(MODE & 1) || p_left > 1u) glds4(ring_lds + ring_w * 4096u, p0, va, p1, vb);   // (MODE bit 0 clear: the last slot reads a little past the row)
+        else glds4_masked(ring_lds + ring_w * 4096u, p0, va, vbl, p1, mA1, mB1);
         p0 += 2048; p1 += 2048;
         --p_left;
         ring_w = (ring_w + 1u == (uint32_t)K) ? 0u : ring_w + 1u;
@@ -60,29 +84,55 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
 #pragma unroll 1
     for (int k = 0; k < K; ++k) issue();
     u32x4 acc = {0, 0, 0, 0};
+    uint32_t j = 0, stores = 0, row_id = 0;   // slot within the row being consumed; stores of the previous row still allowed for
 #pragma unroll 1
     while (inflight) {
-        if (inflight == (uint32_t)K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K - 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (inflight != (uint32_t)K) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (stores && j < 3u) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K - 1) + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (K - 1)) : "memory");
         const uint32_t *rs = ring + ring_r * 1024 + lane * 4;
-        acc ^= *reinterpret_cast<const u32x4 *>(rs) ^ *reinterpret_cast<const u32x4 *>(rs + 256) ^ *reinterpret_cast<const u32x4 *>(rs + 512) ^
-               *reinterpret_cast<const u32x4 *>(rs + 768);
+        bv_u32x4 w0 = *reinterpret_cast<const bv_u32x4 *>(rs), w1 = *reinterpret_cast<const bv_u32x4 *>(rs + 256);
+        bv_u32x4 w2 = *reinterpret_cast<const bv_u32x4 *>(rs + 512), w3 = *reinterpret_cast<const bv_u32x4 *>(rs + 768);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         ring_r = (ring_r + 1u == (uint32_t)K) ? 0u : ring_r + 1u;
         --inflight;
         issue();
+        if (MODE & 2) {
+            w2.x <<= 1; w2.y <<= 1; w2.z <<= 1; w2.w <<= 1; w3.x <<= 1; w3.y <<= 1; w3.z <<= 1; w3.w <<= 1;
+            bv_tally_chunk<1>(w0, w2, hist, one);
+            bv_tally_chunk<1>(w1, w3, hist, one);
+        } else {
+            acc ^= (u32x4){w0.x, w0.y, w0.z, w0.w} ^ (u32x4){w1.x, w1.y, w1.z, w1.w} ^ (u32x4){w2.x, w2.y, w2.z, w2.w} ^ (u32x4){w3.x, w3.y, w3.z, w3.w};
+        }
+        if (++j == n_slots) {  // end of a row
+            j = 0; stores = 0;
+            if (MODE & 4) {
+                uint32_t t = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t += hist[i * 64 + lane];
+                for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+                if (lane < 12) sink[16 + ((size_t)blockIdx.x * 4096 + (row_id & 4095u)) * 12 + lane] = t + acc.x;
+                stores = 1;
+            }
+            if (MODE & 8) {
+                uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+            }
+            ++row_id;
+        }
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = rows;
     if (NIDLE) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && atomicAdd(cursor + 1, 1u) + 1u == (uint32_t)NS) *cursor = 0x40000000u; }
 }
-template <int NS, int K, int NIDLE>
+template <int NS, int K, int NIDLE, int MODE = 0>
 double run(const uint8_t *a, const uint8_t *b, uint32_t S, uint32_t n, uint64_t pitch, uint32_t *sink) {
-    const size_t dyn = (size_t)NS * K * 4096 + 64;
-    hipFuncSetAttribute((const void *)probe<NS, K, NIDLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+    const size_t dyn = (size_t)NS * K * 4096 + 64 + (size_t)NS * 1040 * 4;
+    hipFuncSetAttribute((const void *)probe<NS, K, NIDLE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<NS, K, NIDLE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink);
+    probe<NS, K, NIDLE, MODE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink);
     hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) probe<NS, K, NIDLE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink);
+    for (int i = 0; i < 5; ++i) probe<NS, K, NIDLE, MODE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (hipGetLastError() != hipSuccess) return -1;
@@ -92,7 +142,7 @@ int main() {
     const uint32_t n = 10000, S = 100000;
     const uint64_t pitch = 10240;
     uint8_t *a, *b; uint32_t *sink;
-    hipMalloc(&a, S * pitch + 8192); hipMalloc(&b, S * pitch + 8192); hipMalloc(&sink, 64);
+    hipMalloc(&a, S * pitch + 8192); hipMalloc(&b, S * pitch + 8192); hipMalloc(&sink, 64 + (size_t)256 * 4096 * 48 + 4096);
     hipMemset(a, 8, S * pitch + 8192); hipMemset(b, 30, S * pitch + 8192);
     printf("100000 rows of 10000 B per plane, one workgroup per CU; GB/s of the two planes (8000 = peak)\n");
     printf("NS 8 K 2 (64 KB in flight / CU): %6.0f\n", run<8, 2, 0>(a, b, S, n, pitch, sink));
@@ -104,5 +154,13 @@ int main() {
     printf("NS 12 K 3 (144 KB)             : %6.0f\n", run<12, 3, 0>(a, b, S, n, pitch, sink));
     printf("NS 12 K 2 (96 KB)              : %6.0f\n", run<12, 2, 0>(a, b, S, n, pitch, sink));
     printf("NS 16 K 2 (128 KB)             : %6.0f\n", run<16, 2, 0>(a, b, S, n, pitch, sink));
+    printf("NS 8 K 3 + 4 idle waves, layers of the kernel's streaming loop (uncovered rows: the tally's adds are all masked off):\n");
+    printf("  exact rows (masked last slot)          : %6.0f\n", run<8, 3, 4, 1>(a, b, S, n, pitch, sink));
+    printf("  + tally                                : %6.0f\n", run<8, 3, 4, 3>(a, b, S, n, pitch, sink));
+    printf("  + tally + epilogue (reads, sums, store): %6.0f\n", run<8, 3, 4, 7>(a, b, S, n, pitch, sink));
+    printf("  + tally + epilogue + zeroing           : %6.0f\n", run<8, 3, 4, 15>(a, b, S, n, pitch, sink));
+    printf("  exact rows + epilogue + zeroing        : %6.0f\n", run<8, 3, 4, 13>(a, b, S, n, pitch, sink));
+    hipMemset(a, 2, S * pitch + 8192);   // every cell covered: the worst case for the adds
+    printf("  all layers, every cell a covered 'G'   : %6.0f\n", run<8, 3, 4, 15>(a, b, S, n, pitch, sink));
     return 0;
 }
