@@ -17,6 +17,7 @@
 #include <string>
 #include <vector>
 
+#include "bgzf_tabix.hpp"
 #include "pileup.hpp"
 
 namespace {
@@ -89,17 +90,19 @@ int main(int argc, char **argv) {
         if (end > fa_seq.size()) die("[ERROR] region end beyond the end of " + ref_id);
 
         const bool gz = out_path.size() > 3 && out_path.compare(out_path.size() - 3, 3, ".gz") == 0;
-        gzFile zf = nullptr;
+        // `.gz`: BGZF, as the reference writes its batchfiles ("must be compressed by BGZF", src/basetype_caller.cpp:428) -- a chain
+        // of independent gzip members, which bv_call inflates in parallel (batch_producer.hpp); gzip tools read it as they read .gz
+        bvamd::BgzfWriter zf;
         std::FILE *pf = nullptr;
-        if (gz) { zf = gzopen(out_path.c_str(), "wb"); if (!zf) die("[ERROR] " + out_path + " open failure."); }
+        if (gz) zf.open(out_path);
         else { pf = std::fopen(out_path.c_str(), "wb"); if (!pf) die("[ERROR] " + out_path + " open failure."); }
         auto sink = [&](const std::string &s) {
             if (s.empty()) return;
-            const bool ok = gz ? gzwrite(zf, s.data(), (unsigned)s.size()) == (int)s.size() : std::fwrite(s.data(), 1, s.size(), pf) == s.size();
-            if (!ok) throw std::runtime_error("[ERROR] fail to write data");
+            if (gz) zf.write(s);
+            else if (std::fwrite(s.data(), 1, s.size(), pf) != s.size()) throw std::runtime_error("[ERROR] fail to write data");
         };
         const bool has_data = bvamd::create_a_batchfile(bams, sample_ids, fa_seq, std::make_tuple(ref_id, beg, end), mapq, sink, use_index, threads, window);
-        if (gz) gzclose(zf); else std::fclose(pf);
+        if (gz) zf.close(); else std::fclose(pf);
         std::cerr << "[INFO] " << out_path << ": " << bams.size() << " samples, " << ref_id << ":" << beg << "-" << end
                   << (has_data ? "" : " (no covering reads)") << std::endl;
     } catch (const std::exception &ex) {

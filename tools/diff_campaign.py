@@ -66,6 +66,8 @@ def main():
             n = int(rng.choice([4097, 5000, 6145, 8191, 10000, 12289, 16400, 20003, 30000, 40000, 49151, 49152]))
         elif os.environ.get("CAMPAIGN_SHALLOW") == "1":  # where order-dependent ties live: rows of a few covered samples
             n = int(rng.choice([8, 16, 37, 64, 120, 300, 1000]))
+        elif os.environ.get("CAMPAIGN_TILES") == "1":
+            n = int(rng.choice([8, 37, 64, 300, 2500, 10000, 40000]))
         else:
             n = int(rng.choice([37, 300, 2500, 10000, 40000, 49152, 49153, 60000, 120000, 300000, 1000000]))
         sites = int(max(16, min(4096, 6_000_000 // n)))
@@ -76,13 +78,18 @@ def main():
             a = float(rng.choice([0, 0, 0.0005, 0.002, 0.01, 0.05, 0.2, 0.5, 0.95, 1.0]))
             b = float(rng.choice([0, 0, 0, 0.01, 0.1, 0.3]))
             classes.append((a, min(b, 1.0 - a)))
-        ng = int(rng.choice([0, 0, 2, 5, 32]))
+        ng = int(rng.choice([0, 0, 2, 5, 32, 64 if n <= 60000 else 2]))  # (64: two rounds of 32 groups, round 5)
+        if os.environ.get("CAMPAIGN_TILES") == "1" and (int(os.environ.get("CAMPAIGN_FLAGS", "0"), 0) & 8):
+            ng = min(ng, 32)  # (the per-site-tally realisation holds one histogram per group in the site's state: <= 32 groups)
         slab = make_slab(sites, n, seed=int(rng.integers(1 << 30)), coverage=cov, qual_mean=qm, qual_sd=9.0,
                          qual_min=1, qual_max=60, n_groups=ng, class_af=classes, ref_n_frac=0.03)
         maf = res.min_af(n, float(rng.choice([0.01, 0.001])))
         eng = basevar_amd.BaseTypeEngine(sites, maf, flags=int(os.environ.get("CAMPAIGN_FLAGS", "0"), 0))
         if os.environ.get("CAMPAIGN_CHAIN") == "1":
             got = lrt_chained(eng, slab, rng)  # the same rows as 2-5 slabs through bv_engine_submit_many
+        elif os.environ.get("CAMPAIGN_TILES") == "1":
+            # the sample axis in tiles of a random width (CAMPAIGN_FLAGS=8: the per-site-tally realisation; ranks up to 100: no overflow)
+            got = eng.lrt_tiles(slab, int(rng.choice([7, 64, 200, 1000, max(16, n // 3)])))
         else:
             got = eng.lrt(slab)
         eng.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 # the differential campaigns of a round against the real reference: tools/run_campaigns.sh <tag> [rounds per campaign]
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out
-TAG=${1:-r4}; R=${2:-30}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
+TAG=${1:-r5}; R=${2:-30}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
 run() { echo "### $1" >> $OUT; shift; env "$@" timeout 1500 python3 tools/diff_campaign.py $R 2>&1 | grep -E "TOTAL|tie-excused site [0-9]|MISMATCH|mismatching fields [1-9]" >> $OUT; }
 run "fused short-row kernel: rows of 4,097-49,152 samples, seed 61" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=61
 run "fused short-row kernel, seed 62" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=62
@@ -17,4 +17,7 @@ run "chained launches incl. pop-groups, seed 32" CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=
 run "chained + shallow, seed 33" CAMPAIGN_CHAIN=1 CAMPAIGN_SHALLOW=1 CAMPAIGN_SEED=33
 run "three-launch short-row form BV_FLAG_SHORT_ROW_FORM(9), seed 41" CAMPAIGN_FLAGS=$((9 << 12)) CAMPAIGN_SEED=41
 run "wave solver only (BV_FLAG_WAVE_SOLVER), seed 51" CAMPAIGN_FLAGS=16 CAMPAIGN_SEED=51
+run "tile jobs, per-site tallies (BV_FLAG_TILE_STATE): shallow replay from the cell lists, groups, seed 71" CAMPAIGN_TILES=1 CAMPAIGN_FLAGS=8 CAMPAIGN_SEED=71
+run "tile jobs, per-site tallies, seed 72" CAMPAIGN_TILES=1 CAMPAIGN_FLAGS=8 CAMPAIGN_SEED=72
+run "tile jobs, joined rows, seed 73" CAMPAIGN_TILES=1 CAMPAIGN_SEED=73
 cat $OUT
