@@ -1039,7 +1039,7 @@ __device__ __forceinline__ void bv_team_barrier(BvLrtShared *sh, uint32_t target
     while (__hip_atomic_load(&t->bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1u << 24)) {
-            atomicOr(t->err, 1u);
+            atomicOr(t->err, 0x10000000u);  // BV_TMO_RING (bv_kernels.h)
             break;
         }
     }

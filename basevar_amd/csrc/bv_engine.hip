@@ -204,7 +204,7 @@ struct bv_engine {
     double acc1_ms = 0., acc2_ms = 0., acc_stream_ms = 0.;
     // short rows (bv_pass1_short.hip): HBM scratch between the streaming kernel and the solve kernel
     BvSiteSummary *d_summ = nullptr;
-    uint32_t *d_bins = nullptr, *d_cand_list = nullptr, *d_easy_list = nullptr, *d_easy3_list = nullptr;
+    uint32_t *d_bins = nullptr, *d_cand_list = nullptr, *d_easy_list = nullptr, *d_easy3_list = nullptr, *d_ovf = nullptr;
     uint32_t short_sites = 0;          // sites the short-row scratch holds
     uint32_t *d_gitems = nullptr;      // pop-group calls handed from the pass-2 tally kernels to bv_p2g_solve16_kernel
     uint32_t gitem_cap = 0;            // items (of BV_P2G_ITEM_WORDS words) d_gitems holds
@@ -617,6 +617,7 @@ int bv_engine_destroy(bv_engine *e) {
     if (e->d_cand_list) (void)hipFree(e->d_cand_list);
     if (e->d_easy_list) (void)hipFree(e->d_easy_list);
     if (e->d_easy3_list) (void)hipFree(e->d_easy3_list);
+    if (e->d_ovf) (void)hipFree(e->d_ovf);
     if (e->d_gitems) (void)hipFree(e->d_gitems);
     if (e->d_gidp) (void)hipFree(e->d_gidp);
     if (e->d_chain) (void)hipFree(e->d_chain);
@@ -783,12 +784,15 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
             if (e->d_cand_list) BV_HIP(e, hipFree(e->d_cand_list));
             if (e->d_easy_list) BV_HIP(e, hipFree(e->d_easy_list));
             if (e->d_easy3_list) BV_HIP(e, hipFree(e->d_easy3_list));
+            if (e->d_ovf) BV_HIP(e, hipFree(e->d_ovf));
+            e->d_ovf = nullptr;
             e->d_summ = nullptr; e->d_bins = nullptr; e->d_cand_list = nullptr; e->d_easy_list = nullptr; e->d_easy3_list = nullptr; e->short_sites = 0;
             BV_HIP(e, hipMalloc(&e->d_summ, sizeof(BvSiteSummary) * (size_t)n_sites));
             BV_HIP(e, hipMalloc(&e->d_bins, sizeof(uint32_t) * BV_S_BIN_STRIDE * (size_t)n_sites));
             BV_HIP(e, hipMalloc(&e->d_cand_list, sizeof(uint32_t) * (size_t)n_sites));
             BV_HIP(e, hipMalloc(&e->d_easy_list, sizeof(uint32_t) * (size_t)n_sites));
             BV_HIP(e, hipMalloc(&e->d_easy3_list, sizeof(uint32_t) * (size_t)n_sites));
+            BV_HIP(e, hipMalloc(&e->d_ovf, sizeof(uint32_t) * 4 * (size_t)n_sites));
             e->short_sites = n_sites;
         }
         BvP1ShortArgs s1;
@@ -797,6 +801,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         s1.var_list = e->d_var_list; s1.counters = e->d_counters + (size_t)cb * BV_CTR_WORDS;
         s1.summ = e->d_summ; s1.bins = e->d_bins;
         s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list; s1.easy3_list = e->d_easy3_list;
+        s1.ovf = e->d_ovf;
         s1.ch = chain;
         s1.mapq = nullptr; s1.rpr = nullptr;
         // Rows of at least three 4 KiB slots: pass 1 as ONE persistent kernel (bv_pass1_fused.hip: solver waves beside the
@@ -1582,8 +1587,12 @@ int bv_engine_wait(bv_engine *e) {
         }
         BV_HIP(e, hipStreamSynchronize(e->last_stream));
     }
-    if (timed_out != 0)
-        return fail(e, BV_ERR_HIP, "pass 1: an intra-workgroup hand-off timed out (internal error; results invalid)");
+    if (timed_out != 0) {
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "pass 1: an intra-workgroup hand-off timed out (internal error; results invalid; which: %#x, see BV_TMO_* in "
+                                       "csrc/bv_kernels.h)", timed_out);
+        return fail(e, BV_ERR_HIP, buf);
+    }
     if (zero_freq > 0) {
         char buf[160];
         std::snprintf(buf, sizeof buf,

@@ -25,6 +25,12 @@
 #define BV_CTR_ZEROFREQ (BV_CTR_PER_LAUNCH * BV_CTR_STRIDE)         /* sticky: sites with BV_SITE_ZERO_FREQ       */
 #define BV_CTR_TIMEOUT ((BV_CTR_PER_LAUNCH + 1u) * BV_CTR_STRIDE)   /* sticky: pass-1 pipeline time-out flag      */
 #define BV_CTR_WORDS ((BV_CTR_PER_LAUNCH + 2u) * BV_CTR_STRIDE)
+// what a bounded wait adds to BV_CTR_TIMEOUT when it gives up: which hand-off it was shows in the error text of bv_engine_wait
+#define BV_TMO_PUSH 0x1u              /* fused kernel: a streaming wave, its candidate queue full            */
+#define BV_TMO_PUSH_VARIANT 0x100u    /* fused kernel: a solver wave, the variant queue full                 */
+#define BV_TMO_TAKE 0x10000u          /* fused kernel: a solver wave, a claimed candidate entry never written */
+#define BV_TMO_TAKE_VARIANT 0x1000000u /* fused kernel: a streaming wave, a claimed variant entry never written */
+#define BV_TMO_RING 0x10000000u       /* long-row kernel: a ring flag (published / filled / drained / team)  */
 
 // A queue of slabs (same row length, no pop-groups) solved by ONE launch of each pass -- bv_engine_submit_many: the
 // persistent grid of pass 1 draws its site tickets across the whole queue, so the solve of the last deep sites of one
@@ -144,6 +150,7 @@ struct BvP1ShortArgs {
     // is launched after it as usual)
     const uint8_t *mapq;
     const uint16_t *rpr;
+    uint32_t *ovf;         // bv_pass1_fused.hip: [n_sites][4] the workgroups' overflow lists of variant sites (site, class table, depths, lut)
 };
 // chained short-row launches: reference bases of all segments -> one array; records of all segments <- one array
 void bv_launch_chain_gather_ref(const BvChain *ch, uint32_t n_sites, uint8_t *ref_cat, hipStream_t stream);

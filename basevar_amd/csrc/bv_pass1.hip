@@ -142,7 +142,7 @@ __device__ __forceinline__ void bv_wait_flag(const uint32_t *flag, uint32_t want
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != want) {
         __builtin_amdgcn_s_sleep(BV_SPIN_SLEEP);
         if (++spins > (1u << 22)) {  // ~2 s
-            atomicOr(err, 1u);
+            atomicOr(err, BV_TMO_RING);  // (or, not add: sixteen waves giving up must not wrap the word to 0)
             break;
         }
     }

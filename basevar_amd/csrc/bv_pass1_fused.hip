@@ -85,6 +85,9 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_FC_QV_TAIL 9                   /* variant sites whose rank-sum rows (pass 2) are to be streamed */
 #define BV_FC_QV_HEAD 10
 #define BV_FC_BUSY 11                     /* solver jobs in flight (each may still add to the variant queue) */
+#define BV_FC_OV_TAIL 12                  /* variant sites that did not fit the LDS queue: entries of the workgroup's overflow list (HBM) written */
+#define BV_FC_OV_HEAD 13                  /* ... and claimed by streaming waves */
+#define BV_FC_OV_LOCK 14                  /* one producer wave at a time appends to the list */
 // (A workgroup owns a contiguous range of sites.  Dealing the launch's last eighth in 16-site chunks from a global counter --
 // the XCDs stream at rates 7 % apart -- was built and measured in round 4: the pass-1 rows end within 21 us instead of 30, but
 // the median moves up by as much and the launch ends with its last VARIANT rows, which stay local: 166-174 against 175-176 M
@@ -307,24 +310,62 @@ __device__ __forceinline__ void bv_f_p2_facts(int ref, const uint32_t depth[4], 
     }
     n12 = n1 | (n2 << 16);  // both at most the row length (<= 49,152)
 }
-// a variant site into the workgroup's variant queue (one lane; its record is complete in memory)
-__device__ __forceinline__ void bv_f_push_variant(BvFusedShared &sh, uint32_t site, uint32_t L, uint32_t n12, uint32_t lut, uint32_t *counters) {
-    const uint32_t pos = atomicAdd(&sh.ctl[BV_FC_QV_TAIL], 1u);
-    volatile __attribute__((address_space(3))) uint32_t *e =
-        (volatile __attribute__((address_space(3))) uint32_t *)&sh.qv[pos & (BV_F_QVCAP - 1u)][0];
-    // (a slot still occupied: BV_F_QVCAP variant rows are waiting -- from BV_F_QV_HIGH on the streaming waves take them first)
-    uint32_t spins = 0;
-    while (e[0] != BV_F_EMPTY && spins < BV_F_SPIN_MAX) { __builtin_amdgcn_s_sleep(8); ++spins; }
-    if (spins == BV_F_SPIN_MAX) {  // gave up: nothing is overwritten, the site's rank sums are not formed, the submit fails loudly
-        atomicAdd(&counters[BV_CTR_TIMEOUT], 1u);
+// Variant sites into the workgroup's variant queue; called by the WHOLE wave, `want` marks the lanes that have one (their
+// records are complete in memory).  The queue in LDS takes them while it is at most BV_F_QV_ROOM full: the positions are
+// reserved in one atomic step per lane and counted at once, so whatever number of lanes of whatever number of waves pass that
+// test together (at most 12 waves x 4), the queue cannot overflow and nobody ever waits for a slot of an entry that is not
+// yet claimed.  Beyond that the sites go to the workgroup's OVERFLOW LIST in HBM (a.ovf: one 16-byte entry per site of the
+// workgroup's range, so it cannot fill), appended by one wave at a time, published by the LDS word OV_TAIL behind an
+// s_waitcnt that covers the entries' stores.
+// Why not simply wait for room (as until round 5): the queue is emptied by the streaming waves, which themselves wait -- for
+// room in the candidate queues that the solver waves empty, or, once past their pass-1 rows, inside this very function as
+// solvers.  A workgroup with more variant sites in flight than the queue holds (few workgroups, many variants: 732 sites per
+// workgroup in the campaign that found it) then stopped until the bounded waits gave up.  Now no solver ever waits on a
+// streaming wave.
+#define BV_F_QV_ROOM (BV_F_QVCAP - 48u)
+__device__ __forceinline__ void bv_f_push_variants(const BvP1ShortArgs &a, BvFusedShared &sh, uint32_t B0, bool want, uint32_t site, uint32_t L,
+                                                   uint32_t n12, uint32_t lut, int lane) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return;
+    if (bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) <= BV_F_QV_ROOM) {
+        if (want) {
+            const uint32_t pos = atomicAdd(&sh.ctl[BV_FC_QV_TAIL], 1u);
+            volatile __attribute__((address_space(3))) uint32_t *e =
+                (volatile __attribute__((address_space(3))) uint32_t *)&sh.qv[pos & (BV_F_QVCAP - 1u)][0];
+            // (the entry that had this slot is claimed -- the occupancy test -- but its reader may be a few instructions from
+            // handing the slot back)
+            uint32_t spins = 0;
+            while (e[0] != BV_F_EMPTY && spins < BV_F_SPIN_MAX) { __builtin_amdgcn_s_sleep(1); ++spins; }
+            if (spins == BV_F_SPIN_MAX) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_PUSH_VARIANT);  // (nothing overwritten; loud)
+            else {
+                e[1] = L; e[2] = n12; e[3] = lut;
+                e[0] = site;  // (LDS operations of one wave execute in order: the entry is whole when its site number appears)
+            }
+        }
         return;
     }
-    e[1] = L; e[2] = n12; e[3] = lut;
-    e[0] = site;  // (LDS operations of one wave execute in order: the entry is whole when its site number appears)
+    // ---- the overflow list
+    uint32_t spins = 0, got = 1u;
+    do {
+        if (lane == 0) got = atomicCAS(&sh.ctl[BV_FC_OV_LOCK], 0u, 1u);
+        got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+        if (got != 0u) __builtin_amdgcn_s_sleep(2);
+    } while (got != 0u && ++spins < BV_F_SPIN_MAX);
+    if (got != 0u) { if (lane == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_PUSH_VARIANT); return; }
+    const uint32_t base = bv_f_lds_read_u(&sh.ctl[BV_FC_OV_TAIL]);
+    if (want) {
+        uint32_t *e = a.ovf + 4u * (size_t)(B0 + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+        *reinterpret_cast<uint4 *>(e) = make_uint4(site, L, n12, lut);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the entries are in the L2 before their count says so
+    if (lane == 0) {
+        *(volatile __attribute__((address_space(3))) uint32_t *)&sh.ctl[BV_FC_OV_TAIL] = base + (uint32_t)__popcll(m);
+        *(volatile __attribute__((address_space(3))) uint32_t *)&sh.ctl[BV_FC_OV_LOCK] = 0u;
+    }
 }
 
 // four candidates, one per group of 16 lanes: positions first .. first + n - 1 of queue q
-__device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t *q, uint32_t first,
+__device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t *q, uint32_t first,
                                            uint32_t n, int lane) {
     const int grp = lane >> 4, gl = lane & 15;
     uint32_t *scratch = v.grp + grp * BV_G16_GRP_WORDS;
@@ -332,7 +373,7 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     uint32_t site = 0, pL = 0, pn12 = 0, plut = 0;
     if ((uint32_t)grp < n) site = bv_f_take(q, first + (uint32_t)grp);
     if ((uint32_t)grp < n && site == BV_F_EMPTY) {
-        if (gl == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], 1u);
+        if (gl == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE);
     } else if ((uint32_t)grp < n) {
         const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
         uint32_t nb, badq;
@@ -375,12 +416,12 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     if (v.fuse2 && vm != 0ull) {
         // the records are complete (the rank sums' waves add to them: BV_SITE_RANKSUM is OR-ed into the status stored above)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (variant && gl == 0) bv_f_push_variant(sh, site, pL, pn12, plut, a.counters);
+        bv_f_push_variants(a, sh, B0, variant && gl == 0, site, pL, pn12, plut, lane);
     }
     if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
 }
 // one candidate that needs the wave solver (shallow site: ordered replay; phred-0 calls; more than 128 bins; min_af <= 0)
-__device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t site, int lane) {
+__device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t site, int lane) {
     uint32_t *bin_code = v.big->w.raw, *bin_cnt = bin_code + BV_SLOTS * BV_WAVE, *hq = bin_code + 2 * BV_SLOTS * BV_WAVE;
     BvSolverScratch *sv = &v.big->w.sc;
     constexpr int REC_WORDS = (int)(sizeof(bv_site_result) / 4);
@@ -437,7 +478,7 @@ __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedSha
             if (ref > 4) ref = 4;
             uint32_t pL, pn12, plut;
             bv_f_p2_facts(ref, depth, aw0, aw1, pL, pn12, plut);
-            if (lane == 0) bv_f_push_variant(sh, site, pL, pn12, plut, a.counters);
+            bv_f_push_variants(a, sh, B0, lane == 0, site, pL, pn12, plut, lane);
         }
         if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
     }
@@ -474,12 +515,12 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
         uint32_t *q = sh.q3;
         n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, least, 4u, first, lane);
         if (n == 0u) { q = sh.q2; n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, least, 4u, first, lane); }
-        if (n != 0u) bv_f_job16(a, sh, v, q, first, n, lane);   // (ONE call site: the solver is ~50 KB of code)
+        if (n != 0u) bv_f_job16(a, sh, v, B0, q, first, n, lane);   // (ONE call site: the solver is ~50 KB of code)
         if (n == 0u && v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
             (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, 1u, first, lane)) != 0u) {
             // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
             const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(&a.cand_list[B0 + first]));
-            bv_f_job_hard(a, sh, v, site, lane);
+            bv_f_job_hard(a, sh, v, B0, site, lane);
         }
         if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
 #ifdef BV_TEAM_DEBUG  /* when the workgroup's last solver job ended */
@@ -537,7 +578,8 @@ __device__ __forceinline__ bool bv_f_no_row_ever(const uint32_t *ctl) {
         bv_f_lds_read_u(&ctl[BV_FC_QH_TAIL]) != bv_f_lds_read_u(&ctl[BV_FC_QH_HEAD]))
         return false;
     if (bv_f_lds_read_u(&ctl[BV_FC_BUSY]) != 0u) return false;
-    return bv_f_lds_read_u(&ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&ctl[BV_FC_QV_HEAD]);
+    return bv_f_lds_read_u(&ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&ctl[BV_FC_QV_HEAD]) &&
+           bv_f_lds_read_u(&ctl[BV_FC_OV_TAIL]) == bv_f_lds_read_u(&ctl[BV_FC_OV_HEAD]);
 }
 typedef volatile __attribute__((address_space(3))) uint32_t bv_lds_vu32;
 __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint32_t site, uint32_t *counters, bool lose_first, int lane) {
@@ -549,7 +591,7 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
     if (spins == BV_F_SPIN_MAX) {
         // gave up: the entry that sits there is not overwritten (its consumer may still come), this site is not solved, and the
         // submit fails loudly (the consumer of position `pos` times out in its turn)
-        (void)bv_f_global_fetch_add_wave(&counters[BV_CTR_TIMEOUT], 1u);
+        (void)bv_f_global_fetch_add_wave(&counters[BV_CTR_TIMEOUT], BV_TMO_PUSH);
         return;
     }
     // (BV_FLAG_FAULT_LOST_HANDOFF, tests: the first entry of every workgroup's queue is reserved and never written -- the solver
@@ -678,6 +720,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
         a.cand_list = BV_F_GLOBAL(uint32_t, ka->cand_list); a.easy_list = BV_F_GLOBAL(uint32_t, ka->easy_list);
         a.easy3_list = BV_F_GLOBAL(uint32_t, ka->easy3_list); a.ch = BV_F_GLOBAL(const BvChain, ka->ch);
         a.mapq = BV_F_GLOBAL(const uint8_t, ka->mapq); a.rpr = BV_F_GLOBAL(const uint16_t, ka->rpr);
+        a.ovf = BV_F_GLOBAL(uint32_t, ka->ovf);
     }
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     uint32_t *hist = sh.hist[wave];
@@ -686,6 +729,7 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
     const uint32_t *ring = sh.ring[wave].slot[0];
     const uint32_t cursor_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_CURSOR];
     const uint32_t qvhead_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QV_HEAD];
+    const uint32_t ovhead_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_OV_HEAD];
     // ---- the geometry of a row (the same for every row of a kind)
     const uint32_t n_chunks = (a.n_samples + 15u) >> 4;  // 16-byte chunks of a plane's row
     const int tail = (int)(a.n_samples & 15u);
@@ -748,8 +792,20 @@ __device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka
                     for (uint32_t spins = 0; (s = bv_f_lds_read_u(&e[0])) == BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(4);
                     x = bv_f_lds_read_u(&e[1]); y = bv_f_lds_read_u(&e[2]); z = bv_f_lds_read_u(&e[3]);
                     if (lane == 0) *(bv_lds_vu32 *)&e[0] = BV_F_EMPTY;
-                    if (s == BV_F_EMPTY) { if (lane == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], 1u); }  // (timed out: no row, flagged)
+                    if (s == BV_F_EMPTY) { if (lane == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE_VARIANT); }  // (timed out: no row, flagged)
                     else kind = BV_FK_P2;
+                }
+            }
+            if (FUSE2 && kind == 0u) {
+                // ... or from the overflow list (rare: more variant sites waiting than the LDS queue takes).  Its entries are in
+                // HBM: one vector load, the ring drains
+                const uint32_t oh = bv_f_lds_read_u(&sh.ctl[BV_FC_OV_HEAD]);
+                if (oh != bv_f_lds_read_u(&sh.ctl[BV_FC_OV_TAIL]) && bv_f_lds_cas_wave(ovhead_lds, oh, oh + 1u) == oh) {
+                    bv_u32x4 e;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(e) : "v"(a.ovf + 4u * (size_t)(B0 + oh)) : "memory");
+                    s = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); x = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+                    y = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z); z = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+                    kind = BV_FK_P2;
                 }
             }
             if (kind == 0u) {
@@ -1161,7 +1217,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         bool go = streaming;
         if (streaming && (sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)) {
             if (!FUSE2) { go = false; streaming = false; }
-            else if (bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD])) {
+            else if (bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) &&
+                     bv_f_lds_read_u(&sh.ctl[BV_FC_OV_TAIL]) == bv_f_lds_read_u(&sh.ctl[BV_FC_OV_HEAD])) {
                 go = false;
                 if (bv_f_no_row_ever(sh.ctl)) streaming = false;
             }

@@ -125,7 +125,7 @@ void parallel_ranges(size_t n, int threads, Fn fn) {
 int main(int argc, char **argv) {
     std::vector<std::string> batchfiles, bams;
     std::string out_vcf, out_cvg, pop_group_file, reference = ".", regions, bam_list, devices_arg, timing_file;
-    int mapq_thd = 10, threads = 1, n_gpus = 1;
+    int mapq_thd = 10, threads = 4, n_gpus = 1;  // (`-t`: 4, the reference's default, src/basetype_utils.h:33,94)
     std::vector<bvamd::Contig> contigs;
     float user_min_af = 0.01f;  // BaseTypeARGS default, src/basetype_utils.h:94
     uint32_t batch_sites = 0;   // 0 = from a cell budget once the sample count is known

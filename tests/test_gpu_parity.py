@@ -643,6 +643,29 @@ def test_more_than_32_pop_groups(bv, restatement, n, ng, ranks):
     eng.close()
 
 
+@pytest.mark.parametrize("grid", [1, 2, 3], ids=["one_workgroup", "two_workgroups", "three_workgroups"])
+def test_more_variant_sites_in_flight_than_the_lds_queues_hold(bv, restatement, grid):
+    """1,464 sites of 4,097 samples on one to three workgroups (BV_FLAG_GRID_LIMIT): up to 1,464 sites per workgroup, 47 % of
+    them variant -- several times what the candidate queues (256) and the variant queue (128) hold.  Until round 5 the solver
+    waves WAITED for room in the variant queue, which only the streaming waves empty, while those waited for room in the
+    candidate queues, which only the solvers empty: the launch stood still until the bounded waits gave up (found by the
+    round-5 campaign, seed 64; `which: 0x8080808`).  Variant sites beyond the queue now go to an overflow list in HBM and no
+    solver ever waits.  Five launches per grid: records byte-identical to the full grid's, the reference's values."""
+    classes = [(0.002, 0.01), (0.2, 0.0), (0.0, 0.0), (0.5, 0.0), (0.0, 0.01), (1.0, 0.0), (0.002, 0.0), (0.05, 0.01)]
+    slab = make_slab(1464, 4097, seed=257428233, coverage=0.02, qual_mean=25.0, qual_sd=9.0, qual_min=1, qual_max=60, n_groups=0,
+                     class_af=classes, ref_n_frac=0.03)
+    maf = restatement.min_af(4097, 0.01)
+    want = run_engine(bv, slab, maf)
+    assert want.n_variant > 600
+    for _ in range(5):
+        eng = bv.BaseTypeEngine(max_sites=1464, min_af_value=maf, device=0, flags=grid << 16)
+        got = eng.lrt(slab)
+        eng.close()
+        assert got.sites.tobytes() == want.sites.tobytes()
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(want, exp, gexp, margins)
+
+
 @pytest.mark.parametrize("flags", [0, 1, 2, 4], ids=["default", "tally_only", "skip_fisher", "skip_lrt"])
 def test_workgroups_that_run_dry_together_end_promptly(bv, flags):
     """2,048 sites of 10,000 samples = exactly one row per streaming wave of the fused short-row kernel: every workgroup runs
