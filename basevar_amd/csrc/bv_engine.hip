@@ -1143,7 +1143,7 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
                                          "per-site state per group otherwise), and the joined planes of this job do not fit the device");
     // H1 2048 + Hm 1024 + Hr 4 x W + Hg 512/group (bv_tiles.hip); W = 1024 ranks, or what the caller announced
     const uint32_t rank_win = with_ranks > 1 ? (uint32_t)((with_ranks + 1023) / 1024 * 1024) : 1024u;
-    const uint32_t hg_off = 3072u + 4u * rank_win, ord_off = hg_off + n_groups * 512u, stride = ord_off + BV_TS_ORD_WORDS;
+    const uint32_t hg_off = 3072u + 4u * rank_win, ord_off = hg_off + n_groups * 512u, stride = ord_off + (1u + n_groups) * BV_TS_ORD_WORDS;
     e->tile_rank_win = rank_win; e->tile_hg_off = hg_off; e->tile_ord_off = ord_off;
     if (!e->tile_ovf) BV_HIP(e, hipMalloc(&e->tile_ovf, sizeof(uint32_t) * (2u + 2u * (size_t)bv_engine::kOvfCap)));
     BV_HIP(e, hipMemset(e->tile_ovf, 0, 2 * sizeof(uint32_t)));

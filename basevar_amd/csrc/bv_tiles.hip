@@ -11,7 +11,8 @@
 //     Hr [ base * W + rank ]                   4 x W  read-position ranks 0..W-1 per called base; W = 1024 unless the job
 //                                                     announced longer reads (bv_engine_tiles_begin, with_ranks > 1)
 //     Hg [ (group*4 + base) << 7 | phred ]     512 per pop-group
-//     Ord                                      BV_TS_ORD_WORDS: the site's first covered cells as (sample index, call, phred, group)
+//     Ord                                      BV_TS_ORD_WORDS: the site's first covered cells as (sample index, call, phred, group),
+//                                              then the same list per pop-group
 // Keeping Hm/Hr per BASE (not per REF/ALT class) is what makes a single sweep enough: the alt set
 // is only known after the last tile, and any (ref, alts) partition can be read off per-base tallies.
 // A site of at most 64 covered samples has ALL its cells in Ord: at finish they are put in sample order and the site (and its
@@ -75,12 +76,24 @@ __global__ __launch_bounds__(256) void bv_tile_tally_kernel(BvTileArgs a) {
             gi = a.group_id[smp];
             if (gi < a.n_groups) atomicAdd(&S[a.hg_off + (((gi * 4u + b) << 7) | min(q, 127u))], 1u);
         }
-        // the site's covered cells while they are few (a plain look first: a deep site stops paying for the atomic)
-        if (__builtin_nontemporal_load(&S[a.ord_off]) < (uint32_t)BV_ORD_MAX) {
+        // the site's covered cells while they are few (a plain look first: a deep site stops paying for the atomic), and the
+        // same per pop-group (a shallow group of a deep site ties as easily as a shallow site)
+        // (counted up to BV_ORD_MAX + 1: a count of exactly BV_ORD_MAX must mean "complete", not "stopped counting")
+        if (__builtin_nontemporal_load(&S[a.ord_off]) <= (uint32_t)BV_ORD_MAX) {
             const uint32_t k = atomicAdd(&S[a.ord_off], 1u);
             if (k < (uint32_t)BV_ORD_MAX) {
                 S[a.ord_off + 4u + 2u * k] = a.col0 + smp;
                 S[a.ord_off + 5u + 2u * k] = (c << 8) | q | (gi << 16);
+            }
+        }
+        if (gi < a.n_groups) {
+            uint32_t *GL = S + a.ord_off + (1u + gi) * BV_TS_ORD_WORDS;
+            if (__builtin_nontemporal_load(&GL[0]) <= (uint32_t)BV_ORD_MAX) {
+                const uint32_t k = atomicAdd(&GL[0], 1u);
+                if (k < (uint32_t)BV_ORD_MAX) {
+                    GL[4u + 2u * k] = a.col0 + smp;
+                    GL[5u + 2u * k] = (c << 8) | q | (gi << 16);
+                }
             }
         }
     }
@@ -289,6 +302,14 @@ __global__ __launch_bounds__(BV_WAVE) void bv_tile_finish_kernel(BvTileFinishArg
                 if (mine) sh.sc.ord[__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(sh.cells[lane] & 0xFFFFu);
                 bv_lrt_sync<0>();
                 if ((uint32_t)__popcll(m) == gtotal) { B.ord = sh.sc.ord; B.n_ord = (int)gtotal; }
+            } else if (gtotal >= 2u && gtotal <= (uint32_t)BV_ORD_MAX) {
+                // a shallow group of a deep site: its own list (sh.cells is free: the site's list was not complete)
+                const uint32_t n_list = bv_tile_sorted_cells(S + a.ord_off + (1u + g) * BV_TS_ORD_WORDS, sh.cells, lane);
+                if (n_list == gtotal) {
+                    if ((uint32_t)lane < n_list) sh.sc.ord[lane] = (uint16_t)(sh.cells[lane] & 0xFFFFu);
+                    bv_lrt_sync<0>();
+                    B.ord = sh.sc.ord; B.n_ord = (int)gtotal;
+                }
             }
             B.nb = (int)nb;
             bv_lrt<0>(B, gdepth, gtotal, comb, nc, ref, a.min_af, &sh.sc.lrt, 0, lane, L);

@@ -1186,6 +1186,20 @@ def test_per_site_tallies_replay_shallow_sites_in_sample_order(bv, restatement):
         slab["qual"][site, cols[:k]] = 30
         slab["mapq"][site, cols[:k]] = 60
         slab["rpr"][site, cols[:k]] = 10
+    # ... and deep sites whose pop-group 2 holds exactly two or three reads that tie (the group's own cell list decides)
+    gid = slab["group_id"]
+    g0, g2 = np.nonzero(gid == 0)[0], np.nonzero(gid == 2)[0]
+    for site in range(1, S, 3):
+        slab["base_strand"][site, :] = 8
+        ref = int(slab["ref_base"][site]) & 3
+        slab["base_strand"][site, g0[:100]] = ref                      # 100 reference reads in group 0: the site is deep
+        slab["qual"][site, g0[:100]] = 35
+        k = 2 + (site // 3) % 2
+        cols = rng.permutation(g2)[:k]
+        slab["base_strand"][site, cols] = [(ref + 1 + j) % 4 for j in range(k)]
+        slab["qual"][site, cols] = 30
+        slab["mapq"][site, :] = 60
+        slab["rpr"][site, :] = 10
     maf = bv.min_af(n)
     eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=0x8)
     rows = eng.lrt(slab)

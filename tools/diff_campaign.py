@@ -106,6 +106,14 @@ def main():
             (exc_group if f.startswith("group.") else exc_site).update(idx[amb[idx]].tolist())
         for i in sorted(excused):
             gd = "" if gexp is None else " group depths %s" % gexp[i]["total_depth"].tolist()
+            if os.environ.get("CAMPAIGN_VERBOSE") == "1":
+                print("      fields flagged: %s" % [f for f, idx in bad.items() if i in idx.tolist()])
+            if gexp is not None and os.environ.get("CAMPAIGN_VERBOSE") == "1":
+                for g in range(gexp.shape[1]):
+                    a, b = got.groups[i][g], gexp[i][g]
+                    if a["n_alt"] != b["n_alt"] or a["alt"].tolist() != b["alt"].tolist() or not np.allclose(a["af"], b["af"], rtol=1e-6, atol=0, equal_nan=True):
+                        print("      group %d depth %d: got n_alt %d alt %s af %s | exp n_alt %d alt %s af %s" % (
+                            g, b["total_depth"], a["n_alt"], a["alt"].tolist(), a["af"].tolist(), b["n_alt"], b["alt"].tolist(), b["af"].tolist()))
             print("   tie-excused site %d: depth %s total %d margin %.3g chi2 %.6g got alt %s exp alt %s%s" % (
                 i, exp["depth"][i].tolist(), exp["total_depth"][i], margins[i], exp_r["chi2"][i],
                 got.sites["alt"][i][:got.sites["n_alt"][i]].tolist(), exp["alt"][i][:exp["n_alt"][i]].tolist(), gd))
