@@ -7,6 +7,9 @@ run "fused short-row kernel: rows of 4,097-49,152 samples, seed 61" CAMPAIGN_FUS
 run "fused short-row kernel, seed 62" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=62
 run "fused short-row kernel, chained launches incl. pop-groups, seed 63" CAMPAIGN_FUSED=1 CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=63
 run "fused short-row kernel, two workgroups (BV_FLAG_GRID_LIMIT), seed 64" CAMPAIGN_FUSED=1 CAMPAIGN_FLAGS=$((2 << 16)) CAMPAIGN_SEED=64
+run "fused short-row kernel, ONE workgroup (every queue overflows), seed 65" CAMPAIGN_FUSED=1 CAMPAIGN_FLAGS=$((1 << 16)) CAMPAIGN_SEED=65
+run "fused short-row kernel, three workgroups, chained, seed 66" CAMPAIGN_FUSED=1 CAMPAIGN_CHAIN=1 CAMPAIGN_FLAGS=$((3 << 16)) CAMPAIGN_SEED=66
+run "fused short-row kernel, two workgroups, no rank planes, seed 67" CAMPAIGN_FUSED=1 CAMPAIGN_NORANKS=1 CAMPAIGN_FLAGS=$((2 << 16)) CAMPAIGN_SEED=67
 run "default shapes, seed 11" CAMPAIGN_SEED=11
 run "default shapes, seed 12" CAMPAIGN_SEED=12
 run "default shapes, seed 13" CAMPAIGN_SEED=13
