@@ -700,7 +700,10 @@ __device__ __forceinline__ void bv_f_stash_flush(const BvP1ShortArgs &a, BvFused
 // pointer handed across a call would make every access a flat one), the lane number is formed here.
 #define BV_F_GLOBAL(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
 template <bool FUSE2>
-__device__ __attribute__((noinline)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
+#ifndef BV_F_STREAM_FN_ATTR
+#define BV_F_STREAM_FN_ATTR noinline, not_tail_called
+#endif
+__device__ __attribute__((BV_F_STREAM_FN_ATTR)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
                                                                      uint32_t B1_, uint32_t st_in_) {
     const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
     const int wave = __builtin_amdgcn_readfirstlane((int)wave_);

@@ -341,6 +341,7 @@ def test_bv_call_end_to_end(tmp_path, restatement):
     exact = sum(1 for a, b in zip(got_vcf, exp_vcf) if a == b)
     bad = [(a[:300], b[:300]) for a, b in zip(got_vcf, exp_vcf) if not same(a, b)]
     assert len(bad) <= int(tie.sum()), bad[:2]
+    print("VCF lines byte-identical: %d of %d (ties: %d)" % (exact, len(exp_vcf), int(tie.sum())))
     assert exact >= 0.9 * len(exp_vcf)   # the vast majority is byte-identical
     hdr = [l for l in open(vcf).read().split("\n") if l.startswith("#")]
     assert hdr[-1].split("\t")[9:] == ids and any(l.startswith("##INFO=<ID=AA_AF") for l in hdr)
