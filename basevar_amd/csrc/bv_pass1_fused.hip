@@ -113,6 +113,7 @@ struct __attribute__((aligned(16))) BvFusedShared {
     uint32_t grp[BV_F_NV][4][BV_G16_GRP_WORDS];          // the solver waves' group scratches
     uint32_t vl[BV_F_NV][64];                            // ... and their variant sites since the last flush
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    double tab_loghit[BV_QBINS], tab_logmiss[BV_QBINS];  // (from HBM these cost the 16-lane solver a memory trip per slot of bins)
     uint32_t stage[BV_F_NS][128];                        // a candidate's compacted bins on their way out
     uint32_t q3[BV_F_QCAP], q2[BV_F_QCAP];
     uint32_t qv[BV_F_QVCAP][4];                          // site, class table, n_ref | n_alt << 16, 2-bit lut
@@ -386,7 +387,7 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
             nb = s2.x;
             badq = (s2.y & BV_SUM_BADQ) ? 1u : 0u;
             BvG16Bins B;
-            B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = v.sa.loghit; B.logmiss = v.sa.logmiss;
+            B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sh.tab_loghit; B.logmiss = sh.tab_logmiss;
             B.pm = reinterpret_cast<double *>(scratch) + gl;
 #pragma unroll
             for (int s = 0; s < BV_G16_SLOTS; ++s) {
@@ -1175,6 +1176,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_F_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
+        sh.tab_loghit[i] = a.tables->loghit[i];
+        sh.tab_logmiss[i] = a.tables->logmiss[i];
     }
     if (tid < 16) sh.ctl[tid] = 0u;
     if (tid < BV_F_NS) sh.pub[tid] = B0;
@@ -1194,7 +1197,14 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     BvFusedSolver v;
     v.sa.ref_base = a.ref_base; v.sa.out = a.out; v.sa.var_list = a.var_list; v.sa.counters = a.counters;
     v.sa.min_af = a.min_af; v.sa.flags = a.flags;
-    v.sa.lnfact.t = a.tables->lnfact; v.sa.lnfact.n = (int)a.tables->lnfact_n;
+    {
+        // (wave-uniform values read through vector loads -- the tables are not provably unwritten -- go to scalar registers:
+        // as vector registers they are live across the whole loop and end up in scratch memory)
+        const uint64_t lf = (uint64_t)(uintptr_t)a.tables->lnfact;
+        v.sa.lnfact.t = (decltype(v.sa.lnfact.t))(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(lf >> 32)) << 32) |
+                                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)lf));
+        v.sa.lnfact.n = __builtin_amdgcn_readfirstlane((int)a.tables->lnfact_n);
+    }
     v.sa.loghit = a.tables->loghit; v.sa.logmiss = a.tables->logmiss;
     v.sa.bs = a.bs; v.sa.q = a.q; v.sa.pitch = a.pitch; v.sa.n_samples = a.n_samples;
     v.n_vl = 0;
@@ -1226,14 +1236,20 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
                 if (bv_f_no_row_ever(sh.ctl)) streaming = false;
             }
         }
+        // (the lane number as a value the compiler cannot see through: what the solver derives from it -- lane & 15, masks,
+        // scratch offsets, some forty values -- was hoisted out of this loop and then lived in scratch memory, a memory trip per use)
+        int ln = lane;
+#ifndef BV_F_NO_OPAQUE_LANE
+        asm volatile("" : "+v"(ln));
+#endif
         if (go) {
             // (the wave's variant sites since its last flush sit in its ring's LDS: out before rows stream through it again)
-            if (v.n_vl) bv_f_flush_vl(a, v, lane);
+            if (v.n_vl) bv_f_flush_vl(a, v, ln);
             sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
             if (sst & BV_FS_P_DONE) streaming = false;
         }
         __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
-        const int r = bv_f_solver_step(a, sh, v, B0, B1, lane);
+        const int r = bv_f_solver_step(a, sh, v, B0, B1, ln);
         __builtin_amdgcn_s_setprio(0);
         if (streaming) {
             if (r != 1) __builtin_amdgcn_s_sleep(8);

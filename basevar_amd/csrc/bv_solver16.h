@@ -321,6 +321,9 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
                 uint32_t b, q;
                 double c;
                 if (bv_g16_bin(B, s, b, q, c)) {
+                    // (q as a value of THIS level: the table addresses are invariant over the levels, get hoisted out of their
+                    // loop and, at the register limit, parked in scratch memory -- a memory trip per slot to save a shift and an add)
+                    asm volatile("" : "+v"(q));
                     const double lm = B.logmiss[q], dh = B.loghit[q] - lm;
                     a_ += c * lm;
                     g0 += (b == 0) ? c * dh : 0.;
