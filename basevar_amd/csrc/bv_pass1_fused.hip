@@ -382,11 +382,11 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
         uint4 s0, s1, s2;
         bv_load3_l2(&a.summ[site], s0, s1, s2);
         {
+            BvG16Bins B;
             uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
             const uint32_t total = depth[0] + depth[1] + depth[2] + depth[3];
             nb = s2.x;
             badq = (s2.y & BV_SUM_BADQ) ? 1u : 0u;
-            BvG16Bins B;
             B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sh.tab_loghit; B.logmiss = sh.tab_logmiss;
             B.pm = reinterpret_cast<double *>(scratch) + gl;
 #pragma unroll
@@ -396,19 +396,24 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
             }
             variant = bv_site_lrt_g16(v.sa, site, depth, total, badq, B, scratch, lane, &pre);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the record's first version is out before phase 2 patches it
         BvSiteSums S;
-        // phase 2 needs the strand totals: read again (eight registers that would otherwise sit through the EMs)
+        // phase 2 needs the strand totals and, for the rank sum, the bins again (registers that would otherwise sit through the
+        // EMs).  ONE trip: the bins' loads are issued first, and the summary load's own s_waitcnt vmcnt(0) covers them and the
+        // stores of the record's first version, which phase 2 patches
+        uint32_t w2[BV_G16_SLOTS];
+#pragma unroll
+        for (int s = 0; s < BV_G16_SLOTS; ++s) {
+            const uint32_t i = (uint32_t)(s * 16 + gl);
+            w2[s] = (variant && i < nb) ? src[i] : 0u;
+        }
         bv_load3_l2(&a.summ[site], s0, s1, s2);
         S.fwd[0] = s0.x; S.fwd[1] = s0.y; S.fwd[2] = s0.z; S.fwd[3] = s0.w;
         S.rev[0] = s1.x; S.rev[1] = s1.y; S.rev[2] = s1.z; S.rev[3] = s1.w;
         S.q0_mask = 0; S.nb = nb; S.badq = badq;
-        bv_site_tail_g16(v.sa, site, S, src, nb, scratch, lane, &pre);
+        bv_site_tail_g16(v.sa, site, S, src, nb, scratch, lane, &pre, w2);
         if (variant && v.fuse2) {
             const uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
-            int ref = v.sa.ref_base[site];
-            if (ref > 4) ref = 4;
-            bv_f_p2_facts(ref, depth, pre.aw0, pre.aw1, pL, pn12, plut);
+            bv_f_p2_facts(pre.ref, depth, pre.aw0, pre.aw1, pL, pn12, plut);
         }
     }
     const unsigned long long vm = __ballot(variant && gl == 0);
@@ -699,12 +704,14 @@ __device__ __forceinline__ void bv_f_stash_flush(const BvP1ShortArgs &a, BvFused
 // a kernel: the argument block is read from the kernel's own kernarg segment (scalar loads, wave-uniform by construction; its
 // pointers are marked as device memory), the LDS block comes as an LDS ADDRESS and is turned back into a pointer here (a generic
 // pointer handed across a call would make every access a flat one), the lane number is formed here.
+// not_tail_called: clang marks the kernel's call `tail`, and a function with a tail-marked caller keeps the callee-saved
+// registers of the AMDGPU convention -- its prologue stored the 60 of them it uses (v40-47, v56-63, ...) to scratch memory,
+// 15 KB per wave and call, and the L2 wrote 85 MB of that back per launch.  Without the mark LLVM's inter-procedural register
+// allocation applies to this local, non-recursive function: no saves here, the kernel keeps what IT has live across the call
+// (next to nothing: see the lane number in the kernel's loop).
 #define BV_F_GLOBAL(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
 template <bool FUSE2>
-#ifndef BV_F_STREAM_FN_ATTR
-#define BV_F_STREAM_FN_ATTR noinline, not_tail_called
-#endif
-__device__ __attribute__((BV_F_STREAM_FN_ATTR)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
+__device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
                                                                      uint32_t B1_, uint32_t st_in_) {
     const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
     const int wave = __builtin_amdgcn_readfirstlane((int)wave_);
@@ -1222,11 +1229,10 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
     // is most of the kernel's code).
 #pragma unroll 1
     for (;;) {
-        // A streaming wave past its pass-1 rows calls the streaming function only when a variant row waits: the call is not
-        // free -- the function's prologue saves the 60 callee-saved VGPRs it uses to scratch memory (15 KB per wave and call,
-        // as much again read back on return), and a wave that polled through it hammered the L2 while the launch's last rows
-        // and solver jobs were waiting on the same memory system (and the evicted scratch lines showed as HBM writes: 316 MB
-        // per launch of 8,192 sites, where the records and scratch of the launch are 4 MB).
+        // A streaming wave past its pass-1 rows calls the streaming function only when a variant row waits (two LDS words
+        // tell): until round 5 the function's prologue saved 60 callee-saved VGPRs to scratch memory per call, and waves that
+        // polled through it wrote 316 MB per launch of 8,192 sites.  The saves are gone (see the function), the test stays: a
+        // call still reads the argument block and sets the ring up.
         bool go = streaming;
         if (streaming && (sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)) {
             if (!FUSE2) { go = false; streaming = false; }
@@ -1239,9 +1245,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         // (the lane number as a value the compiler cannot see through: what the solver derives from it -- lane & 15, masks,
         // scratch offsets, some forty values -- was hoisted out of this loop and then lived in scratch memory, a memory trip per use)
         int ln = lane;
-#ifndef BV_F_NO_OPAQUE_LANE
         asm volatile("" : "+v"(ln));
-#endif
         if (go) {
             // (the wave's variant sites since its last flush sit in its ring's LDS: out before rows stream through it again)
             if (v.n_vl) bv_f_flush_vl(a, v, ln);

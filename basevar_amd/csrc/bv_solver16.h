@@ -131,13 +131,19 @@ __device__ inline double bv_fisher_two_sided_g16(int n11, int n12, int n21, int 
     BvHyper h;
     bv_hyper_init(h, T, n1_, n_1, n);
     const int R = imax - imin + 1;
+    // Up to 128 tables (no tails to skip: the blocks below are those of [imin, imax]): the lane's seed table is known here,
+    // and its four log-factorials travel with those of q instead of making a memory trip of their own after it.
+    const bool narrow = R <= 8 * 16;
+    const int i0n = imin + gl * ((R + 15) >> 4);
+    double seed_n = (narrow && i0n <= imax) ? bv_hyper_logp(h, i0n) : 0.;
+    asm volatile("" : "+v"(seed_n));  // (read here, not where it is used)
     const double logq = bv_hyper_logp(h, n11);
     const double q = exp(logq);
     if (q == 0.0) return 0.0;  // kfunc.c:260-289
     const double lo = 0.99999999 * q, hi = 1.00000001 * q;
     const int INF = 0x7fffffff;
     int wl = imin, wr = imax;
-    if (R > 8 * 16) {
+    if (!narrow) {
         // many tables: skip the far tails whose terms are below q * 2^-86 (16-point probes on either side)
         const double cut = logq - 60.0;
         {
@@ -164,7 +170,7 @@ __device__ inline double bv_fisher_two_sided_g16(int n11, int n12, int n21, int 
     const int i0 = wl + gl * Lb;
     const int i1 = min(i0 + Lb - 1, wr);
     const bool mine = i0 <= wr;
-    double p = mine ? bv_hyper_p(h, i0) : 0.;
+    double p = mine ? exp(narrow ? seed_n : bv_hyper_logp(h, i0)) : 0.;
     double tail = 0., pfirst = 0., plast = 0.;
     bool seen = false;
     for (int t = 0; t < Lb; ++t) {
@@ -444,6 +450,7 @@ struct BvG16Lrt {
     uint32_t status;    // with the stash bits
     uint32_t aw0, aw1;  // the record's bytes n_alt, alt[0..3] (+ n_em, em_iters): as stored at bv_site_result::n_alt
     double chi2;
+    int ref;            // the reference base's code (0-3; 4: not ACGT)
 };
 
 // Phase 1.  `scratch`: the group's BV_G16_GRP_WORDS words of LDS -- the EM's previous marginals (B.pm points into it), then
@@ -495,16 +502,17 @@ __device__ inline bool bv_site_lrt_g16(const BvSolveArgs &a, uint32_t site, cons
         pre->aw0 = scratch[offsetof(bv_site_result, n_alt) / 4];
         pre->aw1 = scratch[offsetof(bv_site_result, n_alt) / 4 + 1];
         pre->chi2 = L.chi2;
+        pre->ref = ref;
     }
     return L.n_alt > 0;
 }
 
-// Phase 2.  `S`: the site's strand totals; `bins` / `nb`: its exported bins in device memory (bv_g16_bin layout; read again
-// here, and only for variant sites, rather than kept in 8 registers across phase 1); `cls`: the group's scratch, here
-// 2 x 128 REF / ALT counts per phred for the rank sum.  Everything it computes is patched into the record phase 1 wrote,
-// by the group's first lane.
+// Phase 2.  `S`: the site's strand totals; `bins` / `nb`: its exported bins in device memory (bv_g16_bin layout), or, when both
+// phases run in one kernel, `w_held`: the lane's bin words as phase 1 held them (B.w: no second trip to memory); `cls`: the
+// group's scratch, here 2 x 128 REF / ALT counts per phred for the rank sum.  Everything it computes is patched into the
+// record phase 1 wrote, by the group's first lane.
 __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, const BvSiteSums &S, const uint32_t *bins, uint32_t nb,
-                                        uint32_t *cls, int lane, const BvG16Lrt *pre = nullptr) {
+                                        uint32_t *cls, int lane, const BvG16Lrt *pre = nullptr, const uint32_t *w_held = nullptr) {
     const int gl = lane & 15;
     bv_site_result *rec = &a.out[site];
     uint32_t depth[4], total = 0;
@@ -513,7 +521,7 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
         depth[b] = S.fwd[b] + S.rev[b];
         total += depth[b];
     }
-    int ref = a.ref_base[site];
+    int ref = pre ? pre->ref : (int)a.ref_base[site];
     if (ref > 4) ref = 4;
     // what phase 1 left: status (with the stash), n_alt + alt[4] (8 bytes), chi2
     const uint32_t st = pre ? pre->status : rec->status;
@@ -542,6 +550,24 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
                 ad_sum_u += bv_sel4u(depth, b);
             }
         }
+        // REF / ALT counts per phred value for the base-quality rank sum, scattered from the bins -- first, so that bin words
+        // held in registers (w_held) are done with before QUAL and the strand-bias tests want theirs
+        {
+            for (int i = gl; i < 2 * 128; i += 16) cls[i] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t i = (uint32_t)(s * 16 + gl);
+                const uint32_t ws = w_held ? w_held[s] : (i < nb ? bins[i] : 0u);
+                if (ws & 0xFFFFu) {
+                    const uint32_t q = (ws >> 16) & 127u, b = ws >> 23;
+                    // bins are unique per (base, phred); several ALT bases can share a phred: add, one lane at a time per word
+                    if ((int)b == ref) cls[q] = ws & 0xFFFFu;
+                    else if ((alt_mask >> b) & 1u) atomicAdd(&cls[128 + q], ws & 0xFFFFu);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         // QUAL / QD / CAF (basetype.cpp:180-196, caller.cpp:1113-1122, 1160-1161)
         {
             const double r = (double)bv_sel4u(depth, first) / (double)total;
@@ -565,22 +591,8 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
             if (b == ref) { v_rf += S.fwd[b]; v_rr += S.rev[b]; }
             else if ((alt_mask >> b) & 1u) { v_af += S.fwd[b]; v_ar += S.rev[b]; }
         }
-        // base-quality rank sum (caller.cpp:1157): REF / ALT counts per phred value, scattered from the bins
+        // base-quality rank sum (caller.cpp:1157), from the REF / ALT counts per phred value scattered above
         {
-            for (int i = gl; i < 2 * 128; i += 16) cls[i] = 0u;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-            for (int s = 0; s < BV_G16_SLOTS; ++s) {
-                const uint32_t i = (uint32_t)(s * 16 + gl);
-                const uint32_t ws = i < nb ? bins[i] : 0u;
-                if (ws & 0xFFFFu) {
-                    const uint32_t q = (ws >> 16) & 127u, b = ws >> 23;
-                    // bins are unique per (base, phred); several ALT bases can share a phred: add, one lane at a time per word
-                    if ((int)b == ref) cls[q] = ws & 0xFFFFu;
-                    else if ((alt_mask >> b) & 1u) atomicAdd(&cls[128 + q], ws & 0xFFFFu);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const unsigned long long n1 = (ref < 4) ? bv_sel4u(depth, ref) : 0ull, n2 = ad_sum_u;
             unsigned long long below = 0, twoR = 0;
 #pragma unroll
