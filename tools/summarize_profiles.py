@@ -42,7 +42,9 @@ def counters(dirpat, by_grid=False):
     """average counter value per (kernel, counter) -- or per (kernel, grid size, counter): calls of one kernel with
     different dispatch sizes are different workloads and must not be averaged together"""
     acc, cnt = collections.defaultdict(float), collections.Counter()
-    for fn in glob.glob(dirpat, recursive=True):
+    # (the newest file only: gpurun MERGES a call's outputs into gpurun_out/, so a directory collected twice holds both runs --
+    # files of an older build averaged into a newer one's counters is how a 40 MB WRITE_SIZE once read 88 MB)
+    for fn in newest(dirpat):
         for r in csv.DictReader(open(fn)):
             k = (short(r["Kernel_Name"]), grid_of(r), r["Counter_Name"]) if by_grid else (short(r["Kernel_Name"]), r["Counter_Name"])
             acc[k] += float(r["Counter_Value"])
@@ -53,7 +55,7 @@ def counters(dirpat, by_grid=False):
 def dispatch_groups(dirpat):
     """{kernel: {grid size: [durations ns]}} from the per-dispatch rows collect_profiles.sh keeps"""
     g = collections.defaultdict(lambda: collections.defaultdict(list))
-    for fn in glob.glob(dirpat, recursive=True):
+    for fn in newest(dirpat):
         for r in csv.DictReader(open(fn)):
             g[short(r["Kernel_Name"])][grid_of(r)].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     return g
