@@ -66,11 +66,12 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 // Every wait on another wave's LDS write is bounded (~1-2 s of s_sleep): a wave that gives up sets the sticky BV_CTR_TIMEOUT
 // counter -- the submit then fails loudly in bv_engine_wait -- instead of hanging the GPU on a protocol error.
 #define BV_F_SPIN_MAX (1u << 22)
-// Issue priority of a wave while it solves (s_setprio; streaming: 0).  The solver's chains of dependent FP64 operations lose
-// 2-3 x beside two streaming waves per SIMD at equal priority (jobs of 35-65 us took 100-195 us, measured from the queue
-// lengths at the end of the pass-1 rows: 28 candidates waiting); at priority 3 the solver waves keep up (1 waiting) and the
-// streaming waves, which wait on memory most of the time, lose ~4 %.
-#define BV_F_SOLVER_PRIO 3
+// No issue priorities (s_setprio).  Round 4 ran the solver waves at priority 3: their chains of dependent FP64 operations lost
+// 2-3 x beside two streaming waves per SIMD at equal priority (28 candidates waiting at the end of the pass-1 rows against 1).
+// What they were really losing to was scratch memory -- reloads of hoisted loop invariants inside those chains, a memory trip
+// each (round 5, see bv_f_stream_until_idle and the kernel's loop).  With those gone the priority COSTS: equal priorities
+// measured +3 % at 100 k sites (187 against 181 M sites/s, eight interleaved pairs), +4 % at 524 k (200-207 against 192-201);
+// streaming waves above the solvers (2 over 0) +2 %, (3 over 1) -1 %.
 #define BV_F_MIN_JOB 4u                   /* sites per job of the 16-lane solver while rows are still streaming */
 // control words in LDS
 #define BV_FC_CURSOR 0                    /* sites of the workgroup's range handed out so far */
@@ -1252,9 +1253,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
             sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
             if (sst & BV_FS_P_DONE) streaming = false;
         }
-        __builtin_amdgcn_s_setprio(BV_F_SOLVER_PRIO);
         const int r = bv_f_solver_step(a, sh, v, B0, B1, ln);
-        __builtin_amdgcn_s_setprio(0);
         if (streaming) {
             if (r != 1) __builtin_amdgcn_s_sleep(8);
             continue;
