@@ -54,7 +54,7 @@
 #include <type_traits>
 
 #define BV_F_NS 8                         /* streaming waves per workgroup */
-#define BV_F_NV 4                         /* dedicated solver waves per workgroup (7 + 5 measured -1.2 %) */
+#define BV_F_NV 4                         /* dedicated solver waves per workgroup (7 + 5 measured -1.2 %; round 5, lean solver: 8 + 3 -0.8 %, 8 + 2 -4 %) */
 static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody must be emptying it");
 #define BV_F_NW (BV_F_NS + BV_F_NV)
 #define BV_F_K 3                          /* ring slots per streaming wave */
