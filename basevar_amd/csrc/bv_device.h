@@ -1106,7 +1106,13 @@ __device__ inline void bv_lrt(const BvBins &B, const uint32_t depth[4], uint32_t
             double lr;
             int it;
             if (B.ord != nullptr && s != 0.) {
-                it = bv_em_ordered(B.ord, B.n_ord, B.hit, B.miss, f, &lr, lane, bv_hostlog_of(B.logmiss));
+                // (copies for the call: bv_em_ordered is not inlined, and an array whose address leaves the function lives in
+                // scratch memory -- with f and lr handed over themselves, EVERY subset of every site paid memory trips for them,
+                // also in the kernels that never replay)
+                double fo[4] = {f[0], f[1], f[2], f[3]}, lro;
+                it = bv_em_ordered(B.ord, B.n_ord, B.hit, B.miss, fo, &lro, lane, bv_hostlog_of(B.logmiss));
+                f[0] = fo[0]; f[1] = fo[1]; f[2] = fo[2]; f[3] = fo[3];
+                lr = lro;
             } else if (B.loghit != nullptr && q0_mask == 0u && s != 0. && (in_set & (in_set - 1u)) == 0u) {
                 // A single-base subset {b} with every likelihood positive: the reference's EM needs no arithmetic.  Its
                 // first e_step gives every sample the posterior L/L == 1.0 for b, the m_step f_b == n/n == 1.0, and from
