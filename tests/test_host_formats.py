@@ -341,8 +341,7 @@ def test_bv_call_end_to_end(tmp_path, restatement):
     exact = sum(1 for a, b in zip(got_vcf, exp_vcf) if a == b)
     bad = [(a[:300], b[:300]) for a, b in zip(got_vcf, exp_vcf) if not same(a, b)]
     assert len(bad) <= int(tie.sum()), bad[:2]
-    print("VCF lines byte-identical: %d of %d (ties: %d)" % (exact, len(exp_vcf), int(tie.sum())))
-    assert exact >= 0.9 * len(exp_vcf)   # the vast majority is byte-identical
+    assert exact >= len(exp_vcf) - int(tie.sum())   # byte-identical but for exact ties (measured: 51 of 51, no tie)
     hdr = [l for l in open(vcf).read().split("\n") if l.startswith("#")]
     assert hdr[-1].split("\t")[9:] == ids and any(l.startswith("##INFO=<ID=AA_AF") for l in hdr)
     # the block-parallel producer + emitter (`--thread`) write the same bytes (the byte-level reader itself is pinned against the
@@ -353,6 +352,50 @@ def test_bv_call_end_to_end(tmp_path, restatement):
                                "--batch-sites", "50", "--contig", "chr17:81195210", "--reference", "hg19.fa"] + extra)
         assert open(v2, "rb").read() == open(vcf, "rb").read(), tag
         assert open(c2, "rb").read() == open(cvg, "rb").read(), tag
+
+
+@pytest.mark.gpu
+def test_bv_call_with_more_pop_groups_than_one_round(tmp_path, restatement):
+    """40 pop-groups through bv_call (the engine runs pass 2 in rounds of 32 groups; the reference takes any number,
+    basetype_caller.cpp:372-410): every <group>_AF field of every VCF line equals the line derived from the oracle's records,
+    group names in the reference's (sorted) order, samples without a group left out."""
+    exe = cxx(os.path.join(ROOT, "basevar_amd", "host", "bv_call.cpp"), str(tmp_path / "bv_call"), ["-lz"])
+    n_samples, n_groups = 240, 40
+    paths, ids, sites = make_batchfiles(tmp_path, n_sites=60, n_samples=n_samples, n_files=4, seed=11)
+    names = ["pop%02d" % g for g in range(n_groups)]
+    popfile = str(tmp_path / "groups.info")
+    gid = np.full(n_samples, 0xFF, np.uint8)
+    with open(popfile, "w") as fh:
+        for i, sid in enumerate(ids):
+            if i % 41 != 40:  # a few samples belong to no group
+                g = (i * 7) % n_groups
+                gid[i] = g
+                fh.write("%s\t%s\n" % (sid, names[g]))
+    vcf, cvg = str(tmp_path / "out.vcf"), str(tmp_path / "out.cvg")
+    subprocess.check_call([exe, "--batchfiles", ",".join(paths), "--output-vcf", vcf, "--output-cvg", cvg, "--pop-group", popfile,
+                           "--batch-sites", "25", "--thread", "3"])
+    kept = [s for s in sites if any(t != "N" for t in s["bases"])]
+    slab = sites_to_slab(kept, n_samples)
+    slab["group_id"] = gid; slab["n_groups"] = n_groups
+    exp, gexp, margins = restatement.run_with_margins(slab, restatement.min_af(n_samples, 0.01))
+    got_vcf = [l for l in open(vcf).read().split("\n") if l and not l.startswith("#")]
+    exp_vcf = [x for x in (expected_vcf(s, r, g, names) for s, r, g in zip(kept, exp, gexp)) if x]
+    assert len(got_vcf) == len(exp_vcf) >= 15
+    n_group_fields = 0
+    for a, b in zip(got_vcf, exp_vcf):
+        fa, fb = a.split("\t"), b.split("\t")
+        assert fa[:5] == fb[:5] and fa[8:] == fb[8:], (a[:200], b[:200])
+        ia, ib = fa[7].split(";"), fb[7].split(";")
+        assert [x.split("=")[0] for x in ia] == [x.split("=")[0] for x in ib], (fa[7], fb[7])
+        for x, y in zip(ia, ib):
+            if x.startswith("pop"):
+                n_group_fields += 1
+                if x != y:  # (a last printed digit may round differently: 1e-6)
+                    vx, vy = [float(v) for v in x.split("=")[1].split(",")], [float(v) for v in y.split("=")[1].split(",")]
+                    assert len(vx) == len(vy) and all(abs(p - q) <= 1e-6 * max(1.0, abs(q)) + 1.5e-6 for p, q in zip(vx, vy)), (x, y)
+    assert n_group_fields >= 10 * len(exp_vcf)  # most groups have an alt read at most variant sites
+    hdr = [l for l in open(vcf).read().split("\n") if l.startswith("##INFO=<ID=pop")]
+    assert len(hdr) == n_groups
 
 
 def test_tbi_reader_on_an_index_written_by_htslib():
