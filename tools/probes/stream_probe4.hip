@@ -35,10 +35,23 @@ __device__ __forceinline__ const uint8_t *uni(const uint8_t *p) {
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (const uint8_t *)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
+// three planes, the pass-2 rows' slot: 1 KiB of a, 1 KiB of b, 2 KiB of c
+__device__ __forceinline__ void glds4_p2(uint32_t d0, const uint8_t *pa, const uint8_t *pb, const uint8_t *pc, uint32_t v0, uint32_t v1) {
+    uint32_t keep, t;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[d0]\n\ts_add_u32 %[t], %[d0], 0x400\n\t"
+        "global_load_lds_dwordx4 %[v0], %[pa] nt\n\ts_mov_b32 m0, %[t]\n\ts_add_u32 %[t], %[d0], 0x800\n\t"
+        "global_load_lds_dwordx4 %[v0], %[pb] nt\n\ts_mov_b32 m0, %[t]\n\ts_add_u32 %[t], %[d0], 0xc00\n\t"
+        "global_load_lds_dwordx4 %[v0], %[pc] nt\n\ts_mov_b32 m0, %[t]\n\ts_nop 0\n\t"
+        "global_load_lds_dwordx4 %[v1], %[pc] nt\n\ts_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [t] "=&s"(t) : [d0] "s"(d0), [pa] "s"(pa), [pb] "s"(pb), [pc] "s"(pc), [v0] "v"(v0), [v1] "v"(v1) : "memory", "scc");
+}
+// MODE bit 4 (16): the pass-2 rows' geometry -- slots of 1,024 cells: 1 KiB of plane a, 1 KiB of plane b, 2 KiB of the 2-byte
+// plane c; bit 5 (32): the same bytes as slots of 2,048 cells that alternate between (2 KiB of a + 2 KiB of b) and (4 KiB of c)
 // MODE bit 0: rows end where they end (masked last slot, no read past the row); bit 1: the kernel's per-cell tally into an 8 x 128
 // histogram; bit 2: a per-row epilogue (16 LDS reads, wave reductions, a 48-byte store); bit 3: 4 KiB of LDS zeroed per row
 template <int NS, int K, int NIDLE, int MODE = 0>
-__global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, const uint8_t *q, uint32_t n_sites, uint32_t n_samples, uint64_t pitch, uint32_t *sink) {
+__global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, const uint8_t *q, uint32_t n_sites, uint32_t n_samples, uint64_t pitch, uint32_t *sink, const uint8_t *r16 = nullptr) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];   // [NS][K][1024] ring, the cursor (16 words), [NS][1040] histograms
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     uint32_t *cursor = lds + NS * K * 1024;
@@ -49,7 +62,7 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
         return;
     }
     const uint32_t B0 = (uint32_t)((uint64_t)n_sites * blockIdx.x / gridDim.x), B1 = (uint32_t)((uint64_t)n_sites * (blockIdx.x + 1) / gridDim.x);
-    const uint32_t n_chunks = (n_samples + 15u) >> 4, n_slots = (n_chunks + 127u) >> 7;
+    const uint32_t n_chunks = (n_samples + 15u) >> 4, n_slots = (MODE & 16) ? (n_chunks + 63u) >> 6 : ((MODE & 32) ? 2u * ((n_chunks + 127u) >> 7) : (n_chunks + 127u) >> 7);
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_u32 *)(lds + wave * K * 1024));
     const uint32_t *ring = lds + wave * K * 1024;
     const uint32_t va = lane * 16u, vb = va + 1024u;
@@ -61,7 +74,7 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
     const unsigned long long mB1 = last1 > 64u ? (last1 >= 128u ? ~0ull : ((1ull << (last1 - 64u)) - 1ull)) : 1ull;
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
-    const uint8_t *p0 = bs, *p1 = q;
+    const uint8_t *p0 = bs, *p1 = q, *p2 = r16;
     uint32_t p_left = 0, ring_w = 0, ring_r = 0, inflight = 0, rows = 0;
     bool done = false;
     auto issue = [&]() {
@@ -73,10 +86,17 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
             if (c >= B1 - B0) { done = true; return; }
             const uint64_t off = (uint64_t)(B0 + c) * pitch;
             p0 = uni(bs + off); p1 = uni(q + off); p_left = n_slots; ++rows;
+            if (MODE & 48) p2 = uni(r16 + 2u * off);
         }
+        if (MODE & 16) { glds4_p2(ring_lds + ring_w * 4096u, uni(p0), uni(p1), uni(p2), va, vb); p0 += 1024; p1 += 1024; p2 += 2048; }
+        else if (MODE & 32) {
+            if (p_left & 1u) { glds4(ring_lds + ring_w * 4096u, uni(p2), va, uni(p2 + 2048), vb); p2 += 4096; }   // (second of a pair: the ranks)
+            else { glds4(ring_lds + ring_w * 4096u, uni(p0), va, uni(p1), vb); p0 += 2048; p1 += 2048; }
+        } else {
         if (!(MODE & 1) || p_left > 1u) glds4(ring_lds + ring_w * 4096u, p0, va, p1, vb);   // (MODE bit 0 clear: the last slot reads a little past the row)
         else glds4_masked(ring_lds + ring_w * 4096u, p0, va, vbl, p1, mA1, mB1);
         p0 += 2048; p1 += 2048;
+        }
         --p_left;
         ring_w = (ring_w + 1u == (uint32_t)K) ? 0u : ring_w + 1u;
         ++inflight;
@@ -126,17 +146,17 @@ __global__ __launch_bounds__(64 * (NS + NIDLE)) void probe(const uint8_t *bs, co
     if (NIDLE) { __builtin_amdgcn_s_waitcnt(0); if (lane == 0 && atomicAdd(cursor + 1, 1u) + 1u == (uint32_t)NS) *cursor = 0x40000000u; }
 }
 template <int NS, int K, int NIDLE, int MODE = 0>
-double run(const uint8_t *a, const uint8_t *b, uint32_t S, uint32_t n, uint64_t pitch, uint32_t *sink) {
+double run(const uint8_t *a, const uint8_t *b, uint32_t S, uint32_t n, uint64_t pitch, uint32_t *sink, const uint8_t *c = nullptr) {
     const size_t dyn = (size_t)NS * K * 4096 + 64 + (size_t)NS * 1040 * 4;
     hipFuncSetAttribute((const void *)probe<NS, K, NIDLE, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<NS, K, NIDLE, MODE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink);
+    probe<NS, K, NIDLE, MODE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink, c);
     hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) probe<NS, K, NIDLE, MODE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink);
+    for (int i = 0; i < 5; ++i) probe<NS, K, NIDLE, MODE><<<256, 64 * (NS + NIDLE), dyn>>>(a, b, S, n, pitch, sink, c);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     if (hipGetLastError() != hipSuccess) return -1;
-    return 2.0 * S * n * 5 / (ms * 1e-3) / 1e9;
+    return ((MODE & 48) ? 4.0 : 2.0) * S * n * 5 / (ms * 1e-3) / 1e9;
 }
 int main() {
     const uint32_t n = 10000, S = 100000;
@@ -160,6 +180,15 @@ int main() {
     printf("  + tally + epilogue (reads, sums, store): %6.0f\n", run<8, 3, 4, 7>(a, b, S, n, pitch, sink));
     printf("  + tally + epilogue + zeroing           : %6.0f\n", run<8, 3, 4, 15>(a, b, S, n, pitch, sink));
     printf("  exact rows + epilogue + zeroing        : %6.0f\n", run<8, 3, 4, 13>(a, b, S, n, pitch, sink));
+    {
+        uint8_t *c;
+        hipMalloc(&c, 2 * S * pitch + 16384); hipMemset(c, 1, 2 * S * pitch + 16384);
+        printf("pass-2 geometry (three planes, 4 B per cell; GB/s of all three), NS 8 K 3 + 4 idle waves, bare:\n");
+        printf("  slots of 1 KiB + 1 KiB + 2 KiB (the kernel's)        : %6.0f\n", run<8, 3, 4, 16>(a, b, S, n, pitch, sink, c));
+        printf("  slots alternating (2 KiB + 2 KiB) / (4 KiB)           : %6.0f\n", run<8, 3, 4, 32>(a, b, S, n, pitch, sink, c));
+        printf("  the pass-1 geometry again (two planes, 2 KiB + 2 KiB) : %6.0f\n", run<8, 3, 4, 0>(a, b, S, n, pitch, sink));
+        hipFree(c);
+    }
     hipMemset(a, 2, S * pitch + 8192);   // every cell covered: the worst case for the adds
     printf("  all layers, every cell a covered 'G'   : %6.0f\n", run<8, 3, 4, 15>(a, b, S, n, pitch, sink));
     return 0;
