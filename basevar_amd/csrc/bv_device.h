@@ -627,6 +627,9 @@ __device__ inline void bv_strand_bias_wave(uint32_t ref_fwd, uint32_t ref_rev, u
 __device__ inline unsigned long long bv_ranksum_window(uint32_t ref_v, uint32_t alt_v, unsigned long long n,
                                                        unsigned long long &below, int lane) {
     uint32_t t = ref_v + alt_v;
+    // (a window without a count adds nothing to the sum nor to `below`: mapq stops at 60, read-position ranks at the read length,
+    // so most windows of most rows are empty, and a scan, a 64-bit product and a 64-bit wave sum are ~50 instructions)
+    if (__ballot(t != 0u) == 0ull) return 0ull;
     uint32_t incl = bv_wave_incl_scan_u32(t, lane);
     unsigned long long below_v = below + (incl - t);
     unsigned long long term = (unsigned long long)ref_v * (2ull * n - 2ull * below_v - t + 1ull);

@@ -49,11 +49,27 @@ public:
         if (bi.align_bases.size() != n_ || bi.align_base_quals.size() != n_ || bi.mapqs.size() != n_ ||
             bi.map_strands.size() != n_ || bi.base_pos_ranks.size() != n_)
             throw std::runtime_error("[ERROR] Something is wrong in batchfiles.");  // caller.cpp:736
+        // The reference's order of complaints (basetype_caller.cpp:738-743): _out_cvg_line -> strand_bias runs BEFORE the
+        // BaseType constructor, over every sample whose token does not start with N / + / - -- an empty token (its [0] is the
+        // terminator) and characters outside ACGT included -- and refuses a strand that is neither + nor - (basetype.cpp:253-273);
+        // only a position that passes gets the constructor's checks.  (Held against the reference's own _basevar_caller by
+        // tests/test_host_formats.py.)
+        for (uint32_t i = 0; i < n_; ++i) {
+            const std::string &tok = bi.align_bases[i];
+            const char fb = tok.empty() ? '\0' : tok[0];
+            if (fb == 'N' || fb == '+' || fb == '-') continue;
+            const char s = bi.map_strands[i];
+            if (s != '+' && s != '-') throw std::runtime_error(std::string("[ERROR] Get strange strand symbol: ") + s);
+        }
         const size_t off = bs_.size();
         bs_.resize(off + pitch_, BV_CELL_N);
         q_.resize(off + pitch_, 0);
         mq_.resize(off + pitch_, 0);
         rp_.resize(off + pitch_, 0);
+        struct Undo {  // a refused site leaves nothing behind
+            SlabBuilder &sb; size_t off; bool keep = false;
+            ~Undo() { if (!keep) { sb.bs_.resize(off); sb.q_.resize(off); sb.mq_.resize(off); sb.rp_.resize(off); } }
+        } undo{*this, off};
         for (uint32_t i = 0; i < n_; ++i) {
             const std::string &tok = bi.align_bases[i];
             const char fb = tok.empty() ? '\0' : tok[0];  // (an empty token fails the size() != 1 check below, as in the reference)
@@ -77,10 +93,7 @@ public:
                                              "' is outside ACGTN+-: not representable in the slab (the reference would "
                                              "count it in the depth)");
                 } else {
-                    const char s = bi.map_strands[i];
-                    if (s != '+' && s != '-')  // src/basetype.cpp:272
-                        throw std::runtime_error(std::string("[ERROR] Get strange strand symbol: ") + s);
-                    cell = (uint8_t)(c | (s == '-' ? BV_CELL_REV : 0));
+                    cell = (uint8_t)(c | (bi.map_strands[i] == '-' ? BV_CELL_REV : 0));  // (+ or -: checked above)
                 }
             }
             bs_[off + i] = cell;
@@ -89,6 +102,7 @@ public:
             rp_[off + i] = (uint16_t)bi.base_pos_ranks[i];
         }
         ref_.push_back((uint8_t)base_code((char)std::toupper((unsigned char)(bi.ref_base.empty() ? 'N' : bi.ref_base[0]))));
+        undo.keep = true;
     }
 
     // One site straight from per-sample planes in the slab's own encoding (e.g. a row of a PileupTile, pileup.hpp).

@@ -50,13 +50,19 @@ inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_
     } guard{sb};
     size_t n_mq = 0, n_base = 0, n_qual = 0, n_rank = 0, n_strand = 0;
     uint32_t depth = 0;
-    size_t err_sample = (size_t)-1;  // the first sample (and of one sample the first check) that add_site would refuse
+    // What add_site would refuse, in the reference's order: the strand check of EVERY sample comes before the base tokens' checks
+    // (strand_bias runs from _out_cvg_line, ahead of the BaseType constructor: basetype_caller.cpp:738-743), each in sample order.
+    size_t err_sample = (size_t)-1;
     std::string err_msg;
     auto token_error = [&](size_t sample, int order, const std::string &m) {
-        // order: 0 = the base token's checks, 1 = the strand check (add_site's sequence for one sample)
-        const size_t key = sample * 2 + (size_t)order;
+        // order: 0 = the base token's checks (the constructor), 1 = the strand check (strand_bias: first)
+        const size_t key = sample + (order == 1 ? 0 : ((size_t)1 << 62));
         if (key < err_sample) { err_sample = key; err_msg = m; }
     };
+    // samples whose base token was refused: their cell stays 'N', but strand_bias looks at their strand all the same (the token
+    // does not START with N / + / -); ascending, consumed by the strand column's walk of the same row
+    std::vector<size_t> refused;
+    size_t refused_at = 0;
     for (size_t i = 0; i < rows.size(); ++i) {
         const std::string &row = rows[i];
         const char *col[10];
@@ -102,13 +108,15 @@ inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_
                     st.indel_tokens.emplace_back(p, (size_t)(e - p));
                 } else if (e - p != 1) {  // src/basetype.cpp:54-56
                     token_error(n_base, 0, "[ERROR] Why dose the size of aligned base is not 1? Check: " + std::string(p, (size_t)(e - p)));
+                    refused.push_back(n_base);
                 } else {
                     const int c = base_code(fb);
-                    if (c == BV_BASE_OTHER)
+                    if (c == BV_BASE_OTHER) {
                         token_error(n_base, 0, std::string("[ERROR] base character '") + fb +
                                                    "' is outside ACGTN+-: not representable in the slab (the reference would "
                                                    "count it in the depth)");
-                    else cell = (uint8_t)c;  // strand added below
+                        refused.push_back(n_base);
+                    } else cell = (uint8_t)c;  // strand added below
                 }
                 r.cell[n_base] = cell;
             }
@@ -117,9 +125,11 @@ inline bool parse_site_rows_fast(const std::vector<std::string> &rows, size_t n_
         walk(6, [&](const char *p, const char *e) { if (n_qual < n_sample) r.phred[n_qual] = (uint8_t)((p == e ? '\0' : *p) - 33); ++n_qual; });
         walk(7, [&](const char *p, const char *e) { if (n_rank < n_sample) r.rank[n_rank] = (uint16_t)parse_int_token(p, e); ++n_rank; });
         walk(8, [&](const char *p, const char *e) {
-            if (n_strand < n_sample && n_strand < n_base && !(r.cell[n_strand] & BV_CELL_NOCALL)) {
+            const bool was_refused = refused_at < refused.size() && refused[refused_at] == n_strand;
+            if (was_refused) ++refused_at;
+            if (n_strand < n_sample && n_strand < n_base && (was_refused || !(r.cell[n_strand] & BV_CELL_NOCALL))) {
                 const char s = p == e ? '\0' : *p;
-                if (s == '-') r.cell[n_strand] |= BV_CELL_REV;
+                if (s == '-') { if (!was_refused) r.cell[n_strand] |= BV_CELL_REV; }
                 else if (s != '+') token_error(n_strand, 1, std::string("[ERROR] Get strange strand symbol: ") + s);  // src/basetype.cpp:272
             }
             ++n_strand;

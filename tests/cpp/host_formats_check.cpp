@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
     }
 
     // ---- deterministic sites
-    const uint32_t N = 90, S = 30, NBF = 3;  // 3 batchfiles of 30 samples each
+    const uint32_t N = 90, S = 150, NBF = 3;  // 3 batchfiles of 30 samples each
     uint64_t st = 0x1234567ull;
     auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
     std::vector<BatchInfo> sites;
@@ -183,8 +183,17 @@ int main(int argc, char **argv) {
             return o;
         };
         size_t n_valid = 0, n_skipped = 0, n_threw = 0;
+        // every case also goes to argv[4] with the FAST reader's outcome: the Python test runs the reference's own
+        // _basevar_caller (oracle/_ref/libbvcaller.so) on the same rows and compares outcome kind and exception text
+        FILE *dump = argc > 4 ? std::fopen(argv[4], "w") : nullptr;
         auto compare = [&](const std::vector<std::string> &rows, size_t n, const char *tag) {
             const Outcome a = literal(rows, n), b = fast(rows, n);
+            if (dump) {
+                std::string w = b.what;
+                for (char &ch : w) if (ch == '\n') ch = '\x01';
+                std::fprintf(dump, "CASE %zu %zu %d %s\n", rows.size(), n, b.kind, w.c_str());
+                for (const std::string &r : rows) std::fprintf(dump, "%s\n", r.c_str());
+            }
             // (std::stoi's own exception texts are the library's; the two readers call it on the same fields)
             const bool same = a.kind == b.kind && a.what == b.what && a.planes == b.planes && (a.kind != 0 || a.text == b.text);
             CHECK(same, "fast reader != literal reader (" << tag << "): kinds " << a.kind << "/" << b.kind << " [" << a.what << "] vs [" << b.what << "] rows[0]=" << rows[0].substr(0, 200));
@@ -238,6 +247,7 @@ int main(int argc, char **argv) {
             CHECK(threw, "an empty base token raises the reference's error");
         }
         compare({"chr1\t5\ta\t1\t-3\t+AT\t\t70000\t-"}, 1, "negative mapq, empty quality, rank past 16 bits");
+        if (dump) std::fclose(dump);
         std::cout << "FAST_READER_CASES valid " << n_valid << " skipped " << n_skipped << " threw " << n_threw << std::endl;
         CHECK(n_valid > 100 && n_threw > 100, "the damaged rows exercise both outcomes");
     }
@@ -260,6 +270,13 @@ int main(int argc, char **argv) {
     std::cout << "VCF_HEADER_BEGIN\n" << vcf_header("ref.fa", "/abs/ref.fa", {{"chr11", 135006516}}, {"##INFO=<ID=BJ_AF>"}, {"s1", "s2"}) << "\nVCF_HEADER_END" << std::endl;
     for (size_t i = 0; i < kept.size(); ++i) {
         std::cout << "REC " << i << " " << rec[i].total_depth << " " << (int)rec[i].n_alt << std::endl;
+        // the site as three batchfile rows: the Python test hands them to the reference's own _basevar_caller
+        // (oracle/_ref/libbvcaller.so) and holds the CVG / VCF lines below against what THAT writes
+        for (uint32_t b = 0; b < NBF; ++b) {
+            uint32_t first = b * (N / NBF), cnt = N / NBF, cov = 0;
+            for (uint32_t k = first; k < first + cnt; ++k) cov += kept[i]->align_bases[k] != "N";
+            std::cout << "ROW " << format_batchfile_row(*kept[i], first, cnt, cov);
+        }
         std::string c = format_cvg_line(*kept[i], rec[i]);
         if (!c.empty()) std::cout << "CVG " << c;
         std::string v = format_vcf_line(*kept[i], rec[i], &grec[i * 2], gnames);

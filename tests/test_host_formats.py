@@ -9,6 +9,7 @@ GPU part: bv_call end to end on gzip batchfiles against lines derived from the o
 """
 import gzip
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -179,7 +180,8 @@ def test_host_formats_harness(tmp_path, restatement):
     recs = str(tmp_path / "recs.bin")
     if not have_ref:
         pytest.skip("oracle/_ref not available: primitives cannot be pinned here")
-    out = subprocess.run(args + [recs], capture_output=True, text=True)
+    cases = str(tmp_path / "reader_cases.txt")
+    out = subprocess.run(args + [recs, cases], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-3000:]
     assert "PRIMITIVES_CHECKED 1" in out.stdout and "FAILS 0" in out.stdout
     assert "FAST_READER_CASES" in out.stdout  # the byte-level batchfile reader against the literal one
@@ -224,6 +226,64 @@ def test_host_formats_harness(tmp_path, restatement):
                 else:
                     assert name + "_AF" not in info
     assert n_vcf >= 5
+    # ---- the same sites through the REFERENCE's own per-position caller (text in -> text out): the product's batchfile writer,
+    # its formatters and -- through the records -- its reader against the reference's object code, byte for byte
+    import ref_caller
+    if not ref_caller.available():
+        return
+    assert ref_caller.cvg_header().split("\n") == cvg_h
+    N = 90
+    grp = {"BJ": [i for i in range(N) if i % 3 != 0 and i % 2 == 0], "GD": [i for i in range(N) if i % 3 != 0 and i % 2 == 1]}
+    maf = restatement.min_af(N, 0.01)
+    rows, per_site, cur = [], [], None
+    for l in lines:
+        if l.startswith("REC "):
+            cur = {"rows": [], "cvg": "", "vcf": ""}
+            per_site.append(cur)
+        elif l.startswith("ROW "):
+            cur["rows"].append(l[4:])
+        elif l.startswith("CVG "):
+            cur["cvg"] = l[4:] + "\n"
+        elif l.startswith("VCF "):
+            cur["vcf"] = l[4:] + "\n"
+    assert len(per_site) == nrec and all(len(s["rows"]) == 3 for s in per_site)
+    n_var = 0
+    for k, s in enumerate(per_site):
+        variant, vcf, cvg = ref_caller.call_position(s["rows"], N, maf, grp)
+        assert cvg == s["cvg"], (k, cvg, s["cvg"])
+        assert vcf == s["vcf"], (k, vcf[:400], s["vcf"][:400])
+        n_var += variant
+    assert n_var == n_vcf
+    # ---- the byte-level reader's OUTCOME on valid, ragged and damaged rows against the reference's own: taken (a CVG line comes
+    # out), skipped (total depth 0: nothing), or an exception -- then with the reference's text.  One deliberate difference: a base
+    # character outside ACGTN+- is refused by the product (its slab has no code for it), the reference counts it in the depth.
+    raw_cases = open(cases, "rb").read().decode("latin-1").split("\n")
+    i = n_cases = n_threw = n_refused = 0
+    while i < len(raw_cases) and raw_cases[i].startswith("CASE "):
+        head = raw_cases[i].split(" ", 4)
+        n_rows, n_smp, kind, what = int(head[1]), int(head[2]), int(head[3]), (head[4] if len(head) > 4 else "").replace("\x01", "\n")
+        rows = raw_cases[i + 1:i + 1 + n_rows]
+        i += 1 + n_rows
+        n_cases += 1
+        try:
+            _, _, cvg = ref_caller.call_position([r.encode("latin-1").decode("latin-1") for r in rows], n_smp, restatement.min_af(n_smp, 0.01))
+            ref_kind, ref_what = (0 if cvg else 1), ""
+        except RuntimeError as e:
+            ref_kind, ref_what = 2, str(e)
+        if kind == 2 and "is outside ACGTN+-" in what:
+            n_refused += 1  # (the reference goes on: no CVG line if that was the only read, or an error further down the row)
+            continue
+        if kind == 0 and ref_kind == 1:
+            # taken by the reader, nothing written by the reference: a position whose only reads are indels (its Depth column
+            # counts them, the CVG line's depth is over A, C, G, T: basetype_caller.cpp:1241-1249); the product's emitter
+            # leaves such a site out the same way (format_cvg_line, checked above on the harness's own sites)
+            assert not any(t[:1] in ("A", "C", "G", "T") for r in rows for t in r.split("\t")[5].split(" ")), rows
+            continue
+        assert kind == ref_kind, (kind, what, ref_kind, ref_what, rows[0][:200])
+        if kind == 2:
+            n_threw += 1
+            assert what == ref_what, (what, ref_what, rows[0][:200])
+    assert n_cases > 5000 and n_threw > 1000, (n_cases, n_threw, n_refused)
 
 
 def make_batchfiles(tmp_path, n_sites=120, n_samples=60, n_files=3, seed=3):
@@ -269,6 +329,29 @@ def make_batchfiles(tmp_path, n_sites=120, n_samples=60, n_files=3, seed=3):
             fh.write("\n".join(rows[f]) + "\n")
         paths.append(p)
     return paths, ids, sites
+
+
+def reference_caller_lines(paths, n_samples, maf, groups=None):
+    """(CVG lines, VCF lines) the REFERENCE's own per-position caller writes for these batchfiles (oracle/_ref/libbvcaller.so:
+    `_basevar_caller` compiled where it lies, tests/ref_caller.py); None where that library is not available"""
+    import gzip
+    import ref_caller
+    if not ref_caller.available():
+        # (both reference builds come from one recipe, oracle/Makefile, and travel together)
+        assert not oracle.ref_available(), "oracle/_ref/libbvref.so is there but libbvcaller.so is not: make -C oracle"
+        return None
+    per_file = []
+    for p in paths:
+        opener = gzip.open if open(p, "rb").read(2) == b"\x1f\x8b" else open
+        with opener(p, "rt") as fh:
+            per_file.append([l.rstrip("\n") for l in fh if not l.startswith("#")])
+    assert len(set(len(x) for x in per_file)) == 1
+    cvg, vcf = [], []
+    for rows in zip(*per_file):
+        _, v, c = ref_caller.call_position(list(rows), n_samples, maf, groups)
+        cvg += [l for l in c.split("\n") if l]
+        vcf += [l for l in v.split("\n") if l]
+    return cvg, vcf
 
 
 def sites_to_slab(sites, n_samples):
@@ -342,6 +425,15 @@ def test_bv_call_end_to_end(tmp_path, restatement):
     bad = [(a[:300], b[:300]) for a, b in zip(got_vcf, exp_vcf) if not same(a, b)]
     assert len(bad) <= int(tie.sum()), bad[:2]
     assert exact >= len(exp_vcf) - int(tie.sum())   # byte-identical but for exact ties (measured: 51 of 51, no tie)
+    # the same files through the REFERENCE's own per-position caller: reader, caller, pop-groups and line formatting of the
+    # product (batchfiles -> GPU engine -> text) against the reference's object code, line by line
+    ref_lines = reference_caller_lines(paths, n_samples, maf, {"AA": [i for i in range(n_samples) if i % 4 != 3 and i % 2 == 0],
+                                                               "ZZ": [i for i in range(n_samples) if i % 4 != 3 and i % 2 == 1]})
+    if ref_lines is not None:
+        assert got_cvg == ref_lines[0]
+        assert len(got_vcf) == len(ref_lines[1])
+        assert sum(1 for a, b in zip(got_vcf, ref_lines[1]) if a == b) >= len(got_vcf) - int(tie.sum())
+        assert all(same(a, b) for a, b in zip(got_vcf, ref_lines[1]))
     hdr = [l for l in open(vcf).read().split("\n") if l.startswith("#")]
     assert hdr[-1].split("\t")[9:] == ids and any(l.startswith("##INFO=<ID=AA_AF") for l in hdr)
     # the block-parallel producer + emitter (`--thread`) write the same bytes (the byte-level reader itself is pinned against the
@@ -396,6 +488,24 @@ def test_bv_call_with_more_pop_groups_than_one_round(tmp_path, restatement):
     assert n_group_fields >= 10 * len(exp_vcf)  # most groups have an alt read at most variant sites
     hdr = [l for l in open(vcf).read().split("\n") if l.startswith("##INFO=<ID=pop")]
     assert len(hdr) == n_groups
+    # ... and against the reference's own per-position caller with the same 40 groups
+    ref_lines = reference_caller_lines(paths, n_samples, restatement.min_af(n_samples, 0.01),
+                                       {names[g]: [i for i in range(n_samples) if gid[i] == g] for g in range(n_groups)})
+    if ref_lines is not None:
+        got_cvg = [l for l in open(cvg).read().split("\n") if l and not l.startswith("#")]
+        assert got_cvg == ref_lines[0]
+        assert len(got_vcf) == len(ref_lines[1])
+        n_same = 0
+        for a, b in zip(got_vcf, ref_lines[1]):
+            if a == b:
+                n_same += 1
+                continue
+            fa, fb = re.split("[\t;,=:]", a), re.split("[\t;,=:]", b)  # (deep sites: a last printed digit may round differently)
+            assert len(fa) == len(fb)
+            for x, y in zip(fa, fb):
+                if x != y:
+                    assert abs(float(x) - float(y)) <= 1e-6 * max(1.0, abs(float(y))) + 1.5e-6, (x, y)
+        assert n_same >= 0.9 * len(got_vcf), (n_same, len(got_vcf))
 
 
 def test_tbi_reader_on_an_index_written_by_htslib():
