@@ -3,6 +3,9 @@
 * ``liboracle.so``      plain-C restatement (oracle/refcpu.c)
 * ``_ref/libbvref.so``  the real reference hot path (oracle/ref_driver.cpp + the
                         reference's own sources, compiled by oracle/Makefile)
+* ``_ref/libbvcaller.so``  the reference's own per-position caller, batchfile rows in ->
+                        the CVG / VCF bytes it writes (oracle/ref_caller_driver.cpp; loaded by
+                        tests/ref_caller.py)
 
 Only tests/, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of bench.py may
 import this package.  The product package ``basevar_amd`` never does.
