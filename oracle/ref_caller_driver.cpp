@@ -66,6 +66,35 @@ BVREF_EXPORT int bvref_caller_position(const char *const *lines, int n_lines, co
 
 BVREF_EXPORT void bvref_caller_free(char *p) { free(p); }
 
+// The writer half of the reference's pileup: `__write_record_to_batchfile` (src/basetype_caller.cpp:1027-1101) turns
+// the per-sample position maps that its CIGAR walk filled into batchfile rows.  Entries: (sample, position, reference bases, read
+// bases, mapq, read-position rank, strand, quality character); returns the rows it writes for [beg, end] (malloc'ed).  The CIGAR
+// walk itself (`__seek_position`) reads htslib's bam1_t through htslib functions and stays out of this library.
+BVREF_EXPORT char *bvref_write_batchfile_rows(const char *ref_id, uint32_t beg, uint32_t end, const char *fa_seq, size_t n_samples,
+                                              size_t n_entries, const uint32_t *e_sample, const uint32_t *e_pos,
+                                              const char *const *e_ref_base, const char *const *e_read_base, const int *e_mapq,
+                                              const int *e_rpr, const char *e_strand, const char *e_qual, size_t *len, char *err,
+                                              size_t err_cap) {
+    try {
+        PosMapVector v(n_samples);
+        for (size_t k = 0; k < n_entries; ++k) {
+            AlignBaseInfo a;
+            a.ref_id = ref_id; a.ref_pos = e_pos[k]; a.ref_base = e_ref_base[k]; a.read_base = e_read_base[k];
+            a.mapq = e_mapq[k]; a.rpr = e_rpr[k]; a.map_strand = e_strand[k]; a.read_base_qual = e_qual[k];
+            v[e_sample[k]][e_pos[k]] = a;
+        }
+        Sink out;
+        __write_record_to_batchfile(v, std::string(fa_seq), std::make_tuple(std::string(ref_id), beg, end), reinterpret_cast<BGZF *>(&out));
+        char *p = (char *)malloc(out.bytes.size() + 1);
+        std::memcpy(p, out.bytes.c_str(), out.bytes.size() + 1);
+        *len = out.bytes.size();
+        return p;
+    } catch (const std::exception &e) {
+        if (err && err_cap) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = '\0'; }
+        return nullptr;
+    }
+}
+
 // the CVG file's header lines as the reference defines them (src/basetype_utils.cpp:73-88; pure string work)
 BVREF_EXPORT char *bvref_cvg_header(void) {
     const std::string h = cvg_header_define(std::vector<std::string>(), std::vector<char>{'A', 'C', 'G', 'T'});

@@ -546,6 +546,22 @@ def test_bv_call_deep_rows_against_the_reference_caller(tmp_path, restatement):
     assert n_same >= 0.8 * (len(got_cvg) + len(got_vcf)), (n_same, len(got_cvg), len(got_vcf))
 
 
+def test_pileup_row_writer_against_the_references_own(tmp_path):
+    """SURVEY 8 f2, the writer half: pileup_rows_text (host/pileup.hpp: dense position x sample planes + indel tokens -> batchfile
+    rows) against the reference's `__write_record_to_batchfile` (basetype_caller.cpp:1027-1101, compiled where it lies:
+    oracle/_ref/libbvcaller.so) on random tiles -- uncovered positions, N calls, insertions, deletions, both strands, ranks to
+    65,535: byte for byte.  (The CIGAR walk that fills the planes reads BAM records through htslib and stays unpinned.)"""
+    import ref_caller
+    oracle.build(with_ref=True)
+    if not ref_caller.available():
+        pytest.skip("oracle/_ref/libbvcaller.so not available (no reference sources here)")
+    exe = str(tmp_path / "pileup_rows_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "pileup_rows_check.cpp"), "-ldl", "-lz", "-o", exe])
+    out = subprocess.run([exe, ref_caller.LIB], capture_output=True, text=True)
+    assert out.returncode == 0 and "FAILS 0" in out.stdout, (out.stdout[-500:], out.stderr[-2000:])
+
+
 def test_tbi_reader_on_an_index_written_by_htslib():
     """The reference's test data holds one real tabix index (tests/data/chr22.all.sites.vcf.gz.tbi, written by htslib; kept as
     a fixture under tests/golden/).  The independent reader that checks this repo's .tbi writer must read THAT file the way the
