@@ -1,8 +1,9 @@
 #!/bin/bash
-# the differential campaigns of a round against the real reference: tools/run_campaigns.sh <tag> [rounds per campaign]
+# the differential campaigns of a round against the real reference: tools/run_campaigns.sh <tag> [rounds per campaign] [seed offset]
 cd "$(dirname "$0")/.."; mkdir -p gpurun_out
-TAG=${1:-r5}; R=${2:-30}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
-run() { echo "### $1" >> $OUT; shift; env "$@" timeout 1500 python3 tools/diff_campaign.py $R 2>&1 | grep -E "TOTAL|tie-excused site [0-9]|MISMATCH|mismatching fields [1-9]" >> $OUT; }
+TAG=${1:-r5}; R=${2:-30}; OFF=${3:-0}; OUT=gpurun_out/${TAG}_diff_campaign.txt; : > $OUT
+[ "$OFF" != 0 ] && echo "# every CAMPAIGN_SEED below + $OFF" >> $OUT
+run() { echo "### $1" >> $OUT; shift; local a=(); for kv in "$@"; do case $kv in CAMPAIGN_SEED=*) a+=("CAMPAIGN_SEED=$(( ${kv#CAMPAIGN_SEED=} + OFF ))");; *) a+=("$kv");; esac; done; env "${a[@]}" timeout 1500 python3 tools/diff_campaign.py $R 2>&1 | grep -E "TOTAL|tie-excused site [0-9]|MISMATCH|mismatching fields [1-9]" >> $OUT; }
 run "fused short-row kernel: rows of 4,097-49,152 samples, seed 61" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=61
 run "fused short-row kernel, seed 62" CAMPAIGN_FUSED=1 CAMPAIGN_SEED=62
 run "fused short-row kernel, chained launches incl. pop-groups, seed 63" CAMPAIGN_FUSED=1 CAMPAIGN_CHAIN=1 CAMPAIGN_SEED=63
