@@ -247,6 +247,20 @@ int main(int argc, char **argv) {
             CHECK(threw, "an empty base token raises the reference's error");
         }
         compare({"chr1\t5\ta\t1\t-3\t+AT\t\t70000\t-"}, 1, "negative mapq, empty quality, rank past 16 bits");
+        // more edges, each also run through the reference's own caller by the Python test (argv[4])
+        compare({"chr1\t5\tA\t1\t60\tA\tI\t3\t+\r"}, 1, "CRLF line end");
+        compare({"chr1\t5\tA\t1\t60\tA\tI\t3\t+\t"}, 1, "trailing tab");
+        compare({"chr1\t99999999999\tA\t1\t60\tA\tI\t3\t+"}, 1, "position past int");
+        compare({"chr1\tx5\tA\t1\t60\tA\tI\t3\t+"}, 1, "position not a number");
+        compare({"chr1\t5\tA\tone\t60\tA\tI\t3\t+"}, 1, "depth not a number");
+        compare({"chr1\t5\tA\t-1\t60\tA\tI\t3\t+", "chr1\t5\tA\t1\t60\tC\tI\t3\t-"}, 2, "depths summing to zero hide the row");
+        compare({"chr1\t5\tA\t1\t 60\tA\tI\t3\t+"}, 1, "leading blank in a column");
+        compare({"chr1\t5\t\t1\t60\tA\tI\t3\t+"}, 1, "empty reference base");
+        compare({"chr1\t5\tAC\t1\t60\tA\tI\t3\t+"}, 1, "two reference bases");
+        compare({"chr1\t5\tA\t1\t60\ta\tI\t3\t+"}, 1, "lower-case read base");
+        compare({"chr1\t5\tA\t1\t6e1\tA\tI\t3.7\t+"}, 1, "numbers the int reader stops inside");
+        compare({"chr1\t5\tA\t2\t60 60\t+A -A\tI I\t3 4\t. ."}, 2, "indels only, no strands");
+        compare({"chr1\t5\tA\t2\t60 60\tA N\tI !\t3 0\t+ x"}, 2, "a strange strand on an N call is never looked at");
         if (dump) std::fclose(dump);
         std::cout << "FAST_READER_CASES valid " << n_valid << " skipped " << n_skipped << " threw " << n_threw << std::endl;
         CHECK(n_valid > 100 && n_threw > 100, "the damaged rows exercise both outcomes");
