@@ -4,7 +4,7 @@ pop-groups, VCF / CVG emit) against the REFERENCE's own per-position caller on t
 it lies: oracle/_ref/libbvcaller.so, tests/ref_caller.py).  CVG lines must be byte-identical; VCF lines byte-identical, or equal
 field by field to 1e-6 where a deep site's float rounds differently in its last printed digit.
 
-    python3 tools/text_campaign.py [rounds]          TEXT_CAMPAIGN_SEED=<n>  TEXT_CAMPAIGN_DEEP=1 (rows of 4,000-15,000 samples)
+    python3 tools/text_campaign.py [rounds]          TEXT_CAMPAIGN_SEED=<n>  TEXT_CAMPAIGN_DEEP=1 (rows of 4,000-15,000 samples) | 2 (50,000-72,000)
 """
 import os
 import re
@@ -36,10 +36,12 @@ def main():
         # TEXT_CAMPAIGN_DEEP=1: rows of 4,000-15,000 samples (the fused short-row kernel's lengths), fewer positions per round
         deep = os.environ.get("TEXT_CAMPAIGN_DEEP") == "1"
         per = int(rng.choice([1000, 1700, 2500])) if deep else int(rng.choice([3, 8, 20, 64, 150, 400]))
+        if os.environ.get("TEXT_CAMPAIGN_DEEP") == "2":  # rows of 50,000-72,000 samples: the long-row kernels
+            per, deep = int(rng.choice([10000, 12000])), True
         if deep:
-            n_files = int(rng.integers(4, 7))
+            n_files = int(rng.integers(5 if per >= 10000 else 4, 7))
         n_samples = n_files * per
-        n_sites = int(rng.integers(12, 25)) if os.environ.get("TEXT_CAMPAIGN_DEEP") == "1" else int(rng.integers(20, 70))
+        n_sites = int(rng.integers(20, 70)) if not deep else (int(rng.integers(6, 11)) if per >= 10000 else int(rng.integers(12, 25)))
         n_groups = int(rng.choice([0, 0, 1, 2, 5, 9]))
         d = os.path.join(tmp, "r%d" % r)
         os.makedirs(d)
