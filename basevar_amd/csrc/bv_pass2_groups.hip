@@ -337,6 +337,7 @@ void bv_launch_gid_prepare(const uint8_t *gid, uint8_t *gidp, uint32_t n_bytes, 
 #define BV_P2G_OCC 3  /* 160 VGPRs, no spills; at 4 waves per SIMD (128 VGPRs) 28 registers spilled: equal at 1-2 groups, 19 % slower at 8 */
 struct __attribute__((aligned(16))) BvP2gShared {
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];
+    double tab_loghit[BV_QBINS], tab_logmiss[BV_QBINS];  // (from device memory they are a trip per slot inside a dependent chain)
     uint32_t grp[BV_P2G_NW][4][BV_G16_GRP_WORDS];  // per group of 16 lanes: previous marginals, [slot][lane of the group]
 };
 __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16_kernel(BvPass2Args a) {
@@ -345,6 +346,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
     for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P2G_NW) {
         sh.tab_hit[i] = a.tables->hit[i];
         sh.tab_miss[i] = a.tables->miss[i];
+        sh.tab_loghit[i] = a.tables->loghit[i];
+        sh.tab_logmiss[i] = a.tables->logmiss[i];
     }
     __syncthreads();
     const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         uint32_t gdepth[4] = {it[1], it[2], it[3], it[4]};
         const uint32_t gtotal = gdepth[0] + gdepth[1] + gdepth[2] + gdepth[3];
         BvG16Bins B;
-        B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = a.tables->loghit; B.logmiss = a.tables->logmiss;
+        B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sh.tab_loghit; B.logmiss = sh.tab_logmiss;
         B.pm = reinterpret_cast<double *>(sh.grp[wave][grp]) + gl;
 #pragma unroll
         for (int s = 0; s < BV_G16_SLOTS; ++s) {
