@@ -17,6 +17,7 @@ BV_MAX_ALT = 4
 BV_MAX_GROUPS = 255
 BV_NO_GROUP = 0xFF
 BV_MEM_DEVICE, BV_MEM_HOST = 0, 1
+BV_SLAB_RPR_TAGGED, BV_RPR_TAG_MAX_RANK = 0x1, 0x1FFF  # bv_slab.layout
 BV_FLAG_LANES = 0x10000000
 BV_FLAG_SPARSE_TIMING = 0x20000000  # include/basevar_amd.h
 BV_FORM_SHORT_ROWS, BV_FORM_ONE_KERNEL, BV_FORM_PASS2_FUSED = 0x1, 0x2, 0x4  # include/basevar_amd_diag.h
@@ -47,7 +48,7 @@ class Slab(C.Structure):
     _fields_ = [("n_sites", C.c_uint32), ("n_samples", C.c_uint32), ("pitch", C.c_uint64),
                 ("base_strand", C.c_void_p), ("qual", C.c_void_p), ("mapq", C.c_void_p), ("rpr", C.c_void_p),
                 ("ref_base", C.c_void_p), ("group_id", C.c_void_p), ("n_groups", C.c_uint32),
-                ("mem_kind", C.c_uint32)]
+                ("mem_kind", C.c_uint32), ("layout", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class EngineConfig(C.Structure):
@@ -58,7 +59,7 @@ class EngineConfig(C.Structure):
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("site_offset", C.c_uint64), ("coverage", C.c_float),
                 ("indel_frac", C.c_float), ("qual_mean", C.c_float), ("qual_sd", C.c_float),
-                ("qual_min", C.c_uint32), ("qual_max", C.c_uint32)]
+                ("qual_min", C.c_uint32), ("qual_max", C.c_uint32), ("layout", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 # every symbol include/basevar_amd.h declares

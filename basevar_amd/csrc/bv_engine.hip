@@ -249,6 +249,8 @@ struct bv_engine {
     uint32_t *tile_ovf = nullptr;      // pool of read-position ranks beyond the window (bv_tiles.hip), kOvfCap entries
     static constexpr uint32_t kOvfCap = 1u << 22;
     bool tile_ranks = false, tile_open = false;
+    uint32_t tile_layout = 0;          // bv_slab.layout of the job's tiles (every tile of a job has the first one's)
+    bool tile_layout_set = false;
     hipStream_t copy_stream[2] = {nullptr, nullptr};  // alternate: the set-up of one copy hides under the transfer of the other
     // joined-rows realisation of the tile mode: resident planes [tile_sites][j_pitch]
     bool tile_join = false;
@@ -476,7 +478,7 @@ int stage_host_planes(bv_engine *e, HostPlane *pl, int n, size_t extra, bv_engin
 
 extern "C" {
 
-const char *bv_version(void) { return "basevar_amd 0.1 abi1 gfx950"; }
+const char *bv_version(void) { return "basevar_amd 0.2 abi2 gfx950"; }
 
 double bv_min_af(uint32_t n_samples, float user_min_af) {
     // src/basetype_caller.cpp:122: min_af = std::min(float(100)/input_bf.size(), min_af)
@@ -659,7 +661,8 @@ int bv_engine_destroy(bv_engine *e) {
 static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, const uint8_t *mq, const uint16_t *rp,
                          const uint8_t *refb, const uint8_t *gid, size_t P, uint32_t n_sites, uint32_t n_samples, uint32_t n_groups,
                          bv_site_result *dout, bv_group_result *dgout, hipStream_t st, const BvChain *chain = nullptr /* device */,
-                         bool chain_cat = false /* chained short rows: refb / dout are contiguous copies */) {
+                         bool chain_cat = false /* chained short rows: refb / dout are contiguous copies */, uint32_t layout = 0 /* BV_SLAB_* */) {
+    const uint32_t rpr_tag = (layout & BV_SLAB_RPR_TAGGED) && rp != nullptr ? 1u : 0u;
     const size_t S = n_sites, G = n_groups;
     // The group kernels hold one (base, phred) histogram per group in LDS and are built for at most BV_GROUPS_PER_ROUND of them;
     // the reference takes any number of groups (a std::map, basetype_caller.cpp:372-410).  More groups run as ROUNDS of pass 2:
@@ -715,6 +718,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
     a2.gitems = nullptr; a2.gitem_cap = 0; a2.gidp = nullptr;
     a2.ch = chain;
     a2.ch_cat = chain_cat ? 1u : 0u;
+    a2.rpr_tag = rpr_tag;
     if (G && gid && dgout && !(e->cfg.flags & BV_FLAG_GROUP_INLINE)) {
         // scratch for the group calls of the variant sites (1.5 KiB per site x group), grown on demand and capped at 8 GiB:
         // the variant sites past the cap keep the one-wave-per-group solver inside the tally kernel.  An allocation that
@@ -803,7 +807,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         s1.cand_list = e->d_cand_list; s1.easy_list = e->d_easy_list; s1.easy3_list = e->d_easy3_list;
         s1.ovf = e->d_ovf;
         s1.ch = chain;
-        s1.mapq = nullptr; s1.rpr = nullptr;
+        s1.mapq = nullptr; s1.rpr = nullptr; s1.rpr_tag = rpr_tag;
         // Rows of at least three 4 KiB slots: pass 1 as ONE persistent kernel (bv_pass1_fused.hip: solver waves beside the
         // streaming waves of every workgroup), which streams the variant sites' rank-sum rows (pass 2) too -- with pop-groups
         // where their tallies stream on their own (<= 7 groups): the launch that follows then carries the group kernels only.
@@ -898,6 +902,8 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: planes must be 16-byte aligned");
     if (slab->mem_kind != BV_MEM_HOST && misaligned(out))
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: device record buffers must be 16-byte aligned");
+    if ((slab->layout & ~BV_SLAB_RPR_TAGGED) || slab->reserved_)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit: unknown bv_slab.layout bits (built against another BV_ABI_VERSION?)");
 
     BV_HIP(e, hipSetDevice(e->cfg.device));
     if ((e->cfg.flags & BV_FLAG_LANES) && !e->is_lane && slab->mem_kind != BV_MEM_HOST) {
@@ -972,7 +978,7 @@ int bv_engine_submit(bv_engine *e, const bv_slab *slab, bv_site_result *out, bv_
         if (rc != BV_OK) return rc;
     }
 
-    int rc = launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st);
+    int rc = launch_passes(e, bs, q, mq, rp, refb, gid, P, slab->n_sites, slab->n_samples, slab->n_groups, dout, dgout, st, nullptr, false, slab->layout);
     if (rc == BV_OK && slot) rc = stage_release(e, slot, st);  // planes read, records copied back: the slot may be refilled
     return rc;
 }
@@ -999,7 +1005,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
         if (!outs[k]) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: null record buffer");
         if (s.n_sites == 0 || s.n_samples == 0 || s.pitch < s.n_samples || (s.pitch & 15ull) || !s.base_strand || !s.qual || !s.ref_base ||
             (s.mapq == nullptr) != (s.rpr == nullptr) || misaligned(s.base_strand) || misaligned(s.qual) || misaligned(s.mapq) ||
-            misaligned(s.rpr) || (s.mem_kind != BV_MEM_HOST && misaligned(outs[k])) || s.n_groups > BV_MAX_GROUPS)
+            misaligned(s.rpr) || (s.mem_kind != BV_MEM_HOST && misaligned(outs[k])) || s.n_groups > BV_MAX_GROUPS || (s.layout & ~BV_SLAB_RPR_TAGGED) || s.reserved_)
             return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab fails the checks of bv_engine_submit");
         if (s.n_groups > 0 && (!s.group_id || !gouts || !gouts[k]))
             return fail(e, BV_ERR_INVALID_ARG, "bv_engine_submit_many: a slab with pop-groups needs group_id and its gouts[k] (bv_engine_submit_many_g)");
@@ -1008,7 +1014,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
         // length, one pitch, one set of planes, one group assignment)
         chainable = chainable && s.mem_kind != BV_MEM_HOST && !(e->cfg.flags & (BV_FLAG_PASS2_SWEEP | BV_FLAG_GROUP_INLINE)) &&
                     s.n_samples == slabs[0].n_samples && s.pitch == slabs[0].pitch && (s.mapq == nullptr) == (slabs[0].mapq == nullptr) &&
-                    s.n_groups == slabs[0].n_groups && (s.n_groups == 0 || s.group_id == slabs[0].group_id);
+                    s.n_groups == slabs[0].n_groups && (s.n_groups == 0 || s.group_id == slabs[0].group_id) && s.layout == slabs[0].layout;
         total += s.n_sites;
     }
     const uint32_t G = slabs[0].n_groups;
@@ -1060,7 +1066,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
         const bv_slab &s0 = slabs[k0];
         bv_group_result *g0 = G ? gouts[k0] : nullptr;
         if (nk == 1) {
-            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, gid, P, first, s0.n_samples, G, outs[k0], g0, st);
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, gid, P, first, s0.n_samples, G, outs[k0], g0, st, nullptr, false, s0.layout);
             if (rc != BV_OK) return rc;
             continue;
         }
@@ -1070,7 +1076,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
         BV_HIP(e, hipMemcpyAsync(d_ch, &ch, sizeof(BvChain), hipMemcpyHostToDevice, st));
         if (s0.n_samples > BV_SHORT_ROW_MAX) {
             // long rows: every kernel looks its segment up per site (planes, reference bases, records)
-            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, gid, P, first, s0.n_samples, G, outs[k0], g0, st, d_ch);
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, s0.ref_base, gid, P, first, s0.n_samples, G, outs[k0], g0, st, d_ch, false, s0.layout);
             if (rc != BV_OK) return rc;
         } else {
             // short rows: the planes are looked up per row (wave-uniform places only); the per-site reference bases and records,
@@ -1085,7 +1091,7 @@ int bv_engine_submit_many_g(bv_engine *e, uint32_t n_slabs, const bv_slab *slabs
             }
             bv_launch_chain_gather_ref(d_ch, first, e->d_ref_cat, st);
             BV_HIP(e, hipGetLastError());
-            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, e->d_ref_cat, gid, P, first, s0.n_samples, G, e->d_out_cat, g0, st, d_ch, true);
+            int rc = launch_passes(e, s0.base_strand, s0.qual, s0.mapq, s0.rpr, e->d_ref_cat, gid, P, first, s0.n_samples, G, e->d_out_cat, g0, st, d_ch, true, s0.layout);
             if (rc != BV_OK) return rc;
             bv_launch_chain_scatter_out(d_ch, first, e->d_out_cat, st);
             BV_HIP(e, hipGetLastError());
@@ -1104,6 +1110,7 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
     if (n_groups > BV_MAX_GROUPS) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: n_groups exceeds BV_MAX_GROUPS");
     BV_HIP(e, hipSetDevice(e->cfg.device));
     e->tile_join = false;
+    e->tile_layout = 0; e->tile_layout_set = false;
     if (!(e->cfg.flags & BV_FLAG_TILE_STATE)) {
         // joined rows: [n_sites][pitch] planes resident in HBM, if they fit next to what is already there
         const size_t pitch = ((size_t)n_samples_total + 255) & ~(size_t)255, plane = (size_t)n_sites * pitch;
@@ -1198,6 +1205,9 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     if (e->tile_groups && !t->group_id) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: job has groups, tile has no group_id");
     if ((uint64_t)e->tile_samples_seen + t->n_samples > e->tile_samples_total)
         return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: more samples than announced");
+    if ((t->layout & ~BV_SLAB_RPR_TAGGED) || t->reserved_ || (e->tile_layout_set && t->layout != e->tile_layout))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add: every tile of a job must have the same bv_slab.layout (known bits only)");
+    e->tile_layout = t->layout; e->tile_layout_set = true;
     BV_HIP(e, hipSetDevice(e->cfg.device));
     hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
     {
@@ -1250,6 +1260,7 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     a.rank_win = e->tile_rank_win; a.hg_off = e->tile_hg_off;
     a.maxr = e->tile_maxr;
     a.ord_off = e->tile_ord_off; a.col0 = e->tile_samples_seen; a.ovf = e->tile_ovf; a.ovf_cap = bv_engine::kOvfCap;
+    a.rpr_tag = (e->tile_layout & BV_SLAB_RPR_TAGGED) ? 1u : 0u;
     bv_launch_tile_tally(a, st);
     BV_HIP(e, hipGetLastError());
     if (slot) {
@@ -1276,6 +1287,8 @@ int bv_engine_tiles_add_many(bv_engine *e, uint32_t n_tiles, const bv_slab *tile
         if (e->tile_groups && !t.group_id) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: job has groups, tile has no group_id");
         seen += t.n_samples;
         if (seen > e->tile_samples_total) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: more samples than announced");
+        if ((t.layout & ~BV_SLAB_RPR_TAGGED) || t.reserved_ || t.layout != tiles[0].layout || (e->tile_layout_set && t.layout != e->tile_layout))
+            return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_many: every tile of a job must have the same bv_slab.layout (known bits only)");
         one_launch = one_launch && t.mem_kind != BV_MEM_HOST;
     }
     if (!one_launch) {
@@ -1291,6 +1304,7 @@ int bv_engine_tiles_add_many(bv_engine *e, uint32_t n_tiles, const bv_slab *tile
         int rc = use_stream(e, st);
         if (rc != BV_OK) return rc;
     }
+    e->tile_layout = tiles[0].layout; e->tile_layout_set = true;
     const uint64_t JP = e->j_pitch;
     for (uint32_t k0 = 0; k0 < n_tiles; k0 += BV_TILE_MANY_MAX) {
         const uint32_t nk = n_tiles - k0 < (uint32_t)BV_TILE_MANY_MAX ? n_tiles - k0 : (uint32_t)BV_TILE_MANY_MAX;
@@ -1411,11 +1425,17 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     if (e->tile_join) {
         e->tile_open = false;
         if (e->tile_samples_seen < e->tile_samples_total)  // samples announced but never delivered: uncovered cells
+        {
             BV_HIP(e, hipMemset2DAsync(e->j_buf + e->tile_samples_seen, e->j_pitch, 0x08, e->tile_samples_total - e->tile_samples_seen, S, st));
+            // (tagged ranks: the same cells' rank words must say "no call" too -- 0x8080: the tag's bit 15, rank 128)
+            if (e->tile_ranks && (e->tile_layout & BV_SLAB_RPR_TAGGED))
+                BV_HIP(e, hipMemset2DAsync(e->j_buf + e->j_o_rp + 2 * (size_t)e->tile_samples_seen, 2 * e->j_pitch, 0x80,
+                                           2 * (size_t)(e->tile_samples_total - e->tile_samples_seen), S, st));
+        }
         int rc = launch_passes(e, e->j_buf, e->j_buf + e->j_o_q, e->tile_ranks ? e->j_buf + e->j_o_mq : nullptr,
                                e->tile_ranks ? reinterpret_cast<const uint16_t *>(e->j_buf + e->j_o_rp) : nullptr, dref,
                                G ? e->j_buf + e->j_o_gid : nullptr, e->j_pitch, e->tile_sites, e->tile_samples_total, e->tile_groups,
-                               dout, dgout, st);
+                               dout, dgout, st, nullptr, false, e->tile_layout);
         if (rc == BV_OK && slot) rc = stage_release(e, slot, st);
         return rc;
     }

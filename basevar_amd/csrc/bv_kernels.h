@@ -103,6 +103,7 @@ struct BvPass2Args {
     const BvChain *ch;        // device memory, or NULL: a chained launch -- planes (and gout) come per segment, biased
     uint32_t ch_cat;          // chained short rows: ref_base / out are the engine's CONTIGUOUS copies, indexed with the global site
                               // number as they are; else (long rows) they come per segment too
+    uint32_t rpr_tag;         // 1: the rpr plane is in the tagged layout (BV_SLAB_RPR_TAGGED): rank | base << 13 | nocall << 15
 };
 // item: [0] = number of bins | state, [1..4] = the group's ACGT depths, [5] = bases with a phred-0 call, [8..] = its bins
 // (valid phreds only, (base, phred) order): code << 16 | count for BV_P2G_PENDING items, code << 23 | count for BV_P2G_HARD ones
@@ -151,6 +152,7 @@ struct BvP1ShortArgs {
     const uint8_t *mapq;
     const uint16_t *rpr;
     uint32_t *ovf;         // bv_pass1_fused.hip: [n_sites][4] the workgroups' overflow lists of variant sites (site, class table, depths, lut)
+    uint32_t rpr_tag;      // 1: the rpr plane is in the tagged layout (BV_SLAB_RPR_TAGGED); the pass-2 rows then stream mapq + ranks only
 };
 // chained short-row launches: reference bases of all segments -> one array; records of all segments <- one array
 void bv_launch_chain_gather_ref(const BvChain *ch, uint32_t n_sites, uint8_t *ref_cat, hipStream_t stream);
@@ -178,6 +180,7 @@ struct BvTileArgs {
     uint32_t col0;            // index of the tile's first sample in the job (the list is put in sample order by it)
     uint32_t *ovf;            // pool of read-position ranks >= rank_win: [0] entries appended, then (site, base << 16 | rank) pairs
     uint32_t ovf_cap;         // entries the pool holds
+    uint32_t rpr_tag;         // 1: the tile's rpr plane is in the tagged layout (BV_SLAB_RPR_TAGGED)
 };
 // Per-site list of covered cells (per-site-tally realisation): word 0 = cells appended, then BV_ORD_MAX x (sample index,
 // call << 8 | phred | group << 16).  Complete -- and used, sorted by sample index, for the reference's per-sample replay --

@@ -179,6 +179,37 @@ __device__ __forceinline__ void bv_f_glds4_masked(uint32_t d0, const uint8_t *p0
           [mA] "s"(mA), [mB] "s"(mB)
         : "memory", "scc");
 }
+// A pass-2 slot of the tagged rank layout (BV_SLAB_RPR_TAGGED): no call bytes -- 1 KiB of mapq and 2 KiB of ranks to the slot's
+// second, third and fourth KiB under the lane mask `m` (all lanes; a row's last slot: its valid lanes).  Still FOUR loads, because
+// the counted waits count four per slot whatever its kind: the first is lane 0 alone, 16 bytes of the mapq piece into the unused
+// first KiB (the same line the second load fetches: no traffic of its own).
+__device__ __forceinline__ void bv_f_glds4_tag(uint32_t d0, const uint8_t *p1, uint32_t v1, const uint8_t *p2, uint32_t v2, uint32_t v3,
+                                               unsigned long long m) {
+    uint32_t keep, t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "s_mov_b32 m0, %[d0]\n\t"
+        "s_add_u32 %[t], %[d0], 0x400\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
+        "s_mov_b64 exec, %[m]\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_add_u32 %[t], %[d0], 0x800\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_add_u32 %[t], %[d0], 0xc00\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p2] nt\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
+        : [d0] "s"(d0), [p1] "s"(p1), [p2] "s"(p2), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [m] "s"(m)
+        : "memory", "scc");
+}
 // One wave-level compare-and-swap on an LDS word by lane 0, the old value in an SGPR (no divergent branch, no vector-memory
 // operation: see bv_lds_fetch_add_wave)
 __device__ __forceinline__ uint32_t bv_f_lds_cas_wave(uint32_t lds_addr, uint32_t expect, uint32_t desired) {
@@ -628,7 +659,8 @@ __device__ __forceinline__ void bv_f_publish(const BvP1ShortArgs &a, BvFusedShar
 __device__ __attribute__((noinline)) void bv_f_p2_redo(const uint8_t *bs_, const uint8_t *mapq_, const uint16_t *rpr_, bv_site_result *out_, uint64_t pitch,
                                                        uint32_t n_samples, uint32_t site_, uint32_t lut_, uint32_t n12_, uint32_t hist_lds_) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)site_), lut = (uint32_t)__builtin_amdgcn_readfirstlane((int)lut_);
+    const uint32_t site = (uint32_t)__builtin_amdgcn_readfirstlane((int)site_), lut_tag = (uint32_t)__builtin_amdgcn_readfirstlane((int)lut_);
+    const uint32_t lut = lut_tag & 0xFFu;  // bit 31: the rank plane is tagged (BV_SLAB_RPR_TAGGED)
     const uint32_t n12 = (uint32_t)__builtin_amdgcn_readfirstlane((int)n12_);
     uint32_t *h = (uint32_t *)(bv_lds_u32 *)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hist_lds_);
     bv_site_result *out = (bv_site_result *)(__attribute__((address_space(1))) bv_site_result *)out_;
@@ -647,6 +679,7 @@ __device__ __attribute__((noinline)) void bv_f_p2_redo(const uint8_t *bs_, const
     bv_lrt_sync<0>();
     BvP2Ctx cx;
     cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false;
+    cx.rmask = bv_rpr_rank_mask(lut_tag >> 31);
     bv_p2_sweep<BV_WAVE, true, true, false, 256>(cx, as, site, lane);
     const uint32_t maxr = (uint32_t)bv_wave_max_i32((int)cx.maxr);
     bv_lrt_sync<0>();
@@ -733,6 +766,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         a.easy3_list = BV_F_GLOBAL(uint32_t, ka->easy3_list); a.ch = BV_F_GLOBAL(const BvChain, ka->ch);
         a.mapq = BV_F_GLOBAL(const uint8_t, ka->mapq); a.rpr = BV_F_GLOBAL(const uint16_t, ka->rpr);
         a.ovf = BV_F_GLOBAL(uint32_t, ka->ovf);
+        a.rpr_tag = ka->rpr_tag;
     }
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     uint32_t *hist = sh.hist[wave];
@@ -771,6 +805,9 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     }
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+    // the tagged rank layout (BV_SLAB_RPR_TAGGED): a pass-2 row is mapq + ranks, the class of a cell comes from its rank word
+    const bool tag = FUSE2 && a.rpr_tag != 0u;
+    const uint32_t hi_mask = bv_rpr_hi_mask(tag ? 1u : 0u);
 
     // ---- prefetch side: the next slot to request
     const uint8_t *p0 = a.bs, *p1 = a.q, *p2 = a.q;  // pass 1: calls, phreds; pass 2: calls, mapq, ranks
@@ -847,6 +884,9 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         if (!FUSE2 || p_kind == BV_FK_P1) {
             if (p_left > 1u) { bv_f_glds4(d0, p0, va, p0, vb, p1, va, p1, vb); p0 += 2048; p1 += 2048; }
             else bv_f_glds4_masked(d0, p0, va, p0, vbl, p1, va, p1, vbl, mA1, mB1);
+        } else if (tag) {
+            if (p_left > 1u) { bv_f_glds4_tag(d0, p1, va, p2, vr0, vr1, ~0ull); p1 += 1024; p2 += 2048; }
+            else bv_f_glds4_tag(d0, p1, va, p2, vr0, vr1, mA2);
         } else {
             if (p_left > 1u) { bv_f_glds4(d0, p0, va, p1, va, p2, vr0, p2, vr1); p0 += 1024; p1 += 1024; p2 += 2048; }
             else bv_f_glds4_masked(d0, p0, va, p1, va, p2, vr0, p2, vr1, mA2, mA2);
@@ -931,16 +971,32 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                 // w0: calls; w1: mapq; w2 / w3: ranks 0-7 / 8-15 of the lane's 16 cells.  The tally of bv_pass2_dma_kernel
                 // (bv_pass2.hip): class bytes by one v_perm per dword, class << 8 | value by one v_perm per cell, "< 0x200"
                 // the whole predicate.
-                if (j + 1u == n_slots) {
-                    w0.x = (w0.x & keep2[0]) | (N4 & ~keep2[0]); w0.y = (w0.y & keep2[1]) | (N4 & ~keep2[1]);
-                    w0.z = (w0.z & keep2[2]) | (N4 & ~keep2[2]); w0.w = (w0.w & keep2[3]) | (N4 & ~keep2[3]);
-                    if ((uint32_t)lane >= last2) { w2 = bv_u32x4{0u, 0u, 0u, 0u}; w3 = w2; }  // (not loaded: stale bytes)
-                }
                 const uint32_t L = c_x;
-                const uint32_t c0 = __builtin_amdgcn_perm(L, L, w0.x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, w0.y) ^ 0x80808080u;
-                const uint32_t c2 = __builtin_amdgcn_perm(L, L, w0.z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, w0.w) ^ 0x80808080u;
+                uint32_t c0, c1, c2, c3;
+                if (tag) {
+                    // (w0 is not loaded: the cells' calls are the tags of their rank words)
+                    if (j + 1u == n_slots) {
+                        if ((uint32_t)lane >= last2) { w2 = bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u}; w3 = w2; }  // (not loaded: stale bytes)
+                        else if (tail && (uint32_t)lane == last2 - 1u) {
+                            w2.x = bv_p2t_mask_tail(w2.x, tail); w2.y = bv_p2t_mask_tail(w2.y, tail - 2);
+                            w2.z = bv_p2t_mask_tail(w2.z, tail - 4); w2.w = bv_p2t_mask_tail(w2.w, tail - 6);
+                            w3.x = bv_p2t_mask_tail(w3.x, tail - 8); w3.y = bv_p2t_mask_tail(w3.y, tail - 10);
+                            w3.z = bv_p2t_mask_tail(w3.z, tail - 12); w3.w = bv_p2t_mask_tail(w3.w, tail - 14);
+                        }
+                    }
+                    c0 = bv_p2t_class4(L, w2.x, w2.y); c1 = bv_p2t_class4(L, w2.z, w2.w);
+                    c2 = bv_p2t_class4(L, w3.x, w3.y); c3 = bv_p2t_class4(L, w3.z, w3.w);
+                } else {
+                    if (j + 1u == n_slots) {
+                        w0.x = (w0.x & keep2[0]) | (N4 & ~keep2[0]); w0.y = (w0.y & keep2[1]) | (N4 & ~keep2[1]);
+                        w0.z = (w0.z & keep2[2]) | (N4 & ~keep2[2]); w0.w = (w0.w & keep2[3]) | (N4 & ~keep2[3]);
+                        if ((uint32_t)lane >= last2) { w2 = bv_u32x4{0u, 0u, 0u, 0u}; w3 = w2; }  // (not loaded: stale bytes)
+                    }
+                    c0 = __builtin_amdgcn_perm(L, L, w0.x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, w0.y) ^ 0x80808080u;
+                    c2 = __builtin_amdgcn_perm(L, L, w0.z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, w0.w) ^ 0x80808080u;
+                }
                 // ranks that do not fit the 256-rank window: remembered, the row is then re-done by the window sweeps
-                hi_acc |= (w2.x | w2.y | w2.z | w2.w | w3.x | w3.y | w3.z | w3.w) & 0xFF00FF00u;
+                hi_acc |= (w2.x | w2.y | w2.z | w2.w | w3.x | w3.y | w3.z | w3.w) & hi_mask;
                 uint32_t x[16];
                 x[0] = bv_p2d_xm<0>(c0, w1.x); x[1] = bv_p2d_xm<1>(c0, w1.x); x[2] = bv_p2d_xm<2>(c0, w1.x); x[3] = bv_p2d_xm<3>(c0, w1.x);
                 x[4] = bv_p2d_xm<0>(c1, w1.y); x[5] = bv_p2d_xm<1>(c1, w1.y); x[6] = bv_p2d_xm<2>(c1, w1.y); x[7] = bv_p2d_xm<3>(c1, w1.y);
@@ -1118,7 +1174,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                 const uint32_t sg = bv_chain_seg(ch, site);
                 r_bs = ch->bs[sg]; r_mq = ch->mapq[sg]; r_rp = ch->rpr[sg];
             }
-            bv_f_p2_redo(r_bs, r_mq, r_rp, a.out, a.pitch, a.n_samples, site, c_z, c_y, (uint32_t)(uintptr_t)(bv_lds_u32 *)hist);
+            bv_f_p2_redo(r_bs, r_mq, r_rp, a.out, a.pitch, a.n_samples, site, c_z | (tag ? 0x80000000u : 0u), c_y, (uint32_t)(uintptr_t)(bv_lds_u32 *)hist);
         } else {
             uint32_t *hm = hist, *hr = hist + 512;
             unsigned long long below = 0, twoR = 0;

@@ -44,7 +44,9 @@ extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_g
 // phred byte > 127) in the row, the caller re-does the row with the branchy window sweeps (bv_p2_sweep).  L: class table
 // (byte b = 0x80 REF / 0x81 ALT / 0xFF neither).  ~6 VALU + 2 predicated ds_add per cell for the rank sums, ~4 + 1 for the
 // groups; the branchy sweep takes ~18 VALU for the rank sums alone.
-template <int NT, bool RANKS, bool GROUPS, bool HALF = false>
+// TAG (rank sums without pop-groups, BV_SLAB_RPR_TAGGED): the class of a cell comes from the tag in its rank word
+// (bv_p2t_class4) and the call plane is not read at all -- 3 bytes per cell, SURVEY 8d's figure, instead of 4.
+template <int NT, bool RANKS, bool GROUPS, bool HALF = false, bool TAG = false>
 __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr, uint32_t *hg) {
     const size_t row = (size_t)site * a.pitch;
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
@@ -57,6 +59,9 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
     const bv_u32x4 zero = bv_u32x4{0u, 0u, 0u, 0u}, none = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+    static_assert(!TAG || (RANKS && !GROUPS), "the tagged form: rank sums without pop-groups");
+    const bv_u32x4 nocall = bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+    const uint32_t hi_mask = TAG ? 0x1F001F00u : bv_rpr_hi_mask(a.rpr_tag);
     uint32_t hi_acc = 0;
     constexpr int U = 2;
     for (uint32_t base = 0; base < n_chunks; base += NT * U) {
@@ -65,8 +70,9 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
         for (int u = 0; u < U; ++u) {
             const uint32_t idx = base + u * NT + tid;
             vb[u] = none; vm[u] = vr0[u] = vr1[u] = vq[u] = vg[u] = zero;
+            if (TAG) vr0[u] = vr1[u] = nocall;
             if (idx < n_chunks) {
-                vb[u] = __builtin_nontemporal_load(b4 + idx);
+                if (!TAG) vb[u] = __builtin_nontemporal_load(b4 + idx);
                 if (RANKS) {
                     vm[u] = __builtin_nontemporal_load(m4 + idx);
                     vr0[u] = __builtin_nontemporal_load(r4 + 2 * (size_t)idx);
@@ -82,15 +88,28 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
         for (int u = 0; u < U; ++u) {
             const uint32_t idx = base + u * NT + tid;
             if (tail && idx == n_chunks - 1) {
-                vb[u].x = bv_p2_mask_tail(vb[u].x, tail); vb[u].y = bv_p2_mask_tail(vb[u].y, tail - 4);
-                vb[u].z = bv_p2_mask_tail(vb[u].z, tail - 8); vb[u].w = bv_p2_mask_tail(vb[u].w, tail - 12);
+                if (TAG) {
+                    vr0[u].x = bv_p2t_mask_tail(vr0[u].x, tail); vr0[u].y = bv_p2t_mask_tail(vr0[u].y, tail - 2);
+                    vr0[u].z = bv_p2t_mask_tail(vr0[u].z, tail - 4); vr0[u].w = bv_p2t_mask_tail(vr0[u].w, tail - 6);
+                    vr1[u].x = bv_p2t_mask_tail(vr1[u].x, tail - 8); vr1[u].y = bv_p2t_mask_tail(vr1[u].y, tail - 10);
+                    vr1[u].z = bv_p2t_mask_tail(vr1[u].z, tail - 12); vr1[u].w = bv_p2t_mask_tail(vr1[u].w, tail - 14);
+                } else {
+                    vb[u].x = bv_p2_mask_tail(vb[u].x, tail); vb[u].y = bv_p2_mask_tail(vb[u].y, tail - 4);
+                    vb[u].z = bv_p2_mask_tail(vb[u].z, tail - 8); vb[u].w = bv_p2_mask_tail(vb[u].w, tail - 12);
+                }
             }
             uint32_t x[16];
             if (RANKS) {
                 const bv_u32x4 r0 = vr0[u], r1 = vr1[u], vmq = vm[u];
-                const uint32_t c0 = __builtin_amdgcn_perm(L, L, vb[u].x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, vb[u].y) ^ 0x80808080u;
-                const uint32_t c2 = __builtin_amdgcn_perm(L, L, vb[u].z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, vb[u].w) ^ 0x80808080u;
-                hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & 0xFF00FF00u;
+                uint32_t c0, c1, c2, c3;
+                if (TAG) {
+                    c0 = bv_p2t_class4(L, r0.x, r0.y); c1 = bv_p2t_class4(L, r0.z, r0.w);
+                    c2 = bv_p2t_class4(L, r1.x, r1.y); c3 = bv_p2t_class4(L, r1.z, r1.w);
+                } else {
+                    c0 = __builtin_amdgcn_perm(L, L, vb[u].x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, vb[u].y) ^ 0x80808080u;
+                    c2 = __builtin_amdgcn_perm(L, L, vb[u].z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, vb[u].w) ^ 0x80808080u;
+                }
+                hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & hi_mask;
                 x[0] = bv_p2d_xm<0>(c0, vmq.x); x[1] = bv_p2d_xm<1>(c0, vmq.x); x[2] = bv_p2d_xm<2>(c0, vmq.x); x[3] = bv_p2d_xm<3>(c0, vmq.x);
                 x[4] = bv_p2d_xm<0>(c1, vmq.y); x[5] = bv_p2d_xm<1>(c1, vmq.y); x[6] = bv_p2d_xm<2>(c1, vmq.y); x[7] = bv_p2d_xm<3>(c1, vmq.y);
                 x[8] = bv_p2d_xm<0>(c2, vmq.z); x[9] = bv_p2d_xm<1>(c2, vmq.z); x[10] = bv_p2d_xm<2>(c2, vmq.z); x[11] = bv_p2d_xm<3>(c2, vmq.z);
@@ -125,7 +144,7 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
 
 // HALF (with GROUPS, not INLINE; rows of at most 65,535 samples): the group histograms hold 16-bit counters, 1 KiB per group
 // instead of 2 -- with 16-32 groups that is what decides how many workgroups a CU holds (32 groups: 45 KiB instead of 77).
-template <int NT, bool RANKS, bool GROUPS, bool INLINE = true, bool HALF = false>
+template <int NT, bool RANKS, bool GROUPS, bool INLINE = true, bool HALF = false, bool TAG = false>
 __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     static_assert(!HALF || (GROUPS && !INLINE), "16-bit group counters: the item-exporting form only");
     constexpr uint32_t GW = HALF ? 256u : 512u;  // words of one group's histogram
@@ -190,13 +209,13 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
 
         BvP2Ctx cx;
         cx.hm = sh.hm; cx.hr = sh.hr; cx.hg = hg;
-        cx.lut = lut; cx.win_lo = 0; cx.n_groups = a.n_groups; cx.maxr = 0; cx.half = HALF;
+        cx.lut = lut; cx.win_lo = 0; cx.n_groups = a.n_groups; cx.maxr = 0; cx.half = HALF; cx.rmask = bv_rpr_rank_mask(a.rpr_tag);
         // Rank sums without pop-groups: the perm form first (a third of the instructions; 256-rank window).  A row that holds a
         // rank >= 256 (long reads) is re-done by the window sweeps below.
         const bool FAST = !GROUPS || a.gidp != nullptr;
         bool fast_ok = false;
         if (FAST) {
-            const uint32_t hi = bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
+            const uint32_t hi = bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
             const bool any_hi = __ballot(hi != 0u) != 0ull;
             if (lane == 0) sh.maxr[wave] = any_hi ? 1u : 0u;
             __syncthreads();
@@ -436,7 +455,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2S_WAVES, 4) void bv_pass2_short_kerne
         bv_lrt_sync<0>();
         BvP2Ctx cx;
         cx.hm = hm; cx.hr = hr; cx.hg = nullptr;
-        cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false;
+        cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false; cx.rmask = bv_rpr_rank_mask(a.rpr_tag);
         BvPass2Args as = a;  // the sweeps index the planes with the site number themselves
         if (a.ch != nullptr) {  // a chained launch (short rows: ref_base / out are contiguous): the segment's biased planes
             const BvChainC ch = bv_chain_const(a.ch);
@@ -503,7 +522,11 @@ struct __attribute__((aligned(16))) BvPass2DmaShared {
     uint32_t ring[BV_P2D_WAVES][BV_P2D_K][BV_P2D_SLOT_WORDS];
 };
 
+// TAG (BV_SLAB_RPR_TAGGED): a slot is three pieces -- 1 KiB of mapq, 2 KiB of ranks --, the class of a cell comes from the tag in
+// its rank word (bv_p2t_class4) and the call plane is not read.
+template <bool TAG>
 __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvPass2Args a) {
+    constexpr int PIECES = TAG ? 3 : 4;  // LDS-DMA loads per slot: what the counted waits count
     __shared__ BvPass2DmaShared sh;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -550,7 +573,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
             const uint8_t *pr = bv_uniform_ptr(seg_rp + 2u * row);
             const uint32_t dst = ring_lds + ring_w * (BV_P2D_SLOT_WORDS * 4u);
             if (p_j + 1u < n_slots || (uint32_t)lane < last_valid) {  // lanes past the row's end load nothing (lane 0 always loads)
-                bv_glds16(dst, pb, voff);
+                if (!TAG) bv_glds16(dst, pb, voff);
                 bv_glds16(dst + 1024u, pm, voff);
                 bv_glds16(dst + 2048u, pr, voff * 2u);         // 32 bytes of ranks per lane: two 16-byte halves
                 bv_glds16(dst + 3072u, pr + 16, voff * 2u);
@@ -618,10 +641,11 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
         uint32_t hi_acc = 0;
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
-            if (inflight == (uint32_t)BV_P2D_K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (BV_P2D_K - 1)) : "memory");
+            if (inflight == (uint32_t)BV_P2D_K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (BV_P2D_K - 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const uint32_t *sl = ring + ring_r * BV_P2D_SLOT_WORDS;
-            bv_u32x4 vb = *reinterpret_cast<const bv_u32x4 *>(sl + lane * 4);
+            bv_u32x4 vb = bv_u32x4{0u, 0u, 0u, 0u};
+            if (!TAG) vb = *reinterpret_cast<const bv_u32x4 *>(sl + lane * 4);
             const bv_u32x4 vm = *reinterpret_cast<const bv_u32x4 *>(sl + 256 + lane * 4);
             bv_u32x4 r0 = *reinterpret_cast<const bv_u32x4 *>(sl + 512 + lane * 4);   // ranks 0-7
             bv_u32x4 r1 = *reinterpret_cast<const bv_u32x4 *>(sl + 768 + lane * 4);   // ranks 8-15
@@ -633,19 +657,32 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
                 const uint32_t chunk = j * 64u + (uint32_t)lane;
                 if (chunk >= n_chunks) {  // not loaded: stale bytes
                     vb = bv_u32x4{0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u};
-                    r0 = bv_u32x4{0u, 0u, 0u, 0u};
+                    r0 = TAG ? bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u} : bv_u32x4{0u, 0u, 0u, 0u};
                     r1 = r0;
                 } else if (tail && chunk == n_chunks - 1) {
-                    vb.x = bv_mask_tail_dword(vb.x, tail); vb.y = bv_mask_tail_dword(vb.y, tail - 4);
-                    vb.z = bv_mask_tail_dword(vb.z, tail - 8); vb.w = bv_mask_tail_dword(vb.w, tail - 12);
+                    if (TAG) {
+                        r0.x = bv_p2t_mask_tail(r0.x, tail); r0.y = bv_p2t_mask_tail(r0.y, tail - 2);
+                        r0.z = bv_p2t_mask_tail(r0.z, tail - 4); r0.w = bv_p2t_mask_tail(r0.w, tail - 6);
+                        r1.x = bv_p2t_mask_tail(r1.x, tail - 8); r1.y = bv_p2t_mask_tail(r1.y, tail - 10);
+                        r1.z = bv_p2t_mask_tail(r1.z, tail - 12); r1.w = bv_p2t_mask_tail(r1.w, tail - 14);
+                    } else {
+                        vb.x = bv_mask_tail_dword(vb.x, tail); vb.y = bv_mask_tail_dword(vb.y, tail - 4);
+                        vb.z = bv_mask_tail_dword(vb.z, tail - 8); vb.w = bv_mask_tail_dword(vb.w, tail - 12);
+                    }
                 }
             }
             // class bytes of the 16 cells (REF 0x00, ALT 0x01, neither >= 0x7F)
-            const uint32_t c0 = __builtin_amdgcn_perm(L, L, vb.x) ^ 0x80808080u, c1 = __builtin_amdgcn_perm(L, L, vb.y) ^ 0x80808080u;
-            const uint32_t c2 = __builtin_amdgcn_perm(L, L, vb.z) ^ 0x80808080u, c3 = __builtin_amdgcn_perm(L, L, vb.w) ^ 0x80808080u;
-            // ranks of classified cells that do not fit the 256-rank window: remembered, the row is then re-done by sweeps
-            // (a rank dword counts only if one of its two cells is classified -- valid data has rank 0 in uncovered cells anyway)
-            hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & 0xFF00FF00u;
+            uint32_t c0, c1, c2, c3;
+            if (TAG) {
+                c0 = bv_p2t_class4(L, r0.x, r0.y); c1 = bv_p2t_class4(L, r0.z, r0.w);
+                c2 = bv_p2t_class4(L, r1.x, r1.y); c3 = bv_p2t_class4(L, r1.z, r1.w);
+            } else {
+                c0 = __builtin_amdgcn_perm(L, L, vb.x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, vb.y) ^ 0x80808080u;
+                c2 = __builtin_amdgcn_perm(L, L, vb.z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, vb.w) ^ 0x80808080u;
+            }
+            // ranks that do not fit the 256-rank window: remembered, the row is then re-done by sweeps (valid data has rank 0
+            // in uncovered cells)
+            hi_acc |= (r0.x | r0.y | r0.z | r0.w | r1.x | r1.y | r1.z | r1.w) & (TAG ? 0x1F001F00u : 0xFF00FF00u);
             uint32_t x[16];
             x[0] = bv_p2d_xm<0>(c0, vm.x); x[1] = bv_p2d_xm<1>(c0, vm.x); x[2] = bv_p2d_xm<2>(c0, vm.x); x[3] = bv_p2d_xm<3>(c0, vm.x);
             x[4] = bv_p2d_xm<0>(c1, vm.y); x[5] = bv_p2d_xm<1>(c1, vm.y); x[6] = bv_p2d_xm<2>(c1, vm.y); x[7] = bv_p2d_xm<3>(c1, vm.y);
@@ -670,6 +707,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
             bv_lrt_sync<0>();
             BvP2Ctx cx;
             cx.hm = hm; cx.hr = hr; cx.hg = nullptr; cx.lut = lut; cx.win_lo = 0; cx.n_groups = 0; cx.maxr = 0; cx.half = false;
+            cx.rmask = bv_rpr_rank_mask(a.rpr_tag);
             BvPass2Args as = a;  // the sweeps index the planes with the site number themselves
             if (a.ch != nullptr) {
                 const BvChainC ch = bv_chain_const(a.ch);
@@ -765,6 +803,8 @@ static void bv_launch_pass2_nt(const BvPass2Args &a, hipStream_t stream) {
         hipLaunchKernelGGL((bv_pass2_kernel<NT, true, true, false>), dim3(grid), dim3(NT), dyn, stream, a);
     else if (ranks && groups)
         hipLaunchKernelGGL((bv_pass2_kernel<NT, true, true, true>), dim3(grid), dim3(NT), dyn, stream, a);
+    else if (ranks && a.rpr_tag)
+        hipLaunchKernelGGL((bv_pass2_kernel<NT, true, false, true, false, true>), dim3(grid), dim3(NT), dyn, stream, a);
     else if (ranks)
         hipLaunchKernelGGL((bv_pass2_kernel<NT, true, false>), dim3(grid), dim3(NT), dyn, stream, a);
     else if (items)
@@ -791,7 +831,8 @@ void bv_launch_pass2(const BvPass2Args &a_in, hipStream_t stream) {
         if (grid > need) grid = need;
         const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
         if (cap && grid > cap) grid = cap;
-        hipLaunchKernelGGL(bv_pass2_dma_kernel, dim3(grid), dim3(BV_WAVE * BV_P2D_WAVES), 0, stream, a);
+        if (a.rpr_tag) hipLaunchKernelGGL(bv_pass2_dma_kernel<true>, dim3(grid), dim3(BV_WAVE * BV_P2D_WAVES), 0, stream, a);
+        else hipLaunchKernelGGL(bv_pass2_dma_kernel<false>, dim3(grid), dim3(BV_WAVE * BV_P2D_WAVES), 0, stream, a);
         return;
     }
     if (a.n_samples <= 16384u && ranks && !groups) {

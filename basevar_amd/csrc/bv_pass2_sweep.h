@@ -16,6 +16,7 @@ struct BvP2Ctx {
     uint32_t n_groups;
     uint32_t maxr;     // per-lane running max of classified ranks
     bool half;         // hg holds 16-bit counters, two per word (rows of at most 65,535 samples; bv_pass2_kernel<.., HALF>)
+    uint32_t rmask = 0xFFFFu;  // the rank bits of a word of the rpr plane (0x1FFF: BV_SLAB_RPR_TAGGED)
 };
 
 template <bool RANKS, bool MAPQ, bool GROUPS, int RW = BV_RPR_WIN>
@@ -30,7 +31,7 @@ __device__ __forceinline__ void bv_p2_dword(BvP2Ctx &cx, uint32_t w, uint32_t mq
                 uint32_t cls = (cx.lut >> (2 * b)) & 3u;
                 if (cls < 2u) {
                     if (MAPQ) atomicAdd(&cx.hm[cls * 256u + ((mq >> (8 * j)) & 0xFFu)], 1u);
-                    uint32_t r = ((j < 2 ? r01 : r23) >> (16 * (j & 1))) & 0xFFFFu;
+                    uint32_t r = ((j < 2 ? r01 : r23) >> (16 * (j & 1))) & cx.rmask;
                     cx.maxr = max(cx.maxr, r);
                     uint32_t rr = r - cx.win_lo;
                     if (rr < (uint32_t)RW) atomicAdd(&cx.hr[cls * RW + rr], 1u);

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void bv_synth_kernel(bv_synth_params p, uint32
             wb[j >> 2] |= code << (8 * (j & 3));
             wq[j >> 2] |= qq << (8 * (j & 3));
             wm[j >> 2] |= mq << (8 * (j & 3));
+            if (p.layout & BV_SLAB_RPR_TAGGED) rp = BV_RPR_TAGGED(code, rp);  // the producer's choice: ranks are <= 100 here
             wr[j >> 1] |= rp << (16 * (j & 1));
         }
         const size_t off = (size_t)site * pitch + (size_t)ch * 16u;

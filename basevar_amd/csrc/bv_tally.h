@@ -191,8 +191,29 @@ __device__ __forceinline__ uint32_t bv_p2d_xm(uint32_t cls4, uint32_t mq4) {  //
     return __builtin_amdgcn_perm(cls4, mq4, SEL);
 }
 template <int J, int H>
-__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // rank_hi << 16 | class byte J << 8 | rank_lo (rank H of r2)
-    constexpr uint32_t SEL = 0x0C000000u | ((uint32_t)(2 * H + 1) << 16) | ((4u + J) << 8) | (uint32_t)(2 * H);
+__device__ __forceinline__ uint32_t bv_p2d_xr(uint32_t cls4, uint32_t r2) {  // class byte J << 8 | rank_lo (rank H of r2)
+    // (the rank's high byte stays out: every caller ORs the high bytes of ALL rank words of a row and re-does a row that holds a
+    // rank >= 256 by the window sweeps -- and in the tagged layout, BV_SLAB_RPR_TAGGED, that byte carries the cell's call)
+    constexpr uint32_t SEL = 0x0C0C0000u | ((4u + J) << 8) | (uint32_t)(2 * H);
     return __builtin_amdgcn_perm(cls4, r2, SEL);
+}
+
+// ---- the tagged rank plane (BV_SLAB_RPR_TAGGED, include/basevar_amd.h): rank | base << 13 | nocall << 15 per 16-bit word.
+// what the OR of a row's rank dwords must not hold in the perm form (a rank >= 256), per layout
+__device__ __forceinline__ uint32_t bv_rpr_hi_mask(uint32_t tagged) { return tagged ? 0x1F001F00u : 0xFF00FF00u; }
+__device__ __forceinline__ uint32_t bv_rpr_rank_mask(uint32_t tagged) { return tagged ? 0x1FFFu : 0xFFFFu; }
+// Class bytes (REF 0x00, ALT 0x01, neither >= 0x7F: the values bv_p2d_xm / bv_p2d_xr take) of FOUR cells from the tags of their
+// rank words (r01: cells 0, 1; r23: cells 2, 3) -- no call byte is read.  One v_perm gathers the four high bytes, a shift by
+// five leaves tag = base | nocall << 2 in every byte (the five rank bits that would spill into the neighbour are zero in any
+// row that stays in the perm form; a row with a rank >= 256 is re-done anyway, and whatever selector such a row produces only
+// picks some class: the histogram index stays below 0x200), and the tag selects from {L, 0xFFFFFFFF}: a base -> its class
+// byte in L (0x80 REF, 0x81 ALT, 0xFF neither), no call -> 0xFF.  4 VALU per four cells, against 2 with the call plane.
+__device__ __forceinline__ uint32_t bv_p2t_class4(uint32_t L, uint32_t r01, uint32_t r23) {
+    const uint32_t hb = __builtin_amdgcn_perm(r23, r01, 0x07050301u);
+    return __builtin_amdgcn_perm(0xFFFFFFFFu, L, hb >> 5) ^ 0x80808080u;
+}
+// the cells of a row's last chunk at or beyond n_samples read as "no call": `keep` = cells of this rank dword that stay (<= 0: none)
+__device__ __forceinline__ uint32_t bv_p2t_mask_tail(uint32_t r2, int keep) {
+    return keep >= 2 ? r2 : (keep <= 0 ? 0x80008000u : ((r2 & 0xFFFFu) | 0x80000000u));
 }
 

@@ -27,6 +27,7 @@
 // not fit the HBM even in site chunks); by default the engine joins the tiles into rows resident in HBM
 // (bv_tile_scatter_kernel below) and runs the ordinary two passes on them.
 #include "bv_solver.h"
+#include "bv_tally.h"  // bv_rpr_rank_mask
 
 #define BV_TS_H1 0u
 #define BV_TS_HM 2048u
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void bv_tile_tally_kernel(BvTileArgs a) {
         atomicAdd(&S[BV_TS_H1 + ((c << 8) | q)], 1u);
         if (a.mapq) {
             const uint32_t mq = (wm[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            const uint32_t r = (wr[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const uint32_t r = (wr[j >> 1] >> (16 * (j & 1))) & bv_rpr_rank_mask(a.rpr_tag);
             atomicAdd(&S[BV_TS_HM + ((b << 8) | mq)], 1u);
             maxr = max(maxr, r);
             if (r < a.rank_win) atomicAdd(&S[BV_TS_HR + b * a.rank_win + r], 1u);

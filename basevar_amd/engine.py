@@ -105,14 +105,15 @@ class BaseTypeEngine:
 
     # ---- raw pointer interface (device or host pointers as ints)
     def submit_ptrs(self, n_sites, n_samples, pitch, base_strand, qual, ref_base, out, mapq=0, rpr=0, group_id=0,
-                    n_groups=0, gout=0, mem_kind=_capi.BV_MEM_DEVICE, stream=0):
+                    n_groups=0, gout=0, mem_kind=_capi.BV_MEM_DEVICE, stream=0, layout=0):
+        """`layout`: bv_slab.layout (BV_SLAB_RPR_TAGGED: the rpr plane carries the cells' calls, include/basevar_amd.h)."""
         slab = _capi.Slab(int(n_sites), int(n_samples), int(pitch), base_strand or None, qual or None, mapq or None,
-                          rpr or None, ref_base or None, group_id or None, int(n_groups), int(mem_kind))
+                          rpr or None, ref_base or None, group_id or None, int(n_groups), int(mem_kind), int(layout))
         rc = self._lib.bv_engine_submit(self._h, C.byref(slab), out or None, gout or None, stream or None)
         if rc != 0:
             raise RuntimeError("bv_engine_submit failed (%d): %s" % (rc, self._err()))
 
-    def submit_many_ptrs(self, n_samples, pitch, slabs, stream=0, group_id=0, n_groups=0, gouts=None):
+    def submit_many_ptrs(self, n_samples, pitch, slabs, stream=0, group_id=0, n_groups=0, gouts=None, layout=0):
         """Several device-resident slabs as ONE launch per pass (bv_engine_submit_many / _g).  `slabs`: a sequence of
         (n_sites, base_strand, qual, ref_base, out, mapq, rpr) with device pointers as ints (mapq = rpr = 0: no rank sums);
         pop-groups: one `group_id` array for the whole queue, `gouts[k]` = slab k's group records."""
@@ -122,7 +123,7 @@ class BaseTypeEngine:
         gp = (C.c_void_p * n)() if n_groups else None
         for k, (n_sites, bs, q, ref, out, mq, rp) in enumerate(slabs):
             arr[k] = _capi.Slab(int(n_sites), int(n_samples), int(pitch), bs or None, q or None, mq or None, rp or None, ref or None,
-                                group_id or None, int(n_groups), _capi.BV_MEM_DEVICE)
+                                group_id or None, int(n_groups), _capi.BV_MEM_DEVICE, int(layout))
             outs[k] = out
             if n_groups:
                 gp[k] = gouts[k]
@@ -246,7 +247,7 @@ class BaseTypeEngine:
                 tg = plane(4, np.uint8, 1, 0xFF); tg[0, :w] = np.asarray(gid, dtype=np.uint8)[lo:lo + w]
             keep.append(buf)
             p = lambda a: None if a is None else a.ctypes.data
-            t = _capi.Slab(S, w, P, p(tb), p(tq), p(tm), p(tr), None, p(tg), ng, _capi.BV_MEM_HOST)
+            t = _capi.Slab(S, w, P, p(tb), p(tq), p(tm), p(tr), None, p(tg), ng, _capi.BV_MEM_HOST, int(slab.get("layout", 0)))
             rc = self._lib.bv_engine_tiles_add(self._h, C.byref(t), None)
             if rc != 0:
                 raise RuntimeError("bv_engine_tiles_add failed (%d): %s" % (rc, self._err()))
@@ -289,7 +290,7 @@ class BaseTypeEngine:
         gout = np.zeros((S, ng), dtype=_capi.GROUP_DTYPE) if ng else None
         p = lambda a: 0 if a is None else a.ctypes.data
         self.submit_ptrs(S, N, pitch, p(bs), p(q), p(ref), p(out), p(mq), p(rp), p(gid), ng, p(gout),
-                         mem_kind=_capi.BV_MEM_HOST)
+                         mem_kind=_capi.BV_MEM_HOST, layout=int(slab.get("layout", 0)))
         self.wait()
         ms1, ms2 = self.kernel_ms()
         return BaseTypeBatch(out, gout, self.last_variant_count(), ms1, ms2)
@@ -310,11 +311,11 @@ def tile_packed_layout(n_sites, width, with_ranks=True, with_groups=False):
 
 def synth_fill(device, n_sites, n_samples, pitch, base_strand, qual, ref_base, mapq=0, rpr=0, seed=0xBA5E7A7,
                site_offset=0, coverage=0.08, indel_frac=0.005, qual_mean=32.0, qual_sd=6.0, qual_min=2, qual_max=41,
-               stream=0):
+               stream=0, layout=0):
     """Device-side synthetic pileup (bench helper): all pointers are device pointers (ints)."""
     lib = _capi.load()
     sp = _capi.SynthParams(int(seed), int(site_offset), float(coverage), float(indel_frac), float(qual_mean),
-                           float(qual_sd), int(qual_min), int(qual_max))
+                           float(qual_sd), int(qual_min), int(qual_max), int(layout))
     rc = lib.bv_synth_fill(int(device), C.byref(sp), int(n_sites), int(n_samples), int(pitch), base_strand, qual,
                            mapq or None, rpr or None, ref_base, stream or None)
     if rc != 0:

@@ -81,3 +81,18 @@ def make_slab(n_sites, n_samples, seed=0, coverage=0.08, indel_frac=0.005, qual_
             lo = hi
         slab["group_id"] = gid
     return slab
+
+
+def tag_ranks(slab):
+    """The same slab in the tagged rank layout (BV_SLAB_RPR_TAGGED, include/basevar_amd.h): every word of the rpr plane
+    also carries its cell's call, rpr = rank | (call & 3) << 13 | (call >> 3) << 15 -- what a producer does when every
+    rank of the slab is <= 8,191.  Cells past n_samples are tagged from their (garbage) padding bytes like any other:
+    the engine must ignore them."""
+    rp = np.asarray(slab["rpr"], dtype=np.uint16)
+    if int(rp[:, :int(slab.get("n_samples", rp.shape[1]))].max(initial=0)) > 0x1FFF:
+        raise ValueError("tag_ranks: a read-position rank beyond 8,191 does not fit the tagged layout")
+    bs = np.asarray(slab["base_strand"], dtype=np.uint16)
+    out = dict(slab)
+    out["rpr"] = ((rp & 0x1FFF) | ((bs & 3) << 13) | (((bs >> 3) & 1) << 15)).astype(np.uint16)
+    out["layout"] = 1
+    return out

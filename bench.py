@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--coverage", type=float, default=0.08)
     ap.add_argument("--distinct-batches", type=int, default=2)
     ap.add_argument("--no-rank-planes", action="store_true", help="omit mapq/rpr planes (pass 2 skipped)")
+    ap.add_argument("--rank-layout", choices=("tagged", "plain"), default="tagged",
+                    help="layout of the u16 read-position-rank plane the synthetic producer writes: tagged = BV_SLAB_RPR_TAGGED "
+                         "(rank | base << 13 | nocall << 15: every rank here is <= 100, so the producer may choose it; pass 2 then "
+                         "reads SURVEY 8d's 3 B/cell: mapq + rpr); plain = the rank alone (pass 2 re-reads the call plane: 4 B/cell)")
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0xBA5E7A7)
@@ -155,7 +159,7 @@ def cpu_quota():
         return None
 
 
-def cpu_baseline(torch, planes, n_samples, maf, want_sites):
+def cpu_baseline(torch, planes, n_samples, maf, want_sites, rank_mask=0xFFFF):
     """Times the reference's per-site path on the host cores over rows copied back from HBM: an all-core leg (one thread per
     physical core, static site-range partition as in _variants_discovery, src/basetype_caller.cpp:489-510) and a
     single-thread leg, each at least ~2 s of wall per repeat, median of 3 repeats."""
@@ -184,7 +188,7 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites):
              "n_samples": n_samples}
         if mq is not None:
             d["mapq"] = mq[ti].cpu().numpy()
-            d["rpr"] = rp[ti].cpu().numpy().view(np.uint16)
+            d["rpr"] = rp[ti].cpu().numpy().view(np.uint16) & np.uint16(rank_mask)  # (the tagged layout's call bits are not the reference's)
         return d, idx
 
     last = {}
@@ -269,12 +273,13 @@ class TileRig:
     bv_tile_packed_layout: a tile crosses the link as one copy), allocated and first touched while the thread is bound to the
     CPUs of the GPU's NUMA node (bv_bind_thread_to_device_node), so every rank streams from node-local DRAM."""
 
-    def __init__(self, torch, eng, dev, device_index, St, W, n_tiles, res, src, host=True):
+    def __init__(self, torch, eng, dev, device_index, St, W, n_tiles, res, src, host=True, layout=0):
         import basevar_amd
         from basevar_amd import _capi
         self.torch, self.eng, self.lib, self.capi = torch, eng, eng._lib, _capi
         self.St, self.W, self.Wp, self.n_tiles, self.res = St, W, (W + 15) // 16 * 16, n_tiles, res
         self.n_samples = n_tiles * W
+        self.layout = layout
         bs0, q0, mq0, rp0, ref0 = src
         self.ref = ref0[:St].contiguous()
 
@@ -311,7 +316,7 @@ class TileRig:
         if kind not in self._slabs:
             tiles = self.htiles if kind == self.capi.BV_MEM_HOST else self.dtiles
             self._slabs[kind] = [self.capi.Slab(self.St, self.W, self.Wp, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(),
-                                                t[3].data_ptr(), None, None, 0, kind) for t in (tiles[k % self.res] for k in range(self.n_tiles))]
+                                                t[3].data_ptr(), None, None, 0, kind, self.layout) for t in (tiles[k % self.res] for k in range(self.n_tiles))]
         return self._slabs[kind]
 
     def job(self, out_ptr, kind, many=False, stream=0):
@@ -420,6 +425,7 @@ def main():
         fit = max(1, int(96e9 // (5.0 * B * pitch)))
         nb = max(nb, min(K, fit))
     ranks = not args.no_rank_planes
+    LAY = _capi_mod.BV_SLAB_RPR_TAGGED if (ranks and args.rank_layout == "tagged") else 0  # bv_slab.layout of every slab / tile
 
     # ---- synthetic batches, resident in HBM.  Global site index = ((batch * world) + rank) * B + row,
     # so every rank owns a contiguous site range of every batch (sites shard embarrassingly).
@@ -432,7 +438,7 @@ def main():
         ref = torch.empty(B, dtype=torch.uint8, device=dev)
         basevar_amd.synth_fill(local_rank, B, N_fill, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(),
                                mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0, seed=args.seed,
-                               site_offset=(b * world + rank) * B, coverage=args.coverage)
+                               site_offset=(b * world + rank) * B, coverage=args.coverage, layout=LAY)
         batches.append((bs, q, mq, rp, ref))
     torch.cuda.synchronize()
 
@@ -468,7 +474,7 @@ def main():
     rig = None
     if tj:
         # this rank's tiles: pinned host allocations on the GPU's NUMA node, cut from the rank's own source rows
-        rig = TileRig(torch, eng, dev, local_rank, B, tj["W"], tj["n_tiles"], tj["res"], batches[0], host=True)
+        rig = TileRig(torch, eng, dev, local_rank, B, tj["W"], tj["n_tiles"], tj["res"], batches[0], host=True, layout=LAY)
 
     def step(i):
         bs, q, mq, rp, ref = batches[i % nb]
@@ -491,13 +497,13 @@ def main():
                     sb, sq, smq, srp, sref = batches[(i * K + j) % nb]
                     segs.append((B, sb.data_ptr(), sq.data_ptr(), sref.data_ptr(), out.data_ptr() + j * B * rec,
                                  smq.data_ptr() if ranks else 0, srp.data_ptr() if ranks else 0))
-                engs[k].submit_many_ptrs(N, pitch, segs, stream=streams[k].cuda_stream, group_id=gid.data_ptr() if G else 0, n_groups=G,
+                engs[k].submit_many_ptrs(N, pitch, segs, stream=streams[k].cuda_stream, group_id=gid.data_ptr() if G else 0, n_groups=G, layout=LAY,
                                          gouts=[gouts[slot].data_ptr() + j * B * G * basevar_amd.GROUP_DTYPE.itemsize for j in range(K)] if G else None)
             else:
                 engs[k].submit_ptrs(B, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(),
                                     mq.data_ptr() if ranks else 0, rp.data_ptr() if ranks else 0,
                                     group_id=gid.data_ptr() if G else 0, n_groups=G, gout=gouts[slot].data_ptr() if G else 0,
-                                    stream=(0 if os.environ.get("BASEVAR_BENCH_NULLSTREAM") else streams[k].cuda_stream))
+                                    stream=(0 if os.environ.get("BASEVAR_BENCH_NULLSTREAM") else streams[k].cuda_stream), layout=LAY)
             if gatherer is not None:
                 if args.lanes == 2:
                     engs[k].join(streams[k].cuda_stream)  # the lanes run on streams of their own: order the gather behind them
@@ -561,18 +567,18 @@ def main():
                 vref = torch.empty(V, dtype=torch.uint8, device=dev)
                 basevar_amd.synth_fill(local_rank, V, N_fill, pitch, vb.data_ptr(), vq.data_ptr(), vref.data_ptr(),
                                        vm.data_ptr() if ranks else 0, vr.data_ptr() if ranks else 0, seed=args.seed,
-                                       site_offset=(b_last * world + r) * B, coverage=args.coverage)
+                                       site_offset=(b_last * world + r) * B, coverage=args.coverage, layout=LAY)
                 torch.cuda.synchronize()
                 if tj:
-                    vrig = TileRig(torch, eng, dev, local_rank, V, tj["W"], tj["n_tiles"], tj["res"], (vb, vq, vm, vr, vref), host=False)
+                    vrig = TileRig(torch, eng, dev, local_rank, V, tj["W"], tj["n_tiles"], tj["res"], (vb, vq, vm, vr, vref), host=False, layout=LAY)
                     (jb, jq, jm, jr), jp = vrig.joined_rows(V)
                     torch.cuda.synchronize()  # (torch built the rows on ITS stream; the engine's own stream does not wait for it)
-                    eng.submit_ptrs(V, N, jp, jb.data_ptr(), jq.data_ptr(), vref.data_ptr(), vout.data_ptr(), jm.data_ptr(), jr.data_ptr())
+                    eng.submit_ptrs(V, N, jp, jb.data_ptr(), jq.data_ptr(), vref.data_ptr(), vout.data_ptr(), jm.data_ptr(), jr.data_ptr(), layout=LAY)
                 else:
                     eng.submit_ptrs(V, N, pitch, vb.data_ptr(), vq.data_ptr(), vref.data_ptr(), vout.data_ptr(),
                                     vm.data_ptr() if ranks else 0, vr.data_ptr() if ranks else 0,
                                     group_id=gid.data_ptr() if G else 0, n_groups=G,
-                                    gout=gouts[0].data_ptr() if G else 0)
+                                    gout=gouts[0].data_ptr() if G else 0, layout=LAY)
                 eng.wait()
                 want = vout.cpu().numpy().view(basevar_amd.SITE_DTYPE)
                 got = recs[r * Bl:r * Bl + V]
@@ -623,7 +629,7 @@ def main():
         St = min(B, args.tile_sites)
         Wt = args.tile_width
         n_tiles_t = max(1, N // Wt)
-        trig = TileRig(torch, eng, dev, local_rank, St, Wt, n_tiles_t, min(n_tiles_t, args.tile_distinct), batches[0], host=True)
+        trig = TileRig(torch, eng, dev, local_rank, St, Wt, n_tiles_t, min(n_tiles_t, args.tile_distinct), batches[0], host=True, layout=LAY)
         tout = torch.zeros(St * rec, dtype=torch.uint8, device=dev)
         tms = []
         for kind, many in ((_capi_mod.BV_MEM_DEVICE, True), (_capi_mod.BV_MEM_DEVICE, False), (_capi_mod.BV_MEM_HOST, False)):
@@ -702,7 +708,9 @@ def main():
                                 "strong scaling: the job's %d-site batch split over the ranks" % (world * B)
                                 if args.scaling == "strong" else "weak scaling: per-GPU batch fixed",
                                 (1000000 + world * B - 1) // (world * B) if args.scaling == "strong" else (1000000 + B - 1) // B),
-                "samples": N, "batch_sites": B, "engine_lanes": args.lanes, "chain": K, "sites_per_launch": Bl, "coverage": args.coverage, "planes": "call,phred" + (",mapq,rpr" if ranks else ""),
+                "samples": N, "batch_sites": B, "engine_lanes": args.lanes, "chain": K, "sites_per_launch": Bl, "coverage": args.coverage, "planes": "call u8,phred u8" + ((",mapq u8,rpr u16 " + ("(BV_SLAB_RPR_TAGGED: rank | base << 13 | nocall << 15, written so by the producer; pass 2 reads mapq + rpr = 3 B/cell)"
+                                                                                     if LAY else "(plain ranks; pass 2 re-reads the call plane: 4 B/cell)")) if ranks else ""),
+                "rank_layout": (args.rank_layout if ranks else None),
                 "parallelism": "site-sharded x%d, gather of %d-byte records to rank 0" % (world, rec),
                 "job_batch_sites": world * Bl, "backend": (backend if dist_on else None),
                 "rccl_ranks": (dist.get_world_size() if dist_on and backend == "nccl" else 0),
@@ -771,7 +779,7 @@ def main():
             def hstep():
                 eng.submit_ptrs(hb, N, pitch, host[0].data_ptr(), host[1].data_ptr(), href.data_ptr(), hout.data_ptr(),
                                 host[2].data_ptr() if ranks else 0, host[3].data_ptr() if ranks else 0,
-                                mem_kind=_capi.BV_MEM_HOST)
+                                mem_kind=_capi.BV_MEM_HOST, layout=LAY)
                 eng.wait()
             hstep()
             t0 = time.perf_counter()
@@ -784,13 +792,13 @@ def main():
             line["tile_mode"] = tile_legs
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cb, cpu_rec, cpu_idx = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites)
+                cb, cpu_rec, cpu_idx = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites, rank_mask=0x1FFF if LAY else 0xFFFF)
                 line["cpu_baseline"] = cb
                 # GPU records of the same sites (one more submit of batch 0)
                 bs0, q0, mq0, rp0, ref0 = batches[0]
                 eng.submit_ptrs(B, N, pitch, bs0.data_ptr(), q0.data_ptr(), ref0.data_ptr(), outs[0].data_ptr(),
                                 mq0.data_ptr() if ranks else 0, rp0.data_ptr() if ranks else 0,
-                                stream=streams[0].cuda_stream)
+                                stream=streams[0].cuda_stream, layout=LAY)
                 eng.wait()
                 gpu_rec = outs[0].cpu().numpy().view(basevar_amd.SITE_DTYPE)[cpu_idx]
                 line["parity_sample"] = parity_on_sample(gpu_rec, cpu_rec)

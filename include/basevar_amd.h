@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define BV_ABI_VERSION 1
+#define BV_ABI_VERSION 2 /* 2: bv_slab.layout (BV_SLAB_RPR_TAGGED) */
 
 /* ---- cell encoding of the `base_strand` plane: one byte per (site, sample) = the first character of the reference's
  * per-sample token (src/basetype.cpp:50; domain per src/basetype_caller.cpp:1060-1077) plus the strand (basetype.cpp:257-264).
@@ -69,6 +69,17 @@ typedef enum bv_mem_kind {
 #define BV_SITE_LOG_APPROX 0x80u   /* a shallow site was replayed in the reference's per-sample order with the DEVICE library's log()
                                       (bv_engine_host_log_exact() == 0): exact ties may be picked differently; values within 1e-6 */
 
+/* bv_slab.layout.  BV_SLAB_RPR_TAGGED: every word of the `rpr` plane also carries its cell's call in the three bits a
+ * read-position rank of at most 8,191 leaves free:   rpr = rank | (call & 3) << 13 | (call >> 3) << 15   (BV_RPR_TAGGED(call,
+ * rank); call = the cell's base_strand byte: base in bits 13-14, "not a base call" in bit 15, the strand is not needed).  The
+ * ref_vs_alt_ranksumtest of a variant site (src/basetype.cpp:201-242 on mapqs / base_pos_ranks, caller.cpp:1151-1154) then reads
+ * mapq + rpr only -- SURVEY 8d's 3 bytes per cell -- instead of base_strand + mapq + rpr.  The PRODUCER chooses it per slab, when
+ * every rank of the slab is <= BV_RPR_TAG_MAX_RANK (every short-read cohort); the engine takes the tags on trust, as it takes
+ * the planes.  Records are byte-identical to those of the plain layout.  Plane widths do not change. */
+#define BV_SLAB_RPR_TAGGED 0x1u
+#define BV_RPR_TAG_MAX_RANK 0x1FFFu
+#define BV_RPR_TAGGED(call, rank) ((uint16_t)(((rank) & 0x1FFFu) | (((call) & 3u) << 13) | ((((call) >> 3) & 1u) << 15)))
+
 /* Input: SoA planes [n_sites][pitch], one row per site, one cell per sample: `struct BatchInfo` (src/basetype.h:25-43), batched */
 typedef struct bv_slab {
     uint32_t n_sites;
@@ -77,11 +88,13 @@ typedef struct bv_slab {
     const uint8_t *base_strand;  /* [n_sites][pitch]  align_bases[i][0] + map_strands */
     const uint8_t *qual;         /* [n_sites][pitch]  align_base_quals - 33           */
     const uint8_t *mapq;         /* [n_sites][pitch]  mapqs; may be NULL              */
-    const uint16_t *rpr;         /* [n_sites][pitch]  base_pos_ranks; may be NULL     */
+    const uint16_t *rpr;         /* [n_sites][pitch]  base_pos_ranks; may be NULL; see BV_SLAB_RPR_TAGGED */
     const uint8_t *ref_base;     /* [n_sites] toupper(ref_base[0]) as BV_BASE_*; 4 = not ACGT  */
     const uint8_t *group_id;     /* [n_samples] pop-group index or BV_NO_GROUP; may be NULL; any alignment */
     uint32_t n_groups;           /* 0 if no groups (caller.cpp:746)                   */
     uint32_t mem_kind;           /* bv_mem_kind                                       */
+    uint32_t layout;             /* BV_SLAB_* bits, 0 = the plain planes above        */
+    uint32_t reserved_;          /* must be zero                                      */
 } bv_slab;
 
 /* Output: one fixed-size record per site (208 bytes).  Replaces the BaseType getters (src/basetype.h:121-151), StrandBiasInfo
@@ -145,7 +158,7 @@ typedef struct bv_engine_config {
 
 typedef struct bv_engine bv_engine;
 
-const char *bv_version(void); /* e.g. "basevar_amd 0.1 abi1 gfx950" */
+const char *bv_version(void); /* e.g. "basevar_amd 0.2 abi2 gfx950" */
 
 /* min_af as the reference derives it: (double)std::min(float(100)/n_files, user_min_af), basetype_caller.cpp:122 */
 double bv_min_af(uint32_t n_samples, float user_min_af);

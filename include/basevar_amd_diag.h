@@ -88,6 +88,8 @@ typedef struct bv_synth_params {
     float indel_frac;     /* fraction of covered cells that are indel tokens         */
     float qual_mean, qual_sd;
     uint32_t qual_min, qual_max;
+    uint32_t layout;      /* BV_SLAB_* bits of the slab to fill: BV_SLAB_RPR_TAGGED writes rpr = BV_RPR_TAGGED(call, rank) */
+    uint32_t reserved_;
 } bv_synth_params;
 
 int bv_synth_fill(int device, const bv_synth_params *p, uint32_t n_sites, uint32_t n_samples,

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_public_header_is_the_product_surface_only():
     """include/basevar_amd.h is what a maintainer of the reference reads: no diagnostic / A-B switch in it, and short."""
     hdr = open(os.path.join(ROOT, "include", "basevar_amd.h")).read()
-    assert len(hdr.splitlines()) <= 250
+    assert len(hdr.splitlines()) <= 300  # (round 6: + the tagged rank layout and the packed host tiles)
     for lab in ("TALLY_ONLY", "SKIP_", "GRID_LIMIT", "GROUP_INLINE", "PASS2_SWEEP", "WAVE_SOLVER", "BV_FLAG_SPLIT", "SHORT_ROW_FORM", "FAULT"):
         assert lab not in hdr, lab
 
