@@ -496,6 +496,9 @@ int bv_engine_create(const bv_engine_config *cfg, bv_engine **out) {
     if (cfg->device < 0 || cfg->device >= ndev)
         return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_create: device ordinal out of range");
     if (cfg->max_sites == 0) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_create: max_sites == 0");
+    // the fault-injection bit (basevar_amd_diag.h) makes every launch stall ~2 s and fail: refused unless the process asks for it
+    if ((cfg->flags & BV_FLAG_FAULT_LOST_HANDOFF) && !std::getenv("BASEVAR_AMD_FAULT_INJECT"))
+        return fail(nullptr, BV_ERR_INVALID_ARG, "bv_engine_create: BV_FLAG_FAULT_LOST_HANDOFF is a test-only fault injection; set BASEVAR_AMD_FAULT_INJECT=1 to allow it");
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
         return fail(nullptr, BV_ERR_NO_DEVICE, "bv_engine_create: cannot query device");
@@ -1595,7 +1598,7 @@ int bv_engine_wait(bv_engine *e) {
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 2u) bv_team_debug_report(e->h_counters);
         else if (b == 0 && e->h_counters[BV_CTR_WORDS + 5150] == 4u) bv_fused_debug_report(e->h_counters);
 #endif
-        timed_out += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];
+        timed_out |= e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_TIMEOUT];  // bit-coded BV_TMO_* flags, ORed by the kernels: OR here too
         zero_freq += e->h_counters[(size_t)b * BV_CTR_WORDS + BV_CTR_ZEROFREQ];
     }
     if (timed_out != 0 || zero_freq != 0) {
@@ -1811,7 +1814,8 @@ int bv_bind_thread_to_device_node(int device) {
     CPU_ZERO(&want);
     if (sched_getaffinity(0, sizeof cur, &cur) != 0) return -1;
     int n_set = 0;
-    for (char *tok = std::strtok(buf, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {  // "0-63,128-191"
+    char *save = nullptr;  // (strtok_r: bv_call's per-GPU worker threads bind themselves concurrently)
+    for (char *tok = strtok_r(buf, ",\n", &save); tok; tok = strtok_r(nullptr, ",\n", &save)) {  // "0-63,128-191"
         int lo = 0, hi = 0;
         const int k = std::sscanf(tok, "%d-%d", &lo, &hi);
         if (k < 1) continue;

@@ -369,7 +369,7 @@ __device__ __forceinline__ void bv_f_push_variants(const BvP1ShortArgs &a, BvFus
             // handing the slot back)
             uint32_t spins = 0;
             while (e[0] != BV_F_EMPTY && spins < BV_F_SPIN_MAX) { __builtin_amdgcn_s_sleep(1); ++spins; }
-            if (spins == BV_F_SPIN_MAX) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_PUSH_VARIANT);  // (nothing overwritten; loud)
+            if (spins == BV_F_SPIN_MAX) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_PUSH_VARIANT);  // (nothing overwritten; loud)
             else {
                 e[1] = L; e[2] = n12; e[3] = lut;
                 e[0] = site;  // (LDS operations of one wave execute in order: the entry is whole when its site number appears)
@@ -384,7 +384,7 @@ __device__ __forceinline__ void bv_f_push_variants(const BvP1ShortArgs &a, BvFus
         got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
         if (got != 0u) __builtin_amdgcn_s_sleep(2);
     } while (got != 0u && ++spins < BV_F_SPIN_MAX);
-    if (got != 0u) { if (lane == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_PUSH_VARIANT); return; }
+    if (got != 0u) { if (lane == 0) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_PUSH_VARIANT); return; }
     const uint32_t base = bv_f_lds_read_u(&sh.ctl[BV_FC_OV_TAIL]);
     if (want) {
         uint32_t *e = a.ovf + 4u * (size_t)(B0 + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
@@ -406,7 +406,7 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     uint32_t site = 0, pL = 0, pn12 = 0, plut = 0;
     if ((uint32_t)grp < n) site = bv_f_take(q, first + (uint32_t)grp);
     if ((uint32_t)grp < n && site == BV_F_EMPTY) {
-        if (gl == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE);
+        if (gl == 0) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE);
     } else if ((uint32_t)grp < n) {
         const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
         uint32_t nb, badq;
@@ -629,7 +629,7 @@ __device__ __forceinline__ void bv_f_push(bv_lds_vu32 *q, bv_lds_u32 *tail, uint
     if (spins == BV_F_SPIN_MAX) {
         // gave up: the entry that sits there is not overwritten (its consumer may still come), this site is not solved, and the
         // submit fails loudly (the consumer of position `pos` times out in its turn)
-        (void)bv_f_global_fetch_add_wave(&counters[BV_CTR_TIMEOUT], BV_TMO_PUSH);
+        if (lane == 0) atomicOr(&counters[BV_CTR_TIMEOUT], BV_TMO_PUSH);  // (OR, not add: repeated events must not carry into the next field, or wrap the word to 0)
         return;
     }
     // (BV_FLAG_FAULT_LOST_HANDOFF, tests: the first entry of every workgroup's queue is reserved and never written -- the solver
@@ -841,7 +841,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     for (uint32_t spins = 0; (s = bv_f_lds_read_u(&e[0])) == BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(4);
                     x = bv_f_lds_read_u(&e[1]); y = bv_f_lds_read_u(&e[2]); z = bv_f_lds_read_u(&e[3]);
                     if (lane == 0) *(bv_lds_vu32 *)&e[0] = BV_F_EMPTY;
-                    if (s == BV_F_EMPTY) { if (lane == 0) atomicAdd(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE_VARIANT); }  // (timed out: no row, flagged)
+                    if (s == BV_F_EMPTY) { if (lane == 0) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE_VARIANT); }  // (timed out: no row, flagged)
                     else kind = BV_FK_P2;
                 }
             }

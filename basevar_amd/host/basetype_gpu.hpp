@@ -49,6 +49,7 @@ public:
         if (bi.align_bases.size() != n_ || bi.align_base_quals.size() != n_ || bi.mapqs.size() != n_ ||
             bi.map_strands.size() != n_ || bi.base_pos_ranks.size() != n_)
             throw std::runtime_error("[ERROR] Something is wrong in batchfiles.");  // caller.cpp:736
+        plain_only();
         // The reference's order of complaints (basetype_caller.cpp:738-743): _out_cvg_line -> strand_bias runs BEFORE the
         // BaseType constructor, over every sample whose token does not start with N / + / - -- an empty token (its [0] is the
         // terminator) and characters outside ACGT included -- and refuses a strand that is neither + nor - (basetype.cpp:253-273);
@@ -107,6 +108,7 @@ public:
 
     // One site straight from per-sample planes in the slab's own encoding (e.g. a row of a PileupTile, pileup.hpp).
     void add_row(const uint8_t *cell, const uint8_t *phred, const uint8_t *mapq, const uint16_t *rank, uint8_t ref_code) {
+        plain_only();
         const size_t off = bs_.size();
         bs_.resize(off + pitch_, BV_CELL_N);
         q_.resize(off + pitch_, 0);
@@ -125,6 +127,7 @@ public:
         uint16_t *rank;
     };
     Row begin_row() {
+        plain_only();
         const size_t off = (size_t)n_sites() * pitch_;
         bs_.resize(off + pitch_, BV_CELL_N);
         q_.resize(off + pitch_, 0);
@@ -145,6 +148,7 @@ public:
     // of their own are joined in site order this way (bv_call).
     void append(const SlabBuilder &o) {
         if (o.n_ != n_) throw std::runtime_error("[ERROR] SlabBuilder::append: different sample counts");
+        plain_only(); o.plain_only();
         bs_.insert(bs_.end(), o.bs_.begin(), o.bs_.end());
         q_.insert(q_.end(), o.q_.begin(), o.q_.end());
         mq_.insert(mq_.end(), o.mq_.begin(), o.mq_.end());
@@ -154,6 +158,7 @@ public:
     // rows [first, first + k) of `o` only
     void append_rows(const SlabBuilder &o, size_t first, size_t k) {
         if (o.n_ != n_) throw std::runtime_error("[ERROR] SlabBuilder::append: different sample counts");
+        plain_only(); o.plain_only();
         const size_t a = first * pitch_, b = (first + k) * pitch_;
         bs_.insert(bs_.end(), o.bs_.begin() + a, o.bs_.begin() + b);
         q_.insert(q_.end(), o.q_.begin() + a, o.q_.begin() + b);
@@ -175,7 +180,22 @@ public:
         gid_.resize(pitch_, BV_NO_GROUP);
         n_groups_ = n_groups;
     }
-    void clear() { bs_.clear(); q_.clear(); mq_.clear(); rp_.clear(); ref_.clear(); }
+    void clear() { bs_.clear(); q_.clear(); mq_.clear(); rp_.clear(); ref_.clear(); layout_ = 0; }
+    // The producer's choice of the rank plane's layout (include/basevar_amd.h, BV_SLAB_RPR_TAGGED): when every read-position
+    // rank of the slab is <= 8,191 -- every short-read cohort -- each rank word also takes its cell's call, and the engine's rank
+    // sums (ref_vs_alt_ranksumtest, src/basetype.cpp:201-242) read mapq + rpr only.  Call it on a COMPLETE slab, before slab():
+    // rows cannot be added afterwards (clear() starts a plain slab again), rank_row() then returns the tagged words.  Returns
+    // whether the slab is tagged now; a slab with a longer read stays plain and is submitted as such.  Records do not depend on it.
+    bool tag_ranks() {
+        if (layout_ & BV_SLAB_RPR_TAGGED) return true;
+        uint16_t any = 0;
+        for (uint16_t v : rp_) any |= v;
+        if (any & (uint16_t)~BV_RPR_TAG_MAX_RANK) return false;
+        for (size_t i = 0; i < rp_.size(); ++i) rp_[i] = BV_RPR_TAGGED((uint32_t)bs_[i], (uint32_t)rp_[i]);
+        layout_ = BV_SLAB_RPR_TAGGED;
+        return true;
+    }
+    uint32_t layout() const { return layout_; }
     uint32_t n_sites() const { return (uint32_t)ref_.size(); }
     uint32_t n_samples() const { return n_; }
     uint32_t n_groups() const { return n_groups_; }
@@ -188,11 +208,15 @@ public:
         s.group_id = n_groups_ ? gid_.data() : nullptr;
         s.n_groups = n_groups_;
         s.mem_kind = BV_MEM_HOST;
+        s.layout = layout_;
         return s;
     }
 
 private:
-    uint32_t n_, n_groups_ = 0;
+    void plain_only() const {
+        if (layout_) throw std::runtime_error("[ERROR] SlabBuilder: rows cannot be added to a slab whose ranks are tagged (tag_ranks)");
+    }
+    uint32_t n_, n_groups_ = 0, layout_ = 0;
     uint64_t pitch_;
     std::vector<uint8_t> bs_, q_, mq_, ref_, gid_;
     std::vector<uint16_t> rp_;

@@ -75,7 +75,15 @@ public:
             }
             if (eof_) return !line.empty();
             const int n = gzread(f_, &buf_[0], (unsigned)kBuf);
-            if (n <= 0) { eof_ = true; pos_ = end_ = 0; continue; }
+            if (n <= 0) {
+                // the end of the file -- or of what zlib could make of it: a damaged or truncated gzip member must not read as a
+                // shorter file (the BGZF path says "truncated BGZF member" for the same damage)
+                int errnum = Z_OK;
+                const char *msg = gzerror(f_, &errnum);
+                if (n < 0 || (errnum != Z_OK && errnum != Z_STREAM_END))
+                    throw std::runtime_error(std::string("[ERROR] damaged or truncated gzip input: ") + (msg && *msg ? msg : "read error"));
+                eof_ = true; pos_ = end_ = 0; continue;
+            }
             pos_ = 0; end_ = (size_t)n;
         }
     }

@@ -280,7 +280,8 @@ int main(int argc, char **argv) {
             for (BatchPtr b; (b = to_gpu.pop());) {
                 if (engine) {
                     const double t0 = StageClock::now();
-                    try { b->result = engine->lrt(b->slab); } catch (const std::exception &ex) { b->error = ex.what(); }
+                    // (the producer's choice of layout: short reads -> the rank words carry the calls, basetype_gpu.hpp)
+                    try { b->slab.tag_ranks(); b->result = engine->lrt(b->slab); } catch (const std::exception &ex) { b->error = ex.what(); }
                     const double dt = StageClock::now() - t0;
                     std::lock_guard<std::mutex> lk(err_mu);
                     clk.engine += dt;

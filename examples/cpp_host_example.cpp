@@ -6,6 +6,7 @@
 //   g++ -std=c++17 -Iinclude examples/cpp_host_example.cpp -Lbasevar_amd/lib -lbasevar_amd
 //       (then) -Wl,-rpath,$PWD/basevar_amd/lib -o /tmp/cpp_host_example; /tmp/cpp_host_example /tmp/dump.bin
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,14 @@ int main(int argc, char **argv) {
         std::fwrite(sl.ref_base, 1, S, f);
         std::fwrite(bt.sites.data(), sizeof(bv_site_result), S, f);
         std::fclose(f);
+    }
+    // the producer's choice of layout: every rank here is a short read's, so the rank words can carry the calls
+    // (BV_SLAB_RPR_TAGGED, include/basevar_amd.h) -- the records must not change by a bit
+    if (builder.tag_ranks()) {
+        bvamd::BaseTypeBatch bt2 = engine.lrt(builder);
+        const bool same = std::memcmp(bt2.sites.data(), bt.sites.data(), sizeof(bv_site_result) * S) == 0;
+        std::printf("tagged rank layout: records %s\n", same ? "identical" : "DIFFER");
+        if (!same) return 1;
     }
     return 0;
 }

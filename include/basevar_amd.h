@@ -65,7 +65,8 @@ typedef enum bv_mem_kind {
 #define BV_SITE_ZERO_FREQ 0x8u /* reference would throw at basetype.cpp:113-115        */
 #define BV_SITE_RANKSUM 0x10u  /* mapq/rpr rank sums were computed (planes present)    */
 #define BV_SITE_SOR_OVERFLOW 0x20u /* int product in SOR exceeded 2^31 (basetype.cpp:286 is UB there) */
-#define BV_SITE_RPR_RANGE 0x40u    /* (not set any more: ranks beyond the tile job's announced bound take an exact path at finish) */
+#define BV_SITE_RPR_RANGE 0x40u    /* per-site-tally tile jobs only: the site has > 2,048 read-position ranks beyond the announced bound, or the
+                                      job > 4 Mi such cells: rpr_ranksum is NaN (fewer take an exact path at finish) */
 #define BV_SITE_LOG_APPROX 0x80u   /* a shallow site was replayed in the reference's per-sample order with the DEVICE library's log()
                                       (bv_engine_host_log_exact() == 0): exact ties may be picked differently; values within 1e-6 */
 

@@ -35,7 +35,8 @@ extern "C" {
                                      Records do not depend on it. */
 /* test only: a hand-off is reserved but never written -- the first candidate-queue entry of every workgroup of the fused
  * short-row kernel, the first ring slot of the long-row kernel's workgroup 0 --, so that its consumer runs into its bounded wait:
- * the launch must end (no hung GPU), bv_engine_wait must return BV_ERR_HIP naming the time-out, and the records are invalid */
+ * the launch must end (no hung GPU), bv_engine_wait must return BV_ERR_HIP naming the time-out, and the records are invalid.
+ * bv_engine_create refuses the bit (BV_ERR_INVALID_ARG) unless the environment variable BASEVAR_AMD_FAULT_INJECT is set. */
 #define BV_FLAG_FAULT_LOST_HANDOFF 0x40000000u
 
 /* Which kernels the last launch of pass 1 took (valid after the submit; bench.py names the dominant kernel and its bytes by it) */

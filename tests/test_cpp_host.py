@@ -37,7 +37,7 @@ def test_cpp_wrapper_matches_oracle(tmp_path, restatement):
     exe = build_example(tmp_path)
     dump = str(tmp_path / "dump.bin")
     out = subprocess.check_output([exe, dump], text=True)
-    assert "ALT=" in out
+    assert "ALT=" in out and "tagged rank layout: records identical" in out
     raw = open(dump, "rb").read()
     S, N, P = np.frombuffer(raw[:24], dtype=np.uint64).astype(int)
     o = 24

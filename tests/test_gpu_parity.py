@@ -694,7 +694,7 @@ def test_workgroups_that_run_dry_together_end_promptly(bv, flags):
 
 
 @pytest.mark.parametrize("n", [9000, 70000], ids=["fused_short_row_kernel", "long_row_kernel"])
-def test_lost_handoff_ends_in_a_loud_timeout_not_a_hung_gpu(bv, restatement, n):
+def test_lost_handoff_ends_in_a_loud_timeout_not_a_hung_gpu(bv, restatement, n, monkeypatch):
     """Every wait of the persistent kernels on another wave's LDS write is bounded; this is the test that makes one fire.
     BV_FLAG_FAULT_LOST_HANDOFF (include/basevar_amd_diag.h) loses ONE hand-off of workgroup 0 -- a candidate-queue entry that
     is reserved and never written (bv_p1s_fused_kernel), a ring slot that is never published (bv_pass1_kernel).  The launch
@@ -703,6 +703,11 @@ def test_lost_handoff_ends_in_a_loud_timeout_not_a_hung_gpu(bv, restatement, n):
     import time
     slab = make_slab(600, n, seed=31, coverage=0.1, site_offset=2)
     maf = bv.min_af(n)
+    # the injection is refused unless the process asks for it (a stray bit in cfg.flags must not stall a production launch)
+    monkeypatch.delenv("BASEVAR_AMD_FAULT_INJECT", raising=False)
+    with pytest.raises(RuntimeError, match="BASEVAR_AMD_FAULT_INJECT"):
+        bv.BaseTypeEngine(max_sites=600, min_af_value=maf, device=0, flags=0x40000000)
+    monkeypatch.setenv("BASEVAR_AMD_FAULT_INJECT", "1")
     eng = bv.BaseTypeEngine(max_sites=600, min_af_value=maf, device=0, flags=0x40000000)
     t0 = time.perf_counter()
     with pytest.raises(RuntimeError, match="timed out"):
