@@ -50,6 +50,9 @@ def parse():
                          "reads SURVEY 8d's 3 B/cell: mapq + rpr); plain = the rank alone (pass 2 re-reads the call plane: 4 B/cell)")
     ap.add_argument("--cpu-sites", type=int, default=0, help="sites in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs1", action="store_true",
+                    help="skip the `configs1` object of the default run: BASELINE configs[1] (100,000 sites x 10,000 samples, one "
+                         "batch) timed after the headline on the same box (never `value`)")
     ap.add_argument("--seed", type=int, default=0xBA5E7A7)
     ap.add_argument("--tally-only", action="store_true", help="diagnostic: time pass 1 without its solver")
     ap.add_argument("--flags", type=int, default=0, help="diagnostic BV_FLAG_* bits (ablation)")
@@ -236,6 +239,71 @@ def cpu_baseline(torch, planes, n_samples, maf, want_sites, rank_mask=0xFFFF):
                       n_all, S, n_samples, threads, passes_all, wall_all, n_one, passes_one, wall_one, rate_one),
         "single_thread_value": rate_one, "single_thread_spread": spread_one, "single_thread_sites": n_one,
     }, cpu_records, cpu_idx
+
+
+def traffic_record(kernel_name, variant, sites_per_launch, n_samples, rank_layout, chain=1):
+    """(HBM bytes per launch, source) of the committed PMC record (profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE of the same kernel VARIANT on the same shape, tools/summarize_profiles.py tkey()), or (None, None)."""
+    tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        tjs = json.load(open(tfile))
+    except Exception:
+        return None, None
+    key = "%s%s|%dx%d" % (kernel_name, variant, sites_per_launch, n_samples) + ("|" + rank_layout if variant == "<p2rows>" else "") + \
+          ("|chain%d" % chain if chain > 1 else "")
+    keys = (key,) + (("pass1_%dx%d" % (sites_per_launch, n_samples),) if chain == 1 and kernel_name == "bv_pass1_kernel" else ())
+    for k in keys:
+        if k in tjs:
+            return tjs[k]["hbm_bytes_per_launch"], tjs[k].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % k)
+    return None, None
+
+
+def configs1_leg(torch, basevar_amd, capi, dev, device_index, args, layout):
+    """BASELINE configs[1] under the same clock as the headline: ONE batch of 100,000 sites x 10,000 samples (all four planes,
+    both passes, HBM-resident, coverage as the headline), warm-up, then `steps` back-to-back submits bracketed by synchronize.
+    Returns the `configs1` object of the line: whole-job sites/s, the dominant kernel as the engine names it, its fraction of the
+    HBM peak over section 8d's bytes (2 B/cell + 3 B/cell of the variant rows) and the committed PMC traffic over those bytes."""
+    S, N = 100000, 10000
+    pitch = (N + 255) // 256 * 256
+    bs = torch.empty((S, pitch), dtype=torch.uint8, device=dev); q = torch.empty_like(bs); mq = torch.empty_like(bs)
+    rp = torch.empty((S, pitch), dtype=torch.int16, device=dev); ref = torch.empty(S, dtype=torch.uint8, device=dev)
+    basevar_amd.synth_fill(device_index, S, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), mq.data_ptr(), rp.data_ptr(),
+                           seed=args.seed, site_offset=0, coverage=args.coverage, layout=layout)
+    out = torch.zeros(S * basevar_amd.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng = basevar_amd.BaseTypeEngine(max_sites=S, min_af_value=basevar_amd.min_af(N), device=device_index)
+    steps = 40
+
+    def one():
+        eng.submit_ptrs(S, N, pitch, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(), mq.data_ptr(), rp.data_ptr(), layout=layout)
+    for _ in range(5):
+        one()
+    eng.wait()
+    torch.cuda.synchronize()
+    eng.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    eng.wait()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st_ms, p1_ms, p2_ms, nsub = eng.timing_get_ex()
+    nvar = eng.last_variant_count()
+    form = eng.last_launch_form()
+    eng.close()
+    fused = bool(form & capi.BV_FORM_SHORT_ROWS) and bool(form & capi.BV_FORM_ONE_KERNEL)
+    fused_p2 = bool(form & capi.BV_FORM_PASS2_FUSED)
+    kernel = "bv_p1s_fused_kernel" if fused else "bv_p1s_stream_kernel"
+    variant = ("<p2rows>" if fused_p2 else "<p1only>") if fused else ""
+    algo = 2.0 * S * N + (3.0 * nvar * N if fused_p2 else 0.0)
+    avg_s = st_ms / max(nsub, 1) / 1e3
+    lay = "tagged" if layout else "plain"
+    traffic, src = traffic_record(kernel, variant, S, N, lay)
+    return {"workload": "BASELINE configs[1]: 100,000 sites x 10,000 samples, coverage %.2f, one HBM-resident batch, all four planes (rank layout %s), both passes" % (args.coverage, lay),
+            "sites_per_s": S * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "kernel": kernel + variant,
+            "kernel_avg_ms": avg_s * 1e3, "pass1_avg_ms": p1_ms / max(nsub, 1), "pass2_avg_ms": p2_ms / max(nsub, 1),
+            "algorithmic_bytes_per_launch": algo, "frac": algo / avg_s / 1e9 / HBM_PEAK_GBS, "variant_sites": nvar,
+            "traffic": traffic, "traffic_ratio": (traffic / algo if traffic else None), "traffic_source": src}
 
 
 def parity_on_sample(gpu, cpu):
@@ -426,6 +494,70 @@ def main():
         nb = max(nb, min(K, fit))
     ranks = not args.no_rank_planes
     LAY = _capi_mod.BV_SLAB_RPR_TAGGED if (ranks and args.rank_layout == "tagged") else 0  # bv_slab.layout of every slab / tile
+
+    # ---- preflight: what this run will allocate against what is there -- every rank's HBM, the NUMA node of every GPU, the
+    # host DRAM a tile job pins -- printed (rank 0, stderr) BEFORE anything is allocated; a run that cannot fit ends here on
+    # every rank with a message and a non-zero exit code instead of an allocator error (or the OOM killer) minutes in
+    rec_b = basevar_amd.SITE_DTYPE.itemsize
+    depth_pre = 3 if dist_on else max(1, args.streams) * (args.lanes if args.lanes == 1 else 4)
+    need_dev = nb * B * pitch * (5 if ranks else 2) + nb * B + depth_pre * Bl * rec_b
+    need_dev += Bl * (48 + 2048 + 12 + 16 + 4) if N <= 49152 else Bl * 4          # short-row scratch / variant list
+    need_host_pinned = 0
+    if tj:
+        jp = (N + 255) // 256 * 256
+        _, _, tile_bytes = basevar_amd.tile_packed_layout(B, tj["W"], True, False)
+        need_dev += B * jp * 5 + jp + 4 * (tile_bytes + 4096)                      # joined planes + the staging ring
+        need_dev += tj["res"] * B * ((tj["W"] + 15) // 16 * 16) * 5                # the device-side source tiles
+        need_host_pinned = tj["res"] * tile_bytes
+    if args.groups:
+        need_dev += depth_pre * Bl * min(args.groups, 255) * basevar_amd.GROUP_DTYPE.itemsize + min(Bl * min(args.groups, 32) * 1544, 8 << 30)
+    free_dev, total_dev = torch.cuda.mem_get_info(dev)
+    host_avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                host_avail = int(ln.split()[1]) * 1024
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            cur = int(open("/sys/fs/cgroup/memory.current").read())
+            host_avail = min(host_avail if host_avail is not None else 1 << 62, int(lim) - cur)
+    except (OSError, ValueError):
+        pass
+    numa = _capi_mod.load().bv_device_numa_node(local_rank, None, 0)
+    fits = need_dev <= 0.97 * free_dev and (need_host_pinned == 0 or host_avail is None or need_host_pinned <= 0.9 * host_avail / max(1, world))
+    pre = [float(need_dev), float(free_dev), float(total_dev), float(need_host_pinned), float(host_avail if host_avail is not None else -1), float(numa),
+           1.0 if fits else 0.0]
+    if dist_on:
+        t_ = torch.tensor(pre, dtype=torch.float64)
+        if backend == "nccl":
+            t_ = t_.to(dev)
+            lst = [torch.zeros_like(t_) for _ in range(world)]
+            dist.all_gather(lst, t_)
+        else:
+            lst = [torch.zeros(len(pre), dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(lst, t_)
+        pre_all = [[float(x) for x in v.tolist()] for v in lst]
+    else:
+        pre_all = [pre]
+    all_fit = all(r[6] == 1.0 for r in pre_all)
+    if rank == 0:
+        print("[bench preflight] " + json.dumps({
+            "ranks": world, "fits": all_fit,
+            "hbm_needed_GB_per_rank": [round(r[0] / 1e9, 2) for r in pre_all], "hbm_free_GB_per_rank": [round(r[1] / 1e9, 2) for r in pre_all],
+            "hbm_total_GB_per_rank": [round(r[2] / 1e9, 2) for r in pre_all], "numa_node_of_gpu": [int(r[5]) for r in pre_all],
+            "host_pinned_GB_per_rank": [round(r[3] / 1e9, 2) for r in pre_all],
+            "host_available_GB": (round(pre_all[0][4] / 1e9, 2) if pre_all[0][4] >= 0 else None)}), file=sys.stderr, flush=True)
+    if not all_fit:
+        if rank == 0:
+            bad = [i for i, r in enumerate(pre_all) if r[6] != 1.0]
+            print("[bench] preflight: the run does not fit on rank(s) %s -- HBM needed %.1f GB against %.1f GB free, pinned host memory %.1f GB per rank "
+                  "against %s GB available for %d ranks; lower --batch-sites / --distinct-batches / --tile-sites / --tile-distinct" % (
+                      bad, pre_all[bad[0]][0] / 1e9, pre_all[bad[0]][1] / 1e9, pre_all[bad[0]][3] / 1e9,
+                      ("%.1f" % (pre_all[bad[0]][4] / 1e9)) if pre_all[bad[0]][4] >= 0 else "?", world), file=sys.stderr, flush=True)
+        if dist_on:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
 
     # ---- synthetic batches, resident in HBM.  Global site index = ((batch * world) + rank) * B + row,
     # so every rank owns a contiguous site range of every batch (sites shard embarrassingly).
@@ -677,18 +809,8 @@ def main():
         # HBM bytes per launch of that kernel from the PMC counters: NOT measured in this run (counter collection needs
         # rocprofv3 around the process) but read from the committed record of the SAME kernel and configuration, if one
         # exists (tools/collect_profiles.sh + tools/summarize_profiles.py); `traffic_source` says which
-        traffic = traffic_source = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tjs = json.load(open(tfile))
-                for key in ("%s|%dx%d" % (kernel_name, Bl, N) + ("|chain%d" % K if K > 1 else ""),) + (("pass1_%dx%d" % (Bl, N),) if K == 1 else ()):
-                    if key in tjs and (key.startswith(kernel_name) or kernel_name == "bv_pass1_kernel"):
-                        traffic = tjs[key]["hbm_bytes_per_launch"]
-                        traffic_source = tjs[key].get("source", "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, round 1)" % key)
-                        break
-            except Exception:
-                traffic = traffic_source = None
+        var = ("<p2rows>" if fused_p2 else "<p1only>") if fused else ""
+        traffic, traffic_source = traffic_record(kernel_name, var, Bl, N, args.rank_layout, K)
         line = {
             "metric": "genomic sites/sec through basetype caller at N samples",
             "value": sites_per_s, "unit": "sites/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -790,6 +912,14 @@ def main():
                                       "host_GBps": hb * pitch * (5 if ranks else 2) / dt / 1e9}
         if tile_legs is not None:
             line["tile_mode"] = tile_legs
+        if (world == 1 and not args.no_configs1 and not tj and N == 100000 and K == 1 and ranks and not G and not args.flags and not args.tally_only
+                and args.lanes == 1 and ns == 1):
+            # the default run only: BASELINE configs[1] on the same box, behind the headline's timed region (never `value`)
+            try:
+                line["configs1"] = configs1_leg(torch, basevar_amd, _capi_mod, dev, local_rank, args, LAY)
+            except Exception as ex:
+                line["configs1"] = None
+                print("[bench] configs1 leg failed: %r" % (ex,), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, cpu_rec, cpu_idx = cpu_baseline(torch, batches[0], N, maf, args.cpu_sites, rank_mask=0x1FFF if LAY else 0xFFFF)

@@ -63,7 +63,7 @@ def _run_bench(extra, world, env_extra=None, timeout=900):
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout
     d = json.loads(lines[0])
-    d["_stderr"] = "\n".join(l for l in p.stderr.splitlines() if l.startswith("[bench]"))  # what a failed verification says
+    d["_stderr"] = "\n".join(l for l in p.stderr.splitlines() if l.startswith("[bench"))  # what a failed verification says; the preflight line
     return d
 
 
@@ -206,3 +206,26 @@ def test_bench_two_ranks_rccl_two_devices(scaling):
     assert d["config"]["backend"] == "nccl" and d["config"]["rccl_ranks"] == 2 and d["config"]["dist_world_size"] == 2
     assert d["config"]["gathered_records_ok"] is True
     assert d["config"]["job_batch_sites"] == (4096 if scaling == "strong" else 8192)
+
+
+@pytest.mark.gpu
+def test_bench_preflight_at_eight_ranks_and_a_job_that_does_not_fit():
+    """Before anything is allocated every rank reports what it will allocate against its free HBM, its GPU's NUMA node and the
+    host memory a tile job pins; rank 0 prints the table.  A job that cannot fit ends on EVERY rank with exit code 3 and a
+    message -- not with an allocator error minutes into the run."""
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--tile-job", "--tile-sites", "64", "--samples", "20000", "--tile-width", "200", "--tile-distinct", "8",
+                    "--verify-sites", "32"], 8)
+    pre = [l for l in d["_stderr"].splitlines() if l.startswith("[bench preflight] ")]
+    assert len(pre) == 1, d["_stderr"]
+    t = json.loads(pre[0][len("[bench preflight] "):])
+    assert t["ranks"] == 8 and t["fits"] is True and len(t["hbm_free_GB_per_rank"]) == 8 and len(t["numa_node_of_gpu"]) == 8
+    assert all(x > 0 for x in t["host_pinned_GB_per_rank"]) and all(a < b for a, b in zip(t["hbm_needed_GB_per_rank"], t["hbm_free_GB_per_rank"]))
+    assert d["config"]["ranks_verified"] == 8
+    # ... and one that cannot: 4 M sites x 100 k samples per rank = 2 TB of planes
+    env = dict(os.environ, BASEVAR_BENCH_BACKEND="gloo", BASEVAR_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline", "--batch-sites", "4000000", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode != 0 and "preflight: the run does not fit" in p.stderr, p.stderr[-2000:]
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -254,4 +254,4 @@ def test_tagged_synthetic_generator(bv):
             recs.append(out.cpu().numpy().tobytes())
             eng.close()
         assert recs[0] == recs[1]
-        assert int(((np.frombuffer(recs[0], dtype=bv.SITE_DTYPE)["status"] & 2) != 0).sum()) > S // 5
+        assert int(((np.frombuffer(recs[0], dtype=bv.SITE_DTYPE)["status"] & 2) != 0).sum()) > S // 10

@@ -67,12 +67,14 @@ def algorithmic_bytes(kernel, cfg, nvar):
         return None, "-"  # the tile job's finish runs the pass kernels on other rows than the bench batch: nothing attributed
     if kernel.startswith("bv_p1s_fused_kernel<true>"):
         # pass 1 and the variant sites' pass-2 rows in one kernel: SURVEY 8d's 2 B/cell + 3 B/cell of the variant rows
-        # (its traffic re-reads the call byte of a variant row: 4 B/cell there)
+        # (plain rank layout: its traffic re-reads the call byte of a variant row, 4 B/cell there; tagged: 3 B/cell)
         return (2.0 * B + 3.0 * nvar) * N, "2 B/cell x %d sites x %d samples + 3 B/cell x %d variant rows" % (B, N, nvar)
     if kernel.startswith(("bv_pass1_kernel", "bv_pass1_fused_kernel", "bv_p1s_stream_kernel", "bv_p1s_fused_kernel")):
         return 2.0 * B * N, "2 B/cell x %d sites x %d samples" % (B, N)
     per = None
-    if kernel.startswith(("bv_pass2_dma_kernel", "bv_pass2_short_kernel")):
+    if kernel.startswith("bv_pass2_dma_kernel<true>"):
+        per = 3                      # tagged rank layout: mapq + 2 B rank
+    elif kernel.startswith(("bv_pass2_dma_kernel", "bv_pass2_short_kernel")):
         per = 4                      # call + mapq + 2 B rank
     elif kernel.startswith("bv_p2g_stream_kernel"):
         per = 2                      # call + phred (the group plane is the same 10-50 KB for every row: L2)
@@ -80,15 +82,26 @@ def algorithmic_bytes(kernel, cfg, nvar):
         targs = [t.strip() for t in kernel[kernel.index("<") + 1:kernel.rindex(">")].split(",")] if "<" in kernel else []
         rk = len(targs) > 1 and targs[1] == "true"
         gr = len(targs) > 2 and targs[2] == "true"
-        per = 1 + (3 if rk else 0) + (1 if gr else 0)
+        tag = len(targs) > 5 and targs[5] == "true"   # BV_SLAB_RPR_TAGGED without pop-groups: the call plane is not read
+        per = (0 if tag else 1) + (3 if rk else 0) + (1 if gr else 0)
     if per is not None:
         return float(per) * N * nvar, "%d B/cell x %d variant rows x %d samples" % (per, nvar, N)
     return None, "-"
 
 
 def tkey(kernel, cfg):
-    """pmc_traffic.json key: kernel | sites per launch x samples (| chainK for chained launches); bench.py forms the same"""
-    key = "%s|%dx%d" % (kernel.split("<")[0], cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"])
+    """pmc_traffic.json key: kernel[<variant>] | sites per launch x samples [| rank layout] [| chainK]; bench.py forms the same
+    (bench.py: traffic_key).  The variant and the rank layout are part of the key where the kernel's traffic depends on them: the
+    fused short-row kernel that also streams the variant sites' pass-2 rows (<p2rows>, template <true>) against the one that does
+    not (<p1only>, <false>: pop-groups >= 8, no rank planes, BV_FLAG_SHORT_ROW_FORM(10)), and for <p2rows> whether those rows
+    read the call plane (plain) or not (tagged)."""
+    base = kernel.split("<")[0]
+    var = ""
+    if base == "bv_p1s_fused_kernel":
+        var = "<p2rows>" if kernel.startswith("bv_p1s_fused_kernel<true>") else "<p1only>"
+    key = "%s%s|%dx%d" % (base, var, cfg["batch_sites"] * cfg.get("chain", 1), cfg["samples"])
+    if var == "<p2rows>":
+        key += "|" + cfg.get("rank_layout", "tagged")
     return key + ("|chain%d" % cfg["chain"] if cfg.get("chain", 1) > 1 else "")
 
 
@@ -114,6 +127,8 @@ def main():
             if t == "--groups": cfg["groups"] = int(toks[i + 1])
             if t == "--chain": cfg["chain"] = int(toks[i + 1])
             if t == "--no-rank-planes": cfg["ranks"] = False
+            if t == "--rank-layout": cfg["rank_layout"] = toks[i + 1]
+            if t == "--coverage": cfg["coverage"] = float(toks[i + 1])
             if t in ("--with-tile-mode", "--tile-job"): cfg["tile_job"] = True
         nvar = 0
         bj = os.path.join(src, name + ".bench.json")
@@ -180,6 +195,8 @@ def main():
                 "%.3f" % (hbm / algo) if (algo and f is not None) else "-", "%.3f" % frac if frac else "-"))
             if algo and f is not None and k.startswith(("bv_pass1", "bv_p1s_stream", "bv_p1s_fused")):
                 # (several configurations run the same kernel on the same shape: the first one, in name order, is quoted)
+                if cfg.get("coverage", 0.08) != 0.08:
+                    continue  # (pmc_traffic.json is keyed by shape: BASELINE's coverage only)
                 traffic.setdefault(tkey(k, cfg), {}).update({} if traffic[tkey(k, cfg)] else {
                     "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
                     "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)})
