@@ -543,9 +543,9 @@ def main():
     if rank == 0:
         print("[bench preflight] " + json.dumps({
             "ranks": world, "fits": all_fit,
-            "hbm_needed_GB_per_rank": [round(r[0] / 1e9, 2) for r in pre_all], "hbm_free_GB_per_rank": [round(r[1] / 1e9, 2) for r in pre_all],
+            "hbm_needed_GB_per_rank": [round(r[0] / 1e9, 4) for r in pre_all], "hbm_free_GB_per_rank": [round(r[1] / 1e9, 2) for r in pre_all],
             "hbm_total_GB_per_rank": [round(r[2] / 1e9, 2) for r in pre_all], "numa_node_of_gpu": [int(r[5]) for r in pre_all],
-            "host_pinned_GB_per_rank": [round(r[3] / 1e9, 2) for r in pre_all],
+            "host_pinned_GB_per_rank": [round(r[3] / 1e9, 4) for r in pre_all],
             "host_available_GB": (round(pre_all[0][4] / 1e9, 2) if pre_all[0][4] >= 0 else None)}), file=sys.stderr, flush=True)
     if not all_fit:
         if rank == 0:
