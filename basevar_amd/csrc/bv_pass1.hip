@@ -42,6 +42,8 @@ struct __attribute__((aligned(16))) BvPass1Shared {
     uint32_t filled[NBUF];             // tally-wave arrivals on the slot (NTALLY per fill)
     uint32_t drained[NBUF];            // times the slot has been solved and re-zeroed
     uint32_t site_of[NBUF];            // site held by the slot (0xFFFFFFFF = no more work)
+    uint32_t swz_of[NBUF];             // 1: the slot's row is tallied with the dense-row swizzle (bv_tally_chunk<.., SWZ>); set with site_of
+    uint32_t dense_hint;               // the solver's: the row it solved last was dense (a quarter of its cells covered)
     double tab_hit[BV_QBINS], tab_miss[BV_QBINS];  // LDS copy of BvTables
     BvSolverShared sv[NSOLVE];
 };
@@ -72,7 +74,7 @@ __device__ __forceinline__ void bv_chunks_load(BvChunkSet &c, const uint8_t *bs_
         }
     }
 }
-template <bool FULL>
+template <bool FULL, bool SWZ>
 __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, uint32_t n_chunks, int tail, int lane,
                                                 uint32_t *hist, uint32_t one) {
 #pragma unroll
@@ -86,7 +88,7 @@ __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, ui
                 c.vb[u].w = bv_mask_tail_dword(c.vb[u].w, tail - 12);
             }
         }
-        bv_tally_chunk(c.vb[u], c.vq[u], hist, one);
+        bv_tally_chunk<2, SWZ>(c.vb[u], c.vq[u], hist, one);
     }
 }
 // set at `base`: nothing to do past the row's end; FULL form when the set ends inside the row
@@ -99,11 +101,11 @@ __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, ui
 #define BV_SET_TALLY(C, BASE)                                                                 \
     do {                                                                                      \
         const uint32_t b_ = (BASE);                                                           \
-        if (b_ + BLK <= n_full) bv_chunks_tally<true>(C, b_, n_chunks, tail, lane, hist, one);\
-        else if (b_ < n_chunks) bv_chunks_tally<false>(C, b_, n_chunks, tail, lane, hist, one);\
+        if (b_ + BLK <= n_full) bv_chunks_tally<true, SWZ>(C, b_, n_chunks, tail, lane, hist, one);\
+        else if (b_ < n_chunks) bv_chunks_tally<false, SWZ>(C, b_, n_chunks, tail, lane, hist, one);\
     } while (0)
 // PRE: the row's first set is already in (or on its way into) A -- see bv_row_preload.
-template <int NTALLY, bool PRE = false>
+template <int NTALLY, bool PRE = false, bool SWZ = false>
 __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const uint8_t *q_row, uint32_t n_samples,
                                                   uint32_t *hist, int t, int lane, BvChunkSet *pre = nullptr) {
     const uint32_t n_chunks = (n_samples + 15u) >> 4, n_full = n_samples >> 4;
@@ -330,7 +332,9 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
             sh.published[tid] = 0u;
             sh.filled[tid] = 0u;
             sh.drained[tid] = 0u;
+            sh.swz_of[tid] = 0u;
         }
+        if (tid == 0) sh.dense_hint = 0u;
         if (TEAM && tid == 0) {
             tm->helpers = 0u; tm->last_site = BV_TEAM_NO_SITE; tm->gen = 0u; tm->done = 0u; tm->fv_go = 0u; tm->f_done = 0u;
             tm->lrt.bar = 0u; tm->lrt.err = &a.counters[BV_CTR_TIMEOUT];
@@ -402,7 +406,10 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
 #ifdef BV_TEAM_DEBUG  /* cycles the tally waves of this workgroup stood still because the ring was full */
                 if (TEAM && lane == 0) atomicAdd(&a.counters[BV_CTR_EASY], (uint32_t)((__builtin_readcyclecounter() - tw_) >> 6));
 #endif
-                if (lane == 0) sh.site_of[buf] = site;
+                // dense rows (the solver's last row had a quarter of its cells covered: coverage is a property of the cohort) take
+                // the bank swizzle -- the lead wave decides for the slot, the other tally waves and the solver follow it
+                const uint32_t swz_row = (a.flags & BV_FLAG_NO_DOM) ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&sh.dense_hint, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (lane == 0) { sh.site_of[buf] = site; sh.swz_of[buf] = swz_row; }
                 // (BV_FLAG_FAULT_LOST_HANDOFF, tests: workgroup 0 never publishes its first slot -- the other tally waves must give
                 // up after their bounded wait)
                 if (!((a.flags & BV_FLAG_FAULT_LOST_HANDOFF) && blockIdx.x == 0u && k == 0u))
@@ -431,8 +438,10 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                 pb = ch->bs[sg]; pq = ch->q[sg];
             }
             BV_TEAM_STAMP(wave == 0 && lane == 0 && k == 0, 2);  // first row begins
-            bv_tally_row_wave<NTALLY>(pb + (size_t)site * a.pitch, pq + (size_t)site * a.pitch, a.n_samples,
-                                      sh.hist[buf], wave, lane);
+            if (__builtin_amdgcn_readfirstlane((int)sh.swz_of[buf]) != 0)
+                bv_tally_row_wave<NTALLY, false, true>(pb + (size_t)site * a.pitch, pq + (size_t)site * a.pitch, a.n_samples, sh.hist[buf], wave, lane);
+            else
+                bv_tally_row_wave<NTALLY>(pb + (size_t)site * a.pitch, pq + (size_t)site * a.pitch, a.n_samples, sh.hist[buf], wave, lane);
             if (TEAM && wave == 0) {
                 // Was that this workgroup's last row?  (The next ticket was drawn a row ago and has long arrived.)  The solver
                 // wave then waits the microsecond it takes the tally waves to report as helpers instead of starting alone.
@@ -503,6 +512,8 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                 const uint32_t sg = bv_chain_seg(ch, (uint32_t)__builtin_amdgcn_readfirstlane((int)site));
                 sa.ref_base = ch->ref_base[sg]; sa.out = ch->out[sg]; sa.bs = ch->bs[sg]; sa.q = ch->q[sg];
             }
+            // a row tallied with the dense-row swizzle: back into its plain order before anybody reads it
+            if (__builtin_amdgcn_readfirstlane((int)sh.swz_of[buf]) != 0) bv_hist_unswizzle<8, 8>(sh.hist[buf], lane);
             if (TEAM) {
                 uint32_t *hist = sh.hist[buf], *bin_code = sh.sv[s].bin_code, *bin_cnt = sh.sv[s].bin_cnt;
                 BvSolverScratch *sv = &sh.sv[s].sc;
@@ -551,6 +562,8 @@ __global__ __launch_bounds__(BV_WAVE *(NTALLY + NSOLVE), 4) void bv_pass1_kernel
                                           (BV_LDS uint32_t *)sh.sv[s].bin_cnt, (BV_LDS BvSolverScratch *)&sh.sv[s].sc,
                                           (BV_LDS const double *)sh.tab_hit, (BV_LDS const double *)sh.tab_miss, lane);
             }
+            // what the next rows are likely to be: this one's depth (the record is still staged in the solver's scratch)
+            if (lane == 0) sh.dense_hint = (sh.sv[s].sc.res.total_depth >= (a.n_samples >> 2)) ? 1u : 0u;
             // hand the slot back, zeroed
             uint4 *h4 = reinterpret_cast<uint4 *>(sh.hist[buf]);
 #pragma unroll

@@ -263,6 +263,9 @@ __device__ __forceinline__ uint32_t bv_f_keep_mask(int kept) {  // dword mask of
 }
 
 // the cells of two 16-byte chunks per lane (first and second KiB of a slot) -> the wave's histogram
+// (The dense-row bank swizzle of the long-row kernel, bv_tally_chunk<.., SWZ>, was tried here too, per wave and row: at full
+// coverage it gained nothing -- 120 against 122 M sites/s at 10,000 samples --, rows of coverage 0.3 lost 12 % to its VALU work and
+// the un-swizzle, and its registers cost the sparse rows 3 %: not kept.)
 __device__ __forceinline__ void bv_f_tally2(bv_u32x4 vbA, bv_u32x4 vqA, bv_u32x4 vbB, bv_u32x4 vqB, uint32_t *hist, uint32_t one) {
     // A phred byte >= 128 (invalid input) would carry into its neighbour under the shift below: such a slot takes the
     // exact cell-by-cell path (wave-uniform branch; never taken on valid data).
@@ -935,7 +938,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         const uint32_t site = c_site;
         const bool is_p1 = !FUSE2 || c_kind == BV_FK_P1;
         const uint32_t n_slots = is_p1 ? n_slots1 : n_slots2;
-        uint32_t hi_acc = 0;
+        uint32_t hi_acc = 0, dom = BV_DOM_NONE;
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
             // The oldest slot in flight has landed once at most 8 younger loads are outstanding -- plus, for the three waits
@@ -1002,7 +1005,9 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                 x[4] = bv_p2d_xm<0>(c1, w1.y); x[5] = bv_p2d_xm<1>(c1, w1.y); x[6] = bv_p2d_xm<2>(c1, w1.y); x[7] = bv_p2d_xm<3>(c1, w1.y);
                 x[8] = bv_p2d_xm<0>(c2, w1.z); x[9] = bv_p2d_xm<1>(c2, w1.z); x[10] = bv_p2d_xm<2>(c2, w1.z); x[11] = bv_p2d_xm<3>(c2, w1.z);
                 x[12] = bv_p2d_xm<0>(c3, w1.w); x[13] = bv_p2d_xm<1>(c3, w1.w); x[14] = bv_p2d_xm<2>(c3, w1.w); x[15] = bv_p2d_xm<3>(c3, w1.w);
-                bv_lds_add16<2>(x, hist, one, 0x200u);
+                // (a deep row -- an eighth of its cells are REF / ALT reads --: the dominant mapq's lanes are counted, not added one by one)
+                if (((c_y & 0xFFFFu) + (c_y >> 16)) * 8u >= a.n_samples && !(a.flags & BV_FLAG_NO_DOM)) bv_lds_add16_dom<2>(x, hist, one, 0x200u, dom);
+                else bv_lds_add16<2>(x, hist, one, 0x200u);
                 x[0] = bv_p2d_xr<0, 0>(c0, w2.x); x[1] = bv_p2d_xr<1, 1>(c0, w2.x); x[2] = bv_p2d_xr<2, 0>(c0, w2.y); x[3] = bv_p2d_xr<3, 1>(c0, w2.y);
                 x[4] = bv_p2d_xr<0, 0>(c1, w2.z); x[5] = bv_p2d_xr<1, 1>(c1, w2.z); x[6] = bv_p2d_xr<2, 0>(c1, w2.w); x[7] = bv_p2d_xr<3, 1>(c1, w2.w);
                 x[8] = bv_p2d_xr<0, 0>(c2, w3.x); x[9] = bv_p2d_xr<1, 1>(c2, w3.x); x[10] = bv_p2d_xr<2, 0>(c2, w3.y); x[11] = bv_p2d_xr<3, 1>(c2, w3.y);

@@ -46,7 +46,8 @@ extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_g
 // groups; the branchy sweep takes ~18 VALU for the rank sums alone.
 // TAG (rank sums without pop-groups, BV_SLAB_RPR_TAGGED): the class of a cell comes from the tag in its rank word
 // (bv_p2t_class4) and the call plane is not read at all -- 3 bytes per cell, SURVEY 8d's figure, instead of 4.
-template <int NT, bool RANKS, bool GROUPS, bool HALF = false, bool TAG = false>
+// DOM: the mapq tally takes a dominant value out of the LDS adds (bv_lds_add16_dom): chosen per row by its depth.
+template <int NT, bool RANKS, bool GROUPS, bool HALF = false, bool TAG = false, bool DOM = false>
 __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr, uint32_t *hg) {
     const size_t row = (size_t)site * a.pitch;
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
@@ -62,7 +63,7 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
     static_assert(!TAG || (RANKS && !GROUPS), "the tagged form: rank sums without pop-groups");
     const bv_u32x4 nocall = bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     const uint32_t hi_mask = TAG ? 0x1F001F00u : bv_rpr_hi_mask(a.rpr_tag);
-    uint32_t hi_acc = 0;
+    uint32_t hi_acc = 0, dom = BV_DOM_NONE;
     constexpr int U = 2;
     for (uint32_t base = 0; base < n_chunks; base += NT * U) {
         bv_u32x4 vb[U], vm[U], vr0[U], vr1[U], vq[U], vg[U];
@@ -114,7 +115,8 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
                 x[4] = bv_p2d_xm<0>(c1, vmq.y); x[5] = bv_p2d_xm<1>(c1, vmq.y); x[6] = bv_p2d_xm<2>(c1, vmq.y); x[7] = bv_p2d_xm<3>(c1, vmq.y);
                 x[8] = bv_p2d_xm<0>(c2, vmq.z); x[9] = bv_p2d_xm<1>(c2, vmq.z); x[10] = bv_p2d_xm<2>(c2, vmq.z); x[11] = bv_p2d_xm<3>(c2, vmq.z);
                 x[12] = bv_p2d_xm<0>(c3, vmq.w); x[13] = bv_p2d_xm<1>(c3, vmq.w); x[14] = bv_p2d_xm<2>(c3, vmq.w); x[15] = bv_p2d_xm<3>(c3, vmq.w);
-                bv_lds_add16<2>(x, hm, one, 0x200u);
+                if (DOM) bv_lds_add16_dom<2>(x, hm, one, 0x200u, dom);
+                else bv_lds_add16<2>(x, hm, one, 0x200u);
                 x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
                 x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
                 x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
@@ -215,7 +217,10 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         const bool FAST = !GROUPS || a.gidp != nullptr;
         bool fast_ok = false;
         if (FAST) {
-            const uint32_t hi = bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
+            // a deep row (an eighth of its cells are REF / ALT reads): most lanes of a wave add to the dominant mapq's word
+            const bool deep = RANKS && !GROUPS && (n1 + n2) * 8ull >= (unsigned long long)a.n_samples && !(a.flags & BV_FLAG_NO_DOM);
+            const uint32_t hi = deep ? bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG, RANKS && !GROUPS>(a, site, tid, Ltab, sh.hm, sh.hr, hg)
+                                     : bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG, false>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
             const bool any_hi = __ballot(hi != 0u) != 0ull;
             if (lane == 0) sh.maxr[wave] = any_hi ? 1u : 0u;
             __syncthreads();
@@ -638,7 +643,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
 #pragma unroll
             for (int i = 0; i < 4 * 256 / 4 / BV_WAVE; ++i) z[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
         }
-        uint32_t hi_acc = 0;
+        uint32_t hi_acc = 0, dom = BV_DOM_NONE;
+        const bool deep = (n1 + n2) * 8ull >= (unsigned long long)a.n_samples && !(a.flags & BV_FLAG_NO_DOM);
 #pragma unroll 1
         for (uint32_t j = 0; j < n_slots; ++j) {
             if (inflight == (uint32_t)BV_P2D_K) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (BV_P2D_K - 1)) : "memory");
@@ -688,7 +694,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
             x[4] = bv_p2d_xm<0>(c1, vm.y); x[5] = bv_p2d_xm<1>(c1, vm.y); x[6] = bv_p2d_xm<2>(c1, vm.y); x[7] = bv_p2d_xm<3>(c1, vm.y);
             x[8] = bv_p2d_xm<0>(c2, vm.z); x[9] = bv_p2d_xm<1>(c2, vm.z); x[10] = bv_p2d_xm<2>(c2, vm.z); x[11] = bv_p2d_xm<3>(c2, vm.z);
             x[12] = bv_p2d_xm<0>(c3, vm.w); x[13] = bv_p2d_xm<1>(c3, vm.w); x[14] = bv_p2d_xm<2>(c3, vm.w); x[15] = bv_p2d_xm<3>(c3, vm.w);
-            bv_lds_add16<2>(x, h, one, 0x200u);
+            if (deep) bv_lds_add16_dom<2>(x, h, one, 0x200u, dom);  // (a deep row: the dominant mapq's lanes are counted, not added one by one)
+            else bv_lds_add16<2>(x, h, one, 0x200u);
             x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
             x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
             x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);

@@ -255,3 +255,60 @@ def test_tagged_synthetic_generator(bv):
             eng.close()
         assert recs[0] == recs[1]
         assert int(((np.frombuffer(recs[0], dtype=bv.SITE_DTYPE)["status"] & 2) != 0).sum()) > S // 10
+
+
+@pytest.mark.parametrize("n,sites,cov,flags", [(70000, 48, 1.0, 0), (70003, 48, 0.3, 0), (12000, 300, 1.0, 0), (12007, 300, 0.4, 0), (12000, 300, 1.0, 0x9000),
+                                               (3000, 300, 1.0, 0), (12000, 200, 1.0, 1 << 16)],
+                         ids=["long_rows_full", "long_rows_0.3", "fused_full", "fused_0.4", "three_launches_full", "dma_rows_full", "fused_one_workgroup"])
+def test_deep_rows_count_the_dominant_mapq(bv, restatement, n, sites, cov, flags):
+    """Deep rows (an eighth of the cells are REF / ALT reads) take bv_lds_add16_dom in the mapq tally of the rank sums: the
+    lanes that hold the chunk's dominant value are counted and added once.  Records: those of the plain adds
+    (BV_FLAG_NO_DOM), byte for byte, in both rank layouts -- and the oracle's."""
+    slab = make_slab(sites, n, seed=4242 + n, coverage=cov, class_af=[(0.0, 0.0), (0.05, 0.0), (0.4, 0.0), (0.2, 0.1)], ref_n_frac=0.02)
+    if cov == 1.0:
+        slab["mapq"][5, :] = 60   # one value only; and a row whose first cells are NOT the dominant value
+        slab["mapq"][6, :16] = np.arange(1, 17)
+    maf = bv.min_af(n)
+    plain, tagged = both(bv, slab, maf, flags)
+    same(plain, tagged)
+    no_dom, _ = both(bv, slab, maf, flags | 0x1000000)
+    same(plain, no_dom)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(tagged, exp, gexp, margins)
+    assert plain.n_variant >= sites // 3
+
+
+def test_dense_long_rows_take_the_bank_swizzle(bv, restatement):
+    """Long rows behind a dense row (a quarter of the cells covered) are tallied with the bank swizzle (bv_tally_chunk<.., SWZ>)
+    and put back in order before the solver reads them: 3,000 fully covered rows of 60,000 samples (three per workgroup, so the
+    second and third of each take it), generated on the device.  Records: those of BV_FLAG_NO_DOM (plain adds, no swizzle), byte
+    for byte; a spread of sites against the oracle."""
+    import torch
+    from basevar_amd import synth_fill
+    dev = torch.device("cuda", 0)
+    S, n = 3000, 60000
+    P = (n + 15) // 16 * 16
+    bs = torch.empty((S, P), dtype=torch.uint8, device=dev); q = torch.empty_like(bs); mq = torch.empty_like(bs)
+    rp = torch.empty((S, P), dtype=torch.int16, device=dev); ref = torch.empty(S, dtype=torch.uint8, device=dev)
+    synth_fill(0, S, n, P, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), mq.data_ptr(), rp.data_ptr(), seed=77, site_offset=3, coverage=1.0, layout=1)
+    torch.cuda.synchronize()
+    maf = bv.min_af(n)
+    recs = []
+    for flags in (0, 0x1000000):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=flags)
+        out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        eng.submit_ptrs(S, n, P, bs.data_ptr(), q.data_ptr(), ref.data_ptr(), out.data_ptr(), mq.data_ptr(), rp.data_ptr(), layout=1)
+        eng.wait()
+        recs.append(out.cpu().numpy().view(bv.SITE_DTYPE).copy())
+        eng.close()
+    assert recs[0].tobytes() == recs[1].tobytes()
+    idx = np.linspace(0, S - 1, num=40).astype(np.int64)
+    ti = torch.from_numpy(idx).to(dev)
+    slab = {"base_strand": bs[ti].cpu().numpy(), "qual": q[ti].cpu().numpy(), "mapq": mq[ti].cpu().numpy(),
+            "rpr": rp[ti].cpu().numpy().view(np.uint16) & np.uint16(0x1FFF), "ref_base": ref[ti].cpu().numpy(), "n_samples": n, "pitch": P, "n_sites": 40}
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+
+    class Got:
+        sites = recs[0][idx]; groups = None; n_variant = int(((recs[0][idx]["status"] & 2) != 0).sum())
+    check(Got, exp, gexp, margins)
+    assert (recs[0]["total_depth"] > n * 0.9).all()
