@@ -51,6 +51,12 @@ class Slab(C.Structure):
                 ("mem_kind", C.c_uint32), ("layout", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
+class SparseTile(C.Structure):
+    _fields_ = [("n_sites", C.c_uint32), ("n_samples", C.c_uint32), ("n_entries", C.c_uint32), ("n_groups", C.c_uint32),
+                ("row_start", C.c_void_p), ("sample", C.c_void_p), ("base_strand", C.c_void_p), ("qual", C.c_void_p), ("mapq", C.c_void_p),
+                ("rpr", C.c_void_p), ("group_id", C.c_void_p), ("mem_kind", C.c_uint32), ("layout", C.c_uint32)]
+
+
 class EngineConfig(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_sites", C.c_uint32), ("max_samples", C.c_uint32),
                 ("flags", C.c_uint32), ("min_af", C.c_double)]
@@ -64,7 +70,7 @@ class SynthParams(C.Structure):
 
 # every symbol include/basevar_amd.h declares
 EXPORTS = ["bv_version", "bv_min_af", "bv_engine_create", "bv_engine_destroy", "bv_engine_submit", "bv_engine_submit_many", "bv_engine_submit_many_g", "bv_engine_wait", "bv_engine_join",
-           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_add_many", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
+           "bv_engine_tiles_begin", "bv_engine_tiles_add", "bv_engine_tiles_add_many", "bv_engine_tiles_add_sparse", "bv_sparse_tile_packed_layout", "bv_engine_tiles_finish", "bv_tile_packed_layout", "bv_engine_stream",
            "bv_engine_kernel_ms", "bv_engine_timing_reset", "bv_engine_timing_get", "bv_engine_timing_get_ex",
            "bv_host_log_probe", "bv_host_log_eval", "bv_engine_host_log_exact", "bv_engine_host_log_eval",
            "bv_engine_last_variant_count", "bv_last_error", "bv_synth_fill", "bv_device_numa_node", "bv_bind_thread_to_device_node", "bv_engine_last_launch_form"]
@@ -112,6 +118,10 @@ def load():
     L.bv_engine_tiles_add.argtypes = [C.c_void_p, C.POINTER(Slab), C.c_void_p]
     L.bv_engine_tiles_add_many.restype = C.c_int
     L.bv_engine_tiles_add_many.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(Slab), C.c_void_p]
+    L.bv_engine_tiles_add_sparse.restype = C.c_int
+    L.bv_engine_tiles_add_sparse.argtypes = [C.c_void_p, C.POINTER(SparseTile), C.c_void_p]
+    L.bv_sparse_tile_packed_layout.restype = C.c_int
+    L.bv_sparse_tile_packed_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.bv_tile_packed_layout.restype = C.c_int
     L.bv_tile_packed_layout.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64),
                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]

@@ -251,6 +251,7 @@ struct bv_engine {
     bool tile_ranks = false, tile_open = false;
     uint32_t tile_layout = 0;          // bv_slab.layout of the job's tiles (every tile of a job has the first one's)
     bool tile_layout_set = false;
+    bool j_filled = false;             // joined rows: the columns not yet delivered hold "uncovered" (a packed tile scatters into them)
     hipStream_t copy_stream[2] = {nullptr, nullptr};  // alternate: the set-up of one copy hides under the transfer of the other
     // joined-rows realisation of the tile mode: resident planes [tile_sites][j_pitch]
     bool tile_join = false;
@@ -1113,7 +1114,7 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
     if (n_groups > BV_MAX_GROUPS) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: n_groups exceeds BV_MAX_GROUPS");
     BV_HIP(e, hipSetDevice(e->cfg.device));
     e->tile_join = false;
-    e->tile_layout = 0; e->tile_layout_set = false;
+    e->tile_layout = 0; e->tile_layout_set = false; e->j_filled = false;
     if (!(e->cfg.flags & BV_FLAG_TILE_STATE)) {
         // joined rows: [n_sites][pitch] planes resident in HBM, if they fit next to what is already there
         const size_t pitch = ((size_t)n_samples_total + 255) & ~(size_t)255, plane = (size_t)n_sites * pitch;
@@ -1266,6 +1267,106 @@ int bv_engine_tiles_add(bv_engine *e, const bv_slab *t, void *stream_) {
     a.rpr_tag = (e->tile_layout & BV_SLAB_RPR_TAGGED) ? 1u : 0u;
     bv_launch_tile_tally(a, st);
     BV_HIP(e, hipGetLastError());
+    if (slot) {
+        int rc = stage_release(e, slot, st);
+        if (rc != BV_OK) return rc;
+    }
+    e->tile_samples_seen += t->n_samples;
+    return mark_done(e, st);
+}
+
+// A tile as its covered cells only (include/basevar_amd.h): scattered into the joined planes, which hold "uncovered" wherever no
+// tile has delivered yet (filled once, when the job's first packed tile arrives), or added to the per-site tallies entry by entry.
+int bv_sparse_tile_packed_layout(uint32_t n_sites, uint32_t n_entries, uint32_t width, int with_ranks, int with_groups,
+                                 uint64_t offsets[7], uint64_t *total_bytes) {
+    if (!n_sites || !width || !offsets || !total_bytes) return fail(nullptr, BV_ERR_INVALID_ARG, "bv_sparse_tile_packed_layout: bad argument");
+    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+    const uint64_t E = n_entries ? n_entries : 1u;
+    uint64_t at = 0;
+    offsets[0] = at; at += up(4ull * ((uint64_t)n_sites + 1));
+    offsets[1] = at; at += up(2 * E);
+    offsets[2] = at; at += up(E);
+    offsets[3] = at; at += up(E);
+    offsets[4] = with_ranks ? at : 0; at += with_ranks ? up(E) : 0;
+    offsets[5] = with_ranks ? at : 0; at += with_ranks ? up(2 * E) : 0;
+    offsets[6] = with_groups ? at : 0; at += with_groups ? up(width) : 0;
+    *total_bytes = at;
+    return BV_OK;
+}
+
+int bv_engine_tiles_add_sparse(bv_engine *e, const bv_sparse_tile *t, void *stream_) {
+    if (!e || !t) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: null argument");
+    if (!e->tile_open) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: call bv_engine_tiles_begin first");
+    if (t->n_sites != e->tile_sites) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: tile n_sites differs from the job's");
+    if (t->n_samples == 0 || t->n_samples > 65536u || !t->row_start || (t->n_entries && (!t->sample || !t->base_strand || !t->qual)))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: bad tile geometry (at most 65,536 samples per tile) or missing arrays");
+    if (e->tile_ranks && t->n_entries && (!t->mapq || !t->rpr)) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: job was opened with rank planes");
+    if (e->tile_groups && !t->group_id) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: job has groups, tile has no group_id");
+    if ((uint64_t)e->tile_samples_seen + t->n_samples > e->tile_samples_total)
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: more samples than announced");
+    if ((t->layout & ~BV_SLAB_RPR_TAGGED) || (e->tile_layout_set && t->layout != e->tile_layout))
+        return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_add_sparse: every tile of a job must have the same layout (known bits only)");
+    e->tile_layout = t->layout; e->tile_layout_set = true;
+    BV_HIP(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream_ ? (hipStream_t)stream_ : e->stream;
+    {
+        int rc = use_stream(e, st);
+        if (rc != BV_OK) return rc;
+    }
+    const size_t S = t->n_sites, E = t->n_entries;
+    const bool ranks = e->tile_ranks;
+    const uint32_t *row_start = t->row_start;
+    const uint16_t *smp = t->sample, *rp = ranks ? t->rpr : nullptr;
+    const uint8_t *bs = t->base_strand, *q = t->qual, *mq = ranks ? t->mapq : nullptr, *gid = e->tile_groups ? t->group_id : nullptr;
+    bv_engine::StageSlot *slot = nullptr;
+    if (t->mem_kind == BV_MEM_HOST) {
+        HostPlane pl[7] = {{row_start, 4 * (S + 1), nullptr}, {smp, 2 * E, nullptr}, {bs, E, nullptr}, {q, E, nullptr}, {mq, mq ? E : 0, nullptr},
+                           {rp, rp ? 2 * E : 0, nullptr}, {gid, gid ? (size_t)t->n_samples : 0, nullptr}};
+        int rc = stage_host_planes(e, pl, 7, 0, &slot, nullptr, st);
+        if (rc != BV_OK) return rc;
+        rc = stage_publish(e, slot, st);
+        if (rc != BV_OK) return rc;
+        row_start = reinterpret_cast<const uint32_t *>(pl[0].dev); smp = reinterpret_cast<const uint16_t *>(pl[1].dev);
+        bs = pl[2].dev; q = pl[3].dev; mq = pl[4].dev; rp = reinterpret_cast<const uint16_t *>(pl[5].dev); gid = pl[6].dev;
+    }
+    BvSparseTileArgs a{};
+    a.row_start = row_start; a.sample = smp; a.call = bs; a.phred = q; a.mapq = E ? mq : nullptr; a.rank = rp;
+    a.n_sites = t->n_sites; a.width = t->n_samples; a.n_entries = t->n_entries;
+    a.rpr_tag = (e->tile_layout & BV_SLAB_RPR_TAGGED) ? 1u : 0u;
+    a.col0 = e->tile_samples_seen;
+    if (e->tile_join) {
+        uint8_t *jb = e->j_buf, *jq = e->j_buf + e->j_o_q, *jm = ranks ? e->j_buf + e->j_o_mq : nullptr;
+        uint16_t *jr = ranks ? reinterpret_cast<uint16_t *>(e->j_buf + e->j_o_rp) : nullptr;
+        if (!e->j_filled) {
+            // every column that has not been delivered yet: "nobody covered" (once per job; dense tiles that follow overwrite theirs)
+            if (e->tile_samples_seen == 0) {
+                bv_launch_tile_fill_uncovered(jb, jq, jm, jr, (uint64_t)e->tile_sites * e->j_pitch, a.rpr_tag, st);
+                BV_HIP(e, hipGetLastError());
+            } else {
+                const size_t lo = e->tile_samples_seen, w = e->tile_samples_total - lo;
+                BV_HIP(e, hipMemset2DAsync(jb + lo, e->j_pitch, 0x08, w, S, st));
+                BV_HIP(e, hipMemset2DAsync(jq + lo, e->j_pitch, 0, w, S, st));
+                if (ranks) {
+                    BV_HIP(e, hipMemset2DAsync(jm + lo, e->j_pitch, 0, w, S, st));
+                    BV_HIP(e, hipMemset2DAsync(reinterpret_cast<uint8_t *>(jr) + 2 * lo, 2 * e->j_pitch, a.rpr_tag ? 0x80 : 0, 2 * w, S, st));
+                }
+            }
+            e->j_filled = true;
+        }
+        a.bs = jb; a.q = jq; a.mq = jm; a.rp = jr; a.pitch = e->j_pitch;
+        if (E) {
+            bv_launch_tile_sparse_scatter(a, st);
+            BV_HIP(e, hipGetLastError());
+        }
+        if (gid) BV_HIP(e, hipMemcpyAsync(e->j_buf + e->j_o_gid + e->tile_samples_seen, gid, t->n_samples, hipMemcpyDeviceToDevice, st));
+    } else {
+        a.group_id = gid; a.n_groups = e->tile_groups; a.stride = e->tile_stride; a.rank_win = e->tile_rank_win; a.hg_off = e->tile_hg_off;
+        a.ord_off = e->tile_ord_off; a.ovf_cap = bv_engine::kOvfCap; a.state = e->tile_state; a.maxr = e->tile_maxr; a.ovf = e->tile_ovf;
+        if (E) {
+            bv_launch_tile_sparse_tally(a, st);
+            BV_HIP(e, hipGetLastError());
+        }
+    }
     if (slot) {
         int rc = stage_release(e, slot, st);
         if (rc != BV_OK) return rc;
@@ -1427,7 +1528,7 @@ int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result
     }
     if (e->tile_join) {
         e->tile_open = false;
-        if (e->tile_samples_seen < e->tile_samples_total)  // samples announced but never delivered: uncovered cells
+        if (e->tile_samples_seen < e->tile_samples_total && !e->j_filled)  // samples announced but never delivered: uncovered cells
         {
             BV_HIP(e, hipMemset2DAsync(e->j_buf + e->tile_samples_seen, e->j_pitch, 0x08, e->tile_samples_total - e->tile_samples_seen, S, st));
             // (tagged ranks: the same cells' rank words must say "no call" too -- 0x8080: the tag's bit 15, rank 128)

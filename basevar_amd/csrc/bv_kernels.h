@@ -206,6 +206,27 @@ struct BvTileFinishArgs {
     uint32_t *var_list;
     uint32_t *counters;
 };
+// packed host tiles (bv_engine_tiles_add_sparse): the covered cells of a tile only, row after row
+struct BvSparseTileArgs {
+    const uint32_t *row_start;  // [n_sites + 1] entries of site s: [row_start[s], row_start[s + 1])
+    const uint16_t *sample;     // [n_entries] sample index inside the tile
+    const uint8_t *call, *phred, *mapq;  // [n_entries]; mapq may be NULL together with rank
+    const uint16_t *rank;       // [n_entries] plain read-position ranks
+    uint32_t n_sites, width, n_entries;
+    uint32_t rpr_tag;           // joined rows: write the rank words tagged (BV_SLAB_RPR_TAGGED)
+    // joined-rows realisation: the resident planes and the tile's first column
+    uint8_t *bs, *q, *mq;
+    uint16_t *rp;
+    uint64_t pitch, col0;
+    // per-site-tally realisation: as BvTileArgs
+    const uint8_t *group_id;    // [width] or NULL
+    uint32_t n_groups, stride, rank_win, hg_off, ord_off, ovf_cap;
+    uint32_t *state, *maxr, *ovf;
+};
+void bv_launch_tile_sparse_scatter(const BvSparseTileArgs &a, hipStream_t stream);
+void bv_launch_tile_sparse_tally(const BvSparseTileArgs &a, hipStream_t stream);
+// the whole joined planes as "nobody covered": calls 'N', phred / mapq 0, ranks 0 (tagged: 0x8000)
+void bv_launch_tile_fill_uncovered(uint8_t *bs, uint8_t *q, uint8_t *mq, uint16_t *rp, uint64_t cells, uint32_t rpr_tag, hipStream_t stream);
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream);
 void bv_launch_tile_finish(const BvTileFinishArgs &a, hipStream_t stream);
 // joined-rows tile mode: `width_bytes` bytes of each of n_rows rows go from src (row pitch src_pitch) to

@@ -437,6 +437,111 @@ void bv_launch_tile_join_rows(const BvTileJoinArgs &a, hipStream_t stream) {
     hipLaunchKernelGGL(bv_tile_join_rows_kernel, dim3(gx, (a.n_rows + BV_TILE_JOIN_ROWS - 1) / BV_TILE_JOIN_ROWS), dim3(256), 0, stream, a);
 }
 
+// ------------------------------------------------------------------------------ packed host tiles
+// bv_engine_tiles_add_sparse: a tile arrives as its covered cells only -- per site a run of (sample, call, phred, mapq, rank)
+// entries, 7 bytes per covered cell -- instead of five dense planes: at the 8 % coverage of a low-pass cohort 0.6 B per cell
+// cross the host link, not 5.  A block takes BV_SPARSE_ROWS consecutive sites: their entries are one contiguous run, every
+// thread finds its entry's site in the block's row_start values (LDS, five steps).
+#define BV_SPARSE_ROWS 32
+__device__ __forceinline__ uint32_t bv_sparse_row_of(const uint32_t *rs, uint32_t e) {  // rs[0] <= e < rs[BV_SPARSE_ROWS]: largest r with rs[r] <= e
+    uint32_t lo = 0, hi = BV_SPARSE_ROWS;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rs[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+// joined rows: every entry to its cell of the resident planes (which hold "uncovered" everywhere else: bv_tile_fill_uncovered)
+__global__ __launch_bounds__(256) void bv_tile_sparse_scatter_kernel(BvSparseTileArgs a) {
+    __shared__ uint32_t rs[BV_SPARSE_ROWS + 1];
+    const uint32_t r0 = blockIdx.x * BV_SPARSE_ROWS;
+    if (threadIdx.x <= BV_SPARSE_ROWS) rs[threadIdx.x] = a.row_start[min(r0 + threadIdx.x, a.n_sites)];
+    __syncthreads();
+    const uint32_t e1 = min(rs[BV_SPARSE_ROWS], a.n_entries);
+    for (uint32_t e = rs[0] + threadIdx.x; e < e1; e += 256u) {
+        const uint32_t row = r0 + bv_sparse_row_of(rs, e), smp = a.sample[e];
+        if (smp >= a.width) continue;  // (an entry outside the tile: ignored, as a cell outside a dense tile is)
+        const uint32_t c = a.call[e];
+        const size_t at = (size_t)row * a.pitch + a.col0 + smp;
+        a.bs[at] = (uint8_t)c;
+        a.q[at] = a.phred[e];
+        if (a.mq) {
+            a.mq[at] = a.mapq[e];
+            const uint32_t r = a.rank[e];
+            a.rp[at] = a.rpr_tag ? BV_RPR_TAGGED(c, r) : (uint16_t)r;
+        }
+    }
+}
+void bv_launch_tile_sparse_scatter(const BvSparseTileArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(bv_tile_sparse_scatter_kernel, dim3((a.n_sites + BV_SPARSE_ROWS - 1) / BV_SPARSE_ROWS), dim3(256), 0, stream, a);
+}
+__global__ __launch_bounds__(256) void bv_tile_fill_uncovered_kernel(uint4 *bs, uint4 *q, uint4 *mq, uint4 *rp, uint64_t units, uint32_t rword) {
+    const uint4 n4 = make_uint4(0x08080808u, 0x08080808u, 0x08080808u, 0x08080808u), z4 = make_uint4(0u, 0u, 0u, 0u), r4 = make_uint4(rword, rword, rword, rword);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < units; i += (uint64_t)gridDim.x * 256u) {
+        bs[i] = n4;
+        q[i] = z4;
+        if (mq) { mq[i] = z4; rp[2 * i] = r4; rp[2 * i + 1] = r4; }
+    }
+}
+void bv_launch_tile_fill_uncovered(uint8_t *bs, uint8_t *q, uint8_t *mq, uint16_t *rp, uint64_t cells, uint32_t rpr_tag, hipStream_t stream) {
+    const uint64_t units = cells / 16u;  // (the planes are multiples of 256 cells)
+    uint64_t gx = (units + 255u) / 256u;
+    if (gx > 16384u) gx = 16384u;
+    hipLaunchKernelGGL(bv_tile_fill_uncovered_kernel, dim3((uint32_t)gx), dim3(256), 0, stream, reinterpret_cast<uint4 *>(bs), reinterpret_cast<uint4 *>(q),
+                       reinterpret_cast<uint4 *>(mq), reinterpret_cast<uint4 *>(rp), units, rpr_tag ? 0x80008000u : 0u);
+}
+// per-site tallies: what bv_tile_tally_kernel adds for a covered cell, per entry
+__global__ __launch_bounds__(256) void bv_tile_sparse_tally_kernel(BvSparseTileArgs a) {
+    __shared__ uint32_t rs[BV_SPARSE_ROWS + 1];
+    const uint32_t r0 = blockIdx.x * BV_SPARSE_ROWS;
+    if (threadIdx.x <= BV_SPARSE_ROWS) rs[threadIdx.x] = a.row_start[min(r0 + threadIdx.x, a.n_sites)];
+    __syncthreads();
+    const uint32_t e1 = min(rs[BV_SPARSE_ROWS], a.n_entries);
+    for (uint32_t e = rs[0] + threadIdx.x; e < e1; e += 256u) {
+        const uint32_t site = r0 + bv_sparse_row_of(rs, e), smp = a.sample[e], c = a.call[e];
+        if (smp >= a.width || c > 7u) continue;
+        uint32_t *S = a.state + (size_t)site * a.stride;
+        const uint32_t q = a.phred[e], b = c & 3u;
+        atomicAdd(&S[BV_TS_H1 + ((c << 8) | q)], 1u);
+        if (a.mapq) {
+            const uint32_t mq = a.mapq[e], r = a.rank[e];
+            atomicAdd(&S[BV_TS_HM + ((b << 8) | mq)], 1u);
+            if (r) atomicMax(&a.maxr[site], r);
+            if (r < a.rank_win) atomicAdd(&S[BV_TS_HR + b * a.rank_win + r], 1u);
+            else {
+                const uint32_t k = atomicAdd(&a.ovf[0], 1u);
+                if (k < a.ovf_cap) { a.ovf[2u + 2u * k] = site; a.ovf[3u + 2u * k] = (b << 16) | r; }
+            }
+        }
+        uint32_t gi = BV_NO_GROUP;
+        if (a.n_groups) {
+            gi = a.group_id[smp];
+            if (gi < a.n_groups) atomicAdd(&S[a.hg_off + (((gi * 4u + b) << 7) | min(q, 127u))], 1u);
+        }
+        if (__builtin_nontemporal_load(&S[a.ord_off]) <= (uint32_t)BV_ORD_MAX) {
+            const uint32_t k = atomicAdd(&S[a.ord_off], 1u);
+            if (k < (uint32_t)BV_ORD_MAX) {
+                S[a.ord_off + 4u + 2u * k] = (uint32_t)a.col0 + smp;
+                S[a.ord_off + 5u + 2u * k] = (c << 8) | q | (gi << 16);
+            }
+        }
+        if (gi < a.n_groups) {
+            uint32_t *GL = S + a.ord_off + (1u + gi) * BV_TS_ORD_WORDS;
+            if (__builtin_nontemporal_load(&GL[0]) <= (uint32_t)BV_ORD_MAX) {
+                const uint32_t k = atomicAdd(&GL[0], 1u);
+                if (k < (uint32_t)BV_ORD_MAX) {
+                    GL[4u + 2u * k] = (uint32_t)a.col0 + smp;
+                    GL[5u + 2u * k] = (c << 8) | q | (gi << 16);
+                }
+            }
+        }
+    }
+}
+void bv_launch_tile_sparse_tally(const BvSparseTileArgs &a, hipStream_t stream) {
+    hipLaunchKernelGGL(bv_tile_sparse_tally_kernel, dim3((a.n_sites + BV_SPARSE_ROWS - 1) / BV_SPARSE_ROWS), dim3(256), 0, stream, a);
+}
+
 void bv_launch_tile_tally(const BvTileArgs &a, hipStream_t stream) {
     const uint64_t total = (uint64_t)a.n_sites * ((a.width + 15u) >> 4);
     hipLaunchKernelGGL(bv_tile_tally_kernel, dim3((uint32_t)((total + 255u) / 256u)), dim3(256), 0, stream, a);

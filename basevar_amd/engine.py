@@ -202,8 +202,10 @@ class BaseTypeEngine:
         return n.value
 
     # ---- sample-axis tile mode (numpy tiles in host memory)
-    def lrt_tiles(self, slab, tile_width, max_rank=0):
-        """Same result as lrt(slab), but the slab is fed as column tiles of `tile_width` samples
+    def lrt_tiles(self, slab, tile_width, max_rank=0, packed=False):
+        """`packed`: every tile goes as its covered cells only (bv_engine_tiles_add_sparse: 7 bytes per covered cell, one packed
+        host allocation per tile); a number k > 1: every k-th tile dense, the others packed (a job may mix the two).
+        Same result as lrt(slab), but the slab is fed as column tiles of `tile_width` samples
         (the reference's `-B/--batch-count` batchfiles) that the engine accumulates in HBM.  Every tile is one packed
         host allocation (bv_tile_packed_layout), so it crosses the link as one copy.  `max_rank`: an upper bound on the
         read-position ranks, for the per-site-tally realisation (see bv_engine_tiles_begin)."""
@@ -220,8 +222,44 @@ class BaseTypeEngine:
         if rc != 0:
             raise RuntimeError("bv_engine_tiles_begin failed (%d): %s" % (rc, self._err()))
         keep = []  # the copies are asynchronous: every tile stays alive until the final wait
-        for lo in range(0, N, tile_width):
+        lay = int(slab.get("layout", 0))
+        for k_tile, lo in enumerate(range(0, N, tile_width)):
             w = min(tile_width, N - lo)
+            if packed and not (packed > 1 and k_tile % int(packed) == 0):
+                # the tile's covered cells, site after site (np.nonzero walks row-major: sites in order, samples ascending)
+                cb = bs[:, lo:lo + w]
+                rows, cols = np.nonzero(cb != 8)
+                E = int(rows.size)
+                offs = (C.c_uint64 * 7)()
+                total = C.c_uint64()
+                rc = self._lib.bv_sparse_tile_packed_layout(S, E, w, 1 if ranks else 0, 1 if ng else 0, offs, C.byref(total))
+                if rc != 0:
+                    raise RuntimeError("bv_sparse_tile_packed_layout failed (%d)" % rc)
+                buf = np.zeros(total.value + 256, dtype=np.uint8)
+                pad = (-buf.ctypes.data) % 256
+
+                def arr(kk, dt, n):
+                    return buf[pad + offs[kk]: pad + offs[kk] + n * np.dtype(dt).itemsize].view(dt)
+                rs = arr(0, np.uint32, S + 1); rs[0] = 0; rs[1:] = np.cumsum(np.bincount(rows, minlength=S))
+                a_s = arr(1, np.uint16, E); a_s[:] = cols
+                a_b = arr(2, np.uint8, E); a_b[:] = cb[rows, cols]
+                a_q = arr(3, np.uint8, E); a_q[:] = q[:, lo:lo + w][rows, cols]
+                a_m = a_r = a_g = None
+                if ranks:
+                    a_m = arr(4, np.uint8, E); a_m[:] = np.asarray(mq)[:, lo:lo + w][rows, cols]
+                    a_r = arr(5, np.uint16, E); a_r[:] = np.asarray(rp)[:, lo:lo + w][rows, cols] & (0x1FFF if lay & 1 else 0xFFFF)  # plain ranks
+                if ng:
+                    a_g = arr(6, np.uint8, w); a_g[:] = np.asarray(gid, dtype=np.uint8)[lo:lo + w]
+                keep.append(buf)
+                p = lambda a: None if a is None else a.ctypes.data
+                t = _capi.SparseTile(S, w, E, ng, p(rs), p(a_s), p(a_b), p(a_q), p(a_m), p(a_r), p(a_g), _capi.BV_MEM_HOST, lay)
+                rc = self._lib.bv_engine_tiles_add_sparse(self._h, C.byref(t), None)
+                if rc != 0:
+                    raise RuntimeError("bv_engine_tiles_add_sparse failed (%d): %s" % (rc, self._err()))
+                if len(keep) >= 64:
+                    self.wait()
+                    del keep[:-1]
+                continue
             pitch, total = C.c_uint64(), C.c_uint64()
             offs = (C.c_uint64 * 5)()
             rc = self._lib.bv_tile_packed_layout(S, w, 1 if ranks else 0, 1 if ng else 0, C.byref(pitch), offs, C.byref(total))

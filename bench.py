@@ -81,6 +81,7 @@ def parse():
                          "host memory (bv_engine_tiles_add), joined in HBM, both passes, records gathered to rank 0; every rank owns "
                          "its contiguous site range of the job")
     ap.add_argument("--tile-distinct", type=int, default=64, help="distinct host tiles kept resident per rank (cycled over the job)")
+    ap.add_argument("--no-packed-tiles", action="store_true", help="--tile-job: skip the packed-tile leg (bv_engine_tiles_add_sparse) that runs beside the dense job")
     ap.add_argument("--verify-sites", type=int, default=256,
                     help="N > 1: rank 0 re-runs the first V sites of EVERY rank's last batch on its own device (the synthetic rows "
                          "are stateless in the global site index) and compares them with the gathered records byte for byte "
@@ -348,6 +349,7 @@ class TileRig:
         self.St, self.W, self.Wp, self.n_tiles, self.res = St, W, (W + 15) // 16 * 16, n_tiles, res
         self.n_samples = n_tiles * W
         self.layout = layout
+        self.device_index = device_index
         bs0, q0, mq0, rp0, ref0 = src
         self.ref = ref0[:St].contiguous()
 
@@ -378,6 +380,65 @@ class TileRig:
                 os.sched_setaffinity(0, keep)  # (the CPU baseline and the launch threads want every core again)
             torch.cuda.synchronize()
         self._slabs = {}
+        self.ptiles = []       # the same tiles as their covered cells only (bv_engine_tiles_add_sparse), pinned, one allocation each
+        self.packed_bytes = 0  # host bytes of ONE pass over the `res` distinct packed tiles
+
+    def build_packed(self):
+        """every distinct host tile again as a packed tile: per site the run of its covered cells (sample, call, phred, mapq, rank:
+        7 bytes per covered cell), laid out by bv_sparse_tile_packed_layout in ONE pinned allocation, first touched on the GPU's
+        NUMA node like the dense tiles; built from the device tiles (torch.nonzero walks row-major: sites in order)"""
+        import ctypes as C
+        torch = self.torch
+        keep = os.sched_getaffinity(0)
+        self.lib.bv_bind_thread_to_device_node(self.device_index)
+        try:
+            for tb, tq, tm_, tr in self.dtiles:
+                cb = tb[:, :self.W]
+                nz = torch.nonzero(cb != 8)
+                rows, cols = nz[:, 0], nz[:, 1]
+                E = int(rows.numel())
+                offs = (C.c_uint64 * 7)(); total = C.c_uint64()
+                rc = self.lib.bv_sparse_tile_packed_layout(self.St, E, self.W, 1, 0, offs, C.byref(total))
+                assert rc == 0
+                buf = torch.zeros(total.value, dtype=torch.uint8).pin_memory()
+
+                def put(k, t, dt):
+                    t = t.to(dt).contiguous().cpu()
+                    v = buf[offs[k]:offs[k] + t.numel() * t.element_size()].view(dt)
+                    v.copy_(t)
+                    return v
+                rs = torch.zeros(self.St + 1, dtype=torch.int32)
+                rs[1:] = torch.cumsum(torch.bincount(rows.cpu(), minlength=self.St), 0).to(torch.int32)
+                vr = put(0, rs, torch.int32)
+                vs = put(1, cols, torch.int16)
+                vb = put(2, cb[rows, cols], torch.uint8)
+                vq = put(3, tq[:, :self.W][rows, cols], torch.uint8)
+                vm = put(4, tm_[:, :self.W][rows, cols], torch.uint8)
+                rk = tr[:, :self.W][rows, cols].to(torch.int32) & (0x1FFF if self.layout else 0xFFFF)  # plain ranks: the engine tags the joined rows itself
+                vk = put(5, rk, torch.int16)
+                self.ptiles.append((vr, vs, vb, vq, vm, vk, E, buf))
+                self.packed_bytes += int(total.value)
+        finally:
+            os.sched_setaffinity(0, keep)
+        torch.cuda.synchronize()
+        self._sparse = [self.capi.SparseTile(self.St, self.W, t[6], 0, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(),
+                                             t[5].data_ptr(), None, self.capi.BV_MEM_HOST, self.layout) for t in (self.ptiles[k % self.res] for k in range(self.n_tiles))]
+
+    def job_packed(self, out_ptr, stream=0):
+        """one tile job from the packed host tiles"""
+        import ctypes as C
+        eng, lib = self.eng, self.lib
+        rc = lib.bv_engine_tiles_begin(eng._h, self.St, self.n_samples, 0, 1)
+        assert rc == 0, eng._err()
+        st = C.c_void_p(stream) if stream else None
+        for t in self._sparse:
+            rc = lib.bv_engine_tiles_add_sparse(eng._h, C.byref(t), st)
+            assert rc == 0, eng._err()
+        rc = lib.bv_engine_tiles_finish(eng._h, self.ref.data_ptr(), out_ptr, None, self.capi.BV_MEM_DEVICE, st)
+        assert rc == 0, eng._err()
+
+    def packed_host_bytes_per_job(self):
+        return self.packed_bytes * self.n_tiles // max(1, self.res)
 
     def slabs(self, kind):
         """the job's n_tiles bv_slab descriptors (ctypes), built once per kind"""
@@ -753,6 +814,34 @@ def main():
     per_rank = all_ranks([elapsed, my_p1_frac, my_exposed_ms, my_host_gbps, my_nodes[0], my_nodes[1]])
     elapsed = max(r[0] for r in per_rank)
 
+    packed_leg = None
+    if rig is not None and not args.no_packed_tiles:
+        # the same job from PACKED host tiles (bv_engine_tiles_add_sparse: the covered cells only), beside the dense job that is
+        # `value`: every rank at once; the records must be the dense job's, byte for byte
+        rig.build_packed()
+        dense_rec = outs[last_slot[0]].clone()
+        pout = torch.zeros_like(dense_rec)
+        with torch.cuda.stream(streams[0]):
+            rig.job_packed(pout.data_ptr(), stream=streams[0].cuda_stream)
+        eng.wait(); torch.cuda.synchronize()
+        same_rec = bool(torch.equal(pout, dense_rec))
+        if dist_on:
+            dist.barrier()
+        n_pj = max(2, args.steps // 2)
+        t0p = time.perf_counter()
+        for _ in range(n_pj):
+            with torch.cuda.stream(streams[0]):
+                rig.job_packed(pout.data_ptr(), stream=streams[0].cuda_stream)
+        eng.wait(); torch.cuda.synchronize()
+        dtp = time.perf_counter() - t0p
+        legs = all_ranks([dtp, 1.0 if same_rec else 0.0, float(rig.packed_host_bytes_per_job())])
+        tmax = max(r[0] for r in legs)
+        packed_leg = {"sites_per_s": world * B * n_pj / tmax, "jobs": n_pj, "ms_per_job": tmax / n_pj * 1e3,
+                      "host_bytes_per_job_per_rank": int(legs[0][2]), "host_GBps_per_rank": [r[2] * n_pj / r[0] / 1e9 for r in legs],
+                      "records_identical_to_dense_tiles": all(r[1] == 1.0 for r in legs),
+                      "bytes_per_cell": legs[0][2] / (float(B) * N),
+                      "how": "bv_engine_tiles_add_sparse: per site the run of its covered cells, 7 B each (sample u16, call, phred, mapq, rank u16) + 4 B per site and tile"}
+
     tile_legs = None
     if args.with_tile_mode and not tj:
         # BASELINE configs[4]'s shape beside the row workload, on EVERY rank at once (the ranks share the host's memory
@@ -842,6 +931,7 @@ def main():
                 "ranks_verified": (ranks_verified if dist_on else None), "verify_sites": (max(0, min(args.verify_sites, B)) if dist_on else 0),
                 "tile_job": ({"tiles_per_job": tj["n_tiles"], "tile_width": tj["W"], "distinct_host_tiles": tj["res"],
                               "host_bytes_per_job_per_rank": rig.host_bytes_per_job(),
+                              "packed": packed_leg, "packed_over_dense": (packed_leg["sites_per_s"] / sites_per_s if packed_leg else None),
                               # what every rank pulled over ITS host link per second of the timed region, and all of them together
                               "host_pinned_pcie_GBps_per_rank": [r[3] for r in per_rank],
                               "host_pinned_pcie_GBps_total": sum(r[3] for r in per_rank),

@@ -237,6 +237,29 @@ int bv_engine_tiles_add_many(bv_engine *e, uint32_t n_tiles, const bv_slab *tile
 int bv_engine_tiles_finish(bv_engine *e, const uint8_t *ref_base, bv_site_result *out, bv_group_result *gout,
                            uint32_t mem_kind, void *stream);
 
+/* Packed host tiles (BASELINE config #5 is bound by the host link: 5 B per cell of which 92 % say "nobody covered"): a tile as
+ * its covered cells only, site after site -- 7 bytes per covered cell, ~0.6 B per cell at 8 % coverage.  Entry k of site s
+ * (row_start[s] <= k < row_start[s + 1]) is the cell of sample `sample[k]` of the tile: the token, quality, mapping quality and
+ * read-position rank the reference reads for it from its batchfile row (src/basetype_caller.cpp:688-715); every cell without an
+ * entry is an 'N'.  Same job protocol (begin / add ... / finish), same two realisations and byte-identical records as
+ * bv_engine_tiles_add of the dense tile; dense and packed tiles may alternate within a job.  `rpr` holds plain ranks; with
+ * layout = BV_SLAB_RPR_TAGGED (ranks <= 8,191) the engine writes the joined rows' rank words tagged itself.  Host tiles laid out
+ * by bv_sparse_tile_packed_layout (one allocation: row_start, sample, base_strand, qual, mapq, rpr, group_id) cross the link as
+ * one copy. */
+typedef struct bv_sparse_tile {
+    uint32_t n_sites, n_samples;  /* sites of the job; samples (columns) of this tile, <= 65,536 */
+    uint32_t n_entries, n_groups; /* covered cells of the tile (= row_start[n_sites]); the job's group count */
+    const uint32_t *row_start;    /* [n_sites + 1] */
+    const uint16_t *sample;       /* [n_entries] column inside the tile */
+    const uint8_t *base_strand, *qual, *mapq;  /* [n_entries]; mapq and rpr NULL for a job without rank planes */
+    const uint16_t *rpr;          /* [n_entries] */
+    const uint8_t *group_id;      /* [n_samples] or NULL */
+    uint32_t mem_kind, layout;    /* bv_mem_kind; BV_SLAB_* of the job's tiles */
+} bv_sparse_tile;
+int bv_engine_tiles_add_sparse(bv_engine *e, const bv_sparse_tile *tile, void *stream);
+int bv_sparse_tile_packed_layout(uint32_t n_sites, uint32_t n_entries, uint32_t width, int with_ranks, int with_groups,
+                                 uint64_t offsets[7], uint64_t *total_bytes);
+
 /* 1 when engine e replays tie-prone shallow sites (<= 64 covered samples) with the host libm's own log() restated on the
  * device, verified bit-exact at creation (the reference takes log() with the host libm, src/algorithm.h:243); 0: the device
  * library's log() -- values within 1e-6, exact ties undecided (BV_SITE_LOG_APPROX).  Probes: basevar_amd_diag.h. */

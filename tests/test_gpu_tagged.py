@@ -312,3 +312,47 @@ def test_dense_long_rows_take_the_bank_swizzle(bv, restatement):
         sites = recs[0][idx]; groups = None; n_variant = int(((recs[0][idx]["status"] & 2) != 0).sum())
     check(Got, exp, gexp, margins)
     assert (recs[0]["total_depth"] > n * 0.9).all()
+
+
+@pytest.mark.parametrize("flags", [0, 0x8], ids=["joined_rows", "per_site_tallies"])
+@pytest.mark.parametrize("n,width,groups,tagged", [(3001, 200, 0, False), (1000, 200, 2, True), (70000, 5000, 0, True), (10000, 1000, 3, False), (640, 64, 0, False)])
+def test_packed_host_tiles_give_the_dense_tiles_records(bv, n, width, groups, tagged, flags):
+    """bv_engine_tiles_add_sparse: a tile as its covered cells only (7 bytes per covered cell instead of 5 per cell over the host
+    link) -- the records of the job must be those of the dense tiles, byte for byte, in both realisations, with and without the
+    tagged rank layout, pop-groups included, and in a job that mixes dense and packed tiles (every third tile dense)."""
+    slab = make_slab(60, n, seed=1900 + n % 13, coverage=0.1, n_groups=groups, ref_n_frac=0.02)
+    slab["rpr"][7, np.nonzero(slab["base_strand"][7] < 8)[0][:5]] = 700   # long reads: window sweeps / the overflow pool
+    if tagged:
+        slab = tag_ranks(slab)
+    maf = bv.min_af(n)
+    res = []
+    for packed in (False, True, 3):
+        eng = bv.BaseTypeEngine(max_sites=60, min_af_value=maf, device=0, flags=flags)
+        res.append(eng.lrt_tiles(slab, width, packed=packed))
+        eng.close()
+    same(res[0], res[1])
+    same(res[0], res[2])
+    if flags == 0:
+        same(run_engine(bv, slab, maf), res[1])
+    assert res[0].n_variant >= 2
+
+
+def test_packed_tile_api_errors_and_an_empty_tile(bv):
+    from basevar_amd import _capi
+    S, n, w = 32, 600, 200
+    slab = make_slab(S, n, seed=5, coverage=0.2)
+    slab["base_strand"][:, 200:400] = 8   # the second tile: nobody covered -> a packed tile without entries
+    for k in ("qual", "mapq", "rpr"):
+        slab[k][:, 200:400] = 0
+    maf = bv.min_af(n)
+    want = run_engine(bv, slab, maf)
+    eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0)
+    got = eng.lrt_tiles(slab, w, packed=True)
+    same(want, got)
+    # a tile of more than 65,536 samples has no 16-bit sample index; a job must be open
+    rs = np.zeros(S + 1, dtype=np.uint32)
+    t = _capi.SparseTile(S, 70000, 0, 0, rs.ctypes.data, None, None, None, None, None, None, _capi.BV_MEM_HOST, 0)
+    assert eng._lib.bv_engine_tiles_add_sparse(eng._h, C.byref(t), None) == _capi.BV_ERR_INVALID_ARG
+    assert eng._lib.bv_engine_tiles_begin(eng._h, S, 100000, 0, 1) == 0
+    assert eng._lib.bv_engine_tiles_add_sparse(eng._h, C.byref(t), None) == _capi.BV_ERR_INVALID_ARG
+    eng.close()
