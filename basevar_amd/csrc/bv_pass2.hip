@@ -205,8 +205,10 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
             uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
             for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
         }
-        if (GROUPS)
-            for (uint32_t i = tid; i < a.n_groups * GW; i += NT) hg[i] = 0u;
+        if (GROUPS) {  // (16-byte stores: GW is a multiple of 4 and the dynamic block is 16-byte aligned)
+            uint4 *z = reinterpret_cast<uint4 *>(hg);
+            for (uint32_t i = tid; i < a.n_groups * (GW / 4u); i += NT) z[i] = make_uint4(0, 0, 0, 0);
+        }
         __syncthreads();
 
         BvP2Ctx cx;

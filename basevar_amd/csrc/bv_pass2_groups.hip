@@ -355,6 +355,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
     const uint32_t n_items = all < (uint64_t)a.gitem_cap ? (uint32_t)all : a.gitem_cap;
     const uint32_t n_waves = gridDim.x * BV_P2G_NW, gw = blockIdx.x * BV_P2G_NW + (uint32_t)wave;
     const int grp = lane >> 4, gl = lane & 15;
+    // (Tried, round 6: every group of 16 lanes walking a stream of items of its own and skipping what is not pending sixteen
+    // headers at a time, so that no wave carries an idle quarter -- the probes' load latency in front of every job cost more than
+    // the idle quarters: 60 -> 52 M sites/s at 32 groups.)
     for (uint32_t t = gw; (uint64_t)t * 4u < n_items; t += n_waves) {
         const uint32_t idx = t * 4u + (uint32_t)grp;
         if (idx >= n_items) continue;
@@ -379,6 +382,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         if (ref > 4) ref = 4;
         const int n_alt = res->n_alt;
         int comb = ref, nc = 1;  // caller.cpp:750-753: [toupper(REF)] + alts, 3 bits per entry
+        // (Tried, round 6: site and [REF] + alts riding in the item, so that a job starts from one load instead of the chain
+        // variant list -> record -> reference base: no change, 60.4 against 60.2 M sites/s at 32 groups -- the kernel is bound by
+        // its FP64 instructions, not by these loads.)
 #pragma unroll
         for (int k = 0; k < BV_MAX_ALT; ++k) {
             if (k < n_alt) {
@@ -399,9 +405,10 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         BvLrtOut L;
         // (a job whose four groups all have at most 32 bins -- every job of a run with many groups -- runs the two-slot
         // instance: a third of the eight-slot one's instructions are the tests of empty slots)
-        if (__ballot(nb > 32u) == 0ull) bv_lrt_g16<true, 2>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
-        else if (__ballot(nb > 48u) == 0ull) bv_lrt_g16<true, 3>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
-        else bv_lrt_g16<true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        if (__ballot(nb > 16u) == 0ull) bv_lrt_g16<true, 1, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);  // (64 groups and more: a dozen cells each)
+        else if (__ballot(nb > 32u) == 0ull) bv_lrt_g16<true, 2, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        else if (__ballot(nb > 48u) == 0ull) bv_lrt_g16<true, 3, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        else bv_lrt_g16<true, BV_G16_SLOTS, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
         if ((hdr & BV_P2G_SHALLOW) && L.tie_risk) {
             // a tie (or what rounding makes of one) in a group of at most BV_ORD_MAX covered samples: the reference's per-sample
             // order decides it -- the item goes on to bv_p2g_hard_kernel, which runs behind this kernel, in that kernel's format

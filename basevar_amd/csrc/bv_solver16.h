@@ -227,7 +227,9 @@ __device__ __forceinline__ bool bv_g16_bin(const BvG16Bins &B, int s, uint32_t &
 // EM, algorithm.h:210-255, on the bins (no phred-0 call among them, start frequencies not all zero -- the wave solver
 // takes the other sites).  `in_set`: bit b = base b; bases outside keep frequency +0.0 (their terms are exact zeros).
 // NS: slots in use (every group of the wave has at most 16 * NS bins): the loops over the slots stop there.
-template <int NS = BV_G16_SLOTS>
+// TWO: with the two-base form below (the pop-group solve kernel; the kernels that solve whole sites beside streaming waves sit at
+// their register limit -- with it their solvers spilled 18-23 registers into the dependent chains -- and keep the general form).
+template <int NS = BV_G16_SLOTS, bool TWO = false>
 __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsigned in_set, double n_cov, double *lr_out) {
     const double epsilon = (double)0.001f;
     const double inv_n = 1.0 / n_cov;
@@ -235,6 +237,37 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
 #pragma unroll
     for (int s = 0; s < NS; ++s) pm[s * 16] = 1.0;
     int iters = 0;
+    if (TWO && __popc(in_set) == 2) {
+        // Two bases in the subset -- the EM of nearly every item (REF + one ALT): the two bases outside keep frequency +0.0, their
+        // likelihood terms are exact +0.0 and adding them changes no bit of the marginal or of a posterior sum, so they are left
+        // out: half the multiplies, two row reductions instead of four per iteration.  Bit-identical to the general form below.
+        const int ba = __builtin_ctz(in_set), bb = 31 - __builtin_clz(in_set);
+        double fa = bv_sel4(f[0], f[1], f[2], f[3], ba), fb = bv_sel4(f[0], f[1], f[2], f[3], bb);
+        for (int k = 0; k <= 100; ++k) {
+            double pfa = 0., pfb = 0., delta = 0.;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                uint32_t b, q;
+                double c;
+                if (bv_g16_bin(B, s, b, q, c)) {
+                    const double hit = B.hit[q], miss = B.miss[q];
+                    const double La = ((int)b == ba ? hit : miss) * fa, Lb = ((int)b == bb ? hit : miss) * fb;
+                    const double marg = La + Lb;
+                    const double r = c / marg;
+                    pfa += La * r; pfb += Lb * r;
+                    const double old = pm[s * 16];
+                    if (k > 0 && !(marg < old * 2.7 && marg > old * 0.37)) delta += c * bv_int_abs_trunc(log(marg) - log(old));
+                    pm[s * 16] = marg;
+                }
+            }
+            fa = bv_g16_sum(pfa) * inv_n; fb = bv_g16_sum(pfb) * inv_n;
+            if (k == 0) continue;
+            ++iters;
+            if (bv_g16_sum(delta) < epsilon) break;
+        }
+        f[0] = (ba == 0) ? fa : ((bb == 0) ? fb : 0.); f[1] = (ba == 1) ? fa : ((bb == 1) ? fb : 0.);
+        f[2] = (ba == 2) ? fa : ((bb == 2) ? fb : 0.); f[3] = (ba == 3) ? fa : ((bb == 3) ? fb : 0.);
+    } else
     for (int k = 0; k <= 100; ++k) {
         double pf0 = 0., pf1 = 0., pf2 = 0., pf3 = 0., delta = 0.;
 #pragma unroll
@@ -280,7 +313,7 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
 // SPEC: the candidate bases are `nspec` entries of `specific_packed` (3 bits each, reference order, 4 = not ACGT) as in
 // bv_lrt -- the pop-group calls of pass 2, lrt([REF] + alts); otherwise A, C, G, T.
 #define BV_TIE_TOL 1e-7  /* the sums' rounding is ~1e-13 relative; a true gap this small has never been seen */
-template <bool SPEC = false, int NS = BV_G16_SLOTS>
+template <bool SPEC = false, int NS = BV_G16_SLOTS, bool TWO = false>
 __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], uint32_t total, int ref_code, double min_af,
                                   BvLrtOut &o, int specific_packed = 0, int nspec = 0) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
@@ -368,7 +401,7 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
                 f[0] = (b1 == 0) ? 1.0 : 0.; f[1] = (b1 == 1) ? 1.0 : 0.;
                 f[2] = (b1 == 2) ? 1.0 : 0.; f[3] = (b1 == 3) ? 1.0 : 0.;
             } else {
-                it = bv_em_g16<NS>(B, f, in_set, n_cov, &lr);
+                it = bv_em_g16<NS, TWO>(B, f, in_set, n_cov, &lr);
             }
             o.em_iters += it;
             o.n_em += 1;
