@@ -30,6 +30,7 @@ struct __attribute__((aligned(16))) BvPass2Shared {
     BvLrtShared lrt[INLINE ? NW : 1];
     double tab_hit[INLINE ? BV_QBINS : 2], tab_miss[INLINE ? BV_QBINS : 2];
     alignas(8) uint16_t ord[INLINE ? NW : 1][BV_ORD_ALLOC];  // shallow pop-groups: the group's covered cells in sample order (bv_gather_ordered)
+    uint32_t ghdr[INLINE ? 1 : BV_GROUPS_PER_ROUND];  // !INLINE: the header words of the site's items, until the site's kind of small-group solver is known
 };
 
 extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_groups][4][128]
@@ -334,11 +335,12 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                         }
                     }
                     const uint32_t hdr = gt == 0u ? 0u : (nbv | (four ? BV_P2G_PENDING : BV_P2G_HARD) | (shal ? BV_P2G_SHALLOW : 0u));
-                    uint32_t w = hdr;
+                    uint32_t w = 0u;  // (word 0, the header, follows when the site's kind is known: below)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) w = (lane == 1 + b) ? gd[b] : w;
                     w = (lane == 5) ? q0 : w;
-                    if (lane < 6) dst[lane] = w;
+                    if (lane >= 1 && lane < 6) dst[lane] = w;
+                    if (lane == 0) sh.ghdr[g] = hdr;
                     continue;
                 }
                 uint32_t nb = 0, gdepth[4], gtotal = 0, q0_mask = 0;
@@ -415,6 +417,22 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     a.gout[(size_t)site * a.n_groups + g] = gr;
                 }
                 bv_lrt_sync<0>();
+            }
+            if (!INLINE) {
+                // the site's items are written: which small-group solver takes them (BV_P2G_L4 / BV_P2G_L8, bv_kernels.h) is a
+                // property of the site -- lane g of wave 0 classifies group g and writes its header
+                __syncthreads();
+                if (wave == 0) {
+                    const uint32_t hdr = (uint32_t)lane < a.n_groups ? sh.ghdr[lane] : 0u;
+                    const bool pend = (hdr & BV_P2G_PENDING) != 0u;
+                    const uint32_t nbv = hdr & 0xFFFFu;
+                    const uint32_t n_pend = (uint32_t)__popcll(__ballot(pend)), n_16 = (uint32_t)__popcll(__ballot(pend && nbv <= 16u));
+                    const bool site_l4 = 4u * n_16 >= 3u * n_pend;
+                    uint32_t kind = 0u;
+                    if (pend && site_l4 && nbv <= 32u) kind = BV_P2G_L4;
+                    else if (pend && nbv <= 64u) kind = BV_P2G_L8;
+                    if ((uint32_t)lane < a.n_groups) a.gitems[((size_t)v * a.n_groups + (uint32_t)lane) * BV_P2G_ITEM_WORDS] = hdr | kind;
+                }
             }
         }
     }

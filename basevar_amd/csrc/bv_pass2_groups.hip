@@ -365,6 +365,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         const uint32_t hdr = it[0];
         if (!(hdr & BV_P2G_PENDING)) continue;
         const uint32_t nb = hdr & 0xFFFFu;
+        if (hdr & (BV_P2G_L4 | BV_P2G_L8)) continue;  // bv_p2g_solve_small_kernel's: sixteen or eight such items per wave
         const uint32_t v = idx / a.n_groups, g = idx - v * a.n_groups;
         const uint32_t site = a.var_list[v];
         // a chained launch: the segment's records and reference bases, looked up per group of 16 lanes (its site is its own)
@@ -405,9 +406,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
         BvLrtOut L;
         // (a job whose four groups all have at most 32 bins -- every job of a run with many groups -- runs the two-slot
         // instance: a third of the eight-slot one's instructions are the tests of empty slots)
-        if (__ballot(nb > 16u) == 0ull) bv_lrt_g16<true, 1, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);  // (64 groups and more: a dozen cells each)
-        else if (__ballot(nb > 32u) == 0ull) bv_lrt_g16<true, 2, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
-        else if (__ballot(nb > 48u) == 0ull) bv_lrt_g16<true, 3, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
+        if (__ballot(nb > 48u) == 0ull) bv_lrt_g16<true, 3, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
         else bv_lrt_g16<true, BV_G16_SLOTS, true>(B, gdepth, gtotal, ref, a.min_af, L, comb, nc);
         if ((hdr & BV_P2G_SHALLOW) && L.tie_risk) {
             // a tie (or what rounding makes of one) in a group of at most BV_ORD_MAX covered samples: the reference's per-sample
@@ -437,6 +436,106 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve16
     }
 }
 
+// ------------------------------------------------------------------------------ small pop-groups, eight or sixteen per wave
+// With 32 or 64 pop-groups a group sees a dozen or two covered cells per site: the LRT of such an item is a few hundred FP64
+// instructions of which most do not depend on the number of bins -- divisions, two logarithms' worth of polynomial, the LRT's
+// control flow, DPP reductions -- and on 16 lanes per item a wave spends them four items at a time (bv_p2g_solve16_kernel:
+// 2,370 VALU instructions per job of four, the kernel FP64-issue-bound at 0.72 ms for the 640 k items of 100 k sites x 32 groups).
+// Here an item owns L = 4 or 8 lanes -- an aligned part of a DPP row, four register slots per lane: up to 16 / 32 bins -- so the
+// same instructions serve 16 or 8 items (eight slots when an item of the job has more); the row reductions are two or three DPP
+// steps instead of four.  Which kernel takes an item is decided per SITE by the tally kernel (BV_P2G_L4 / BV_P2G_L8 in the item's
+// header, bv_kernels.h): a wave's consecutive items belong to one site and are of one kind, and a site's records do not depend
+// on what else is in the launch; every kernel walks all items and skips the other kinds (a skipped item costs its header's load).
+// Same arithmetic per term as bv_lrt_g16 on 16 lanes; only the order of the sums over bins differs (~1e-16 relative).
+template <int L>
+__global__ __launch_bounds__(BV_WAVE *BV_P2G_NW, BV_P2G_OCC) void bv_p2g_solve_small_kernel(BvPass2Args a) {
+    constexpr uint32_t IPW = BV_WAVE / L, KIND = (L == 4) ? BV_P2G_L4 : BV_P2G_L8;  // items per wave; the header bit of this kernel's items
+    __shared__ BvP2gShared sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < BV_QBINS; i += BV_WAVE * BV_P2G_NW) {
+        sh.tab_hit[i] = a.tables->hit[i];
+        sh.tab_miss[i] = a.tables->miss[i];
+        sh.tab_loghit[i] = a.tables->loghit[i];
+        sh.tab_logmiss[i] = a.tables->logmiss[i];
+    }
+    __syncthreads();
+    const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
+    const uint64_t all = (uint64_t)n_var * a.n_groups;
+    const uint32_t n_items = all < (uint64_t)a.gitem_cap ? (uint32_t)all : a.gitem_cap;
+    const uint32_t n_waves = gridDim.x * BV_P2G_NW, gw = blockIdx.x * BV_P2G_NW + (uint32_t)wave;
+    const uint32_t sub = (uint32_t)lane / L, gl = (uint32_t)lane % L;
+    const int row = lane >> 4, lr = lane & 15;
+    for (uint32_t t = gw; (uint64_t)t * IPW < n_items; t += n_waves) {
+        const uint32_t idx = t * IPW + sub;
+        if (idx >= n_items) continue;
+        const uint32_t *it = a.gitems + (size_t)idx * BV_P2G_ITEM_WORDS;
+        const uint32_t hdr = it[0];
+        if (!(hdr & BV_P2G_PENDING) || !(hdr & KIND)) continue;
+        const uint32_t nb = hdr & 0xFFFFu;  // <= 8 * L (the tally kernel's rule)
+        const uint32_t v = idx / a.n_groups, g = idx - v * a.n_groups;
+        const uint32_t site = a.var_list[v];
+        const bv_site_result *outp = a.out;
+        const uint8_t *refp = a.ref_base;
+        bv_group_result *goutp = a.gout;
+        if (a.ch != nullptr) {  // a chained launch: the segment's records and reference bases (the item's site is its own)
+            const BvChainC ch = bv_chain_const(a.ch);
+            const uint32_t sg = bv_chain_seg(ch, site);
+            if (!a.ch_cat) { outp = ch->out[sg]; refp = ch->ref_base[sg]; }
+            goutp = ch->gout[sg];
+        }
+        const bv_site_result *res = &outp[site];
+        int ref = refp[site];
+        if (ref > 4) ref = 4;
+        const int n_alt = res->n_alt;
+        int comb = ref, nc = 1;  // caller.cpp:750-753: [toupper(REF)] + alts, 3 bits per entry
+#pragma unroll
+        for (int k = 0; k < BV_MAX_ALT; ++k) {
+            if (k < n_alt) {
+                comb |= (res->alt[k] & 3) << (3 * nc);
+                ++nc;
+            }
+        }
+        uint32_t gdepth[4] = {it[1], it[2], it[3], it[4]};
+        const uint32_t gtotal = gdepth[0] + gdepth[1] + gdepth[2] + gdepth[3];
+        BvG16Bins B;
+        B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sh.tab_loghit; B.logmiss = sh.tab_logmiss;
+        B.pm = reinterpret_cast<double *>(sh.grp[wave][row]) + lr;  // (the row's scratch: every lane of the row has a column of its own)
+#pragma unroll
+        for (int s = 0; s < BV_G16_SLOTS; ++s) {
+            const uint32_t i = (uint32_t)s * L + gl;
+            B.w[s] = i < nb ? it[8u + i] : 0u;
+        }
+        BvLrtOut Lo;
+        // (four slots when no item of the job needs more: the loops over the slots stop there)
+        if (__ballot(nb > 4u * L) == 0ull) bv_lrt_g16<true, 4, true, L>(B, gdepth, gtotal, ref, a.min_af, Lo, comb, nc);
+        else bv_lrt_g16<true, BV_G16_SLOTS, true, L>(B, gdepth, gtotal, ref, a.min_af, Lo, comb, nc);
+        if ((hdr & BV_P2G_SHALLOW) && Lo.tie_risk) {
+            // a tie in a group of at most BV_ORD_MAX covered samples: on to bv_p2g_hard_kernel, in that kernel's format (as bv_p2g_solve16_kernel)
+            uint32_t *itw = a.gitems + (size_t)idx * BV_P2G_ITEM_WORDS;
+#pragma unroll
+            for (int s = 0; s < BV_G16_SLOTS; ++s) {
+                const uint32_t i = (uint32_t)s * L + gl;
+                if (i < nb) itw[8u + i] = ((B.w[s] >> 16) << 23) | (B.w[s] & 0xFFFFu);
+            }
+            if (gl == 0) itw[0] = nb | BV_P2G_HARD | BV_P2G_SHALLOW;
+            continue;
+        }
+        if (gl == 0) {
+            bv_group_result gr;
+            gr.n_alt = (uint8_t)Lo.n_alt;
+            gr.reserved[0] = gr.reserved[1] = gr.reserved[2] = 0;
+            gr.total_depth = gtotal;
+            gr.reserved2 = 0;
+#pragma unroll
+            for (int k = 0; k < BV_MAX_ALT; ++k) {
+                gr.alt[k] = (k < Lo.n_alt) ? (uint8_t)bv_alt_at(Lo, k) : 0;
+                gr.af[k] = (k < Lo.n_alt) ? Lo.af[k] : 0.0;
+            }
+            goutp[(size_t)site * a.n_groups + g] = gr;
+        }
+    }
+}
+
 void bv_launch_p2g_solve16(const BvPass2Args &a, hipStream_t stream) {
     const bool groups = a.n_groups > 0 && a.group_id != nullptr && a.gout != nullptr;
     if (!groups || a.gitems == nullptr || a.gitem_cap == 0u) return;
@@ -446,6 +545,18 @@ void bv_launch_p2g_solve16(const BvPass2Args &a, hipStream_t stream) {
     if ((uint64_t)grid > need) grid = need > 0 ? (uint32_t)need : 1u;
     const uint32_t cap = (a.flags >> 16) & 0xFFu;  // BV_FLAG_GRID_LIMIT
     if (cap && grid > cap) grid = cap;
+    // the small classes first (sixteen / eight items per wave), then everything larger four per wave
+    {
+        auto grid_for = [&](uint32_t ipw) {
+            uint32_t gsm = (a.n_cu ? a.n_cu : 256u) * (uint32_t)BV_P2G_OCC;
+            const uint64_t nd = (items + (uint64_t)ipw * BV_P2G_NW - 1u) / ((uint64_t)ipw * BV_P2G_NW);
+            if ((uint64_t)gsm > nd) gsm = nd > 0 ? (uint32_t)nd : 1u;
+            if (cap && gsm > cap) gsm = cap;
+            return gsm;
+        };
+        hipLaunchKernelGGL(bv_p2g_solve_small_kernel<4>, dim3(grid_for(16u)), dim3(BV_WAVE * BV_P2G_NW), 0, stream, a);
+        hipLaunchKernelGGL(bv_p2g_solve_small_kernel<8>, dim3(grid_for(8u)), dim3(BV_WAVE * BV_P2G_NW), 0, stream, a);
+    }
     hipLaunchKernelGGL(bv_p2g_solve16_kernel, dim3(grid), dim3(BV_WAVE * BV_P2G_NW), 0, stream, a);
     if (bv_p2g_all_items(a)) {  // (when some items do not fit the scratch, the workgroup-per-row kernel solves the rest of them itself)
         uint32_t gridh = (a.n_cu ? a.n_cu : 256u) * 4u;  // 127 VGPRs: four waves per SIMD

@@ -28,11 +28,14 @@
 
 // All-reduce over the 16 lanes of a row.  Every step pairs lanes symmetrically (i <-> i^1, i^2, 7-i, 15-i) and IEEE
 // addition is commutative, so all 16 lanes end with the bit-identical sum -- no broadcast needed.
+// L: the lanes that own the item -- 16 (a whole DPP row), or 8 / 4 (aligned parts of one: the pop-group solver for small groups,
+// bv_p2g_solve_small_kernel): the first log2(L) steps of the same pairing.
+template <int L = 16>
 __device__ __forceinline__ double bv_g16_sum(double v) {
     v += bv_dpp_f64<BV_DPP_QUAD_XOR1, 0xf>(v);
     v += bv_dpp_f64<BV_DPP_QUAD_XOR2, 0xf>(v);
-    v += bv_dpp_f64<BV_DPP_ROW_HALF_MIRROR, 0xf>(v);
-    v += bv_dpp_f64<BV_DPP_ROW_MIRROR, 0xf>(v);
+    if (L >= 8) v += bv_dpp_f64<BV_DPP_ROW_HALF_MIRROR, 0xf>(v);
+    if (L >= 16) v += bv_dpp_f64<BV_DPP_ROW_MIRROR, 0xf>(v);
     return v;
 }
 __device__ __forceinline__ uint32_t bv_g16_sum_u32(uint32_t v) {
@@ -229,7 +232,7 @@ __device__ __forceinline__ bool bv_g16_bin(const BvG16Bins &B, int s, uint32_t &
 // NS: slots in use (every group of the wave has at most 16 * NS bins): the loops over the slots stop there.
 // TWO: with the two-base form below (the pop-group solve kernel; the kernels that solve whole sites beside streaming waves sit at
 // their register limit -- with it their solvers spilled 18-23 registers into the dependent chains -- and keep the general form).
-template <int NS = BV_G16_SLOTS, bool TWO = false>
+template <int NS = BV_G16_SLOTS, bool TWO = false, int L = 16>
 __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsigned in_set, double n_cov, double *lr_out) {
     const double epsilon = (double)0.001f;
     const double inv_n = 1.0 / n_cov;
@@ -260,10 +263,10 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
                     pm[s * 16] = marg;
                 }
             }
-            fa = bv_g16_sum(pfa) * inv_n; fb = bv_g16_sum(pfb) * inv_n;
+            fa = bv_g16_sum<L>(pfa) * inv_n; fb = bv_g16_sum<L>(pfb) * inv_n;
             if (k == 0) continue;
             ++iters;
-            if (bv_g16_sum(delta) < epsilon) break;
+            if (bv_g16_sum<L>(delta) < epsilon) break;
         }
         f[0] = (ba == 0) ? fa : ((bb == 0) ? fb : 0.); f[1] = (ba == 1) ? fa : ((bb == 1) ? fb : 0.);
         f[2] = (ba == 2) ? fa : ((bb == 2) ? fb : 0.); f[3] = (ba == 3) ? fa : ((bb == 3) ? fb : 0.);
@@ -287,23 +290,52 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
                 pm[s * 16] = marg;
             }
         }
-        pf0 = bv_g16_sum(pf0); pf1 = bv_g16_sum(pf1); pf2 = bv_g16_sum(pf2); pf3 = bv_g16_sum(pf3);
+        pf0 = bv_g16_sum<L>(pf0); pf1 = bv_g16_sum<L>(pf1); pf2 = bv_g16_sum<L>(pf2); pf3 = bv_g16_sum<L>(pf3);
         f[0] = (in_set & 1u) ? pf0 * inv_n : 0.;
         f[1] = (in_set & 2u) ? pf1 * inv_n : 0.;
         f[2] = (in_set & 4u) ? pf2 * inv_n : 0.;
         f[3] = (in_set & 8u) ? pf3 * inv_n : 0.;
         if (k == 0) continue;
         ++iters;
-        if (bv_g16_sum(delta) < epsilon) break;  // zero unless some bin's log-marginal moved by >= 1
+        if (bv_g16_sum<L>(delta) < epsilon) break;  // zero unless some bin's log-marginal moved by >= 1
     }
     double lr = 0.;
+    bool one_log = false;
+    if (TWO) {
+        // Small groups: every bin holds a handful of cells.  sum(c x log(marg)) over the lane's slots is then taken as ONE
+        // logarithm of prod(marg ^ c) -- a log() is ~70 FP64 instructions, the lane's four or eight of them were a third of an EM
+        // run.  Counts up to 4 only (wave-uniform test): the smallest marginal is ~eps/3 of phred 41 = 3e-5, so a lane's product
+        // stays above 1e-145.  Same value to ~1e-16 relative (the LRT's tie guard, BV_TIE_TOL, is nine orders wider).
+        uint32_t cmax = 0;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        uint32_t b, q;
-        double c;
-        if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * 16]);
+        for (int s = 0; s < NS; ++s) cmax = max(cmax, B.w[s] & 0xFFFFu);
+        one_log = __ballot(cmax > 4u) == 0ull;
     }
-    *lr_out = bv_g16_sum(lr);
+    if (TWO && one_log) {
+        double P = 1.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            uint32_t b, q;
+            double c;
+            if (bv_g16_bin(B, s, b, q, c)) {
+                const uint32_t ci = B.w[s] & 0xFFFFu;
+                const double m = pm[s * 16], m2 = m * m;
+                double t = (ci & 1u) ? m : 1.0;
+                t *= (ci & 2u) ? m2 : 1.0;
+                t *= (ci & 4u) ? m2 * m2 : 1.0;
+                P *= t;
+            }
+        }
+        lr = log(P);
+    } else {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            uint32_t b, q;
+            double c;
+            if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * 16]);
+        }
+    }
+    *lr_out = bv_g16_sum<L>(lr);
     return iters;
 }
 
@@ -313,7 +345,7 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
 // SPEC: the candidate bases are `nspec` entries of `specific_packed` (3 bits each, reference order, 4 = not ACGT) as in
 // bv_lrt -- the pop-group calls of pass 2, lrt([REF] + alts); otherwise A, C, G, T.
 #define BV_TIE_TOL 1e-7  /* the sums' rounding is ~1e-13 relative; a true gap this small has never been seen */
-template <bool SPEC = false, int NS = BV_G16_SLOTS, bool TWO = false>
+template <bool SPEC = false, int NS = BV_G16_SLOTS, bool TWO = false, int L = 16>
 __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], uint32_t total, int ref_code, double min_af,
                                   BvLrtOut &o, int specific_packed = 0, int nspec = 0) {
     o.n_alt = 0; o.alt_packed = 0; o.af[0] = o.af[1] = o.af[2] = o.af[3] = 0.;
@@ -371,9 +403,9 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
                     g3 += (b == 3) ? c * dh : 0.;
                 }
             }
-            a_ = bv_g16_sum(a_);
-            single0 = a_ + bv_g16_sum(g0); single1 = a_ + bv_g16_sum(g1);
-            single2 = a_ + bv_g16_sum(g2); single3 = a_ + bv_g16_sum(g3);
+            a_ = bv_g16_sum<L>(a_);
+            single0 = a_ + bv_g16_sum<L>(g0); single1 = a_ + bv_g16_sum<L>(g1);
+            single2 = a_ + bv_g16_sum<L>(g2); single3 = a_ + bv_g16_sum<L>(g3);
         }
         double best_v = 0., best_lr = 0., bf0 = 0., bf1 = 0., bf2 = 0., bf3 = 0.;
         int best_c = 0;
@@ -401,7 +433,7 @@ __device__ inline void bv_lrt_g16(const BvG16Bins &B, const uint32_t depth[4], u
                 f[0] = (b1 == 0) ? 1.0 : 0.; f[1] = (b1 == 1) ? 1.0 : 0.;
                 f[2] = (b1 == 2) ? 1.0 : 0.; f[3] = (b1 == 3) ? 1.0 : 0.;
             } else {
-                it = bv_em_g16<NS, TWO>(B, f, in_set, n_cov, &lr);
+                it = bv_em_g16<NS, TWO, L>(B, f, in_set, n_cov, &lr);
             }
             o.em_iters += it;
             o.n_em += 1;

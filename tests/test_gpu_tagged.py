@@ -356,3 +356,21 @@ def test_packed_tile_api_errors_and_an_empty_tile(bv):
     assert eng._lib.bv_engine_tiles_begin(eng._h, S, 100000, 0, 1) == 0
     assert eng._lib.bv_engine_tiles_add_sparse(eng._h, C.byref(t), None) == _capi.BV_ERR_INVALID_ARG
     eng.close()
+
+
+@pytest.mark.parametrize("n,G,cov,ranks", [(10000, 32, 0.08, True), (10000, 64, 0.08, True), (6000, 12, 0.05, False), (20000, 40, 0.1, True), (3000, 9, 0.3, True)],
+                         ids=["g32", "g64_two_rounds", "g12_no_rank_planes", "g40_mixed_with_big_groups", "g9_deep_groups"])
+def test_small_pop_groups_through_the_small_solvers(bv, restatement, n, G, cov, ranks):
+    """8 and more pop-groups on short rows: the items of small groups go through bv_p2g_solve_small_kernel -- 4 or 8 lanes per
+    item, sixteen or eight items per wave, the kind chosen per site by the tally kernel (BV_P2G_L4 / BV_P2G_L8) --, bigger groups
+    keep the 16-lane solver; the fused kernel streams the rank-sum rows whatever the number of groups.  Against the oracle."""
+    slab = make_slab(300, n, seed=77 + G, coverage=cov, n_groups=G, ref_n_frac=0.02, site_offset=11)
+    if not ranks:
+        slab.pop("mapq"); slab.pop("rpr")
+    if G == 40:
+        slab["group_id"][: n // 2] = 0      # one group holds half the cohort: its items are big beside 39 small ones
+    maf = bv.min_af(n)
+    got = run_engine(bv, slab, maf)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(got, exp, gexp, margins, check_ranks=ranks)
+    assert got.n_variant >= 20
