@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import basevar_amd  # noqa: E402
 import oracle  # noqa: E402
-from basevar_amd.synth import make_slab  # noqa: E402
+from basevar_amd.synth import make_slab, tag_ranks  # noqa: E402
 from parity import ambiguous_sites, compare_groups, compare_sites, describe  # noqa: E402
 
 
@@ -22,7 +22,7 @@ class _Got:
     pass
 
 
-def lrt_chained(eng, slab, rng):
+def lrt_chained(eng, slab, rng, layout=0):
     """The slab cut into 2-5 row ranges, uploaded, and submitted as ONE chained launch (CAMPAIGN_CHAIN=1; pop-groups too)."""
     import torch
     dev = torch.device("cuda", 0)
@@ -43,7 +43,7 @@ def lrt_chained(eng, slab, rng):
                      out.data_ptr() + lo * rec, t["mapq"][lo].data_ptr(), t["rpr"][lo].data_ptr()))
     torch.cuda.synchronize()
     eng.submit_many_ptrs(n, pitch, segs, group_id=gid.data_ptr() if G else 0, n_groups=G,
-                         gouts=[gout.data_ptr() + lo * G * grec for lo in cuts[:-1]] if G else None)
+                         gouts=[gout.data_ptr() + lo * G * grec for lo in cuts[:-1]] if G else None, layout=layout)
     eng.wait()
     g = _Got()
     g.sites = out.cpu().numpy().view(basevar_amd.SITE_DTYPE)
@@ -87,13 +87,17 @@ def main():
             slab.pop("mapq"); slab.pop("rpr")
         maf = res.min_af(n, float(rng.choice([0.01, 0.001])))
         eng = basevar_amd.BaseTypeEngine(sites, maf, flags=int(os.environ.get("CAMPAIGN_FLAGS", "0"), 0))
+        # round 6: every other slab reaches the engine in the tagged rank layout (BV_SLAB_RPR_TAGGED: the producer's choice -- ranks
+        # here are <= 100); the oracle always gets the plain ranks
+        fed = tag_ranks(slab) if ("rpr" in slab and rng.random() < 0.5) else slab
         if os.environ.get("CAMPAIGN_CHAIN") == "1":
-            got = lrt_chained(eng, slab, rng)  # the same rows as 2-5 slabs through bv_engine_submit_many
+            got = lrt_chained(eng, fed, rng, layout=int(fed.get("layout", 0)))  # the same rows as 2-5 slabs through bv_engine_submit_many
         elif os.environ.get("CAMPAIGN_TILES") == "1":
-            # the sample axis in tiles of a random width (CAMPAIGN_FLAGS=8: the per-site-tally realisation; ranks up to 100: no overflow)
-            got = eng.lrt_tiles(slab, int(rng.choice([7, 64, 200, 1000, max(16, n // 3)])))
+            # the sample axis in tiles of a random width (CAMPAIGN_FLAGS=8: the per-site-tally realisation; ranks up to 100: no overflow);
+            # round 6: dense tiles, packed tiles (bv_engine_tiles_add_sparse) or a mix of the two
+            got = eng.lrt_tiles(fed, int(rng.choice([7, 64, 200, 1000, max(16, n // 3)])), packed=[False, True, 3][int(rng.integers(0, 3))])
         else:
-            got = eng.lrt(slab)
+            got = eng.lrt(fed)
         eng.close()
         exp, gexp = chk.run(slab, maf, n_threads=threads)
         # decision margins always come from the restatement (bit-identical to the reference)
