@@ -1115,6 +1115,15 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
     if (n_sites > e->cfg.max_sites) return fail(e, BV_ERR_TOO_LARGE, "bv_engine_tiles_begin: n_sites exceeds cfg.max_sites");
     if (n_groups > BV_MAX_GROUPS) return fail(e, BV_ERR_INVALID_ARG, "bv_engine_tiles_begin: n_groups exceeds BV_MAX_GROUPS");
     BV_HIP(e, hipSetDevice(e->cfg.device));
+    // The job's state is cleared ON THE ENGINE'S STREAM, ordered like a submit (use_stream / mark_done): a tile added on another
+    // stream waits for it.  (Until round 6 these were hipMemset calls on the null stream, which nothing orders against the engine's
+    // non-blocking stream: a tally kernel could meet the state of a fresh allocation -- once in the round-6 campaigns, 8,037
+    // mismatching fields in one 4,096-site job, gone on the re-run.)
+    hipStream_t st0 = e->stream;
+    {
+        int rc = use_stream(e, st0);
+        if (rc != BV_OK) return rc;
+    }
     e->tile_join = false;
     e->tile_layout = 0; e->tile_layout_set = false; e->j_filled = false;
     if (!(e->cfg.flags & BV_FLAG_TILE_STATE)) {
@@ -1142,13 +1151,13 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
             e->j_pitch = pitch; e->j_o_q = o_q; e->j_o_mq = o_mq; e->j_o_rp = o_rp; e->j_o_gid = o_gid;
             // (tiles fill the columns from the left in the order they are added; what a job leaves unfilled is set to 'N' at
             // finish -- not the whole plane here: 8.6 GB of memset for 8 Ki sites x 1 M samples)
-            BV_HIP(e, hipMemset(e->j_buf + o_gid, 0xFF, pitch));   // no pop-group
+            BV_HIP(e, hipMemsetAsync(e->j_buf + o_gid, 0xFF, pitch, st0));   // no pop-group
             e->tile_sites = n_sites; e->tile_groups = n_groups; e->tile_stride = 0;
             e->tile_samples_total = n_samples_total; e->tile_samples_seen = 0;
             e->tile_ranks = with_ranks != 0;
             e->tile_join = true;
             e->tile_open = true;
-            return BV_OK;
+            return mark_done(e, st0);
         }
     }
     if (n_groups > BV_GROUPS_PER_ROUND)
@@ -1159,7 +1168,7 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
     const uint32_t hg_off = 3072u + 4u * rank_win, ord_off = hg_off + n_groups * 512u, stride = ord_off + (1u + n_groups) * BV_TS_ORD_WORDS;
     e->tile_rank_win = rank_win; e->tile_hg_off = hg_off; e->tile_ord_off = ord_off;
     if (!e->tile_ovf) BV_HIP(e, hipMalloc(&e->tile_ovf, sizeof(uint32_t) * (2u + 2u * (size_t)bv_engine::kOvfCap)));
-    BV_HIP(e, hipMemset(e->tile_ovf, 0, 2 * sizeof(uint32_t)));
+    BV_HIP(e, hipMemsetAsync(e->tile_ovf, 0, 2 * sizeof(uint32_t), st0));
     const size_t bytes = (size_t)n_sites * stride * sizeof(uint32_t), mbytes = (size_t)n_sites * sizeof(uint32_t);
     if (bytes > e->tile_state_bytes) {
         if (e->tile_state) BV_HIP(e, hipFree(e->tile_state));
@@ -1175,13 +1184,13 @@ int bv_engine_tiles_begin(bv_engine *e, uint32_t n_sites, uint32_t n_samples_tot
         BV_HIP(e, hipMalloc(&e->tile_maxr, mbytes));
         e->tile_maxr_bytes = mbytes;
     }
-    BV_HIP(e, hipMemset(e->tile_state, 0, bytes));
-    BV_HIP(e, hipMemset(e->tile_maxr, 0, mbytes));
+    BV_HIP(e, hipMemsetAsync(e->tile_state, 0, bytes, st0));
+    BV_HIP(e, hipMemsetAsync(e->tile_maxr, 0, mbytes, st0));
     e->tile_sites = n_sites; e->tile_groups = n_groups; e->tile_stride = stride;
     e->tile_samples_total = n_samples_total; e->tile_samples_seen = 0;
     e->tile_ranks = with_ranks != 0;
     e->tile_open = true;
-    return BV_OK;
+    return mark_done(e, st0);
 }
 
 int bv_tile_packed_layout(uint32_t n_sites, uint32_t width, int with_ranks, int with_groups, uint64_t *pitch,

@@ -20,10 +20,12 @@
 
 // INLINE: the kernel solves pop-groups itself (one wave per group) and needs the solver's LDS; otherwise every group leaves
 // as an item for the group solve kernels and that LDS (and the solver's registers) are not taken.
-template <int NW, bool INLINE = true>
+// RANKS: the kernel forms the rank sums; without them (the group tallies behind a fused pass-1 kernel that has streamed the
+// rank-sum rows itself) their 10 KiB are not taken either -- at 32 groups that is a fourth workgroup per CU.
+template <int NW, bool INLINE = true, bool RANKS = true>
 struct __attribute__((aligned(16))) BvPass2Shared {
-    uint32_t hm[2 * 256];         // [class][mapq]        class 0 = REF reads, 1 = ALT reads
-    uint32_t hr[2 * BV_RPR_WIN];  // [class][rank - win_lo]
+    uint32_t hm[RANKS ? 2 * 256 : 4];         // [class][mapq]        class 0 = REF reads, 1 = ALT reads
+    uint32_t hr[RANKS ? 2 * BV_RPR_WIN : 4];  // [class][rank - win_lo]
     uint32_t maxr[NW];
     uint32_t bin_code[INLINE ? NW : 1][INLINE ? BV_SLOTS * BV_WAVE : 4];
     uint32_t bin_cnt[INLINE ? NW : 1][INLINE ? BV_SLOTS * BV_WAVE : 4];
@@ -65,7 +67,9 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
     const bv_u32x4 nocall = bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     const uint32_t hi_mask = TAG ? 0x1F001F00u : bv_rpr_hi_mask(a.rpr_tag);
     uint32_t hi_acc = 0, dom = BV_DOM_NONE;
-    constexpr int U = 2;
+    // chunks per thread and trip: without the rank planes three loads per chunk, so four chunks -- a 10,000-sample row is then
+    // ONE round of loads for a workgroup of 256 (the kernel waits for memory, not for instructions)
+    constexpr int U = RANKS ? 2 : 4;
     for (uint32_t base = 0; base < n_chunks; base += NT * U) {
         bv_u32x4 vb[U], vm[U], vr0[U], vr1[U], vq[U], vg[U];
 #pragma unroll
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
     static_assert(!HALF || (GROUPS && !INLINE), "16-bit group counters: the item-exporting form only");
     constexpr uint32_t GW = HALF ? 256u : 512u;  // words of one group's histogram
     constexpr int NW = NT / BV_WAVE;
-    __shared__ BvPass2Shared<NW, INLINE> sh;
+    __shared__ BvPass2Shared<NW, INLINE, RANKS> sh;
     uint32_t *hg = bv_dyn_lds;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t n_var = a.counters[BV_CTR_VARIANTS];
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         }
 
         // ---- clear histograms
-        {
+        if (RANKS) {
             // hm and hr are adjacent and 16-byte aligned: clear them with 128-bit stores
             uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
             for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
@@ -233,7 +237,8 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
             __syncthreads();
             if (!fast_ok) {
                 uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
-                for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
+                if (RANKS)
+                    for (int i = tid; i < (2 * 256 + 2 * BV_RPR_WIN) / 4; i += NT) z[i] = make_uint4(0, 0, 0, 0);
                 if (GROUPS)
                     for (uint32_t i = tid; i < a.n_groups * GW; i += NT) hg[i] = 0u;
                 __syncthreads();

@@ -299,41 +299,14 @@ __device__ __forceinline__ int bv_em_g16(const BvG16Bins &B, double f[4], unsign
         ++iters;
         if (bv_g16_sum<L>(delta) < epsilon) break;  // zero unless some bin's log-marginal moved by >= 1
     }
+    // (Tried, round 6, for small groups: ONE logarithm per lane, of the product of the lane's marginals -- a third of an EM run's
+    // instructions on paper, +0-2 % measured, two more spilled registers: not kept.)
     double lr = 0.;
-    bool one_log = false;
-    if (TWO) {
-        // Small groups: every bin holds a handful of cells.  sum(c x log(marg)) over the lane's slots is then taken as ONE
-        // logarithm of prod(marg ^ c) -- a log() is ~70 FP64 instructions, the lane's four or eight of them were a third of an EM
-        // run.  Counts up to 4 only (wave-uniform test): the smallest marginal is ~eps/3 of phred 41 = 3e-5, so a lane's product
-        // stays above 1e-145.  Same value to ~1e-16 relative (the LRT's tie guard, BV_TIE_TOL, is nine orders wider).
-        uint32_t cmax = 0;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) cmax = max(cmax, B.w[s] & 0xFFFFu);
-        one_log = __ballot(cmax > 4u) == 0ull;
-    }
-    if (TWO && one_log) {
-        double P = 1.0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            uint32_t b, q;
-            double c;
-            if (bv_g16_bin(B, s, b, q, c)) {
-                const uint32_t ci = B.w[s] & 0xFFFFu;
-                const double m = pm[s * 16], m2 = m * m;
-                double t = (ci & 1u) ? m : 1.0;
-                t *= (ci & 2u) ? m2 : 1.0;
-                t *= (ci & 4u) ? m2 * m2 : 1.0;
-                P *= t;
-            }
-        }
-        lr = log(P);
-    } else {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            uint32_t b, q;
-            double c;
-            if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * 16]);
-        }
+    for (int s = 0; s < NS; ++s) {
+        uint32_t b, q;
+        double c;
+        if (bv_g16_bin(B, s, b, q, c)) lr += c * log(pm[s * 16]);
     }
     *lr_out = bv_g16_sum<L>(lr);
     return iters;

@@ -140,6 +140,9 @@ def test_short_row_kernels_stay_out_of_scratch_memory():
     for k in fused:
         assert k["vgpr_spill"] <= 2 and k["private"] <= 80, k
         assert k["lds"] <= 160 * 1024, k
-    for frag in ("bv_p1s_solve16_kernel", "bv_p2g_solve16_kernel"):
-        k = [v for n, v in ks.items() if frag in n]
-        assert len(k) == 1 and k[0]["vgpr_spill"] == 0 and k[0]["private"] <= 48, k
+    k = [v for n, v in ks.items() if "bv_p1s_solve16_kernel" in n]
+    assert len(k) == 1 and k[0]["vgpr_spill"] == 0 and k[0]["private"] <= 48, k
+    # the pop-group solve kernels (round 6: the two-base EM form beside the general one, +3 % measured WITH its three spilled
+    # registers; the 4- and 8-lane kernels share the code)
+    k = [v for n, v in ks.items() if "bv_p2g_solve16_kernel" in n or "bv_p2g_solve_small_kernel" in n]
+    assert len(k) == 3 and all(v["vgpr_spill"] <= 3 and v["private"] <= 48 for v in k), k
