@@ -4,7 +4,7 @@
 # For each configuration below: one un-profiled bench run (the JSON line), one `--kernel-trace --stats` run and two PMC
 # runs (FETCH_SIZE, WRITE_SIZE -- separate passes, no tracing beside them), all of the same bench command.
 # Back in the container:  python tools/summarize_profiles.py <tag>
-TAG=${1:-r5}
+TAG=${1:-r6}
 cd "$(dirname "$0")/.."; ROOT=$PWD
 export TMPDIR=/tmp
 O=$ROOT/gpurun_out/prof_$TAG
@@ -45,10 +45,15 @@ sq_cfg() {  # name, bench args: SQ instruction-mix / wait counters of every kern
     i=$((i+1))
   done
 }
-run_cfg n100k                                               # headline: bv_pass1_kernel<3,1,false,2>, bv_pass2_kernel<256,true,false>
+run_cfg n100k                                               # headline (tagged ranks): bv_pass1_kernel<3,1,false,2>, bv_pass2_kernel<256,true,false,true,false,true> (TAG: 3 B/cell)
+run_cfg n100k_plain --rank-layout plain                     # the same rows with plain ranks: bv_pass2_kernel<256,true,false> re-reads the call plane (4 B/cell)
 run_cfg n100k_groups2 --groups 2 --batch-sites 65536        # bv_pass2_kernel<256,true,true,false> + bv_p2g_solve16_kernel on long rows
 run_cfg n1M --samples 1000000 --batch-sites 16384 --steps 8 # the same kernels at 1 M samples
-run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1]: bv_p1s_fused_kernel<true> (pass 1 + the variant sites' pass-2 rows in one persistent kernel)
+run_cfg n10k --samples 10000 --batch-sites 100000           # configs[1] (tagged ranks): bv_p1s_fused_kernel<true> (pass 1 + the variant sites' pass-2 rows in one persistent kernel)
+run_cfg n10k_plain --samples 10000 --batch-sites 100000 --rank-layout plain   # ... with plain ranks
+# dense rows (round 6): coverage 1.0 -- the dominant-value count in the mapq tallies, the bank swizzle of dense long rows
+run_cfg n100k_cov1 --coverage 1.0 --batch-sites 65536 --steps 10
+run_cfg n10k_cov1 --samples 10000 --batch-sites 100000 --coverage 1.0
 run_cfg n10k_p2sep --samples 10000 --batch-sites 100000 --flags 40960   # BV_FLAG_SHORT_ROW_FORM(10): pass 2 a launch of its own: bv_p1s_fused_kernel<false> + bv_pass2_dma_kernel
 run_cfg n10k_three_launches --samples 10000 --batch-sites 100000 --flags 36864  # BV_FLAG_SHORT_ROW_FORM(9): the kernels rows of <= 4,096 samples take: bv_p1s_stream_kernel, bv_p1s_solve16_kernel, bv_pass2_dma_kernel
 run_cfg n10k_lanes2 --samples 10000 --batch-sites 100000 --lanes 2   # the same through the engine's two lanes (BV_FLAG_LANES)
@@ -60,7 +65,8 @@ run_cfg n10k_32768 --samples 10000 --batch-sites 32768 --steps 20
 run_cfg n10k_groups2 --samples 10000 --batch-sites 100000 --groups 2   # short rows with pop-groups: bv_p2g_stream_kernel + bv_p2g_solve16/hard behind the fused kernel
 run_cfg n10k_groups1 --samples 10000 --batch-sites 100000 --groups 1
 run_cfg n10k_noranks --samples 10000 --batch-sites 100000 --groups 2 --no-rank-planes   # groups without rank planes: bv_p2g_stream_kernel alone
-run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more than 7 groups: bv_pass2_kernel<256,true,true,false> + the group solve kernels
+run_cfg n10k_groups8 --samples 10000 --batch-sites 100000 --groups 8   # more than 7 groups: bv_pass2_kernel<256,false,true,false> (group tallies only: the fused kernel streams the rank-sum rows) + the group solve kernels
+run_cfg n10k_groups16 --samples 10000 --batch-sites 100000 --groups 16 # bv_p2g_solve_small_kernel<8>: eight items per wave
 run_cfg n10k_groups32 --samples 10000 --batch-sites 100000 --groups 32 # one round of groups: every group of the cohort is shallow (<= 64 covered samples)
 run_cfg n10k_groups64 --samples 10000 --batch-sites 100000 --groups 64 # two rounds of 32 groups (BV_GROUPS_PER_ROUND): pass 2 runs twice, the rank sums once
 run_cfg n100k_chain16 --batch-sites 8192 --chain 16                    # small batches chained: bv_pass1_kernel<3,1,true>
