@@ -53,8 +53,8 @@ def test_record_layout_matches_header(tmp_path):
     body = "".join('printf("s %s %%zu\\n", offsetof(bv_site_result, %s));\n' % (f, f) for f in fields)
     body += "".join('printf("g %s %%zu\\n", offsetof(bv_group_result, %s));\n' % (f, f) for f in gfields)
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "basevar_amd_diag.h"\nint main(void){\n'
-                   'printf("S %zu\\nG %zu\\nslab %zu\\ncfg %zu\\nsynth %zu\\n", sizeof(bv_site_result), sizeof(bv_group_result),'
-                   ' sizeof(bv_slab), sizeof(bv_engine_config), sizeof(bv_synth_params));\n' + body + "return 0;}\n")
+                   'printf("S %zu\\nG %zu\\nslab %zu\\ncfg %zu\\nsynth %zu\\nsparse %zu\\nslab_layout %zu\\nsparse_layout %zu\\n", sizeof(bv_site_result), sizeof(bv_group_result),'
+                   ' sizeof(bv_slab), sizeof(bv_engine_config), sizeof(bv_synth_params), sizeof(bv_sparse_tile), offsetof(bv_slab, layout), offsetof(bv_sparse_tile, layout));\n' + body + "return 0;}\n")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split("\n")
@@ -70,6 +70,8 @@ def test_record_layout_matches_header(tmp_path):
     assert vals["slab"] == C.sizeof(_capi.Slab)
     assert vals["cfg"] == C.sizeof(_capi.EngineConfig)
     assert vals["synth"] == C.sizeof(_capi.SynthParams)
+    assert vals["sparse"] == C.sizeof(_capi.SparseTile) and vals["sparse_layout"] == _capi.SparseTile.layout.offset
+    assert vals["slab_layout"] == _capi.Slab.layout.offset == 72  # (ABI 2: the layout word follows ABI 1's 72-byte bv_slab)
     for f in fields:
         assert vals[("s", f)] == _capi.SITE_DTYPE.fields[f][1], f
     for f in gfields:
