@@ -374,3 +374,47 @@ def test_small_pop_groups_through_the_small_solvers(bv, restatement, n, G, cov, 
     exp, gexp, margins = oracle_run(restatement, slab, maf)
     check(got, exp, gexp, margins, check_ranks=ranks)
     assert got.n_variant >= 20
+
+
+def test_dense_long_rows_of_binned_qualities_and_one_value(bv, restatement):
+    """Dense long rows whose cells sit on a handful of (strand, base, phred) words -- a sequencer that bins its qualities (2, 12,
+    23, 37), and the degenerate row of ONE call and ONE phred in every sample: the dense-row tally counts its two dominant values
+    per chunk (bv_lds_add16_dom2) instead of adding them lane by lane.  Records: those of BV_FLAG_NO_DOM (plain adds), byte for
+    byte, and the oracle's on a spread of sites."""
+    import torch
+    dev = torch.device("cuda", 0)
+    S, n = 2600, 50000
+    P = (n + 15) // 16 * 16
+    g = torch.Generator(device="cpu").manual_seed(99)
+    ref = torch.randint(0, 4, (S,), generator=g, dtype=torch.uint8)
+    strand = torch.randint(0, 2, (S, P), generator=g, dtype=torch.uint8)
+    alt = torch.rand((S, P), generator=g) < 0.03
+    base = torch.where(alt, (ref[:, None] + 1) % 4, ref[:, None].expand(S, P)).to(torch.uint8)
+    bs = (base | (strand << 2)).to(torch.uint8)
+    qb = torch.tensor([2, 12, 23, 37], dtype=torch.uint8)[torch.randint(0, 4, (S, P), generator=g)]
+    qb = torch.where(torch.rand((S, P), generator=g) < 0.7, torch.full_like(qb, 37), qb)
+    # rows 0-99: every sample the same call and phred (forward reference base, phred 37)
+    bs[:100] = ref[:100, None]
+    qb[:100] = 37
+    mq = torch.full((S, P), 60, dtype=torch.uint8)
+    rp = torch.randint(1, 101, (S, P), generator=g, dtype=torch.int16)
+    bs_d, q_d, mq_d, rp_d, ref_d = (t.to(dev).contiguous() for t in (bs, qb, mq, rp, ref))
+    maf = bv.min_af(n)
+    recs = []
+    for flags in (0, 0x1000000):
+        eng = bv.BaseTypeEngine(max_sites=S, min_af_value=maf, device=0, flags=flags)
+        out = torch.zeros(S * bv.SITE_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        eng.submit_ptrs(S, n, P, bs_d.data_ptr(), q_d.data_ptr(), ref_d.data_ptr(), out.data_ptr(), mq_d.data_ptr(), rp_d.data_ptr())
+        eng.wait()
+        recs.append(out.cpu().numpy().view(bv.SITE_DTYPE).copy())
+        eng.close()
+    assert recs[0].tobytes() == recs[1].tobytes()
+    idx = np.concatenate([np.arange(0, 6), np.linspace(100, S - 1, num=26).astype(np.int64)])
+    slab = {"base_strand": bs[idx].numpy(), "qual": qb[idx].numpy(), "mapq": mq[idx].numpy(), "rpr": rp[idx].numpy().view(np.uint16),
+            "ref_base": ref[idx].numpy(), "n_samples": n, "pitch": P, "n_sites": len(idx)}
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+
+    class Got:
+        sites = recs[0][idx]; groups = None; n_variant = int(((recs[0][idx]["status"] & 2) != 0).sum())
+    check(Got, exp, gexp, margins)
+    assert (recs[0]["total_depth"] == n).all()
