@@ -118,9 +118,10 @@ struct BvPass2Args {
 #define BV_P2G_HARD 0x40000000u     /* for bv_p2g_hard_kernel: one wave per item (shallow group, phred-0 calls, > 128 bins, min_af <= 0) */
 #define BV_P2G_SHALLOW 0x20000000u  /* ... and its EMs replay the reference's per-sample order */
 // Small groups (bv_p2g_solve_small_kernel): a PENDING item with one of these bits is solved on 4 / 8 lanes, sixteen / eight items
-// per wave: at most 32 bins -> 4 lanes (eight register slots per lane when an item of the job has more than 16), at most 64 -> 8
-// lanes.  A property of the item alone (set by the workgroup-per-row tally kernel), so what solves it does not depend on the
-// rest of the launch; a wave's consecutive items belong to one site and are mostly of one kind.
+// per wave (four register slots per lane, eight when an item of the job needs them).  The workgroup-per-row tally kernel sets
+// them: 4 lanes where three quarters of the SITE's pending groups have at most 16 bins (and this one at most 32), else 8 lanes
+// where this one has at most 64.  A wave's consecutive items belong to one site and are mostly of one kind, and what solves an
+// item does not depend on the rest of the launch.
 #define BV_P2G_L4 0x10000000u
 #define BV_P2G_L8 0x08000000u
 

@@ -76,7 +76,7 @@ __device__ __forceinline__ void bv_chunks_load(BvChunkSet &c, const uint8_t *bs_
 }
 template <bool FULL, bool SWZ>
 __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, uint32_t n_chunks, int tail, int lane,
-                                                uint32_t *hist, uint32_t one, uint32_t *dom) {
+                                                uint32_t *hist, uint32_t one) {
 #pragma unroll
     for (int u = 0; u < BV_TALLY_U; ++u) {
         if (!FULL) {
@@ -88,7 +88,7 @@ __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, ui
                 c.vb[u].w = bv_mask_tail_dword(c.vb[u].w, tail - 12);
             }
         }
-        bv_tally_chunk<2, SWZ>(c.vb[u], c.vq[u], hist, one, SWZ ? dom : nullptr);
+        bv_tally_chunk<2, SWZ>(c.vb[u], c.vq[u], hist, one);
     }
 }
 // set at `base`: nothing to do past the row's end; FULL form when the set ends inside the row
@@ -101,8 +101,8 @@ __device__ __forceinline__ void bv_chunks_tally(BvChunkSet &c, uint32_t base, ui
 #define BV_SET_TALLY(C, BASE)                                                                 \
     do {                                                                                      \
         const uint32_t b_ = (BASE);                                                           \
-        if (b_ + BLK <= n_full) bv_chunks_tally<true, SWZ>(C, b_, n_chunks, tail, lane, hist, one, dom);\
-        else if (b_ < n_chunks) bv_chunks_tally<false, SWZ>(C, b_, n_chunks, tail, lane, hist, one, dom);\
+        if (b_ + BLK <= n_full) bv_chunks_tally<true, SWZ>(C, b_, n_chunks, tail, lane, hist, one);\
+        else if (b_ < n_chunks) bv_chunks_tally<false, SWZ>(C, b_, n_chunks, tail, lane, hist, one);\
     } while (0)
 // PRE: the row's first set is already in (or on its way into) A -- see bv_row_preload.
 template <int NTALLY, bool PRE = false, bool SWZ = false>
@@ -114,7 +114,6 @@ __device__ __forceinline__ void bv_tally_row_wave(const uint8_t *bs_row, const u
     constexpr uint32_t STRIDE = BLK * NTALLY;       // the row's blocks go round-robin over the tally waves
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));  // opaque: not re-materialised per cell
-    uint32_t dom[2] = {BV_DOM_NONE, BV_DOM_NONE};  // (dense rows: this wave's two dominant values, bv_lds_add16_dom2)
     BvChunkSet A, B;
     uint32_t base = (uint32_t)t * BLK;
     if (PRE) A = *pre;

@@ -424,15 +424,20 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                 bv_lrt_sync<0>();
             }
             if (!INLINE) {
-                // the site's items are written: which small-group solver takes an item (BV_P2G_L4 / BV_P2G_L8, bv_kernels.h) -- lane g
-                // of wave 0 classifies group g and writes its header
+                // the site's items are written: which small-group solver takes them (BV_P2G_L4 / BV_P2G_L8, bv_kernels.h) is decided
+                // for the site -- lane g of wave 0 classifies group g and writes its header
                 __syncthreads();
                 if (wave == 0) {
                     const uint32_t hdr = (uint32_t)lane < a.n_groups ? sh.ghdr[lane] : 0u;
                     const bool pend = (hdr & BV_P2G_PENDING) != 0u;
                     const uint32_t nbv = hdr & 0xFFFFu;
+                    // (Measured, 100 k sites x 10 k samples, 8 / 16 / 32 / 64 groups: this rule 115 / 93 / 70 / 45 M sites/s; "at most 32
+                    // bins -> 4 lanes" per item 103 / 80 / 73 / 46, per site 109 / 80 / 73 / 46: a job whose items need eight slots per
+                    // lane takes three times as long as one that needs four, so 4 lanes pay only where the items fit 16 bins.)
+                    const uint32_t n_pend = (uint32_t)__popcll(__ballot(pend)), n_16 = (uint32_t)__popcll(__ballot(pend && nbv <= 16u));
+                    const bool site_l4 = 4u * n_16 >= 3u * n_pend;
                     uint32_t kind = 0u;
-                    if (pend && nbv <= 32u) kind = BV_P2G_L4;
+                    if (pend && site_l4 && nbv <= 32u) kind = BV_P2G_L4;
                     else if (pend && nbv <= 64u) kind = BV_P2G_L8;
                     if ((uint32_t)lane < a.n_groups) a.gitems[((size_t)v * a.n_groups + (uint32_t)lane) * BV_P2G_ITEM_WORDS] = hdr | kind;
                 }

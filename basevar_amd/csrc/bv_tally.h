@@ -158,93 +158,6 @@ __device__ __forceinline__ void bv_lds_add16_dom(const uint32_t x[16], uint32_t 
     if (cnt < 128u) D = BV_DOM_NONE;  // (of the chunk's 1,024 cells)
 }
 
-// bv_lds_add16_dom with TWO values counted: the pass-1 tally of dense rows (bv_tally_chunk<.., SWZ> rows), where the cells of a
-// cohort whose sequencer bins its qualities -- or of a degenerate input, every sample one call and one phred -- sit on one hot
-// (strand, base, phred) word per strand.  Same rule per value: picked from slot 0's passing lanes (the second differs from the
-// first), kept while it collects an eighth of a chunk's cells.
-template <int SH>
-__device__ __forceinline__ void bv_lds_add16_dom2(const uint32_t x[16], uint32_t *hist, uint32_t one, uint32_t lim, uint32_t &D1, uint32_t &D2) {
-    const uint32_t hbase = (uint32_t)(uintptr_t)(bv_lds_u32 *)hist;
-    uint32_t ad[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) ad[j] = hbase + (x[j] << SH);
-    if (D1 == BV_DOM_NONE) {
-        const unsigned long long m0 = __ballot(x[0] < lim && x[0] != D2);
-        if (m0 != 0ull) D1 = (uint32_t)__builtin_amdgcn_readlane((int)x[0], (int)__builtin_ctzll(m0));
-    }
-    if (D2 == BV_DOM_NONE) {
-        const unsigned long long m0 = __ballot(x[0] < lim && x[0] != D1);
-        if (m0 != 0ull) D2 = (uint32_t)__builtin_amdgcn_readlane((int)x[0], (int)__builtin_ctzll(m0));
-    }
-    const uint32_t adD1 = hbase + ((D1 == BV_DOM_NONE ? 0u : D1) << SH), adD2 = hbase + ((D2 == BV_DOM_NONE ? 0u : D2) << SH);
-    unsigned long long m[16], n[4], t, sv;
-    uint32_t cnt1, cnt2, c, va, vc;
-    asm volatile(
-        "v_cmp_gt_u32_e64 %[m0], %[lim], %[x0]\n\t"
-        "v_cmp_gt_u32_e64 %[m1], %[lim], %[x1]\n\t"
-        "v_cmp_gt_u32_e64 %[m2], %[lim], %[x2]\n\t"
-        "v_cmp_gt_u32_e64 %[m3], %[lim], %[x3]\n\t"
-        "v_cmp_gt_u32_e64 %[m4], %[lim], %[x4]\n\t"
-        "v_cmp_gt_u32_e64 %[m5], %[lim], %[x5]\n\t"
-        "v_cmp_gt_u32_e64 %[m6], %[lim], %[x6]\n\t"
-        "v_cmp_gt_u32_e64 %[m7], %[lim], %[x7]\n\t"
-        "v_cmp_gt_u32_e64 %[m8], %[lim], %[x8]\n\t"
-        "v_cmp_gt_u32_e64 %[m9], %[lim], %[x9]\n\t"
-        "v_cmp_gt_u32_e64 %[m10], %[lim], %[x10]\n\t"
-        "v_cmp_gt_u32_e64 %[m11], %[lim], %[x11]\n\t"
-        "v_cmp_gt_u32_e64 %[m12], %[lim], %[x12]\n\t"
-        "v_cmp_gt_u32_e64 %[m13], %[lim], %[x13]\n\t"
-        "v_cmp_gt_u32_e64 %[m14], %[lim], %[x14]\n\t"
-        "v_cmp_gt_u32_e64 %[m15], %[lim], %[x15]\n\t"
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_mov_b32 %[cnt1], 0\n\t"
-        "s_mov_b32 %[cnt2], 0\n\t"
-#define BV_DOM2(a, b)                                                                                                            \
-        "v_cmp_ne_u32_e64 %[n0], %[D1], %[x" #a "]\n\t"                                                                          \
-        "v_cmp_ne_u32_e64 %[n1], %[D2], %[x" #a "]\n\t"                                                                          \
-        "v_cmp_ne_u32_e64 %[n2], %[D1], %[x" #b "]\n\t"                                                                          \
-        "v_cmp_ne_u32_e64 %[n3], %[D2], %[x" #b "]\n\t"                                                                          \
-        "s_and_b64 %[m" #a "], %[m" #a "], %[n0]\n\ts_andn2_b64 %[t], %[sv], %[n0]\n\ts_bcnt1_i32_b64 %[c], %[t]\n\ts_add_u32 %[cnt1], %[cnt1], %[c]\n\t" \
-        "s_and_b64 %[m" #a "], %[m" #a "], %[n1]\n\ts_andn2_b64 %[t], %[sv], %[n1]\n\ts_bcnt1_i32_b64 %[c], %[t]\n\ts_add_u32 %[cnt2], %[cnt2], %[c]\n\t" \
-        "s_and_b64 %[m" #b "], %[m" #b "], %[n2]\n\ts_andn2_b64 %[t], %[sv], %[n2]\n\ts_bcnt1_i32_b64 %[c], %[t]\n\ts_add_u32 %[cnt1], %[cnt1], %[c]\n\t" \
-        "s_and_b64 %[m" #b "], %[m" #b "], %[n3]\n\ts_andn2_b64 %[t], %[sv], %[n3]\n\ts_bcnt1_i32_b64 %[c], %[t]\n\ts_add_u32 %[cnt2], %[cnt2], %[c]\n\t"
-        BV_DOM2(0, 1) BV_DOM2(2, 3) BV_DOM2(4, 5) BV_DOM2(6, 7) BV_DOM2(8, 9) BV_DOM2(10, 11) BV_DOM2(12, 13) BV_DOM2(14, 15)
-#undef BV_DOM2
-        "s_and_b64 exec, %[sv], %[m0]\n\tds_add_u32 %[a0], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m1]\n\tds_add_u32 %[a1], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m2]\n\tds_add_u32 %[a2], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m3]\n\tds_add_u32 %[a3], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m4]\n\tds_add_u32 %[a4], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m5]\n\tds_add_u32 %[a5], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m6]\n\tds_add_u32 %[a6], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m7]\n\tds_add_u32 %[a7], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m8]\n\tds_add_u32 %[a8], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m9]\n\tds_add_u32 %[a9], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m10]\n\tds_add_u32 %[a10], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m11]\n\tds_add_u32 %[a11], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m12]\n\tds_add_u32 %[a12], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m13]\n\tds_add_u32 %[a13], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m14]\n\tds_add_u32 %[a14], %[one]\n\t"
-        "s_and_b64 exec, %[sv], %[m15]\n\tds_add_u32 %[a15], %[one]\n\t"
-        "s_ff1_i32_b64 %[c], %[sv]\n\t"
-        "s_lshl_b64 %[t], 1, %[c]\n\t"
-        "s_mov_b64 exec, %[t]\n\t"
-        "v_mov_b32 %[va], %[adD1]\n\t"
-        "v_mov_b32 %[vc], %[cnt1]\n\t"
-        "ds_add_u32 %[va], %[vc]\n\t"
-        "v_mov_b32 %[va], %[adD2]\n\t"
-        "v_mov_b32 %[vc], %[cnt2]\n\t"
-        "ds_add_u32 %[va], %[vc]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [m2] "=&s"(m[2]), [m3] "=&s"(m[3]), [m4] "=&s"(m[4]), [m5] "=&s"(m[5]), [m6] "=&s"(m[6]), [m7] "=&s"(m[7]), [m8] "=&s"(m[8]), [m9] "=&s"(m[9]), [m10] "=&s"(m[10]), [m11] "=&s"(m[11]), [m12] "=&s"(m[12]), [m13] "=&s"(m[13]), [m14] "=&s"(m[14]), [m15] "=&s"(m[15]),
-          [n0] "=&s"(n[0]), [n1] "=&s"(n[1]), [n2] "=&s"(n[2]), [n3] "=&s"(n[3]), [t] "=&s"(t), [sv] "=&s"(sv), [cnt1] "=&s"(cnt1), [cnt2] "=&s"(cnt2), [c] "=&s"(c), [va] "=&v"(va), [vc] "=&v"(vc)
-        : [x0] "v"(x[0]), [a0] "v"(ad[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]),
-          [one] "v"(one), [lim] "s"(lim), [D1] "s"(D1), [D2] "s"(D2), [adD1] "s"(adD1), [adD2] "s"(adD2)
-        : "memory", "scc");
-    if (cnt1 < 128u) D1 = BV_DOM_NONE;  // (of the chunk's 1,024 cells)
-    if (cnt2 < 128u) D2 = BV_DOM_NONE;
-}
-
 // The same into 16-bit counters (two per word): X = x[j] is the BYTE offset of the cell's half-word; the word X & ~3 gets
 // 1 << 16 * ((X >> 1) & 1).  For rows of at most 65,535 cells, where no count can carry into its neighbour.
 __device__ __forceinline__ void bv_lds_add16_half(const uint32_t x[16], uint32_t *hist, uint32_t one, uint32_t lim) {
@@ -308,9 +221,8 @@ __device__ __forceinline__ void bv_lds_add16_half(const uint32_t x[16], uint32_t
 // at full coverage, pass 1 0.59 -> 0.67 of the HBM peak.  (Bits 3-5, the first try, changed nothing: bit 5 is no bank bit.)
 // The permutation stays inside the cell's histogram row for any byte; bv_hist_unswizzle puts the row back before anybody reads
 // it.  Three VALU per four cells: sparse rows do not pay it.
-// `dom` (with SWZ): the wave's two dominant values of this row, counted instead of added (bv_lds_add16_dom2).
 template <int SH = 2, bool SWZ = false>
-__device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x4 &vq_in, uint32_t *hist, uint32_t one, uint32_t *dom = nullptr) {
+__device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x4 &vq_in, uint32_t *hist, uint32_t one) {
     bv_u32x4 vq = vq_in;
     if (SWZ) {
         constexpr uint32_t M = 0x1C1C1C1Cu << (2 - SH);  // SH 1: the phred bytes arrive shifted left by one
@@ -325,8 +237,10 @@ __device__ __forceinline__ void bv_tally_chunk(const bv_u32x4 &vb, const bv_u32x
     x[10] = bv_cell_index<2>(vb.z, vq.z); x[11] = bv_cell_index<3>(vb.z, vq.z);
     x[12] = bv_cell_index<0>(vb.w, vq.w); x[13] = bv_cell_index<1>(vb.w, vq.w);
     x[14] = bv_cell_index<2>(vb.w, vq.w); x[15] = bv_cell_index<3>(vb.w, vq.w);
-    if (SWZ && dom != nullptr) bv_lds_add16_dom2<SH>(x, hist, one, 0x800u, dom[0], dom[1]);
-    else bv_lds_add16<SH>(x, hist, one, 0x800u);
+    // (Tried, round 6, for dense rows of binned qualities: counting the wave's TWO dominant values per chunk here too
+    // (bv_lds_add16_dom with two values).  Rows without such values -- every row of an un-binned sequencer -- lost 12-40 % of pass 1
+    // to it, even when the search was given up after two chunks: its registers alone cost the dense instance 12 %.  Not kept.)
+    bv_lds_add16<SH>(x, hist, one, 0x800u);
 }
 // A histogram tallied with SWZ back in its plain order, in place, by one wave: `rows` rows of `1 << LOGW` words (column c of
 // row r holds phred c ^ ((r & 7) << 3)).  Every lane reads its words, then writes them where they belong.

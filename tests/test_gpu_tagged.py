@@ -378,9 +378,9 @@ def test_small_pop_groups_through_the_small_solvers(bv, restatement, n, G, cov, 
 
 def test_dense_long_rows_of_binned_qualities_and_one_value(bv, restatement):
     """Dense long rows whose cells sit on a handful of (strand, base, phred) words -- a sequencer that bins its qualities (2, 12,
-    23, 37), and the degenerate row of ONE call and ONE phred in every sample: the dense-row tally counts its two dominant values
-    per chunk (bv_lds_add16_dom2) instead of adding them lane by lane.  Records: those of BV_FLAG_NO_DOM (plain adds), byte for
-    byte, and the oracle's on a spread of sites."""
+    23, 37), and the degenerate row of ONE call and ONE phred in every sample: the worst case of the LDS tallies (one hot word per
+    strand).  Slow, but exact: records those of BV_FLAG_NO_DOM (plain adds, no swizzle), byte for byte, and the oracle's on a spread
+    of sites."""
     import torch
     dev = torch.device("cuda", 0)
     S, n = 2600, 50000
