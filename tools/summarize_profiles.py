@@ -181,7 +181,15 @@ def main():
                 continue
             f, w = fetch.get((k, "FETCH_SIZE")), write.get((k, "WRITE_SIZE"))
             hbm = (2.0 * f * 1024.0 if f is not None else 0.0) + (w * 1024.0 if w is not None else 0.0)
-            algo, how = algorithmic_bytes(k, cfg, nvar)
+            kcfg, knvar = cfg, nvar
+            if bench and bench.get("configs1") and cfg["samples"] > 49152 and k.startswith("bv_p1s_"):
+                # the default bench command runs BASELINE configs[1] (100,000 sites x 10,000 samples) as a second leg of the same
+                # process (bench.py: configs1_leg): the short-row kernels of this profile are that leg's
+                kcfg = dict(cfg, samples=10000, batch_sites=100000)
+                knvar = int(bench["configs1"]["variant_sites"])
+            algo, how = algorithmic_bytes(k, kcfg, knvar)
+            if kcfg is not cfg:
+                how += "; the configs1 leg of the same command"
             v.update({"FETCH_SIZE_KiB": f, "WRITE_SIZE_KiB": w, "hbm_bytes": hbm if f is not None else None, "algorithmic_bytes": algo,
                       "algorithmic_how": how})
             frac = (algo / (v["avg_ns"] * 1e-9) / 1e9 / HBM_PEAK) if algo else None
@@ -197,7 +205,7 @@ def main():
                 # (several configurations run the same kernel on the same shape: the first one, in name order, is quoted)
                 if cfg.get("coverage", 0.08) != 0.08:
                     continue  # (pmc_traffic.json is keyed by shape: BASELINE's coverage only)
-                traffic.setdefault(tkey(k, cfg), {}).update({} if traffic[tkey(k, cfg)] else {
+                traffic.setdefault(tkey(k, kcfg), {}).update({} if traffic[tkey(k, kcfg)] else {
                     "hbm_bytes_per_launch": hbm, "read_bytes": 2.0 * f * 1024.0, "write_bytes": (w or 0.0) * 1024.0,
                     "algorithmic_bytes": algo, "source": "profiles/%s_rocprof_summary.md#%s" % (tag, name)})
         lines.append("")
