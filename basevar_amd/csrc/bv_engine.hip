@@ -1643,6 +1643,27 @@ static void bv_fused_debug_report(const uint32_t *h) {
         for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", cnt[x] ? sum[x] / cnt[x] : 0.);
         fprintf(stderr, "\n");
     }
+#ifdef BV_PHASE_DEBUG
+    {
+        const char *pn[12] = {"wait for the slot (vmcnt)", "slot -> registers (4 ds_read_b128)", "request the next slot: the 4 DMA pieces", "tally, pass-1 slot", "tally, pass-2 slot",
+                              "row epilogue, pass 1", "row epilogue, pass 2", "slots", "leaving (drain)", "inside the streaming function", "request the next slot: draw a row", "slot requested -> found landed"};
+        for (int part = 0; part < 2; ++part) {
+            const uint32_t *c = d + 4220 + 12 * part;
+            fprintf(stderr, "[fused phases] -- streaming waves, %s\n", part ? "past their last pass-1 row" : "while they have pass-1 rows");
+            for (int i = 0; i < 12; ++i) {
+                if (i == 7) fprintf(stderr, "[fused phases] %-38s %u\n", pn[i], c[i]);
+                else if (i != 9 || part == 0) fprintf(stderr, "[fused phases] %-38s %12.0f cycles  (%.0f per slot)\n", pn[i], 16.0 * c[i], c[7] ? 16.0 * c[i] / c[7] : 0.);
+            }
+        }
+    }
+#endif
+#ifdef BV_PHASE_DEBUG
+    for (int l = 0; l < 2; ++l) {
+        const uint32_t *j = d + 4212 + 4 * l;
+        fprintf(stderr, "[fused phases] 16-lane jobs %s: %u (of them from q3: %u), %.2f sites per job, mean %.0f cycles\n", l ? "after the last pass-1 row" : "while rows stream", j[1], j[3],
+                j[1] ? (double)j[2] / j[1] : 0., j[1] ? 16.0 * j[0] / j[1] : 0.);
+    }
+#endif
     const char *qn[3] = {"q3 entries", "q2 entries", "variant rows (or blocks of 64)"};
     for (int j = 0; j < 3; ++j) {
         std::vector<uint32_t> v;

@@ -53,15 +53,58 @@
 
 #include <type_traits>
 
+#ifndef BV_F_NS
 #define BV_F_NS 8                         /* streaming waves per workgroup */
+#endif
+#ifndef BV_F_NV
 #define BV_F_NV 4                         /* dedicated solver waves per workgroup (7 + 5 measured -1.2 %; round 5, lean solver: 8 + 3 -0.8 %, 8 + 2 -4 %) */
+#endif
 static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody must be emptying it");
 #define BV_F_NW (BV_F_NS + BV_F_NV)
+#ifndef BV_F_K
 #define BV_F_K 3                          /* ring slots per streaming wave */
+#endif
+// the counted waits (every slot is four vector-memory operations): BV_F_W_ALL -- at most the K slots in flight are outstanding;
+// BV_F_W_OLDEST -- the oldest of K slots has landed; _1 / _3 -- the same with one / three younger stores outstanding.
+// (Round 6 tried counts kept per slot -- a slot of the tagged pass-2 rows then needs no fourth, one-lane load -- with the wait picked
+// by a chain of scalar compares: the chain cost 4-5 % of the launch, the saved loads gained nothing measurable.  Not kept.)
+#if BV_F_K == 3
+#define BV_F_W_ALL "s_waitcnt vmcnt(12)"
+#define BV_F_W_OLDEST "s_waitcnt vmcnt(8)"
+#define BV_F_W_OLDEST_1 "s_waitcnt vmcnt(9)"
+#define BV_F_W_OLDEST_3 "s_waitcnt vmcnt(11)"
+#elif BV_F_K == 2
+#define BV_F_W_ALL "s_waitcnt vmcnt(8)"
+#define BV_F_W_OLDEST "s_waitcnt vmcnt(4)"
+#define BV_F_W_OLDEST_1 "s_waitcnt vmcnt(5)"
+#define BV_F_W_OLDEST_3 "s_waitcnt vmcnt(7)"
+#elif BV_F_K == 4
+#define BV_F_W_ALL "s_waitcnt vmcnt(16)"
+#define BV_F_W_OLDEST "s_waitcnt vmcnt(12)"
+#define BV_F_W_OLDEST_1 "s_waitcnt vmcnt(13)"
+#define BV_F_W_OLDEST_3 "s_waitcnt vmcnt(15)"
+#else
+#error "BV_F_K: 2, 3 or 4 ring slots"
+#endif
+// -DBV_TEAM_DEBUG -DBV_PHASE_DEBUG: where the streaming waves' cycles go (s_memtime around the phases of a slot, summed over
+// the launch's waves in units of 16 cycles; printed by bv_engine_wait with the [fused debug] lines)
+#ifdef BV_PHASE_DEBUG
+#define BV_PH_DECL uint32_t ph_[24]; for (int i_ = 0; i_ < 24; ++i_) ph_[i_] = 0u; uint32_t ph_t_ = (uint32_t)__builtin_amdgcn_s_memtime(); const uint32_t ph_t0_ = ph_t_; uint32_t ph_i0_ = 0, ph_i1_ = 0, ph_i2_ = 0
+#define BV_PH(i) do { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph_[(i) + ((st & BV_FS_P1_FIN) ? 12 : 0)] += n_ - ph_t_; ph_t_ = n_; } while (0)
+#define BV_PH_COUNT(i) (++ph_[(i) + ((st & BV_FS_P1_FIN) ? 12 : 0)])
+#define BV_PH_FLUSH(ctr, lane) do { ph_[9] = (uint32_t)__builtin_amdgcn_s_memtime() - ph_t0_; if ((lane) == 0) for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&(ctr)[BV_CTR_WORDS + 4220 + i_], (i_ % 12) == 7 ? ph_[i_] : ph_[i_] >> 4); } while (0)
+#else
+#define BV_PH_DECL
+#define BV_PH(i)
+#define BV_PH_COUNT(i)
+#define BV_PH_FLUSH(ctr, lane)
+#endif
+#ifndef BV_F_NT
+#define BV_F_NT " nt"   /* cache policy of the rows' LDS-DMA loads (experiments: -DBV_F_NT='""') */
+#endif
 #define BV_F_SLOT_WORDS 1024              /* pass-1 rows: 2 KiB of calls, 2 KiB of phreds; pass-2 rows: 1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks */
 #define BV_F_QCAP 256                     /* entries per candidate queue (ring buffers) */
 #define BV_F_QVCAP 128                    /* entries of the variant queue */
-#define BV_F_QV_HIGH 64u                  /* from this many waiting variant rows on, a streaming wave takes one before its next pass-1 row */
 #define BV_F_EMPTY 0xFFFFFFFFu
 // Every wait on another wave's LDS write is bounded (~1-2 s of s_sleep): a wave that gives up sets the sticky BV_CTR_TIMEOUT
 // counter -- the submit then fails loudly in bv_engine_wait -- instead of hanging the GPU on a protocol error.
@@ -122,7 +165,7 @@ struct __attribute__((aligned(16))) BvFusedShared {
     uint32_t ctl[16];
 };
 static_assert(sizeof(BvFusedShared) <= 160 * 1024, "one workgroup per CU must fit the LDS");
-static_assert(sizeof(BvFusedRing) == sizeof(uint32_t) * BV_F_K * BV_F_SLOT_WORDS, "the solver scratch must fit the ring");
+static_assert(BV_F_K < 3 || sizeof(BvFusedRing) == sizeof(uint32_t) * BV_F_K * BV_F_SLOT_WORDS, "the solver scratch must fit the ring");
 
 // ---- LDS-DMA of one slot: four 1 KiB pieces (64 lanes x 16 bytes from p_i + v_i) to d0, d0 + 1 KiB, ..., always four (the
 // counted waits rely on it).  M0 is written inside the statement; the s_add between the write and the load is the wait state.
@@ -133,16 +176,16 @@ __device__ __forceinline__ void bv_f_glds4(uint32_t d0, const uint8_t *p0, uint3
         "s_mov_b32 %[keep], m0\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t)
         : [d0] "s"(d0), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3)
@@ -161,17 +204,17 @@ __device__ __forceinline__ void bv_f_glds4_masked(uint32_t d0, const uint8_t *p0
         "s_mov_b64 exec, %[mA]\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3]" BV_F_NT "\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
@@ -180,11 +223,9 @@ __device__ __forceinline__ void bv_f_glds4_masked(uint32_t d0, const uint8_t *p0
         : "memory", "scc");
 }
 // A pass-2 slot of the tagged rank layout (BV_SLAB_RPR_TAGGED): no call bytes -- 1 KiB of mapq and 2 KiB of ranks to the slot's
-// second, third and fourth KiB under the lane mask `m` (all lanes; a row's last slot: its valid lanes).  Still FOUR loads, because
-// the counted waits count four per slot whatever its kind: the first is lane 0 alone, 16 bytes of the mapq piece into the unused
-// first KiB (the same line the second load fetches: no traffic of its own).
-__device__ __forceinline__ void bv_f_glds4_tag(uint32_t d0, const uint8_t *p1, uint32_t v1, const uint8_t *p2, uint32_t v2, uint32_t v3,
-                                               unsigned long long m) {
+// second, third and fourth KiB.  Still FOUR loads, because the counted waits count four per slot whatever its kind: the first is
+// lane 0 alone, 16 bytes of the mapq piece into the unused first KiB (the same line the second load fetches: no traffic of its own).
+__device__ __forceinline__ void bv_f_glds4_tag(uint32_t d0, const uint8_t *p1, uint32_t v1, const uint8_t *p2, uint32_t v2, uint32_t v3) {
     uint32_t keep, t;
     unsigned long long sv;
     asm volatile(
@@ -193,21 +234,59 @@ __device__ __forceinline__ void bv_f_glds4_tag(uint32_t d0, const uint8_t *p1, u
         "s_mov_b64 exec, 1\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
-        "s_mov_b64 exec, %[m]\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p2] nt\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p2]" BV_F_NT "\n\t"
+        "s_mov_b32 m0, %[keep]"
+        : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
+        : [d0] "s"(d0), [p1] "s"(p1), [p2] "s"(p2), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3)
+        : "memory", "scc");
+}
+// Four pieces, each under a lane mask of its own (never empty): the last slot of a pass-2 row, whose 2 KiB of ranks end at twice the
+// lane count of its 1 KiB of mapq.
+__device__ __forceinline__ void bv_f_glds4_m4(uint32_t d0, const uint8_t *p0, uint32_t v0, unsigned long long m0, const uint8_t *p1, uint32_t v1,
+                                              unsigned long long m1, const uint8_t *p2, uint32_t v2, unsigned long long m2, const uint8_t *p3,
+                                              uint32_t v3, unsigned long long m3) {
+    // (a row's last slot only: the operands are made scalar here, whatever the compiler believes about them at the call site)
+    auto u32 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); };
+    auto u64 = [&](unsigned long long x) { return ((unsigned long long)u32((uint32_t)(x >> 32)) << 32) | u32((uint32_t)x); };
+    d0 = u32(d0); m0 = u64(m0); m1 = u64(m1); m2 = u64(m2); m3 = u64(m3);
+    p0 = (const uint8_t *)(uintptr_t)u64((uintptr_t)p0); p1 = (const uint8_t *)(uintptr_t)u64((uintptr_t)p1);
+    p2 = (const uint8_t *)(uintptr_t)u64((uintptr_t)p2); p3 = (const uint8_t *)(uintptr_t)u64((uintptr_t)p3);
+    uint32_t keep, t;
+    unsigned long long sv;
+    asm volatile(
+        "s_mov_b32 %[keep], m0\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_mov_b32 m0, %[d0]\n\t"
+        "s_mov_b64 exec, %[m0_]\n\t"
+        "s_add_u32 %[t], %[d0], 0x400\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0]" BV_F_NT "\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_mov_b64 exec, %[m1_]\n\t"
+        "s_add_u32 %[t], %[d0], 0x800\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_mov_b64 exec, %[m2_]\n\t"
+        "s_add_u32 %[t], %[d0], 0xc00\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
+        "s_mov_b32 m0, %[t]\n\t"
+        "s_mov_b64 exec, %[m3_]\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3]" BV_F_NT "\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
-        : [d0] "s"(d0), [p1] "s"(p1), [p2] "s"(p2), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3), [m] "s"(m)
+        : [d0] "s"(d0), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3),
+          [m0_] "s"(m0), [m1_] "s"(m1), [m2_] "s"(m2), [m3_] "s"(m3)
         : "memory", "scc");
 }
 // One wave-level compare-and-swap on an LDS word by lane 0, the old value in an SGPR (no divergent branch, no vector-memory
@@ -401,36 +480,51 @@ __device__ __forceinline__ void bv_f_push_variants(const BvP1ShortArgs &a, BvFus
 }
 
 // four candidates, one per group of 16 lanes: positions first .. first + n - 1 of queue q
+// A variant site enters the variant queue BETWEEN the two phases of its solve (bv_solver16.h): its rank-sum row needs the LRT's
+// alleles only, and the jobs behind a workgroup's last pass-1 row are the end of the launch -- with the push behind phase 2 (until
+// round 6) the last rows waited for the QUAL and the strand-bias tests of their sites too.  Phase 2 and the row's wave then write
+// the same record at the same time: different fields, and the status word by atomic OR on both sides (phase 1 stores it whole).
 __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t *q, uint32_t first,
                                            uint32_t n, int lane) {
     const int grp = lane >> 4, gl = lane & 15;
     uint32_t *scratch = v.grp + grp * BV_G16_GRP_WORDS;
-    bool variant = false;
-    uint32_t site = 0, pL = 0, pn12 = 0, plut = 0;
+    bool variant = false, live = false;
+    uint32_t site = 0, pL = 0, pn12 = 0, plut = 0, nb = 0, badq = 0;
+    const uint32_t *src = a.bins;
+    BvG16Lrt pre;
+    pre.status = 0; pre.aw0 = 0; pre.aw1 = 0; pre.chi2 = 0.; pre.ref = 4;
     if ((uint32_t)grp < n) site = bv_f_take(q, first + (uint32_t)grp);
     if ((uint32_t)grp < n && site == BV_F_EMPTY) {
         if (gl == 0) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE);
     } else if ((uint32_t)grp < n) {
-        const uint32_t *src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
-        uint32_t nb, badq;
-        BvG16Lrt pre;
+        live = true;
+        src = a.bins + (size_t)site * BV_S_BIN_STRIDE;
         uint4 s0, s1, s2;
         bv_load3_l2(&a.summ[site], s0, s1, s2);
-        {
-            BvG16Bins B;
-            uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
-            const uint32_t total = depth[0] + depth[1] + depth[2] + depth[3];
-            nb = s2.x;
-            badq = (s2.y & BV_SUM_BADQ) ? 1u : 0u;
-            B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sh.tab_loghit; B.logmiss = sh.tab_logmiss;
-            B.pm = reinterpret_cast<double *>(scratch) + gl;
+        BvG16Bins B;
+        uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
+        const uint32_t total = depth[0] + depth[1] + depth[2] + depth[3];
+        nb = s2.x;
+        badq = (s2.y & BV_SUM_BADQ) ? 1u : 0u;
+        B.hit = sh.tab_hit; B.miss = sh.tab_miss; B.loghit = sh.tab_loghit; B.logmiss = sh.tab_logmiss;
+        B.pm = reinterpret_cast<double *>(scratch) + gl;
 #pragma unroll
-            for (int s = 0; s < BV_G16_SLOTS; ++s) {
-                const uint32_t i = (uint32_t)(s * 16 + gl);
-                B.w[s] = i < nb ? src[i] : 0u;
-            }
-            variant = bv_site_lrt_g16(v.sa, site, depth, total, badq, B, scratch, lane, &pre);
+        for (int s = 0; s < BV_G16_SLOTS; ++s) {
+            const uint32_t i = (uint32_t)(s * 16 + gl);
+            B.w[s] = i < nb ? src[i] : 0u;
         }
+        variant = bv_site_lrt_g16(v.sa, site, depth, total, badq, B, scratch, lane, &pre);
+        if (variant && v.fuse2) bv_f_p2_facts(pre.ref, depth, pre.aw0, pre.aw1, pL, pn12, plut);
+    }
+    const unsigned long long vm = __ballot(variant && gl == 0);
+    if (variant && gl == 0) v.vl[v.n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
+    v.n_vl += (uint32_t)__popcll(vm);
+    if (v.fuse2 && vm != 0ull) {
+        // the records' first versions are complete (the rank sums' waves add to them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bv_f_push_variants(a, sh, B0, variant && gl == 0, site, pL, pn12, plut, lane);
+    }
+    if (live) {
         BvSiteSums S;
         // phase 2 needs the strand totals and, for the rank sum, the bins again (registers that would otherwise sit through the
         // EMs).  ONE trip: the bins' loads are issued first, and the summary load's own s_waitcnt vmcnt(0) covers them and the
@@ -441,23 +535,12 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
             const uint32_t i = (uint32_t)(s * 16 + gl);
             w2[s] = (variant && i < nb) ? src[i] : 0u;
         }
+        uint4 s0, s1, s2;
         bv_load3_l2(&a.summ[site], s0, s1, s2);
         S.fwd[0] = s0.x; S.fwd[1] = s0.y; S.fwd[2] = s0.z; S.fwd[3] = s0.w;
         S.rev[0] = s1.x; S.rev[1] = s1.y; S.rev[2] = s1.z; S.rev[3] = s1.w;
         S.q0_mask = 0; S.nb = nb; S.badq = badq;
         bv_site_tail_g16(v.sa, site, S, src, nb, scratch, lane, &pre, w2);
-        if (variant && v.fuse2) {
-            const uint32_t depth[4] = {s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w};
-            bv_f_p2_facts(pre.ref, depth, pre.aw0, pre.aw1, pL, pn12, plut);
-        }
-    }
-    const unsigned long long vm = __ballot(variant && gl == 0);
-    if (variant && gl == 0) v.vl[v.n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
-    v.n_vl += (uint32_t)__popcll(vm);
-    if (v.fuse2 && vm != 0ull) {
-        // the records are complete (the rank sums' waves add to them: BV_SITE_RANKSUM is OR-ed into the status stored above)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        bv_f_push_variants(a, sh, B0, variant && gl == 0, site, pL, pn12, plut, lane);
     }
     if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
 }
@@ -556,7 +639,20 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
         uint32_t *q = sh.q3;
         n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, least, 4u, first, lane);
         if (n == 0u) { q = sh.q2; n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, least, 4u, first, lane); }
+#ifdef BV_F_DRAIN_PRIO  /* experiment: the jobs behind the last pass-1 row are the launch's critical path */
+        if (n != 0u && n_done == (uint32_t)BV_F_NS) __builtin_amdgcn_s_setprio(BV_F_DRAIN_PRIO);
+#endif
+#ifdef BV_PHASE_DEBUG
+        const uint32_t jt0_ = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
         if (n != 0u) bv_f_job16(a, sh, v, B0, q, first, n, lane);   // (ONE call site: the solver is ~50 KB of code)
+#ifdef BV_PHASE_DEBUG
+        if (n != 0u && lane == 0) {
+            const uint32_t dt_ = ((uint32_t)__builtin_amdgcn_s_memtime() - jt0_) >> 4, late_ = n_done == (uint32_t)BV_F_NS ? 4u : 0u;
+            atomicAdd(&a.counters[BV_CTR_WORDS + 4212 + late_], dt_); atomicAdd(&a.counters[BV_CTR_WORDS + 4213 + late_], 1u);
+            atomicAdd(&a.counters[BV_CTR_WORDS + 4214 + late_], n); if (q == sh.q3) atomicAdd(&a.counters[BV_CTR_WORDS + 4215 + late_], 1u);
+        }
+#endif
         if (n == 0u && v.big != nullptr && n_done == (uint32_t)BV_F_NS &&
             (n = bv_f_claim(sh.ctl, BV_FC_QH_TAIL, BV_FC_QH_HEAD, 1u, 1u, first, lane)) != 0u) {
             // (every streaming wave ran s_waitcnt vmcnt(0) behind its last list entry before it counted itself done)
@@ -564,6 +660,9 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
             bv_f_job_hard(a, sh, v, B0, site, lane);
         }
         if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
+#ifdef BV_F_DRAIN_PRIO
+        if (n != 0u && n_done == (uint32_t)BV_F_NS) __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef BV_TEAM_DEBUG  /* when the workgroup's last solver job ended */
         if (n != 0u && lane == 0) atomicMax(&a.counters[BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u + 5u], (uint32_t)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -792,8 +891,16 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     // pass-2 rows: slots of 64 chunks (1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks: 32 bytes per lane in two pieces)
     const uint32_t n_slots2 = (n_chunks + 63u) >> 6;
     const uint32_t last2 = n_chunks - (n_slots2 - 1u) * 64u;   // 1 .. 64
-    const uint32_t vr0 = (uint32_t)lane * 32u, vr1 = vr0 + 16u;
+    // The 2 KiB of ranks arrive as two CONTIGUOUS KiB (lane l: bytes 16 l .. 16 l + 15 of each), not as the lane's own 32 bytes in two
+    // halves: a piece of 64 x 16 bytes at a stride of 32 touches sixteen 128-byte lines instead of eight, and its twin the same
+    // sixteen again -- in the launch's last phase, where only such rows stream, requesting a slot took 1,260 cycles against 420
+    // for a pass-1 slot and the slot then came late (1,870 cycles of waiting per slot; round 6, -DBV_PHASE_DEBUG).  The lane's own
+    // 32 bytes are put together where the slot is read: two ds_read_b128 at a stride of 32.
     const unsigned long long mA2 = last2 >= 64u ? ~0ull : ((1ull << last2) - 1ull);
+    // a row's last slot: the lanes of the two rank pieces that lie inside the row (2 x last2 chunks of 16 bytes)
+    const unsigned long long mR0 = last2 >= 32u ? ~0ull : ((1ull << (2u * last2)) - 1ull);
+    const unsigned long long mR1 = last2 > 32u ? (last2 >= 64u ? ~0ull : ((1ull << (2u * last2 - 64u)) - 1ull)) : 1ull;
+    const uint32_t vrl = last2 > 32u ? vb : va;  // (a second piece wholly past the row's end: lane 0 alone re-reads valid bytes)
     // the last slot's cells past the row's end are forced to 'N': per lane and dword, the mask of the bytes that stay
     uint32_t keepA[4], keepB[4], keep2[4];
     {
@@ -820,17 +927,17 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     // x / y: pass 1: reference base / -; pass 2: class table / n_ref | n_alt << 16; z: pass 2: the sweeps' 2-bit table
     uint32_t c_site = 0, c_kind = 0, c_x = 0, c_y = 0, c_z = 0, n_site = 0, n_kind = 0, n_x = 0, n_y = 0, n_z = 0;
     uint32_t st = st_io;
+    BV_PH_DECL;
     constexpr uint32_t P_DONE = BV_FS_P_DONE, C_HAVE = 2u, N_HAVE = 4u, CUR_DONE = BV_FS_CUR_DONE, P1_FIN = BV_FS_P1_FIN;
     auto issue = [&]() __attribute__((always_inline)) {
         if (p_left == 0u) {
             if (st & P_DONE) return;
             uint32_t s = 0, kind = 0, x = 0, y = 0, z = 0;
-            // the next row: a pass-1 row while the cursor has any -- unless the variant queue is filling up (the solvers wait
-            // on a full one) --, else a variant site's pass-2 row
-            bool p2_first = false;
-            if (FUSE2 && !(st & CUR_DONE))
-                p2_first = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) >= BV_F_QV_HIGH;
-            if (!(st & CUR_DONE) && !p2_first) {
+            // the next row: a pass-1 row while the cursor has any, then the variant sites' pass-2 rows.  (Until round 6 a wave took a
+            // variant row first whenever 64 of them were waiting.  Rows of the two kinds mixed cost more than the same rows one
+            // kind after the other -- thresholds of 2 / 8 / 24 measured -9 / -9 / -5 % at 100,000 sites, "never" +2.5 % at 524,288,
+            // where the queue does reach 64 --, and nothing needs it: a full variant queue spills to the overflow list.)
+            if (!(st & CUR_DONE)) {
                 const uint32_t c = bv_lds_fetch_add_wave(cursor_lds, 1u);
                 if (c < B1 - B0) { s = B0 + c; kind = BV_FK_P1; x = bv_f_ref_scalar(a.ref_base, s); }
                 else st |= CUR_DONE;
@@ -883,16 +990,20 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             if (!(st & C_HAVE)) { c_site = s; c_kind = kind; c_x = x; c_y = y; c_z = z; st |= C_HAVE; }
             else { n_site = s; n_kind = kind; n_x = x; n_y = y; n_z = z; st |= N_HAVE; }
         }
+        BV_PH(10);
+#ifdef BV_PHASE_DEBUG
+        { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (ring_w == 0u) ph_i0_ = n_; else if (ring_w == 1u) ph_i1_ = n_; else ph_i2_ = n_; }
+#endif
         const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
         if (!FUSE2 || p_kind == BV_FK_P1) {
             if (p_left > 1u) { bv_f_glds4(d0, p0, va, p0, vb, p1, va, p1, vb); p0 += 2048; p1 += 2048; }
             else bv_f_glds4_masked(d0, p0, va, p0, vbl, p1, va, p1, vbl, mA1, mB1);
         } else if (tag) {
-            if (p_left > 1u) { bv_f_glds4_tag(d0, p1, va, p2, vr0, vr1, ~0ull); p1 += 1024; p2 += 2048; }
-            else bv_f_glds4_tag(d0, p1, va, p2, vr0, vr1, mA2);
+            if (p_left > 1u) { bv_f_glds4_tag(d0, p1, va, p2, va, vb); p1 += 1024; p2 += 2048; }
+            else bv_f_glds4_m4(d0, p1, va, 1ull, p1, va, mA2, p2, va, mR0, p2, vrl, mR1);
         } else {
-            if (p_left > 1u) { bv_f_glds4(d0, p0, va, p1, va, p2, vr0, p2, vr1); p0 += 1024; p1 += 1024; p2 += 2048; }
-            else bv_f_glds4_masked(d0, p0, va, p1, va, p2, vr0, p2, vr1, mA2, mA2);
+            if (p_left > 1u) { bv_f_glds4(d0, p0, va, p1, va, p2, va, p2, vb); p0 += 1024; p1 += 1024; p2 += 2048; }
+            else bv_f_glds4_m4(d0, p0, va, mA2, p1, va, mA2, p2, va, mR0, p2, vrl, mR1);
         }
         --p_left;
         ring_w = (ring_w + 1u == (uint32_t)BV_F_K) ? 0u : ring_w + 1u;
@@ -907,7 +1018,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     // the end of this wave's pass-1 rows: its last one published, the wave counted in NDONE
     auto finish_p1 = [&]() __attribute__((always_inline)) {
         if (prev_kind != 0u) {
-            if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (inflight == (uint32_t)BV_F_K) asm volatile(BV_F_W_ALL ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
             if (prev_kind == 4u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (its cand_list entry; rare)
@@ -933,6 +1044,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
 
 #pragma unroll 1
     for (int k = 0; k < BV_F_K; ++k) issue();
+    BV_PH(2);
 #pragma unroll 1
     while (st & C_HAVE) {
         const uint32_t site = c_site;
@@ -945,18 +1057,27 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             // that follow a pass-1 row's epilogue, that row's S stores, which are younger than the slot waited for (vmcnt
             // counts in issue order).  Unknown S, or fewer than K slots in flight: the conservative wait.
             if (inflight != (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (j >= 3u || wsel == 0u) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (wsel == 1u) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+            else if (j >= (uint32_t)BV_F_K || wsel == 0u) asm volatile(BV_F_W_OLDEST ::: "memory");
+            else if (wsel == 1u) asm volatile(BV_F_W_OLDEST_1 ::: "memory");
+            else asm volatile(BV_F_W_OLDEST_3 ::: "memory");
+            BV_PH(0); BV_PH_COUNT(7);
+#ifdef BV_PHASE_DEBUG
+            ph_[11 + ((st & BV_FS_P1_FIN) ? 12 : 0)] += ph_t_ - (ring_r == 0u ? ph_i0_ : (ring_r == 1u ? ph_i1_ : ph_i2_));  // requested -> found landed
+#endif
             const uint32_t *rs = ring + ring_r * BV_F_SLOT_WORDS + lane * 4;
+            // (a pass-2 slot: the lane's 16 ranks are 32 contiguous bytes of the slot's second half)
+            const uint32_t *rs2 = (!FUSE2 || c_kind == BV_FK_P1) ? rs + 512 : rs + 512 + lane * 4;
+            const uint32_t o3 = (!FUSE2 || c_kind == BV_FK_P1) ? 256u : 4u;
             bv_u32x4 w0 = *reinterpret_cast<const bv_u32x4 *>(rs);
             bv_u32x4 w1 = *reinterpret_cast<const bv_u32x4 *>(rs + 256);
-            bv_u32x4 w2 = *reinterpret_cast<const bv_u32x4 *>(rs + 512);
-            bv_u32x4 w3 = *reinterpret_cast<const bv_u32x4 *>(rs + 768);
+            bv_u32x4 w2 = *reinterpret_cast<const bv_u32x4 *>(rs2);
+            bv_u32x4 w3 = *reinterpret_cast<const bv_u32x4 *>(rs2 + o3);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // in registers: the slot may be refilled
             ring_r = (ring_r + 1u == (uint32_t)BV_F_K) ? 0u : ring_r + 1u;
             --inflight;
+            BV_PH(1);
             issue();
+            BV_PH(2);
             const uint32_t N4 = 0x08080808u;
             if (is_p1) {
                 // w0 / w1: calls of the slot's first / second KiB; w2 / w3: their phreds
@@ -969,7 +1090,12 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     w2.x &= keepA[0]; w2.y &= keepA[1]; w2.z &= keepA[2]; w2.w &= keepA[3];
                     w3.x &= keepB[0]; w3.y &= keepB[1]; w3.z &= keepB[2]; w3.w &= keepB[3];
                 }
+#ifdef BV_F_SKIP_TALLY  /* experiment: how fast the rows stream when nothing is tallied (records are wrong) */
+                asm volatile("" :: "v"(w0.x), "v"(w1.x), "v"(w2.x), "v"(w3.x), "v"(w0.w), "v"(w1.w), "v"(w2.w), "v"(w3.w));
+#else
                 bv_f_tally2(w0, w2, w1, w3, hist, one);
+#endif
+                BV_PH(3);
             } else {
                 // w0: calls; w1: mapq; w2 / w3: ranks 0-7 / 8-15 of the lane's 16 cells.  The tally of bv_pass2_dma_kernel
                 // (bv_pass2.hip): class bytes by one v_perm per dword, class << 8 | value by one v_perm per cell, "< 0x200"
@@ -998,6 +1124,11 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     c0 = __builtin_amdgcn_perm(L, L, w0.x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, w0.y) ^ 0x80808080u;
                     c2 = __builtin_amdgcn_perm(L, L, w0.z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, w0.w) ^ 0x80808080u;
                 }
+#ifdef BV_F_SKIP_P2TALLY  /* experiment: the pass-2 rows stream, nothing is tallied (rank sums are wrong) */
+                asm volatile("" :: "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w));
+                if (false)
+#endif
+                {
                 // ranks that do not fit the 256-rank window: remembered, the row is then re-done by the window sweeps
                 hi_acc |= (w2.x | w2.y | w2.z | w2.w | w3.x | w3.y | w3.z | w3.w) & hi_mask;
                 uint32_t x[16];
@@ -1013,13 +1144,15 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                 x[8] = bv_p2d_xr<0, 0>(c2, w3.x); x[9] = bv_p2d_xr<1, 1>(c2, w3.x); x[10] = bv_p2d_xr<2, 0>(c2, w3.y); x[11] = bv_p2d_xr<3, 1>(c2, w3.y);
                 x[12] = bv_p2d_xr<0, 0>(c3, w3.z); x[13] = bv_p2d_xr<1, 1>(c3, w3.z); x[14] = bv_p2d_xr<2, 0>(c3, w3.w); x[15] = bv_p2d_xr<3, 1>(c3, w3.w);
                 bv_lds_add16<2>(x, hist + 512, one, 0x200u);
+                }
+                BV_PH(4);
             }
         }
         bv_lrt_sync<0>();
 
         // ---- the previous pass-1 row's stores are older than the (at most) K slots in flight: wait for exactly them, publish it
         if (prev_kind != 0u) {
-            if (inflight == (uint32_t)BV_F_K) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (inflight == (uint32_t)BV_F_K) asm volatile(BV_F_W_ALL ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             bv_f_publish(a, sh, B0, prev_site, prev_kind, lane);
             prev_kind = 0;
@@ -1031,6 +1164,12 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             if (lane == 0 && !(st & P1_FIN)) sh.pub[wave] = mark;
         }
 
+#ifdef BV_F_SKIP_EPI  /* experiment (with BV_F_SKIP_TALLY, --flags 1): rows stream, nothing else happens */
+        if (is_p1) {
+            if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = 0u;
+            prev_site = site; prev_kind = 1u; wsel = 1u;
+        } else
+#endif
         if (is_p1) {
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
@@ -1196,6 +1335,9 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         }
         }
         // ---- hand the histogram back, zeroed
+#ifdef BV_F_SKIP_EPI
+        if (!is_p1)
+#endif
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
@@ -1203,6 +1345,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             if (lane < 2) h4[BV_S_HWORDS / 4 + lane] = make_uint4(0, 0, 0, 0);
         }
         bv_lrt_sync<0>();
+        if (is_p1) BV_PH(5); else BV_PH(6);
         if (st & N_HAVE) { c_site = n_site; c_kind = n_kind; c_x = n_x; c_y = n_y; c_z = n_z; st &= ~N_HAVE; }
         else st &= ~C_HAVE;
         // the last pass-1 row of this wave is behind it: publish it, count the wave
@@ -1222,6 +1365,8 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     if ((st & CUR_DONE) && !(st & P1_FIN)) finish_p1();
     if (FUSE2 && stash.n != 0u) bv_f_stash_flush(a, stash, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BV_PH(8);
+    BV_PH_FLUSH(a.counters, lane);
     (void)c_z;
     return st & (P_DONE | CUR_DONE | P1_FIN);
 }
@@ -1256,6 +1401,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         dbg_[0] = (uint32_t)__builtin_amdgcn_s_memrealtime(); dbg_[3] = 0u; dbg_[5] = 0u;
         dbg_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
         if (blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 4u;  // whose stamps these are
+#ifdef BV_PHASE_DEBUG
+        if (blockIdx.x == 0) for (int i = 0; i < 48; ++i) a.counters[BV_CTR_WORDS + 4200 + i] = 0u;
+#endif
     }
 #endif
     __syncthreads();

@@ -51,7 +51,8 @@ extern __shared__ __attribute__((aligned(16))) uint32_t bv_dyn_lds[];  // hg[n_g
 // (bv_p2t_class4) and the call plane is not read at all -- 3 bytes per cell, SURVEY 8d's figure, instead of 4.
 // DOM: the mapq tally takes a dominant value out of the LDS adds (bv_lds_add16_dom): chosen per row by its depth.
 template <int NT, bool RANKS, bool GROUPS, bool HALF = false, bool TAG = false, bool DOM = false>
-__device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr, uint32_t *hg) {
+__device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint32_t site, int tid, uint32_t L, uint32_t *hm, uint32_t *hr, uint32_t *hg,
+                                                     uint32_t *q64 = nullptr /* with GROUPS: this thread's OR of bit 6 of the row's phred bytes */) {
     const size_t row = (size_t)site * a.pitch;
     const bv_u32x4 *b4 = reinterpret_cast<const bv_u32x4 *>(a.bs + row);
     const bv_u32x4 *m4 = RANKS ? reinterpret_cast<const bv_u32x4 *>(a.mapq + row) : nullptr;
@@ -66,7 +67,7 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
     static_assert(!TAG || (RANKS && !GROUPS), "the tagged form: rank sums without pop-groups");
     const bv_u32x4 nocall = bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
     const uint32_t hi_mask = TAG ? 0x1F001F00u : bv_rpr_hi_mask(a.rpr_tag);
-    uint32_t hi_acc = 0, dom = BV_DOM_NONE;
+    uint32_t hi_acc = 0, dom = BV_DOM_NONE, q64_acc = 0;
     // chunks per thread and trip: without the rank planes three loads per chunk, so four chunks -- a 10,000-sample row is then
     // ONE round of loads for a workgroup of 256 (the kernel waits for memory, not for instructions)
     constexpr int U = RANKS ? 2 : 4;
@@ -134,6 +135,7 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
                 // fit the packed index: reported like a long read, the row is then re-done by the branchy sweep
                 bv_u32x4 q2 = vq[u];
                 hi_acc |= ((vb[u].x | vb[u].y | vb[u].z | vb[u].w) & 0xF0F0F0F0u) | ((q2.x | q2.y | q2.z | q2.w) & 0x80808080u);
+                q64_acc |= (q2.x | q2.y | q2.z | q2.w) & 0x40404040u;
                 const uint32_t y0 = (((vb[u].x & 0x08080808u) << 4) | (vb[u].x & 0x03030303u)) | vg[u].x, y1 = (((vb[u].y & 0x08080808u) << 4) | (vb[u].y & 0x03030303u)) | vg[u].y;
                 const uint32_t y2 = (((vb[u].z & 0x08080808u) << 4) | (vb[u].z & 0x03030303u)) | vg[u].z, y3 = (((vb[u].w & 0x08080808u) << 4) | (vb[u].w & 0x03030303u)) | vg[u].w;
                 q2.x = (q2.x & 0x7F7F7F7Fu) << 1; q2.y = (q2.y & 0x7F7F7F7Fu) << 1; q2.z = (q2.z & 0x7F7F7F7Fu) << 1; q2.w = (q2.w & 0x7F7F7F7Fu) << 1;
@@ -146,6 +148,7 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
             }
         }
     }
+    if (GROUPS && q64 != nullptr) *q64 = q64_acc;
     return hi_acc;
 }
 
@@ -222,18 +225,22 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
         // Rank sums without pop-groups: the perm form first (a third of the instructions; 256-rank window).  A row that holds a
         // rank >= 256 (long reads) is re-done by the window sweeps below.
         const bool FAST = !GROUPS || a.gidp != nullptr;
-        bool fast_ok = false;
+        bool fast_ok = false, lo_only = false;
         if (FAST) {
             // a deep row (an eighth of its cells are REF / ALT reads): most lanes of a wave add to the dominant mapq's word
             const bool deep = RANKS && !GROUPS && (n1 + n2) * 8ull >= (unsigned long long)a.n_samples && !(a.flags & BV_FLAG_NO_DOM);
+            uint32_t q64 = 0;
             const uint32_t hi = deep ? bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG, RANKS && !GROUPS>(a, site, tid, Ltab, sh.hm, sh.hr, hg)
-                                     : bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG, false>(a, site, tid, Ltab, sh.hm, sh.hr, hg);
-            const bool any_hi = __ballot(hi != 0u) != 0ull;
-            if (lane == 0) sh.maxr[wave] = any_hi ? 1u : 0u;
+                                     : bv_p2_fast_sweep<NT, RANKS, GROUPS, HALF, TAG, false>(a, site, tid, Ltab, sh.hm, sh.hr, hg, &q64);
+            const bool any_hi = __ballot(hi != 0u) != 0ull, any_q64 = GROUPS && __ballot(q64 != 0u) != 0ull;
+            if (lane == 0) sh.maxr[wave] = (any_hi ? 1u : 0u) | (any_q64 ? 2u : 0u);
             __syncthreads();
             uint32_t slow = 0;
             for (int w = 0; w < NW; ++w) slow |= sh.maxr[w];
-            fast_ok = slow == 0u;
+            fast_ok = (slow & 1u) == 0u;
+            // no phred byte of the row has bit 6 or 7 set (every Illumina row: phreds stop at 41): the upper halves of the group
+            // histograms -- phred 64-127 -- are empty, and the export below does not read them
+            lo_only = fast_ok && (slow & 2u) == 0u;
             __syncthreads();
             if (!fast_ok) {
                 uint4 *z = reinterpret_cast<uint4 *>(sh.hm);
@@ -305,6 +312,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                     uint32_t c[8], dpart[4], q0 = 0, cm = 0, nbv = 0;
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
+                        if ((r & 1) && lo_only) { c[r] = 0u; continue; }  // (wave-uniform: see lo_only)
                         if (HALF) c[r] = (h[(((r >> 1) << 7) | ((r & 1) << 6) | lane) >> 1] >> (16 * (lane & 1))) & 0xFFFFu;
                         else c[r] = h[((r >> 1) << 7) | ((r & 1) << 6) | lane];
                         cm = max(cm, c[r]);
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(NT) void bv_pass2_kernel(BvPass2Args a) {
                         uint32_t pos0 = 0;
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
+                            if ((r & 1) && lo_only) continue;
                             const uint32_t code = ((uint32_t)(r >> 1) << 7) | (uint32_t)(((r & 1) << 6) | lane);
                             const bool valid = c[r] != 0u && (code & 127u) < (uint32_t)BV_NQ_VALID;
                             const unsigned long long m = __ballot(valid);

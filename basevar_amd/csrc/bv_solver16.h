@@ -516,7 +516,9 @@ __device__ inline bool bv_site_lrt_g16(const BvSolveArgs &a, uint32_t site, cons
 #pragma unroll
         for (int b = 0; b < 4; ++b) res->depth[b] = depth[b];
         res->total_depth = total;
-        res->status = flags;
+        // (both phases in one kernel: the stash travels in `pre`, and the record's status word is final but for the bits that
+        // phase 2 and the rank-sum kernels OR into it)
+        res->status = pre != nullptr ? (flags & ~BV_G16_STASH_MASK) : flags;
         res->n_alt = (uint8_t)L.n_alt;
 #pragma unroll
         for (int k = 0; k < BV_MAX_ALT; ++k) {
@@ -658,7 +660,9 @@ __device__ inline void bv_site_tail_g16(const BvSolveArgs &a, uint32_t site, con
         if (same) { v_fs = c_fs; v_sor = c_sor; }
     }
     if (gl == 0) {
-        rec->status = flags;
+        // (with `pre` the rank sums of the site may be on their way into the record already: their BV_SITE_RANKSUM must survive)
+        if (pre == nullptr) rec->status = flags;
+        else if (flags & ~st & BV_SITE_SOR_OVERFLOW) atomicOr(&rec->status, BV_SITE_SOR_OVERFLOW);
         if (!(a.flags & BV_FLAG_SKIP_FISHER)) {
             *reinterpret_cast<uint2 *>(&rec->cvg_sb[0]) = make_uint2(c_rf, c_rr);
             *reinterpret_cast<uint2 *>(&rec->cvg_sb[2]) = make_uint2(c_af, c_ar);
