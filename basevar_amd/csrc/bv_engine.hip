@@ -711,7 +711,11 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         e->ring_one_kernel[slot] = false;
     }
     // Rows of at most BV_SHORT_ROW_MAX samples take the short-row forms of pass 1 (bv_pass1_fused.hip; bv_pass1_short.hip)
+#ifdef BV_EXPERIMENT_LONG_KERNEL_ALWAYS  /* experiment: short rows through the long-row kernel (plain loads into registers) */
+    const bool two_kernel = false;
+#else
     const bool two_kernel = n_samples <= BV_SHORT_ROW_MAX;
+#endif
 
     // ---- pass-2 arguments common to every chunk; scratch of the pop-group calls
     BvPass2Args a2;
@@ -1652,6 +1656,7 @@ static void bv_fused_debug_report(const uint32_t *h) {
             fprintf(stderr, "[fused phases] -- streaming waves, %s\n", part ? "past their last pass-1 row" : "while they have pass-1 rows");
             for (int i = 0; i < 12; ++i) {
                 if (i == 7) fprintf(stderr, "[fused phases] %-38s %u\n", pn[i], c[i]);
+                else if (i == 11) fprintf(stderr, "[fused phases] %-38s %12.0f cycles  (%.0f per timed slot, %u timed)\n", pn[i], 16.0 * c[i], d[4244 + part] ? 16.0 * c[i] / d[4244 + part] : 0., d[4244 + part]);
                 else if (i != 9 || part == 0) fprintf(stderr, "[fused phases] %-38s %12.0f cycles  (%.0f per slot)\n", pn[i], 16.0 * c[i], c[7] ? 16.0 * c[i] / c[7] : 0.);
             }
         }

@@ -89,10 +89,10 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 // -DBV_TEAM_DEBUG -DBV_PHASE_DEBUG: where the streaming waves' cycles go (s_memtime around the phases of a slot, summed over
 // the launch's waves in units of 16 cycles; printed by bv_engine_wait with the [fused debug] lines)
 #ifdef BV_PHASE_DEBUG
-#define BV_PH_DECL uint32_t ph_[24]; for (int i_ = 0; i_ < 24; ++i_) ph_[i_] = 0u; uint32_t ph_t_ = (uint32_t)__builtin_amdgcn_s_memtime(); const uint32_t ph_t0_ = ph_t_; uint32_t ph_i0_ = 0, ph_i1_ = 0, ph_i2_ = 0
+#define BV_PH_DECL uint32_t ph_[24]; for (int i_ = 0; i_ < 24; ++i_) ph_[i_] = 0u; uint32_t ph_t_ = (uint32_t)__builtin_amdgcn_s_memtime(); const uint32_t ph_t0_ = ph_t_; uint32_t ph_i0_ = 0, ph_i1_ = 0, ph_i2_ = 0, ph_n1_ = 0, ph_n2_ = 0
 #define BV_PH(i) do { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); ph_[(i) + ((st & BV_FS_P1_FIN) ? 12 : 0)] += n_ - ph_t_; ph_t_ = n_; } while (0)
 #define BV_PH_COUNT(i) (++ph_[(i) + ((st & BV_FS_P1_FIN) ? 12 : 0)])
-#define BV_PH_FLUSH(ctr, lane) do { ph_[9] = (uint32_t)__builtin_amdgcn_s_memtime() - ph_t0_; if ((lane) == 0) for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&(ctr)[BV_CTR_WORDS + 4220 + i_], (i_ % 12) == 7 ? ph_[i_] : ph_[i_] >> 4); } while (0)
+#define BV_PH_FLUSH(ctr, lane) do { ph_[9] = (uint32_t)__builtin_amdgcn_s_memtime() - ph_t0_; ph_[11] = ph_i1_; ph_[23] = ph_i2_; if ((lane) == 0) { atomicAdd(&(ctr)[BV_CTR_WORDS + 4244], ph_n1_); atomicAdd(&(ctr)[BV_CTR_WORDS + 4245], ph_n2_); } if ((lane) == 0) for (int i_ = 0; i_ < 24; ++i_) atomicAdd(&(ctr)[BV_CTR_WORDS + 4220 + i_], (i_ % 12) == 7 ? ph_[i_] : ph_[i_] >> 4); } while (0)
 #else
 #define BV_PH_DECL
 #define BV_PH(i)
@@ -992,7 +992,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         }
         BV_PH(10);
 #ifdef BV_PHASE_DEBUG
-        { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); if (ring_w == 0u) ph_i0_ = n_; else if (ring_w == 1u) ph_i1_ = n_; else ph_i2_ = n_; }
+        if (ring_w == 0u) ph_i0_ = (uint32_t)__builtin_amdgcn_s_memtime();  // (ring position 0 only: one in K slots is timed)
 #endif
         const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
         if (!FUSE2 || p_kind == BV_FK_P1) {
@@ -1062,7 +1062,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             else asm volatile(BV_F_W_OLDEST_3 ::: "memory");
             BV_PH(0); BV_PH_COUNT(7);
 #ifdef BV_PHASE_DEBUG
-            ph_[11 + ((st & BV_FS_P1_FIN) ? 12 : 0)] += ph_t_ - (ring_r == 0u ? ph_i0_ : (ring_r == 1u ? ph_i1_ : ph_i2_));  // requested -> found landed
+            if (ring_r == 0u) { if (st & BV_FS_P1_FIN) { ph_i2_ += ph_t_ - ph_i0_; ++ph_n2_; } else { ph_i1_ += ph_t_ - ph_i0_; ++ph_n1_; } }  // requested -> found landed
 #endif
             const uint32_t *rs = ring + ring_r * BV_F_SLOT_WORDS + lane * 4;
             // (a pass-2 slot: the lane's 16 ranks are 32 contiguous bytes of the slot's second half)
