@@ -1669,6 +1669,14 @@ static void bv_fused_debug_report(const uint32_t *h) {
                 j[1] ? (double)j[2] / j[1] : 0., j[1] ? 16.0 * j[0] / j[1] : 0.);
     }
 #endif
+#ifdef BV_PHASE_DEBUG
+    {
+        const char *jn[5] = {"the entry, the summary's and the bins' loads", "phase 1: LRT, the record's first version", "its stores complete, variant sites queued",
+                             "phase 2's loads", "phase 2: rank sum, QUAL, strand-bias tests"};
+        const uint32_t nj = d[4213] + d[4217];
+        for (int i = 0; i < 5; ++i) fprintf(stderr, "[fused phases] a 16-lane job, %-48s %8.0f cycles\n", jn[i], nj ? 16.0 * d[4250 + i] / nj : 0.);
+    }
+#endif
     const char *qn[3] = {"q3 entries", "q2 entries", "variant rows (or blocks of 64)"};
     for (int j = 0; j < 3; ++j) {
         std::vector<uint32_t> v;

@@ -493,6 +493,12 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
     const uint32_t *src = a.bins;
     BvG16Lrt pre;
     pre.status = 0; pre.aw0 = 0; pre.aw1 = 0; pre.chi2 = 0.; pre.ref = 4;
+#ifdef BV_PHASE_DEBUG
+    uint32_t jp_t_ = (uint32_t)__builtin_amdgcn_s_memtime(), jp_[6] = {0, 0, 0, 0, 0, 0};
+#define BV_JP(i) do { const uint32_t n_ = (uint32_t)__builtin_amdgcn_s_memtime(); jp_[i] += n_ - jp_t_; jp_t_ = n_; } while (0)
+#else
+#define BV_JP(i)
+#endif
     if ((uint32_t)grp < n) site = bv_f_take(q, first + (uint32_t)grp);
     if ((uint32_t)grp < n && site == BV_F_EMPTY) {
         if (gl == 0) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE);
@@ -513,9 +519,14 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
             const uint32_t i = (uint32_t)(s * 16 + gl);
             B.w[s] = i < nb ? src[i] : 0u;
         }
+#ifdef BV_PHASE_DEBUG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        BV_JP(0);  // the entry, the summary's and the bins' loads
         variant = bv_site_lrt_g16(v.sa, site, depth, total, badq, B, scratch, lane, &pre);
         if (variant && v.fuse2) bv_f_p2_facts(pre.ref, depth, pre.aw0, pre.aw1, pL, pn12, plut);
     }
+    BV_JP(1);  // phase 1: the LRT and the record's first version
     const unsigned long long vm = __ballot(variant && gl == 0);
     if (variant && gl == 0) v.vl[v.n_vl + (uint32_t)__popcll(vm & ((1ull << lane) - 1ull))] = site;
     v.n_vl += (uint32_t)__popcll(vm);
@@ -524,6 +535,7 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bv_f_push_variants(a, sh, B0, variant && gl == 0, site, pL, pn12, plut, lane);
     }
+    BV_JP(2);  // the record's stores complete, the variant sites queued
     if (live) {
         BvSiteSums S;
         // phase 2 needs the strand totals and, for the rank sum, the bins again (registers that would otherwise sit through the
@@ -540,9 +552,15 @@ __device__ __forceinline__ void bv_f_job16(const BvP1ShortArgs &a, BvFusedShared
         S.fwd[0] = s0.x; S.fwd[1] = s0.y; S.fwd[2] = s0.z; S.fwd[3] = s0.w;
         S.rev[0] = s1.x; S.rev[1] = s1.y; S.rev[2] = s1.z; S.rev[3] = s1.w;
         S.q0_mask = 0; S.nb = nb; S.badq = badq;
+        BV_JP(3);  // phase 2's loads
         bv_site_tail_g16(v.sa, site, S, src, nb, scratch, lane, &pre, w2);
     }
+    BV_JP(4);  // phase 2: rank sum, QUAL, strand-bias tests
     if (v.n_vl > 56u) bv_f_flush_vl(a, v, lane);
+#ifdef BV_PHASE_DEBUG
+    if (lane == 0) for (int i = 0; i < 5; ++i) atomicAdd(&a.counters[BV_CTR_WORDS + 4250 + i], jp_[i] >> 4);
+#endif
+#undef BV_JP
 }
 // one candidate that needs the wave solver (shallow site: ordered replay; phred-0 calls; more than 128 bins; min_af <= 0)
 __device__ __forceinline__ void bv_f_job_hard(const BvP1ShortArgs &a, BvFusedShared &sh, BvFusedSolver &v, uint32_t B0, uint32_t site, int lane) {
@@ -1402,7 +1420,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         dbg_[7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
         if (blockIdx.x == 0) a.counters[BV_CTR_WORDS + 5150] = 4u;  // whose stamps these are
 #ifdef BV_PHASE_DEBUG
-        if (blockIdx.x == 0) for (int i = 0; i < 48; ++i) a.counters[BV_CTR_WORDS + 4200 + i] = 0u;
+        if (blockIdx.x == 0) for (int i = 0; i < 60; ++i) a.counters[BV_CTR_WORDS + 4200 + i] = 0u;
 #endif
     }
 #endif
