@@ -18,7 +18,8 @@
 //   waves 8-11 (solve)   take the candidates from two queues in LDS (three or four active bases first), four sites per
 //                        wave on 16-lane groups (bv_solver16.h), and finish the non-candidate sites one lane per site in
 //                        blocks of 64 as soon as every streaming wave has passed them.  A variant site goes into a third
-//                        queue with what its rank sums need (class table, REF / ALT depths).
+//                        queue with what its rank sums need (class table, REF / ALT depths) -- between the two phases of
+//                        its solve: the LRT decides the alleles, QUAL and the strand-bias tests then run beside the site's row.
 //   pass-2 rows          (FUSE2: rank planes given) a streaming wave past its pass-1 rows takes variant sites from that queue
 //                        and streams calls + mapq + ranks through the same ring (again four 1 KiB pieces per slot: the
 //                        counted waits are unchanged), tallied as bv_pass2_dma_kernel tallies them; the solvers' last jobs
