@@ -1155,14 +1155,17 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                 x[4] = bv_p2d_xm<0>(c1, w1.y); x[5] = bv_p2d_xm<1>(c1, w1.y); x[6] = bv_p2d_xm<2>(c1, w1.y); x[7] = bv_p2d_xm<3>(c1, w1.y);
                 x[8] = bv_p2d_xm<0>(c2, w1.z); x[9] = bv_p2d_xm<1>(c2, w1.z); x[10] = bv_p2d_xm<2>(c2, w1.z); x[11] = bv_p2d_xm<3>(c2, w1.z);
                 x[12] = bv_p2d_xm<0>(c3, w1.w); x[13] = bv_p2d_xm<1>(c3, w1.w); x[14] = bv_p2d_xm<2>(c3, w1.w); x[15] = bv_p2d_xm<3>(c3, w1.w);
-                // (a deep row -- an eighth of its cells are REF / ALT reads --: the dominant mapq's lanes are counted, not added one by one)
-                if (((c_y & 0xFFFFu) + (c_y >> 16)) * 8u >= a.n_samples && !(a.flags & BV_FLAG_NO_DOM)) bv_lds_add16_dom<2>(x, hist, one, 0x200u, dom);
-                else bv_lds_add16<2>(x, hist, one, 0x200u);
-                x[0] = bv_p2d_xr<0, 0>(c0, w2.x); x[1] = bv_p2d_xr<1, 1>(c0, w2.x); x[2] = bv_p2d_xr<2, 0>(c0, w2.y); x[3] = bv_p2d_xr<3, 1>(c0, w2.y);
-                x[4] = bv_p2d_xr<0, 0>(c1, w2.z); x[5] = bv_p2d_xr<1, 1>(c1, w2.z); x[6] = bv_p2d_xr<2, 0>(c1, w2.w); x[7] = bv_p2d_xr<3, 1>(c1, w2.w);
-                x[8] = bv_p2d_xr<0, 0>(c2, w3.x); x[9] = bv_p2d_xr<1, 1>(c2, w3.x); x[10] = bv_p2d_xr<2, 0>(c2, w3.y); x[11] = bv_p2d_xr<3, 1>(c2, w3.y);
-                x[12] = bv_p2d_xr<0, 0>(c3, w3.z); x[13] = bv_p2d_xr<1, 1>(c3, w3.z); x[14] = bv_p2d_xr<2, 0>(c3, w3.w); x[15] = bv_p2d_xr<3, 1>(c3, w3.w);
-                bv_lds_add16<2>(x, hist + 512, one, 0x200u);
+                uint32_t y[16];
+                y[0] = bv_p2d_xr<0, 0>(c0, w2.x); y[1] = bv_p2d_xr<1, 1>(c0, w2.x); y[2] = bv_p2d_xr<2, 0>(c0, w2.y); y[3] = bv_p2d_xr<3, 1>(c0, w2.y);
+                y[4] = bv_p2d_xr<0, 0>(c1, w2.z); y[5] = bv_p2d_xr<1, 1>(c1, w2.z); y[6] = bv_p2d_xr<2, 0>(c1, w2.w); y[7] = bv_p2d_xr<3, 1>(c1, w2.w);
+                y[8] = bv_p2d_xr<0, 0>(c2, w3.x); y[9] = bv_p2d_xr<1, 1>(c2, w3.x); y[10] = bv_p2d_xr<2, 0>(c2, w3.y); y[11] = bv_p2d_xr<3, 1>(c2, w3.y);
+                y[12] = bv_p2d_xr<0, 0>(c3, w3.z); y[13] = bv_p2d_xr<1, 1>(c3, w3.z); y[14] = bv_p2d_xr<2, 0>(c3, w3.w); y[15] = bv_p2d_xr<3, 1>(c3, w3.w);
+                // (a deep row -- an eighth of its cells are REF / ALT reads --: the dominant mapq's lanes are counted, not added one by
+                // one; every other row: both histograms under ONE predicate -- the class byte is the same in x and y)
+                if (((c_y & 0xFFFFu) + (c_y >> 16)) * 8u >= a.n_samples && !(a.flags & BV_FLAG_NO_DOM)) {
+                    bv_lds_add16_dom<2>(x, hist, one, 0x200u, dom);
+                    bv_lds_add16<2>(y, hist + 512, one, 0x200u);
+                } else bv_lds_add16x2<2>(x, y, hist, hist + 512, one, 0x200u);
                 }
                 BV_PH(4);
             }

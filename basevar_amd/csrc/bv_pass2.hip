@@ -121,13 +121,17 @@ __device__ __forceinline__ uint32_t bv_p2_fast_sweep(const BvPass2Args &a, uint3
                 x[4] = bv_p2d_xm<0>(c1, vmq.y); x[5] = bv_p2d_xm<1>(c1, vmq.y); x[6] = bv_p2d_xm<2>(c1, vmq.y); x[7] = bv_p2d_xm<3>(c1, vmq.y);
                 x[8] = bv_p2d_xm<0>(c2, vmq.z); x[9] = bv_p2d_xm<1>(c2, vmq.z); x[10] = bv_p2d_xm<2>(c2, vmq.z); x[11] = bv_p2d_xm<3>(c2, vmq.z);
                 x[12] = bv_p2d_xm<0>(c3, vmq.w); x[13] = bv_p2d_xm<1>(c3, vmq.w); x[14] = bv_p2d_xm<2>(c3, vmq.w); x[15] = bv_p2d_xm<3>(c3, vmq.w);
-                if (DOM) bv_lds_add16_dom<2>(x, hm, one, 0x200u, dom);
-                else bv_lds_add16<2>(x, hm, one, 0x200u);
-                x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
-                x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
-                x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
-                x[12] = bv_p2d_xr<0, 0>(c3, r1.z); x[13] = bv_p2d_xr<1, 1>(c3, r1.z); x[14] = bv_p2d_xr<2, 0>(c3, r1.w); x[15] = bv_p2d_xr<3, 1>(c3, r1.w);
-                bv_lds_add16<2>(x, hr, one, 0x200u);
+                uint32_t y[16];
+                y[0] = bv_p2d_xr<0, 0>(c0, r0.x); y[1] = bv_p2d_xr<1, 1>(c0, r0.x); y[2] = bv_p2d_xr<2, 0>(c0, r0.y); y[3] = bv_p2d_xr<3, 1>(c0, r0.y);
+                y[4] = bv_p2d_xr<0, 0>(c1, r0.z); y[5] = bv_p2d_xr<1, 1>(c1, r0.z); y[6] = bv_p2d_xr<2, 0>(c1, r0.w); y[7] = bv_p2d_xr<3, 1>(c1, r0.w);
+                y[8] = bv_p2d_xr<0, 0>(c2, r1.x); y[9] = bv_p2d_xr<1, 1>(c2, r1.x); y[10] = bv_p2d_xr<2, 0>(c2, r1.y); y[11] = bv_p2d_xr<3, 1>(c2, r1.y);
+                y[12] = bv_p2d_xr<0, 0>(c3, r1.z); y[13] = bv_p2d_xr<1, 1>(c3, r1.z); y[14] = bv_p2d_xr<2, 0>(c3, r1.w); y[15] = bv_p2d_xr<3, 1>(c3, r1.w);
+                // (both histograms under one predicate -- the class byte is the same in x and y -- unless the row is deep and its mapq
+                // tally counts the dominant value)
+                if (DOM) {
+                    bv_lds_add16_dom<2>(x, hm, one, 0x200u, dom);
+                    bv_lds_add16<2>(y, hr, one, 0x200u);
+                } else bv_lds_add16x2<2>(x, y, hm, hr, one, 0x200u);
             }
             if (GROUPS) {
                 // the group tally of bv_p2g_stream_kernel: byte = group << 2 | base, bit 7 for "no call" / "no group"; X = byte << 8 |
@@ -731,13 +735,15 @@ __global__ __launch_bounds__(BV_WAVE *BV_P2D_WAVES) void bv_pass2_dma_kernel(BvP
             x[4] = bv_p2d_xm<0>(c1, vm.y); x[5] = bv_p2d_xm<1>(c1, vm.y); x[6] = bv_p2d_xm<2>(c1, vm.y); x[7] = bv_p2d_xm<3>(c1, vm.y);
             x[8] = bv_p2d_xm<0>(c2, vm.z); x[9] = bv_p2d_xm<1>(c2, vm.z); x[10] = bv_p2d_xm<2>(c2, vm.z); x[11] = bv_p2d_xm<3>(c2, vm.z);
             x[12] = bv_p2d_xm<0>(c3, vm.w); x[13] = bv_p2d_xm<1>(c3, vm.w); x[14] = bv_p2d_xm<2>(c3, vm.w); x[15] = bv_p2d_xm<3>(c3, vm.w);
-            if (deep) bv_lds_add16_dom<2>(x, h, one, 0x200u, dom);  // (a deep row: the dominant mapq's lanes are counted, not added one by one)
-            else bv_lds_add16<2>(x, h, one, 0x200u);
-            x[0] = bv_p2d_xr<0, 0>(c0, r0.x); x[1] = bv_p2d_xr<1, 1>(c0, r0.x); x[2] = bv_p2d_xr<2, 0>(c0, r0.y); x[3] = bv_p2d_xr<3, 1>(c0, r0.y);
-            x[4] = bv_p2d_xr<0, 0>(c1, r0.z); x[5] = bv_p2d_xr<1, 1>(c1, r0.z); x[6] = bv_p2d_xr<2, 0>(c1, r0.w); x[7] = bv_p2d_xr<3, 1>(c1, r0.w);
-            x[8] = bv_p2d_xr<0, 0>(c2, r1.x); x[9] = bv_p2d_xr<1, 1>(c2, r1.x); x[10] = bv_p2d_xr<2, 0>(c2, r1.y); x[11] = bv_p2d_xr<3, 1>(c2, r1.y);
-            x[12] = bv_p2d_xr<0, 0>(c3, r1.z); x[13] = bv_p2d_xr<1, 1>(c3, r1.z); x[14] = bv_p2d_xr<2, 0>(c3, r1.w); x[15] = bv_p2d_xr<3, 1>(c3, r1.w);
-            bv_lds_add16<2>(x, h + 512, one, 0x200u);
+            uint32_t y[16];
+            y[0] = bv_p2d_xr<0, 0>(c0, r0.x); y[1] = bv_p2d_xr<1, 1>(c0, r0.x); y[2] = bv_p2d_xr<2, 0>(c0, r0.y); y[3] = bv_p2d_xr<3, 1>(c0, r0.y);
+            y[4] = bv_p2d_xr<0, 0>(c1, r0.z); y[5] = bv_p2d_xr<1, 1>(c1, r0.z); y[6] = bv_p2d_xr<2, 0>(c1, r0.w); y[7] = bv_p2d_xr<3, 1>(c1, r0.w);
+            y[8] = bv_p2d_xr<0, 0>(c2, r1.x); y[9] = bv_p2d_xr<1, 1>(c2, r1.x); y[10] = bv_p2d_xr<2, 0>(c2, r1.y); y[11] = bv_p2d_xr<3, 1>(c2, r1.y);
+            y[12] = bv_p2d_xr<0, 0>(c3, r1.z); y[13] = bv_p2d_xr<1, 1>(c3, r1.z); y[14] = bv_p2d_xr<2, 0>(c3, r1.w); y[15] = bv_p2d_xr<3, 1>(c3, r1.w);
+            if (deep) {  // (a deep row: the dominant mapq's lanes are counted, not added one by one)
+                bv_lds_add16_dom<2>(x, h, one, 0x200u, dom);
+                bv_lds_add16<2>(y, h + 512, one, 0x200u);
+            } else bv_lds_add16x2<2>(x, y, h, h + 512, one, 0x200u);  // (both histograms under one predicate: the class byte is the same in x and y)
         }
         bv_lrt_sync<0>();
         uint32_t *hm = h, *hr = h + 512;

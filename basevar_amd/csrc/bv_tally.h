@@ -68,6 +68,61 @@ __device__ __forceinline__ void bv_lds_add16(const uint32_t x[16], uint32_t *his
 }
 
 
+// Two tallies under ONE predicate: cell j adds to hist_a at x[j] and to hist_b at y[j] when x[j] < lim.  For pairs whose predicates are
+// the same cell by cell -- the mapq and the read-position-rank histograms of pass 2: both X = class << 8 | value with the same class
+// byte, "< 0x200" <=> the cell is a REF or an ALT read -- : 16 v_cmp and 16 exec writes per 16 cells instead of 32 and 32 (the
+// variant rows' tally is issue-bound: ~124 VALU + 40 SALU + 32 ds_add per 1,024 cells and wave).
+template <int SH>
+__device__ __forceinline__ void bv_lds_add16x2(const uint32_t x[16], const uint32_t y[16], uint32_t *hist_a, uint32_t *hist_b, uint32_t one, uint32_t lim) {
+    const uint32_t abase = (uint32_t)(uintptr_t)(bv_lds_u32 *)hist_a, bbase = (uint32_t)(uintptr_t)(bv_lds_u32 *)hist_b;
+    uint32_t ad[16], bd[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        ad[j] = abase + (x[j] << SH);
+        bd[j] = bbase + (y[j] << SH);
+    }
+    unsigned long long m[16], sv;
+    asm volatile(
+        "v_cmp_gt_u32_e64 %[m0], %[lim], %[x0]\n\t"
+        "v_cmp_gt_u32_e64 %[m1], %[lim], %[x1]\n\t"
+        "v_cmp_gt_u32_e64 %[m2], %[lim], %[x2]\n\t"
+        "v_cmp_gt_u32_e64 %[m3], %[lim], %[x3]\n\t"
+        "v_cmp_gt_u32_e64 %[m4], %[lim], %[x4]\n\t"
+        "v_cmp_gt_u32_e64 %[m5], %[lim], %[x5]\n\t"
+        "v_cmp_gt_u32_e64 %[m6], %[lim], %[x6]\n\t"
+        "v_cmp_gt_u32_e64 %[m7], %[lim], %[x7]\n\t"
+        "v_cmp_gt_u32_e64 %[m8], %[lim], %[x8]\n\t"
+        "v_cmp_gt_u32_e64 %[m9], %[lim], %[x9]\n\t"
+        "v_cmp_gt_u32_e64 %[m10], %[lim], %[x10]\n\t"
+        "v_cmp_gt_u32_e64 %[m11], %[lim], %[x11]\n\t"
+        "v_cmp_gt_u32_e64 %[m12], %[lim], %[x12]\n\t"
+        "v_cmp_gt_u32_e64 %[m13], %[lim], %[x13]\n\t"
+        "v_cmp_gt_u32_e64 %[m14], %[lim], %[x14]\n\t"
+        "v_cmp_gt_u32_e64 %[m15], %[lim], %[x15]\n\t"
+        "s_mov_b64 %[sv], exec\n\t"
+        "s_and_b64 exec, %[sv], %[m0]\n\tds_add_u32 %[a0], %[one]\n\tds_add_u32 %[b0], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m1]\n\tds_add_u32 %[a1], %[one]\n\tds_add_u32 %[b1], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m2]\n\tds_add_u32 %[a2], %[one]\n\tds_add_u32 %[b2], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m3]\n\tds_add_u32 %[a3], %[one]\n\tds_add_u32 %[b3], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m4]\n\tds_add_u32 %[a4], %[one]\n\tds_add_u32 %[b4], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m5]\n\tds_add_u32 %[a5], %[one]\n\tds_add_u32 %[b5], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m6]\n\tds_add_u32 %[a6], %[one]\n\tds_add_u32 %[b6], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m7]\n\tds_add_u32 %[a7], %[one]\n\tds_add_u32 %[b7], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m8]\n\tds_add_u32 %[a8], %[one]\n\tds_add_u32 %[b8], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m9]\n\tds_add_u32 %[a9], %[one]\n\tds_add_u32 %[b9], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m10]\n\tds_add_u32 %[a10], %[one]\n\tds_add_u32 %[b10], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m11]\n\tds_add_u32 %[a11], %[one]\n\tds_add_u32 %[b11], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m12]\n\tds_add_u32 %[a12], %[one]\n\tds_add_u32 %[b12], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m13]\n\tds_add_u32 %[a13], %[one]\n\tds_add_u32 %[b13], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m14]\n\tds_add_u32 %[a14], %[one]\n\tds_add_u32 %[b14], %[one]\n\t"
+        "s_and_b64 exec, %[sv], %[m15]\n\tds_add_u32 %[a15], %[one]\n\tds_add_u32 %[b15], %[one]\n\t"
+        "s_mov_b64 exec, %[sv]"
+        : [m0] "=&s"(m[0]), [m1] "=&s"(m[1]), [m2] "=&s"(m[2]), [m3] "=&s"(m[3]), [m4] "=&s"(m[4]), [m5] "=&s"(m[5]), [m6] "=&s"(m[6]), [m7] "=&s"(m[7]), [m8] "=&s"(m[8]), [m9] "=&s"(m[9]), [m10] "=&s"(m[10]), [m11] "=&s"(m[11]), [m12] "=&s"(m[12]), [m13] "=&s"(m[13]), [m14] "=&s"(m[14]), [m15] "=&s"(m[15]), [sv] "=&s"(sv)
+        : [x0] "v"(x[0]), [a0] "v"(ad[0]), [b0] "v"(bd[0]), [x1] "v"(x[1]), [a1] "v"(ad[1]), [b1] "v"(bd[1]), [x2] "v"(x[2]), [a2] "v"(ad[2]), [b2] "v"(bd[2]), [x3] "v"(x[3]), [a3] "v"(ad[3]), [b3] "v"(bd[3]), [x4] "v"(x[4]), [a4] "v"(ad[4]), [b4] "v"(bd[4]), [x5] "v"(x[5]), [a5] "v"(ad[5]), [b5] "v"(bd[5]), [x6] "v"(x[6]), [a6] "v"(ad[6]), [b6] "v"(bd[6]), [x7] "v"(x[7]), [a7] "v"(ad[7]), [b7] "v"(bd[7]), [x8] "v"(x[8]), [a8] "v"(ad[8]), [b8] "v"(bd[8]), [x9] "v"(x[9]), [a9] "v"(ad[9]), [b9] "v"(bd[9]), [x10] "v"(x[10]), [a10] "v"(ad[10]), [b10] "v"(bd[10]), [x11] "v"(x[11]), [a11] "v"(ad[11]), [b11] "v"(bd[11]), [x12] "v"(x[12]), [a12] "v"(ad[12]), [b12] "v"(bd[12]), [x13] "v"(x[13]), [a13] "v"(ad[13]), [b13] "v"(bd[13]), [x14] "v"(x[14]), [a14] "v"(ad[14]), [b14] "v"(bd[14]), [x15] "v"(x[15]), [a15] "v"(ad[15]), [b15] "v"(bd[15]), [one] "v"(one), [lim] "s"(lim)
+        : "memory", "scc");
+}
+
+
 // bv_lds_add16 for tallies with ONE dominant value (the mapq histogram of a deep row: 80 % of a cohort's reads carry the
 // aligner's top mapping quality and most reads of a site are REF reads, so at full coverage ~50 of a wave's 64 lanes add to
 // the same LDS word, and LDS atomics on one address are served one lane at a time -- measured: pass 2 of 100,000-sample
