@@ -711,11 +711,7 @@ static int launch_passes(bv_engine *e, const uint8_t *bs, const uint8_t *q, cons
         e->ring_one_kernel[slot] = false;
     }
     // Rows of at most BV_SHORT_ROW_MAX samples take the short-row forms of pass 1 (bv_pass1_fused.hip; bv_pass1_short.hip)
-#ifdef BV_EXPERIMENT_LONG_KERNEL_ALWAYS  /* experiment: short rows through the long-row kernel (plain loads into registers) */
-    const bool two_kernel = false;
-#else
     const bool two_kernel = n_samples <= BV_SHORT_ROW_MAX;
-#endif
 
     // ---- pass-2 arguments common to every chunk; scratch of the pop-group calls
     BvPass2Args a2;

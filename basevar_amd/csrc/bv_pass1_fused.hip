@@ -100,9 +100,6 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_PH_COUNT(i)
 #define BV_PH_FLUSH(ctr, lane)
 #endif
-#ifndef BV_F_NT
-#define BV_F_NT " nt"   /* cache policy of the rows' LDS-DMA loads (experiments: -DBV_F_NT='""') */
-#endif
 #define BV_F_SLOT_WORDS 1024              /* pass-1 rows: 2 KiB of calls, 2 KiB of phreds; pass-2 rows: 1 KiB of calls, 1 KiB of mapq, 2 KiB of ranks */
 #define BV_F_QCAP 256                     /* entries per candidate queue (ring buffers) */
 #define BV_F_QVCAP 128                    /* entries of the variant queue */
@@ -177,16 +174,16 @@ __device__ __forceinline__ void bv_f_glds4(uint32_t d0, const uint8_t *p0, uint3
         "s_mov_b32 %[keep], m0\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v0], %[p0]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p3]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t)
         : [d0] "s"(d0), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [p3] "s"(p3), [v0] "v"(v0), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3)
@@ -205,17 +202,17 @@ __device__ __forceinline__ void bv_f_glds4_masked(uint32_t d0, const uint8_t *p0
         "s_mov_b64 exec, %[mA]\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v0], %[p0]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
         "s_mov_b64 exec, %[mB]\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p3]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
@@ -235,17 +232,17 @@ __device__ __forceinline__ void bv_f_glds4_tag(uint32_t d0, const uint8_t *p1, u
         "s_mov_b64 exec, 1\n\t"
         "s_mov_b32 m0, %[d0]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p2]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p2] nt\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
         : [d0] "s"(d0), [p1] "s"(p1), [p2] "s"(p2), [v1] "v"(v1), [v2] "v"(v2), [v3] "v"(v3)
@@ -270,19 +267,19 @@ __device__ __forceinline__ void bv_f_glds4_m4(uint32_t d0, const uint8_t *p0, ui
         "s_mov_b32 m0, %[d0]\n\t"
         "s_mov_b64 exec, %[m0_]\n\t"
         "s_add_u32 %[t], %[d0], 0x400\n\t"
-        "global_load_lds_dwordx4 %[v0], %[p0]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v0], %[p0] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_mov_b64 exec, %[m1_]\n\t"
         "s_add_u32 %[t], %[d0], 0x800\n\t"
-        "global_load_lds_dwordx4 %[v1], %[p1]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v1], %[p1] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_mov_b64 exec, %[m2_]\n\t"
         "s_add_u32 %[t], %[d0], 0xc00\n\t"
-        "global_load_lds_dwordx4 %[v2], %[p2]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v2], %[p2] nt\n\t"
         "s_mov_b32 m0, %[t]\n\t"
         "s_mov_b64 exec, %[m3_]\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %[v3], %[p3]" BV_F_NT "\n\t"
+        "global_load_lds_dwordx4 %[v3], %[p3] nt\n\t"
         "s_mov_b64 exec, %[sv]\n\t"
         "s_mov_b32 m0, %[keep]"
         : [keep] "=&s"(keep), [t] "=&s"(t), [sv] "=&s"(sv)
@@ -658,9 +655,6 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
         uint32_t *q = sh.q3;
         n = bv_f_claim(sh.ctl, BV_FC_Q3_TAIL, BV_FC_Q3_HEAD, least, 4u, first, lane);
         if (n == 0u) { q = sh.q2; n = bv_f_claim(sh.ctl, BV_FC_Q2_TAIL, BV_FC_Q2_HEAD, least, 4u, first, lane); }
-#ifdef BV_F_DRAIN_PRIO  /* experiment: the jobs behind the last pass-1 row are the launch's critical path */
-        if (n != 0u && n_done == (uint32_t)BV_F_NS) __builtin_amdgcn_s_setprio(BV_F_DRAIN_PRIO);
-#endif
 #ifdef BV_PHASE_DEBUG
         const uint32_t jt0_ = (uint32_t)__builtin_amdgcn_s_memtime();
 #endif
@@ -679,9 +673,6 @@ __device__ __forceinline__ int bv_f_solver_step(const BvP1ShortArgs &a, BvFusedS
             bv_f_job_hard(a, sh, v, B0, site, lane);
         }
         if (lane == 0) atomicSub(&sh.ctl[BV_FC_BUSY], 1u);
-#ifdef BV_F_DRAIN_PRIO
-        if (n != 0u && n_done == (uint32_t)BV_F_NS) __builtin_amdgcn_s_setprio(0);
-#endif
 #ifdef BV_TEAM_DEBUG  /* when the workgroup's last solver job ended */
         if (n != 0u && lane == 0) atomicMax(&a.counters[BV_CTR_WORDS + (blockIdx.x < 512u ? blockIdx.x : 511u) * 8u + 5u], (uint32_t)__builtin_amdgcn_s_memrealtime());
 #endif
@@ -1109,11 +1100,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     w2.x &= keepA[0]; w2.y &= keepA[1]; w2.z &= keepA[2]; w2.w &= keepA[3];
                     w3.x &= keepB[0]; w3.y &= keepB[1]; w3.z &= keepB[2]; w3.w &= keepB[3];
                 }
-#ifdef BV_F_SKIP_TALLY  /* experiment: how fast the rows stream when nothing is tallied (records are wrong) */
-                asm volatile("" :: "v"(w0.x), "v"(w1.x), "v"(w2.x), "v"(w3.x), "v"(w0.w), "v"(w1.w), "v"(w2.w), "v"(w3.w));
-#else
                 bv_f_tally2(w0, w2, w1, w3, hist, one);
-#endif
                 BV_PH(3);
             } else {
                 // w0: calls; w1: mapq; w2 / w3: ranks 0-7 / 8-15 of the lane's 16 cells.  The tally of bv_pass2_dma_kernel
@@ -1143,10 +1130,6 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     c0 = __builtin_amdgcn_perm(L, L, w0.x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, w0.y) ^ 0x80808080u;
                     c2 = __builtin_amdgcn_perm(L, L, w0.z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, w0.w) ^ 0x80808080u;
                 }
-#ifdef BV_F_SKIP_P2TALLY  /* experiment: the pass-2 rows stream, nothing is tallied (rank sums are wrong) */
-                asm volatile("" :: "v"(c0), "v"(c1), "v"(c2), "v"(c3), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w));
-                if (false)
-#endif
                 {
                 // ranks that do not fit the 256-rank window: remembered, the row is then re-done by the window sweeps
                 hi_acc |= (w2.x | w2.y | w2.z | w2.w | w3.x | w3.y | w3.z | w3.w) & hi_mask;
@@ -1186,12 +1169,6 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             if (lane == 0 && !(st & P1_FIN)) sh.pub[wave] = mark;
         }
 
-#ifdef BV_F_SKIP_EPI  /* experiment (with BV_F_SKIP_TALLY, --flags 1): rows stream, nothing else happens */
-        if (is_p1) {
-            if (lane < 12) reinterpret_cast<uint32_t *>(&a.summ[site])[lane] = 0u;
-            prev_site = site; prev_kind = 1u; wsel = 1u;
-        } else
-#endif
         if (is_p1) {
         // ---- the row's totals (LDS operations of one wave execute in order: the adds above are done)
         uint32_t c[4][2], facc[4], racc[4];
@@ -1357,9 +1334,6 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         }
         }
         // ---- hand the histogram back, zeroed
-#ifdef BV_F_SKIP_EPI
-        if (!is_p1)
-#endif
         {
             uint4 *h4 = reinterpret_cast<uint4 *>(hist);
 #pragma unroll
