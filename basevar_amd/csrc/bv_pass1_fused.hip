@@ -20,9 +20,10 @@
 //                        blocks of 64 as soon as every streaming wave has passed them.  A variant site goes into a third
 //                        queue with what its rank sums need (class table, REF / ALT depths) -- between the two phases of
 //                        its solve: the LRT decides the alleles, QUAL and the strand-bias tests then run beside the site's row.
-//   pass-2 rows          (FUSE2: rank planes given) a streaming wave past its pass-1 rows takes variant sites from that queue
-//                        and streams calls + mapq + ranks through the same ring (again four 1 KiB pieces per slot: the
-//                        counted waits are unchanged), tallied as bv_pass2_dma_kernel tallies them; the solvers' last jobs
+//   pass-2 rows          (FUSE2: rank planes given) a wave past its pass-1 rows takes variant sites from that queue and tallies
+//                        mapq + ranks (+ calls) as bv_pass2_dma_kernel tallies them -- from registers, by plain loads
+//                        (bv_f_p2_rows; the solver waves too, once they are out of jobs), or with BV_FLAG_P2_TAIL_DMA through the
+//                        ring (again four 1 KiB pieces per slot: the counted waits are unchanged).  The solvers' last jobs
 //                        run UNDER these rows, and pass 2 has no launch, fill or drain of its own.
 //   no row to stream     a streaming wave whose ring is idle (waiting for a variant row, or done) solves with the ring as
 //                        scratch; only such waves (12 KiB each) take the candidates that need the wave solver of bv_solver.h
@@ -138,6 +139,7 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_FS_P_DONE 1u                   /* no row will ever come again */
 #define BV_FS_CUR_DONE 8u                 /* the cursor is exhausted */
 #define BV_FS_P1_FIN 16u                  /* the wave's last pass-1 row is published, the wave counted in NDONE */
+#define BV_FS_NO_P2 32u                   /* (in only) this call draws no pass-2 rows: they are tallied from registers by bv_f_p2_rows */
 // kinds of rows in a streaming wave's ring
 #define BV_FK_P1 1u                       /* calls + phreds of a site: the pass-1 tally */
 #define BV_FK_P2 2u                       /* calls + mapq + ranks of a variant site: the two rank sums of pass 2 */
@@ -163,6 +165,7 @@ struct __attribute__((aligned(16))) BvFusedShared {
     uint32_t ctl[16];
 };
 static_assert(sizeof(BvFusedShared) <= 160 * 1024, "one workgroup per CU must fit the LDS");
+static_assert(4 * BV_G16_GRP_WORDS >= BV_S_HWORDS, "a solver wave's group scratch serves as its rank-sum histogram (bv_f_p2_rows)");
 static_assert(BV_F_K < 3 || sizeof(BvFusedRing) == sizeof(uint32_t) * BV_F_K * BV_F_SLOT_WORDS, "the solver scratch must fit the ring");
 
 // ---- LDS-DMA of one slot: four 1 KiB pieces (64 lanes x 16 bytes from p_i + v_i) to d0, d0 + 1 KiB, ..., always four (the
@@ -954,7 +957,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             }
             // (a wave past its pass-1 rows streams what variant rows there are; one that solved first instead measured 168
             // against 175 M sites/s: HBM idles while twelve waves solve)
-            if (FUSE2 && kind == 0u) {
+            if (FUSE2 && kind == 0u && !(st & BV_FS_NO_P2)) {
                 const uint32_t h = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]);
                 if (h != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) && bv_f_lds_cas_wave(qvhead_lds, h, h + 1u) == h) {
                     const uint32_t *e = sh.qv[h & (BV_F_QVCAP - 1u)];
@@ -965,7 +968,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     else kind = BV_FK_P2;
                 }
             }
-            if (FUSE2 && kind == 0u) {
+            if (FUSE2 && kind == 0u && !(st & BV_FS_NO_P2)) {
                 // ... or from the overflow list (rare: more variant sites waiting than the LDS queue takes).  Its entries are in
                 // HBM: one vector load, the ring drains
                 const uint32_t oh = bv_f_lds_read_u(&sh.ctl[BV_FC_OV_HEAD]);
@@ -1367,6 +1370,215 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     return st & (P_DONE | CUR_DONE | P1_FIN);
 }
 
+// ------------------------------------------------------------------------------ pass-2 rows, tallied from REGISTERS
+// Behind the last pass-1 row the launch is ~140 us of the variant sites' rank-sum rows and of the solver's last jobs, and that phase
+// is issue-bound: two streaming waves per SIMD tallying (~170 instructions per 1,024 cells and wave) beside a solver wave that runs
+// out of jobs 70-100 us in.  Here those rows come by plain non-temporal loads, two blocks of 1,024 cells in flight
+// per wave -- no ring, no LDS-DMA: all a wave needs is a 4 KiB histogram -- so the SOLVER waves, out of jobs, tally them too (their
+// group scratch is the histogram): half as many waves again on every SIMD for the launch's last stretch.  Same tally, same epilogue,
+// same records as the ring's pass-2 slots (bv_f_stream_until_idle); BV_FLAG_P2_TAIL_DMA keeps the rows in the ring (A/B, tests).
+// Returns when no variant row can be had right now, or -- candidates first -- when a candidate waits for a solver.
+struct BvP2Blk {
+    bv_u32x4 w0, w1, w2, w3;  // 16 cells per lane: calls (plain layout only), mapq, ranks 0-7, ranks 8-15
+};
+// 16 bytes of a plane, non-temporal, as a GLOBAL load (a generic pointer makes a flat one, which the compiler can only wait for with
+// vmcnt(0) and lgkmcnt(0): no second block in flight under the first one's tally)
+__device__ __forceinline__ bv_u32x4 bv_f_ntload16(const uint8_t *base, uint32_t off) {
+    typedef const __attribute__((address_space(1))) bv_u32x4 *gp;
+    return __builtin_nontemporal_load((gp)(uintptr_t)(base + off));
+}
+__device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t hist_lds_, uint32_t B0_) {
+    const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
+    const uint32_t hist_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)hist_lds_);
+    const uint32_t B0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)B0_);
+    BvFusedShared &sh = *(BvFusedShared *)(__attribute__((address_space(3))) BvFusedShared *)(uintptr_t)sh_lds;
+    uint32_t *hist = (uint32_t *)(__attribute__((address_space(3))) uint32_t *)(uintptr_t)hist_lds;  // [2][256] mapq, [2][256] ranks: zero on entry, zero on return
+    BvP1ShortArgs a;
+    {
+        const uint64_t kp = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)ka_hi_) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)ka_lo_);
+        const __attribute__((address_space(4))) BvP1ShortArgs *ka = (const __attribute__((address_space(4))) BvP1ShortArgs *)(uintptr_t)kp;
+        a.bs = BV_F_GLOBAL(const uint8_t, ka->bs); a.pitch = ka->pitch; a.n_samples = ka->n_samples; a.flags = ka->flags;
+        a.out = BV_F_GLOBAL(bv_site_result, ka->out); a.counters = BV_F_GLOBAL(uint32_t, ka->counters); a.ch = BV_F_GLOBAL(const BvChain, ka->ch);
+        a.mapq = BV_F_GLOBAL(const uint8_t, ka->mapq); a.rpr = BV_F_GLOBAL(const uint16_t, ka->rpr); a.ovf = BV_F_GLOBAL(uint32_t, ka->ovf);
+        a.rpr_tag = ka->rpr_tag;
+    }
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t qvhead_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_QV_HEAD];
+    const uint32_t ovhead_lds = (uint32_t)(uintptr_t)(bv_lds_u32 *)&sh.ctl[BV_FC_OV_HEAD];
+    const uint32_t n_chunks = (a.n_samples + 15u) >> 4;
+    const int tail = (int)(a.n_samples & 15u);
+    const uint32_t n_blk = (n_chunks + 63u) >> 6;
+    const uint32_t last2 = n_chunks - (n_blk - 1u) * 64u;  // chunks of a row's last block: 1 .. 64
+    const bool tag = a.rpr_tag != 0u;
+    const uint32_t hi_mask = bv_rpr_hi_mask(tag ? 1u : 0u);
+    const uint32_t N4 = 0x08080808u;
+    uint32_t one;
+    asm volatile("v_mov_b32 %0, 1" : "=v"(one));
+    BvFusedStash stash;
+    stash.site = 0; stash.n12 = 0; stash.tw_m = 0; stash.tw_r = 0; stash.n = 0;
+    // a row: the variant site's facts (class table, REF / ALT depths, the window sweeps' 2-bit table) and its planes
+    struct Row {
+        uint32_t site, L, n12w, lut;
+        const uint8_t *pb, *pm, *pr, *r_bs, *r_mq;
+        const uint16_t *r_rp;
+    };
+    // a variant site from the queue in LDS, else from the overflow list (as bv_f_stream_until_idle draws them); false: none right now
+    auto pop = [&](Row &r) __attribute__((always_inline)) -> bool {
+#pragma unroll 1
+        for (;;) {
+            const uint32_t h = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]);
+            if (h != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL])) {
+                if (bv_f_lds_cas_wave(qvhead_lds, h, h + 1u) != h) continue;  // (another wave took it: look again)
+                const uint32_t *e = sh.qv[h & (BV_F_QVCAP - 1u)];
+                uint32_t site = BV_F_EMPTY;
+                for (uint32_t spins = 0; (site = bv_f_lds_read_u(&e[0])) == BV_F_EMPTY && spins < BV_F_SPIN_MAX; ++spins) __builtin_amdgcn_s_sleep(4);
+                r.L = bv_f_lds_read_u(&e[1]); r.n12w = bv_f_lds_read_u(&e[2]); r.lut = bv_f_lds_read_u(&e[3]);
+                if (lane == 0) *(bv_lds_vu32 *)&e[0] = BV_F_EMPTY;
+                if (site == BV_F_EMPTY) { if (lane == 0) atomicOr(&a.counters[BV_CTR_TIMEOUT], BV_TMO_TAKE_VARIANT); continue; }  // (timed out: flagged)
+                r.site = site;
+            } else {
+                const uint32_t oh = bv_f_lds_read_u(&sh.ctl[BV_FC_OV_HEAD]);
+                if (oh == bv_f_lds_read_u(&sh.ctl[BV_FC_OV_TAIL])) return false;
+                if (bv_f_lds_cas_wave(ovhead_lds, oh, oh + 1u) != oh) continue;
+                bv_u32x4 e;  // (through the L2: the entry was written by a solver wave of this workgroup)
+                asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(e) : "v"(a.ovf + 4u * (size_t)(B0 + oh)) : "memory");
+                r.site = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x); r.L = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+                r.n12w = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z); r.lut = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+            }
+            r.r_bs = a.bs; r.r_mq = a.mapq; r.r_rp = a.rpr;
+            if (a.ch != nullptr) {
+                const BvChainC ch = bv_chain_const(a.ch);
+                const uint32_t sg = bv_chain_seg(ch, r.site);
+                r.r_bs = ch->bs[sg]; r.r_mq = ch->mapq[sg]; r.r_rp = ch->rpr[sg];
+            }
+            const uint64_t off = (uint64_t)r.site * a.pitch;
+            r.pb = bv_uniform_ptr(r.r_bs + off); r.pm = bv_uniform_ptr(r.r_mq + off);
+            r.pr = bv_uniform_ptr(reinterpret_cast<const uint8_t *>(r.r_rp) + 2u * off);
+            return true;
+        }
+    };
+    // The rows as ONE stream of blocks, a row on an even number of positions (an odd row's last position is read again and not
+    // tallied), even positions in A, odd ones in B: position g of the current row -- or, from g = n_even on, position g - n_even of the
+    // NEXT row, so that a row's first two blocks are in flight under the epilogue of the row before it.  Every load UNCONDITIONAL (a
+    // block past the last row's end is that row's last block again; a lane past the end of a last block reads the block's last
+    // valid chunk -- in bounds, and replaced by cells that count nowhere before the tally looks at it): behind a branch the compiler
+    // waits for everything in flight, in straight-line code it counts.
+    const uint32_t n_even = (n_blk + 1u) & ~1u;
+    Row cur, nxt;
+    bool have_nxt = false;
+    auto load_pos = [&](uint32_t g, BvP2Blk &W) __attribute__((always_inline)) {
+        const bool in_next = g >= n_even && have_nxt;
+        uint32_t b = in_next ? g - n_even : g;
+        b = b < n_blk ? b : n_blk - 1u;
+        const uint8_t *pm = in_next ? nxt.pm : cur.pm, *pr = in_next ? nxt.pr : cur.pr, *pb = in_next ? nxt.pb : cur.pb;
+        const uint32_t ln = (b + 1u == n_blk && (uint32_t)lane >= last2) ? last2 - 1u : (uint32_t)lane;
+        W.w1 = bv_f_ntload16(pm + (size_t)b * 1024u, ln * 16u);
+        W.w2 = bv_f_ntload16(pr + (size_t)b * 2048u, ln * 32u);
+        W.w3 = bv_f_ntload16(pr + (size_t)b * 2048u, ln * 32u + 16u);
+        if (!tag) W.w0 = bv_f_ntload16(pb + (size_t)b * 1024u, ln * 16u);
+        else W.w0 = bv_u32x4{N4, N4, N4, N4};
+    };
+    BvP2Blk A, B;
+    bool have = pop(cur);
+    if (have) {
+        load_pos(0u, A);
+        load_pos(1u, B);
+    }
+#pragma unroll 1
+    while (have) {
+        const uint32_t site = cur.site, L = cur.L, n12w = cur.n12w;
+        const bool deep = ((n12w & 0xFFFFu) + (n12w >> 16)) * 8u >= a.n_samples && !(a.flags & BV_FLAG_NO_DOM);
+        uint32_t hi_acc = 0, dom = BV_DOM_NONE;
+        // the tally of a block, as the ring's pass-2 slots are tallied (bv_f_stream_until_idle)
+        auto tally_blk = [&](uint32_t b, BvP2Blk &W) __attribute__((always_inline)) {
+            const bool lastb = b + 1u == n_blk;
+            if (lastb && (uint32_t)lane >= last2) {  // (not the lane's own cells: see load_pos)
+                W.w0 = bv_u32x4{N4, N4, N4, N4};
+                W.w1 = bv_u32x4{0u, 0u, 0u, 0u};
+                W.w2 = tag ? bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u} : bv_u32x4{0u, 0u, 0u, 0u};
+                W.w3 = W.w2;
+            }
+            uint32_t c0, c1, c2, c3;
+            if (tag) {
+                if (lastb && tail && (uint32_t)lane == last2 - 1u) {
+                    W.w2.x = bv_p2t_mask_tail(W.w2.x, tail); W.w2.y = bv_p2t_mask_tail(W.w2.y, tail - 2);
+                    W.w2.z = bv_p2t_mask_tail(W.w2.z, tail - 4); W.w2.w = bv_p2t_mask_tail(W.w2.w, tail - 6);
+                    W.w3.x = bv_p2t_mask_tail(W.w3.x, tail - 8); W.w3.y = bv_p2t_mask_tail(W.w3.y, tail - 10);
+                    W.w3.z = bv_p2t_mask_tail(W.w3.z, tail - 12); W.w3.w = bv_p2t_mask_tail(W.w3.w, tail - 14);
+                }
+                c0 = bv_p2t_class4(L, W.w2.x, W.w2.y); c1 = bv_p2t_class4(L, W.w2.z, W.w2.w);
+                c2 = bv_p2t_class4(L, W.w3.x, W.w3.y); c3 = bv_p2t_class4(L, W.w3.z, W.w3.w);
+            } else {
+                if (lastb && tail && (uint32_t)lane == last2 - 1u) {
+                    W.w0.x = bv_mask_tail_dword(W.w0.x, tail); W.w0.y = bv_mask_tail_dword(W.w0.y, tail - 4);
+                    W.w0.z = bv_mask_tail_dword(W.w0.z, tail - 8); W.w0.w = bv_mask_tail_dword(W.w0.w, tail - 12);
+                }
+                c0 = __builtin_amdgcn_perm(L, L, W.w0.x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, W.w0.y) ^ 0x80808080u;
+                c2 = __builtin_amdgcn_perm(L, L, W.w0.z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, W.w0.w) ^ 0x80808080u;
+            }
+            // ranks that do not fit the 256-rank window: remembered, the row is then re-done by the window sweeps
+            hi_acc |= (W.w2.x | W.w2.y | W.w2.z | W.w2.w | W.w3.x | W.w3.y | W.w3.z | W.w3.w) & hi_mask;
+            uint32_t x[16], y[16];
+            x[0] = bv_p2d_xm<0>(c0, W.w1.x); x[1] = bv_p2d_xm<1>(c0, W.w1.x); x[2] = bv_p2d_xm<2>(c0, W.w1.x); x[3] = bv_p2d_xm<3>(c0, W.w1.x);
+            x[4] = bv_p2d_xm<0>(c1, W.w1.y); x[5] = bv_p2d_xm<1>(c1, W.w1.y); x[6] = bv_p2d_xm<2>(c1, W.w1.y); x[7] = bv_p2d_xm<3>(c1, W.w1.y);
+            x[8] = bv_p2d_xm<0>(c2, W.w1.z); x[9] = bv_p2d_xm<1>(c2, W.w1.z); x[10] = bv_p2d_xm<2>(c2, W.w1.z); x[11] = bv_p2d_xm<3>(c2, W.w1.z);
+            x[12] = bv_p2d_xm<0>(c3, W.w1.w); x[13] = bv_p2d_xm<1>(c3, W.w1.w); x[14] = bv_p2d_xm<2>(c3, W.w1.w); x[15] = bv_p2d_xm<3>(c3, W.w1.w);
+            y[0] = bv_p2d_xr<0, 0>(c0, W.w2.x); y[1] = bv_p2d_xr<1, 1>(c0, W.w2.x); y[2] = bv_p2d_xr<2, 0>(c0, W.w2.y); y[3] = bv_p2d_xr<3, 1>(c0, W.w2.y);
+            y[4] = bv_p2d_xr<0, 0>(c1, W.w2.z); y[5] = bv_p2d_xr<1, 1>(c1, W.w2.z); y[6] = bv_p2d_xr<2, 0>(c1, W.w2.w); y[7] = bv_p2d_xr<3, 1>(c1, W.w2.w);
+            y[8] = bv_p2d_xr<0, 0>(c2, W.w3.x); y[9] = bv_p2d_xr<1, 1>(c2, W.w3.x); y[10] = bv_p2d_xr<2, 0>(c2, W.w3.y); y[11] = bv_p2d_xr<3, 1>(c2, W.w3.y);
+            y[12] = bv_p2d_xr<0, 0>(c3, W.w3.z); y[13] = bv_p2d_xr<1, 1>(c3, W.w3.z); y[14] = bv_p2d_xr<2, 0>(c3, W.w3.w); y[15] = bv_p2d_xr<3, 1>(c3, W.w3.w);
+            if (deep) {
+                bv_lds_add16_dom<2>(x, hist, one, 0x200u, dom);
+                bv_lds_add16<2>(y, hist + 512, one, 0x200u);
+            } else bv_lds_add16x2<2>(x, y, hist, hist + 512, one, 0x200u);
+        };
+#pragma unroll 1
+        for (uint32_t b = 0; b < n_even; b += 2u) {
+            tally_blk(b, A);
+            if (b + 2u == n_even) {
+                // the row's last pair: the next row is drawn here, its first two blocks are requested below -- unless a candidate waits:
+                // the solver's jobs come first (see the kernel's loop), and the wave leaves behind this row's epilogue
+                const bool cand = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) ||
+                                  bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]);
+                have_nxt = !cand && pop(nxt);
+            }
+            load_pos(b + 2u, A);
+            if (b + 1u < n_blk) tally_blk(b + 1u, B);
+            load_pos(b + 3u, B);
+        }
+        bv_lrt_sync<0>();
+        // ---- the site's two rank sums (as in bv_f_stream_until_idle)
+        const unsigned long long n12 = (unsigned long long)(n12w & 0xFFFFu) + (unsigned long long)(n12w >> 16);
+        if (__ballot(hi_acc != 0u) != 0ull) {
+            bv_f_p2_redo(cur.r_bs, cur.r_mq, cur.r_rp, a.out, a.pitch, a.n_samples, site, cur.lut | (tag ? 0x80000000u : 0u), n12w, hist_lds);
+        } else {
+            uint32_t *hm = hist, *hr = hist + 512;
+            unsigned long long below = 0, twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hm[w * 64 + lane], hm[256 + w * 64 + lane], n12, below, lane);
+            stash.tw_m = ((uint32_t)lane == stash.n) ? twoR : stash.tw_m;
+            below = 0; twoR = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) twoR += bv_ranksum_window(hr[w * 64 + lane], hr[256 + w * 64 + lane], n12, below, lane);
+            stash.tw_r = ((uint32_t)lane == stash.n) ? twoR : stash.tw_r;
+            stash.site = ((uint32_t)lane == stash.n) ? site : stash.site;
+            stash.n12 = ((uint32_t)lane == stash.n) ? n12w : stash.n12;
+            if (++stash.n == 64u) bv_f_stash_flush(a, stash, lane);
+        }
+        {
+            uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+#pragma unroll
+            for (int i = 0; i < BV_S_HWORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + lane] = make_uint4(0, 0, 0, 0);
+        }
+        bv_lrt_sync<0>();
+        have = have_nxt;
+        cur = nxt;
+        have_nxt = false;
+    }
+    if (stash.n != 0u) bv_f_stash_flush(a, stash, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <bool FUSE2>
 __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1ShortArgs a) {
     __shared__ BvFusedShared sh;
@@ -1439,6 +1651,7 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         // tell): until round 5 the function's prologue saved 60 callee-saved VGPRs to scratch memory per call, and waves that
         // polled through it wrote 316 MB per launch of 8,192 sites.  The saves are gone (see the function), the test stays: a
         // call still reads the argument block and sets the ring up.
+        const bool p2_regs = FUSE2 && !(a.flags & BV_FLAG_P2_TAIL_DMA);
         bool go = streaming;
         if (streaming && (sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)) {
             if (!FUSE2) { go = false; streaming = false; }
@@ -1455,12 +1668,43 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         if (go) {
             // (the wave's variant sites since its last flush sit in its ring's LDS: out before rows stream through it again)
             if (v.n_vl) bv_f_flush_vl(a, v, ln);
-            sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
+            // past its pass-1 rows a wave tallies the variant sites' rows from registers (bv_f_p2_rows); until then -- and with
+            // BV_FLAG_P2_TAIL_DMA always -- rows go through the ring
+            if (p2_regs && (sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)) {
+                // Candidates first.  Behind the last pass-1 row the launch is as long as the solver's last jobs (62-74 us each) plus the rows
+                // of the variant sites they find; a candidate that waits for a solver wave to finish its job first adds up to a whole
+                // job to that -- and keeps the solver waves from joining the tally of the rows.
+                const uint32_t least = bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS ? 1u : BV_F_MIN_JOB;
+                const bool cand = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= least ||
+                                  bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= least;
+                if (!cand) bv_f_p2_rows((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)(uintptr_t)(bv_lds_u32 *)sh.hist[wave], B0);
+            } else
+                sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1,
+                                                                                                  sst | (p2_regs ? BV_FS_NO_P2 : 0u)));
             if (sst & BV_FS_P_DONE) streaming = false;
         }
         const int r = bv_f_solver_step(a, sh, v, B0, B1, ln);
         if (streaming) {
             if (r != 1) __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        if (p2_regs && !is_stream && r != 1) {
+            // A solver wave with nothing to solve: once every streaming wave is past its pass-1 rows it tallies variant rows too -- from
+            // registers, with its group scratch as the histogram (zeroed here, and left zero) -- and stays until no row can come any more.
+            if (bv_f_lds_read_u(&sh.ctl[BV_FC_NDONE]) == (uint32_t)BV_F_NS) {
+                if (bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]) ||
+                    bv_f_lds_read_u(&sh.ctl[BV_FC_OV_TAIL]) != bv_f_lds_read_u(&sh.ctl[BV_FC_OV_HEAD])) {
+                    if (v.n_vl) bv_f_flush_vl(a, v, ln);
+                    uint4 *h4 = reinterpret_cast<uint4 *>(v.grp);
+#pragma unroll
+                    for (int i = 0; i < BV_S_HWORDS / 4 / BV_WAVE; ++i) h4[i * BV_WAVE + ln] = make_uint4(0, 0, 0, 0);
+                    bv_lrt_sync<0>();
+                    bv_f_p2_rows((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)(uintptr_t)(bv_lds_u32 *)v.grp, B0);
+                    continue;
+                }
+                if (r == 2 && bv_f_no_row_ever(sh.ctl)) break;
+            }
+            __builtin_amdgcn_s_sleep(8);
             continue;
         }
         if (r == 2) break;

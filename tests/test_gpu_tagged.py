@@ -418,3 +418,27 @@ def test_dense_long_rows_of_binned_qualities_and_one_value(bv, restatement):
         sites = recs[0][idx]; groups = None; n_variant = int(((recs[0][idx]["status"] & 2) != 0).sum())
     check(Got, exp, gexp, margins)
     assert (recs[0]["total_depth"] == n).all()
+
+
+@pytest.mark.parametrize("n,sites,groups,flags", [
+    (10000, 900, 0, 0), (10007, 400, 0, 0), (4097, 300, 0, 0), (5120, 300, 0, 0), (6145, 200, 0, 0), (16384, 150, 0, 0), (16385, 150, 0, 0),
+    (49151, 64, 0, 0), (12000, 400, 9, 0), (12000, 300, 0, 1 << 16), (20011, 300, 0, 2 << 16), (10000, 6000, 0, 4 << 16)],
+    ids=["configs1", "ragged", "shortest", "5120", "6145", "16384", "16385", "longest", "groups9", "one_workgroup", "two_workgroups", "four_workgroups_6000"])
+def test_fused_pass2_rows_in_registers_or_through_the_ring(bv, restatement, n, sites, groups, flags):
+    """Behind their pass-1 rows the waves of the fused short-row kernel -- the streaming waves and, out of jobs, the solver waves --
+    tally the variant sites' rank-sum rows from registers (bv_f_p2_rows, round 6: plain loads, no ring); BV_FLAG_P2_TAIL_DMA keeps
+    those rows in the LDS-DMA ring.  Records: byte-identical, in both rank layouts, at every block boundary of a row (1,024 cells per
+    block, partial last blocks and chunks), with pop-groups, with every queue overflowing (one workgroup), with thousands of sites
+    per workgroup -- and the oracle's.  Long reads (ranks >= 256: the row is re-done by the window sweeps) too."""
+    slab = make_slab(sites, n, seed=977 + n, coverage=0.08 if n > 6000 else 0.3, class_af=[(0.0, 0.0), (0.05, 0.0), (0.4, 0.0), (0.2, 0.1)],
+                     ref_n_frac=0.02, n_groups=groups)
+    slab["rpr"][3::7, :] = np.minimum(slab["rpr"][3::7, :].astype(np.int64) * 9, 8000).astype(slab["rpr"].dtype)   # every seventh row: long reads
+    maf = bv.min_af(n)
+    plain, tagged = both(bv, slab, maf, flags)
+    same(plain, tagged)
+    ring_plain, ring_tagged = both(bv, slab, maf, flags | 0x2000000)
+    same(plain, ring_plain)
+    same(tagged, ring_tagged)
+    exp, gexp, margins = oracle_run(restatement, slab, maf)
+    check(tagged, exp, gexp, margins)
+    assert plain.n_variant >= sites // 4
