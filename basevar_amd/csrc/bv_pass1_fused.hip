@@ -1376,10 +1376,11 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
 // out of jobs 70-100 us in.  Here those rows come by plain non-temporal loads, two blocks of 1,024 cells in flight
 // per wave -- no ring, no LDS-DMA: all a wave needs is a 4 KiB histogram -- so the SOLVER waves, out of jobs, tally them too (their
 // group scratch is the histogram): half as many waves again on every SIMD for the launch's last stretch.  Same tally, same epilogue,
-// same records as the ring's pass-2 slots (bv_f_stream_until_idle); BV_FLAG_P2_TAIL_DMA keeps the rows in the ring (A/B, tests).
+// same records as the ring's pass-2 slots (bv_f_stream_until_idle).  For the tagged rank layout (BV_SLAB_RPR_TAGGED: mapq + ranks,
+// the class of a cell from its rank word); rows of the plain layout, and every row with BV_FLAG_P2_TAIL_DMA (A/B, tests), keep the ring.
 // Returns when no variant row can be had right now, or -- candidates first -- when a candidate waits for a solver.
 struct BvP2Blk {
-    bv_u32x4 w0, w1, w2, w3;  // 16 cells per lane: calls (plain layout only), mapq, ranks 0-7, ranks 8-15
+    bv_u32x4 w1, w2, w3;  // 16 cells per lane: mapq, ranks 0-7, ranks 8-15 (tagged: no call plane)
 };
 // 16 bytes of a plane, non-temporal, as a GLOBAL load (a generic pointer makes a flat one, which the compiler can only wait for with
 // vmcnt(0) and lgkmcnt(0): no second block in flight under the first one's tally)
@@ -1409,9 +1410,7 @@ __device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t
     const int tail = (int)(a.n_samples & 15u);
     const uint32_t n_blk = (n_chunks + 63u) >> 6;
     const uint32_t last2 = n_chunks - (n_blk - 1u) * 64u;  // chunks of a row's last block: 1 .. 64
-    const bool tag = a.rpr_tag != 0u;
-    const uint32_t hi_mask = bv_rpr_hi_mask(tag ? 1u : 0u);
-    const uint32_t N4 = 0x08080808u;
+    const uint32_t hi_mask = bv_rpr_hi_mask(1u);
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
     BvFusedStash stash;
@@ -1419,7 +1418,7 @@ __device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t
     // a row: the variant site's facts (class table, REF / ALT depths, the window sweeps' 2-bit table) and its planes
     struct Row {
         uint32_t site, L, n12w, lut;
-        const uint8_t *pb, *pm, *pr, *r_bs, *r_mq;
+        const uint8_t *pm, *pr, *r_bs, *r_mq;
         const uint16_t *r_rp;
     };
     // a variant site from the queue in LDS, else from the overflow list (as bv_f_stream_until_idle draws them); false: none right now
@@ -1452,7 +1451,7 @@ __device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t
                 r.r_bs = ch->bs[sg]; r.r_mq = ch->mapq[sg]; r.r_rp = ch->rpr[sg];
             }
             const uint64_t off = (uint64_t)r.site * a.pitch;
-            r.pb = bv_uniform_ptr(r.r_bs + off); r.pm = bv_uniform_ptr(r.r_mq + off);
+            r.pm = bv_uniform_ptr(r.r_mq + off);
             r.pr = bv_uniform_ptr(reinterpret_cast<const uint8_t *>(r.r_rp) + 2u * off);
             return true;
         }
@@ -1470,13 +1469,11 @@ __device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t
         const bool in_next = g >= n_even && have_nxt;
         uint32_t b = in_next ? g - n_even : g;
         b = b < n_blk ? b : n_blk - 1u;
-        const uint8_t *pm = in_next ? nxt.pm : cur.pm, *pr = in_next ? nxt.pr : cur.pr, *pb = in_next ? nxt.pb : cur.pb;
+        const uint8_t *pm = in_next ? nxt.pm : cur.pm, *pr = in_next ? nxt.pr : cur.pr;
         const uint32_t ln = (b + 1u == n_blk && (uint32_t)lane >= last2) ? last2 - 1u : (uint32_t)lane;
         W.w1 = bv_f_ntload16(pm + (size_t)b * 1024u, ln * 16u);
         W.w2 = bv_f_ntload16(pr + (size_t)b * 2048u, ln * 32u);
         W.w3 = bv_f_ntload16(pr + (size_t)b * 2048u, ln * 32u + 16u);
-        if (!tag) W.w0 = bv_f_ntload16(pb + (size_t)b * 1024u, ln * 16u);
-        else W.w0 = bv_u32x4{N4, N4, N4, N4};
     };
     BvP2Blk A, B;
     bool have = pop(cur);
@@ -1493,29 +1490,18 @@ __device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t
         auto tally_blk = [&](uint32_t b, BvP2Blk &W) __attribute__((always_inline)) {
             const bool lastb = b + 1u == n_blk;
             if (lastb && (uint32_t)lane >= last2) {  // (not the lane's own cells: see load_pos)
-                W.w0 = bv_u32x4{N4, N4, N4, N4};
                 W.w1 = bv_u32x4{0u, 0u, 0u, 0u};
-                W.w2 = tag ? bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u} : bv_u32x4{0u, 0u, 0u, 0u};
+                W.w2 = bv_u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
                 W.w3 = W.w2;
             }
-            uint32_t c0, c1, c2, c3;
-            if (tag) {
-                if (lastb && tail && (uint32_t)lane == last2 - 1u) {
-                    W.w2.x = bv_p2t_mask_tail(W.w2.x, tail); W.w2.y = bv_p2t_mask_tail(W.w2.y, tail - 2);
-                    W.w2.z = bv_p2t_mask_tail(W.w2.z, tail - 4); W.w2.w = bv_p2t_mask_tail(W.w2.w, tail - 6);
-                    W.w3.x = bv_p2t_mask_tail(W.w3.x, tail - 8); W.w3.y = bv_p2t_mask_tail(W.w3.y, tail - 10);
-                    W.w3.z = bv_p2t_mask_tail(W.w3.z, tail - 12); W.w3.w = bv_p2t_mask_tail(W.w3.w, tail - 14);
-                }
-                c0 = bv_p2t_class4(L, W.w2.x, W.w2.y); c1 = bv_p2t_class4(L, W.w2.z, W.w2.w);
-                c2 = bv_p2t_class4(L, W.w3.x, W.w3.y); c3 = bv_p2t_class4(L, W.w3.z, W.w3.w);
-            } else {
-                if (lastb && tail && (uint32_t)lane == last2 - 1u) {
-                    W.w0.x = bv_mask_tail_dword(W.w0.x, tail); W.w0.y = bv_mask_tail_dword(W.w0.y, tail - 4);
-                    W.w0.z = bv_mask_tail_dword(W.w0.z, tail - 8); W.w0.w = bv_mask_tail_dword(W.w0.w, tail - 12);
-                }
-                c0 = __builtin_amdgcn_perm(L, L, W.w0.x) ^ 0x80808080u; c1 = __builtin_amdgcn_perm(L, L, W.w0.y) ^ 0x80808080u;
-                c2 = __builtin_amdgcn_perm(L, L, W.w0.z) ^ 0x80808080u; c3 = __builtin_amdgcn_perm(L, L, W.w0.w) ^ 0x80808080u;
+            if (lastb && tail && (uint32_t)lane == last2 - 1u) {
+                W.w2.x = bv_p2t_mask_tail(W.w2.x, tail); W.w2.y = bv_p2t_mask_tail(W.w2.y, tail - 2);
+                W.w2.z = bv_p2t_mask_tail(W.w2.z, tail - 4); W.w2.w = bv_p2t_mask_tail(W.w2.w, tail - 6);
+                W.w3.x = bv_p2t_mask_tail(W.w3.x, tail - 8); W.w3.y = bv_p2t_mask_tail(W.w3.y, tail - 10);
+                W.w3.z = bv_p2t_mask_tail(W.w3.z, tail - 12); W.w3.w = bv_p2t_mask_tail(W.w3.w, tail - 14);
             }
+            const uint32_t c0 = bv_p2t_class4(L, W.w2.x, W.w2.y), c1 = bv_p2t_class4(L, W.w2.z, W.w2.w);
+            const uint32_t c2 = bv_p2t_class4(L, W.w3.x, W.w3.y), c3 = bv_p2t_class4(L, W.w3.z, W.w3.w);
             // ranks that do not fit the 256-rank window: remembered, the row is then re-done by the window sweeps
             hi_acc |= (W.w2.x | W.w2.y | W.w2.z | W.w2.w | W.w3.x | W.w3.y | W.w3.z | W.w3.w) & hi_mask;
             uint32_t x[16], y[16];
@@ -1550,7 +1536,7 @@ __device__ __attribute__((noinline, not_tail_called)) void bv_f_p2_rows(uint32_t
         // ---- the site's two rank sums (as in bv_f_stream_until_idle)
         const unsigned long long n12 = (unsigned long long)(n12w & 0xFFFFu) + (unsigned long long)(n12w >> 16);
         if (__ballot(hi_acc != 0u) != 0ull) {
-            bv_f_p2_redo(cur.r_bs, cur.r_mq, cur.r_rp, a.out, a.pitch, a.n_samples, site, cur.lut | (tag ? 0x80000000u : 0u), n12w, hist_lds);
+            bv_f_p2_redo(cur.r_bs, cur.r_mq, cur.r_rp, a.out, a.pitch, a.n_samples, site, cur.lut | 0x80000000u, n12w, hist_lds);
         } else {
             uint32_t *hm = hist, *hr = hist + 512;
             unsigned long long below = 0, twoR = 0;
@@ -1651,7 +1637,8 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
         // tell): until round 5 the function's prologue saved 60 callee-saved VGPRs to scratch memory per call, and waves that
         // polled through it wrote 316 MB per launch of 8,192 sites.  The saves are gone (see the function), the test stays: a
         // call still reads the argument block and sets the ring up.
-        const bool p2_regs = FUSE2 && !(a.flags & BV_FLAG_P2_TAIL_DMA);
+        // (the tagged rank layout only: with the call plane to read as well the plain loads lose to the ring -- 0.533 against 0.519 ms)
+        const bool p2_regs = FUSE2 && a.rpr_tag != 0u && !(a.flags & BV_FLAG_P2_TAIL_DMA);
         bool go = streaming;
         if (streaming && (sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)) {
             if (!FUSE2) { go = false; streaming = false; }

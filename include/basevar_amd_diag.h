@@ -26,7 +26,8 @@ extern "C" {
 #define BV_FLAG_PASS2_SWEEP 0x20u /* diagnostic: short rows take the plain-load pass-2 kernels (not the LDS-DMA one) */
 #define BV_FLAG_NO_DOM 0x1000000u /* A-B runs / tests: deep rows keep the plain LDS adds in the rank-sum tallies (no dominant-value count, bv_lds_add16_dom) */
 #define BV_FLAG_P2_TAIL_DMA 0x2000000u /* A-B runs / tests: the fused short-row kernel streams the variant sites' rank-sum rows through its LDS-DMA
-                                     rings (rounds 4-6), not into registers (csrc/bv_pass1_fused.hip: bv_f_p2_rows).  Records do not depend on it. */
+                                     rings (rounds 4-6; what slabs with plain ranks always take), not into registers (csrc/bv_pass1_fused.hip: bv_f_p2_rows).
+                                     Records do not depend on it. */
 #define BV_FLAG_WAVE_SOLVER 0x10u /* diagnostic: short-row candidates and pop-group calls all take the one-per-wave solver (none the 16-lane one) */
 #define BV_FLAG_LONG_ROW_FORM(n) (((uint32_t)(n) & 0xFu) << 8) /* tests: 2 = rows of more than 49,152 samples take the long-row kernel
                                      WITHOUT the team helpers whatever the launch size (default: launches of up to 65,536 sites spread

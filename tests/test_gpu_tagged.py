@@ -426,10 +426,11 @@ def test_dense_long_rows_of_binned_qualities_and_one_value(bv, restatement):
     ids=["configs1", "ragged", "shortest", "5120", "6145", "16384", "16385", "longest", "groups9", "one_workgroup", "two_workgroups", "four_workgroups_6000"])
 def test_fused_pass2_rows_in_registers_or_through_the_ring(bv, restatement, n, sites, groups, flags):
     """Behind their pass-1 rows the waves of the fused short-row kernel -- the streaming waves and, out of jobs, the solver waves --
-    tally the variant sites' rank-sum rows from registers (bv_f_p2_rows, round 6: plain loads, no ring); BV_FLAG_P2_TAIL_DMA keeps
-    those rows in the LDS-DMA ring.  Records: byte-identical, in both rank layouts, at every block boundary of a row (1,024 cells per
-    block, partial last blocks and chunks), with pop-groups, with every queue overflowing (one workgroup), with thousands of sites
-    per workgroup -- and the oracle's.  Long reads (ranks >= 256: the row is re-done by the window sweeps) too."""
+    tally the variant sites' rank-sum rows of a TAGGED slab from registers (bv_f_p2_rows, round 6: plain loads, no ring);
+    BV_FLAG_P2_TAIL_DMA keeps those rows in the LDS-DMA ring, where the plain layout's rows always are.  Records: byte-identical
+    between the two paths and the two rank layouts, at every block boundary of a row (1,024 cells per block, partial last blocks
+    and chunks), with pop-groups, with every queue overflowing (one workgroup), with thousands of sites per workgroup -- and the
+    oracle's.  Long reads (ranks >= 256: the row is re-done by the window sweeps) too."""
     slab = make_slab(sites, n, seed=977 + n, coverage=0.08 if n > 6000 else 0.3, class_af=[(0.0, 0.0), (0.05, 0.0), (0.4, 0.0), (0.2, 0.1)],
                      ref_n_frac=0.02, n_groups=groups)
     slab["rpr"][3::7, :] = np.minimum(slab["rpr"][3::7, :].astype(np.int64) * 9, 8000).astype(slab["rpr"].dtype)   # every seventh row: long reads
