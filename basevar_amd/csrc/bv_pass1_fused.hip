@@ -139,7 +139,6 @@ static_assert(BV_F_NV >= 1, "the streaming waves wait on a full queue: somebody 
 #define BV_FS_P_DONE 1u                   /* no row will ever come again */
 #define BV_FS_CUR_DONE 8u                 /* the cursor is exhausted */
 #define BV_FS_P1_FIN 16u                  /* the wave's last pass-1 row is published, the wave counted in NDONE */
-#define BV_FS_NO_P2 32u                   /* (in only) this call draws no pass-2 rows: they are tallied from registers by bv_f_p2_rows */
 // kinds of rows in a streaming wave's ring
 #define BV_FK_P1 1u                       /* calls + phreds of a site: the pass-1 tally */
 #define BV_FK_P2 2u                       /* calls + mapq + ranks of a variant site: the two rank sums of pass 2 */
@@ -859,7 +858,9 @@ __device__ __forceinline__ void bv_f_stash_flush(const BvP1ShortArgs &a, BvFused
 // allocation applies to this local, non-recursive function: no saves here, the kernel keeps what IT has live across the call
 // (next to nothing: see the lane number in the kernel's loop).
 #define BV_F_GLOBAL(T, p) ((T *)(__attribute__((address_space(1))) T *)(p))
-template <bool FUSE2>
+// P2RING: the ring carries the variant sites' pass-2 rows too (FUSE2 with plain ranks, or BV_FLAG_P2_TAIL_DMA); false: pass-1 rows only
+// -- the instance FUSE2 launches of tagged slabs take: without the pass-2 tally in its loop it has no scalar registers spilled there.
+template <bool FUSE2, bool P2RING = FUSE2>
 __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until_idle(uint32_t ka_lo_, uint32_t ka_hi_, uint32_t sh_lds_, uint32_t wave_, uint32_t B0_,
                                                                      uint32_t B1_, uint32_t st_in_) {
     const uint32_t sh_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh_lds_);
@@ -929,7 +930,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
     uint32_t one;
     asm volatile("v_mov_b32 %0, 1" : "=v"(one));
     // the tagged rank layout (BV_SLAB_RPR_TAGGED): a pass-2 row is mapq + ranks, the class of a cell comes from its rank word
-    const bool tag = FUSE2 && a.rpr_tag != 0u;
+    const bool tag = P2RING && a.rpr_tag != 0u;
     const uint32_t hi_mask = bv_rpr_hi_mask(tag ? 1u : 0u);
 
     // ---- prefetch side: the next slot to request
@@ -957,7 +958,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
             }
             // (a wave past its pass-1 rows streams what variant rows there are; one that solved first instead measured 168
             // against 175 M sites/s: HBM idles while twelve waves solve)
-            if (FUSE2 && kind == 0u && !(st & BV_FS_NO_P2)) {
+            if (P2RING && kind == 0u) {
                 const uint32_t h = bv_f_lds_read_u(&sh.ctl[BV_FC_QV_HEAD]);
                 if (h != bv_f_lds_read_u(&sh.ctl[BV_FC_QV_TAIL]) && bv_f_lds_cas_wave(qvhead_lds, h, h + 1u) == h) {
                     const uint32_t *e = sh.qv[h & (BV_F_QVCAP - 1u)];
@@ -968,7 +969,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
                     else kind = BV_FK_P2;
                 }
             }
-            if (FUSE2 && kind == 0u && !(st & BV_FS_NO_P2)) {
+            if (P2RING && kind == 0u) {
                 // ... or from the overflow list (rare: more variant sites waiting than the LDS queue takes).  Its entries are in
                 // HBM: one vector load, the ring drains
                 const uint32_t oh = bv_f_lds_read_u(&sh.ctl[BV_FC_OV_HEAD]);
@@ -1008,7 +1009,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         if (ring_w == 0u) ph_i0_ = (uint32_t)__builtin_amdgcn_s_memtime();  // (ring position 0 only: one in K slots is timed)
 #endif
         const uint32_t d0 = ring_lds + ring_w * (BV_F_SLOT_WORDS * 4u);
-        if (!FUSE2 || p_kind == BV_FK_P1) {
+        if (!P2RING || p_kind == BV_FK_P1) {
             if (p_left > 1u) { bv_f_glds4(d0, p0, va, p0, vb, p1, va, p1, vb); p0 += 2048; p1 += 2048; }
             else bv_f_glds4_masked(d0, p0, va, p0, vbl, p1, va, p1, vbl, mA1, mB1);
         } else if (tag) {
@@ -1061,7 +1062,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
 #pragma unroll 1
     while (st & C_HAVE) {
         const uint32_t site = c_site;
-        const bool is_p1 = !FUSE2 || c_kind == BV_FK_P1;
+        const bool is_p1 = !P2RING || c_kind == BV_FK_P1;
         const uint32_t n_slots = is_p1 ? n_slots1 : n_slots2;
         uint32_t hi_acc = 0, dom = BV_DOM_NONE;
 #pragma unroll 1
@@ -1079,8 +1080,8 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
 #endif
             const uint32_t *rs = ring + ring_r * BV_F_SLOT_WORDS + lane * 4;
             // (a pass-2 slot: the lane's 16 ranks are 32 contiguous bytes of the slot's second half)
-            const uint32_t *rs2 = (!FUSE2 || c_kind == BV_FK_P1) ? rs + 512 : rs + 512 + lane * 4;
-            const uint32_t o3 = (!FUSE2 || c_kind == BV_FK_P1) ? 256u : 4u;
+            const uint32_t *rs2 = (!P2RING || c_kind == BV_FK_P1) ? rs + 512 : rs + 512 + lane * 4;
+            const uint32_t o3 = (!P2RING || c_kind == BV_FK_P1) ? 256u : 4u;
             bv_u32x4 w0 = *reinterpret_cast<const bv_u32x4 *>(rs);
             bv_u32x4 w1 = *reinterpret_cast<const bv_u32x4 *>(rs + 256);
             bv_u32x4 w2 = *reinterpret_cast<const bv_u32x4 *>(rs2);
@@ -1362,7 +1363,7 @@ __device__ __attribute__((noinline, not_tail_called)) uint32_t bv_f_stream_until
         }
     }
     if ((st & CUR_DONE) && !(st & P1_FIN)) finish_p1();
-    if (FUSE2 && stash.n != 0u) bv_f_stash_flush(a, stash, lane);
+    if (P2RING && stash.n != 0u) bv_f_stash_flush(a, stash, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     BV_PH(8);
     BV_PH_FLUSH(a.counters, lane);
@@ -1665,9 +1666,10 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
                 const bool cand = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= least ||
                                   bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= least;
                 if (!cand) bv_f_p2_rows((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)(uintptr_t)(bv_lds_u32 *)sh.hist[wave], B0);
-            } else
-                sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1,
-                                                                                                  sst | (p2_regs ? BV_FS_NO_P2 : 0u)));
+            } else if (p2_regs)  // (the ring carries pass-1 rows only: an instance of the function without the pass-2 tally)
+                sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2, false>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
+            else
+                sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2, FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
             if (sst & BV_FS_P_DONE) streaming = false;
         }
         const int r = bv_f_solver_step(a, sh, v, B0, B1, ln);
