@@ -1666,7 +1666,9 @@ __global__ __launch_bounds__(BV_WAVE *BV_F_NW) void bv_p1s_fused_kernel(BvP1Shor
                 const bool cand = bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q3_HEAD]) >= least ||
                                   bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_TAIL]) - bv_f_lds_read_u(&sh.ctl[BV_FC_Q2_HEAD]) >= least;
                 if (!cand) bv_f_p2_rows((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)(uintptr_t)(bv_lds_u32 *)sh.hist[wave], B0);
-            } else if (p2_regs)  // (the ring carries pass-1 rows only: an instance of the function without the pass-2 tally)
+            } else if (FUSE2 && !((sst & BV_FS_CUR_DONE) && (sst & BV_FS_P1_FIN)))
+                // (until a wave is past its pass-1 rows its ring carries nothing else, whatever streams the variant rows later: the
+                // instance of the function without the pass-2 tally -- it returns when the cursor is exhausted and its rows are out)
                 sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2, false>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
             else
                 sst = (uint32_t)__builtin_amdgcn_readfirstlane((int)bv_f_stream_until_idle<FUSE2, FUSE2>((uint32_t)ka_ptr, (uint32_t)(ka_ptr >> 32), sh_lds, (uint32_t)wave, B0, B1, sst));
